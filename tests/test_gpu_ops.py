@@ -1,0 +1,268 @@
+"""-m gpu: every HIP kernel of the path, called through the C ABI, against the fp32 oracle of the same op.
+
+Inputs are bf16-representable, so the only differences are fp32 summation order and the final bf16 rounding of the
+kernel's output (relative 2^-9): tolerances are rel-L2 <= 4e-3 and max-abs <= 2e-2 of max|ref| for bf16 outputs,
+1e-5-class for fp32 outputs.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, bf, call, check_close, dev_bf16, dev_f32, lib, stream  # noqa: E402
+from fastvla_hip import _lib  # noqa: E402
+from oracle import fastvit_hd, preprocess, qwen2  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device (no CPU fallback in the product path)")
+
+
+def _gemm(A, W, epi, bias=None, scale=None, res=None, lda=None, out_f32=False, ncols=None):
+    M, K = A.shape
+    N = W.shape[0]
+    ncols = ncols or N
+    a = dev_bf16(A)
+    if lda:
+        buf = torch.zeros(M, lda, dtype=torch.bfloat16, device=DEV)
+        buf[:, :K] = a
+        a = buf
+    w = dev_bf16(W)
+    out = torch.full((M, ncols), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=DEV)
+    b = dev_f32(bias) if bias is not None else None
+    s = dev_f32(scale) if scale is not None else None
+    r = None
+    if res is not None:
+        r = dev_f32(res) if out_f32 else dev_bf16(res)
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    call(lib().fv_op_gemm(a.data_ptr(), lda or K, w.data_ptr(), M, N, K, p(b), p(s), p(r), N if r is not None else 0,
+                          out.data_ptr(), ncols, epi, stream()), "fv_op_gemm")
+    torch.cuda.synchronize()
+    return out.float().cpu()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 96, 96), (200, 384, 96), (77, 1152, 896), (1024, 896, 4864),
+                                   (130, 3072, 1536), (4096, 96, 384)])
+def test_gemm_bias_and_gelu(M, N, K):
+    torch.manual_seed(M + N + K)
+    A, W, b = bf(torch.randn(M, K)), bf(torch.randn(N, K) / math.sqrt(K)), torch.randn(N) * 0.1
+    ref = A.double() @ W.double().t() + b.double()
+    check_close(_gemm(A, W, _lib.EPI_BIAS, bias=b), ref.float(), what=f"gemm bias {M}x{N}x{K}")
+    check_close(_gemm(A, W, _lib.EPI_BIAS_GELU, bias=b), F.gelu(ref.float()), what=f"gemm gelu {M}x{N}x{K}")
+    check_close(_gemm(A, W, _lib.EPI_BIAS), (A.double() @ W.double().t()).float(), what="gemm nobias")
+
+
+def test_gemm_is_not_transposed():
+    # A = I with an ASYMMETRIC W catches a swapped row/col map in the C write
+    n = 128
+    W = bf(torch.arange(n * n, dtype=torch.float32).view(n, n) % 251 - 100.0)
+    out = _gemm(torch.eye(n), W, _lib.EPI_BIAS)
+    assert torch.equal(out, W.t().contiguous())
+
+
+def test_gemm_layerscale_residual_and_strided_a():
+    torch.manual_seed(3)
+    M, N, K = 300, 192, 768
+    A, W = bf(torch.randn(M, K)), bf(torch.randn(N, K) / math.sqrt(K))
+    b, ls, res = torch.randn(N) * 0.1, torch.rand(N) * 0.3, bf(torch.randn(M, N))
+    ref = res.double() + ls.double() * (A.double() @ W.double().t() + b.double())
+    check_close(_gemm(A, W, _lib.EPI_LS_RES, bias=b, scale=ls, res=res, lda=K + 64), ref.float(), what="ls_res")
+
+
+def test_gemm_f32_residual_and_f32_out():
+    torch.manual_seed(4)
+    M, N, K = 260, 896, 4864
+    A, W, res = bf(torch.randn(M, K)), bf(torch.randn(N, K) * 0.02), torch.randn(M, N)
+    ref = (res.double() + A.double() @ W.double().t()).float()
+    check_close(_gemm(A, W, _lib.EPI_RES_F32, res=res, out_f32=True), ref, rel=2e-5, amax=2e-5, what="res_f32")
+    b = torch.randn(N)
+    ref = (A.double() @ W.double().t() + b.double()).float()
+    check_close(_gemm(A, W, _lib.EPI_F32, bias=b, out_f32=True), ref, rel=2e-5, amax=2e-5, what="f32 out")
+
+
+def test_gemm_swiglu_interleaved():
+    torch.manual_seed(5)
+    M, I, K = 150, 256, 128
+    A, G, U = bf(torch.randn(M, K)), bf(torch.randn(I, K) / math.sqrt(K)), bf(torch.randn(I, K) / math.sqrt(K))
+    Wi = torch.empty(2 * I, K)
+    j = torch.arange(I)
+    Wi[(j // 8) * 16 + j % 8] = G
+    Wi[(j // 8) * 16 + 8 + j % 8] = U
+    ref = F.silu(A.double() @ G.double().t()) * (A.double() @ U.double().t())
+    check_close(_gemm(A, Wi, _lib.EPI_SWIGLU, ncols=I), ref.float(), what="swiglu")
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(8, 8, dtype=torch.bfloat16, device=DEV)
+    rc = lib().fv_op_gemm(a.data_ptr(), 8, a.data_ptr(), 8, 8, 4, None, None, None, 0, a.data_ptr(), 8, 0, stream())
+    assert rc == -1 and b"multiples of 8" in lib().fv_last_error(None)
+    rc = lib().fv_op_gemm(None, 8, a.data_ptr(), 8, 8, 8, None, None, None, 0, a.data_ptr(), 8, 0, stream())
+    assert rc == -1
+
+
+@pytest.mark.parametrize("k,stride,mult,gelu,C,H,W", [(3, 1, 1, 0, 96, 20, 24), (7, 1, 1, 0, 64, 19, 33),
+                                                       (3, 2, 1, 1, 32, 32, 32), (7, 2, 2, 1, 64, 24, 24),
+                                                       (3, 1, 2, 0, 512, 4, 4), (7, 1, 1, 0, 768, 8, 8),
+                                                       (7, 1, 1, 0, 96, 5, 3)])
+def test_dwconv(k, stride, mult, gelu, C, H, W):
+    torch.manual_seed(k * 100 + C)
+    B = 2
+    x = bf(torch.randn(B, C, H, W))
+    w = torch.randn(C * mult, 1, k, k) / k
+    b = torch.randn(C * mult) * 0.1
+    ref = F.conv2d(x, w, b, stride=stride, padding=k // 2, groups=C)
+    if gelu:
+        ref = F.gelu(ref)
+    Ho, Wo = ref.shape[2:]
+    xd = dev_bf16(x.permute(0, 2, 3, 1))
+    wd = dev_f32(w.view(C * mult, k * k).t())  # [k*k][Cout]
+    bd = dev_f32(b)  # keep every device operand alive in a named variable until the sync
+    y = torch.full((B, Ho, Wo, C * mult), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_dwconv(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, C, k, stride, mult,
+                            gelu, stream()), "fv_op_dwconv")
+    torch.cuda.synchronize()
+    check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"dwconv k{k} s{stride} m{mult}")
+
+
+def test_stem_conv_and_letterbox():
+    torch.manual_seed(11)
+    B, S, C0 = 2, 64, 32
+    img = torch.rand(B, 3, 21, 30)
+    ref_pix = preprocess.letterbox(img, S, pad_value=0.25)
+    pix = torch.empty(B, S, S, 4, dtype=torch.bfloat16, device=DEV)
+    # fv_preprocess needs a handle for image_size only: use the letterbox through a tiny engine-free path
+    from fastvla_hip import FastVLAEngine, arch
+    m = arch.ModelConfig("lb", arch.LLMConfig(hidden=64, layers=1, heads=2, kv_heads=1, head_dim=32, inter=64, vocab=64),
+                         arch.TowerConfig(layers=(1, 1, 1, 1, 1), dims=(32, 64, 128, 256, 512), image_size=S))
+    eng = FastVLAEngine(m, hidden_dim=32, fusion_dim=32)
+    pix = eng.preprocess(img.to(DEV), pad_value=0.25)
+    torch.cuda.synchronize()
+    got = pix.float().cpu()
+    assert float(got[..., 3].abs().max()) == 0.0
+    check_close(got[..., :3].permute(0, 3, 1, 2), ref_pix, rel=3e-3, amax=5e-3, what="letterbox")
+    u8 = (torch.rand(1, 1, 40, 17) * 255).to(torch.uint8)
+    ref_u8 = preprocess.letterbox(u8, S)
+    got = eng.preprocess(u8.to(DEV)).float().cpu()[..., :3].permute(0, 3, 1, 2)
+    check_close(got, ref_u8, rel=3e-3, amax=5e-3, what="letterbox u8 gray")
+    got = eng.preprocess(img.to(DEV), resize_with_padding=False).float().cpu()[..., :3].permute(0, 3, 1, 2)
+    check_close(got, preprocess.letterbox(img, S, resize_with_padding=False), rel=3e-3, amax=5e-3, what="stretch")
+    with pytest.raises(ValueError):
+        eng.preprocess(torch.zeros(3, 8, 8))
+    # stem conv on the bf16 pixels
+    x = pix.float().cpu()[..., :3].permute(0, 3, 1, 2)
+    w = torch.randn(C0, 3, 3, 3) / 5
+    b = torch.randn(C0) * 0.1
+    ref = F.gelu(F.conv2d(x, w, b, stride=2, padding=1))
+    wd = dev_f32(w.permute(2, 3, 1, 0).reshape(27, C0))  # [(ky,kx,ci)][co]
+    bd = dev_f32(b)
+    y = torch.full((B, S // 2, S // 2, C0), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_stem_conv(pix.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, S, C0, stream()),
+         "fv_op_stem_conv")
+    torch.cuda.synchronize()
+    check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what="stem conv")
+    eng.close()
+
+
+def test_layernorm_rows_and_rmsnorm():
+    torch.manual_seed(12)
+    for rows, C in [(37, 768), (5, 1536), (64, 256)]:
+        x = bf(torch.randn(rows, C) * 2 + 0.5)
+        w, b = 1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C)
+        ref = F.layer_norm(x, (C,), w, b, 1e-5)
+        y = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+        xd, wd, bd = dev_bf16(x), dev_f32(w), dev_f32(b)
+        call(lib().fv_op_layernorm_rows(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(),
+                                        rows, C, 1e-5, stream()), "ln rows")
+        torch.cuda.synchronize()
+        check_close(y.float().cpu(), ref, what="layernorm rows")
+    for rows, H in [(70, 896), (3, 3584), (9, 128)]:
+        x = torch.randn(rows, H) * 3
+        w = 1 + 0.1 * torch.randn(H)
+        y = torch.empty(rows, H, dtype=torch.bfloat16, device=DEV)
+        xd, wd = dev_f32(x), dev_f32(w)
+        call(lib().fv_op_rmsnorm(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), rows, H, 1e-6, stream()), "rmsnorm")
+        torch.cuda.synchronize()
+        check_close(y.float().cpu(), qwen2.rmsnorm(x, w, 1e-6), what="rmsnorm")
+
+
+def test_rope_matches_rotate_half():
+    torch.manual_seed(13)
+    B, T, heads, kv, D = 2, 9, 4, 2, 64
+    ld = (heads + 2 * kv) * D
+    qkv = bf(torch.randn(B * T, ld))
+    d = dev_bf16(qkv)
+    call(lib().fv_op_rope(d.data_ptr(), ld, B * T, T, heads, kv, D, 1e6, stream()), "rope")
+    torch.cuda.synchronize()
+    cfg = qwen2.Qwen2Cfg(head_dim=D, rope_theta=1e6)
+    cos, sin = qwen2.rope_tables(cfg, torch.arange(T))
+    x = qkv.view(B, T, heads + 2 * kv, D)
+    rot = x * cos[None, :, None, :] + qwen2._rotate_half(x) * sin[None, :, None, :]
+    ref = x.clone()
+    ref[:, :, : heads + kv] = rot[:, :, : heads + kv]  # v untouched
+    check_close(d.float().cpu().view(B, T, heads + 2 * kv, D), ref, what="rope")
+
+
+def _attn_ref(q, k, v, causal, lens, scale):
+    B, T, Hh, D = q.shape
+    g = Hh // k.shape[2]
+    kk, vv = k.repeat_interleave(g, dim=2), v.repeat_interleave(g, dim=2)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.double(), kk.double()) * scale
+    pos = torch.arange(T)
+    mask = torch.ones(B, 1, T, T, dtype=torch.bool)
+    if causal:
+        mask = mask & (pos[None, :] <= pos[:, None])[None, None]
+    if lens is not None:
+        mask = mask & (pos[None, :] < lens[:, None])[:, None, None, :]
+    s = s.masked_fill(~mask, -1e300)
+    return torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, dim=-1), vv.double()).float()
+
+
+@pytest.mark.parametrize("B,T,heads,kv,D,causal", [(2, 256, 4, 4, 32, 0), (1, 1024, 2, 2, 32, 0), (3, 64, 14, 2, 64, 1),
+                                                   (2, 77, 4, 2, 64, 1), (2, 40, 4, 1, 128, 1), (1, 320, 14, 2, 64, 1)])
+def test_attention(B, T, heads, kv, D, causal):
+    torch.manual_seed(T + D)
+    ld = (heads + 2 * kv) * D
+    qkv = bf(torch.randn(B, T, ld))
+    q = qkv[..., : heads * D].reshape(B, T, heads, D)
+    k = qkv[..., heads * D: (heads + kv) * D].reshape(B, T, kv, D)
+    v = qkv[..., (heads + kv) * D:].reshape(B, T, kv, D)
+    lens = None
+    if causal:
+        lens = torch.tensor([T, max(1, T // 2), 1][:B], dtype=torch.int32)
+    d = dev_bf16(qkv)
+    out = torch.full((B, T, heads * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ld_dev = None if lens is None else lens.to(DEV)
+    base = d.data_ptr()
+    call(lib().fv_op_attention(base, base + heads * D * 2, base + (heads + kv) * D * 2, ld, ld, ld, out.data_ptr(), heads * D,
+                               B, T, heads, kv, D, causal, None if ld_dev is None else ld_dev.data_ptr(), D ** -0.5, stream()),
+         "attention")
+    torch.cuda.synchronize()
+    ref = _attn_ref(q, k, v, causal, None if lens is None else lens.long(), D ** -0.5)
+    got = out.float().cpu().view(B, T, heads, D)
+    if lens is not None:  # rows past len are padding: never consumed, compare the valid ones
+        for b in range(B):
+            check_close(got[b, : int(lens[b])], ref[b, : int(lens[b])], rel=6e-3, what=f"attention b{b}")
+    else:
+        check_close(got, ref, rel=6e-3, what="attention")
+
+
+def test_se_gelu_tail():
+    torch.manual_seed(17)
+    B, P, Cc, R = 3, 16, 1024, 64
+    x = bf(torch.randn(B, P, Cc))
+    w1, b1 = torch.randn(R, Cc) / 32, torch.randn(R) * 0.1
+    w2, b2 = torch.randn(Cc, R) / 8, torch.randn(Cc) * 0.1
+    s = torch.sigmoid(F.linear(F.relu(F.linear(x.mean(1), w1, b1)), w2, b2))
+    ref = F.gelu(x * s[:, None, :])
+    y = torch.empty(B, P, Cc, dtype=torch.bfloat16, device=DEV)
+    scratch = torch.empty(B * (2 * Cc + R), dtype=torch.float32, device=DEV)
+    xd, w1d, b1d, w2d, b2d = dev_bf16(x), dev_f32(w1), dev_f32(b1), dev_f32(w2), dev_f32(b2)
+    call(lib().fv_op_se_gelu(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(),
+                             b2d.data_ptr(), y.data_ptr(), scratch.data_ptr(), B, P, Cc, R, stream()), "se_gelu")
+    torch.cuda.synchronize()
+    check_close(y.float().cpu(), ref, what="se+gelu")

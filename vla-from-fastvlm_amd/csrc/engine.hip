@@ -1,0 +1,605 @@
+// engine.hip -- the native runtime behind the C ABI (include/fastvla_hip.h): owns the packed frozen weights, plans the
+// caller-owned workspace and issues the kernel schedule of the policy step on the caller's stream.
+//
+// Replaces, on the reference side:
+//   FastVLMBackbone.__init__/_load_model            model/fastvlm_adapter.py:90-201     -> fv_create + fv_load_weights
+//   FastVLMBackbone._prepare_images_tensor          model/fastvlm_adapter.py:479-488    -> fv_preprocess
+//   self.model(**inputs) [LlavaQwen2ForCausalLM]     model/fastvlm_adapter.py:533        -> fv_vision_forward + fv_llm_forward_pooled
+//   FastVLMBackbone._pool_hidden                     model/fastvlm_adapter.py:337-359    -> fused into fv_llm_forward_pooled
+//   FastVLMWithExpert head, MSE, backward, optimiser fastvla/fastvlm_with_expert.py:50-54, trainer.py:171-182 -> fv_head_*
+// Work the reference does and this path deliberately does not: lm_head logits, retained per-layer hidden states,
+// KV-cache write-back, the D2H -> CPU resize -> H2D round trip.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------ error plumbing
+static thread_local char g_err[768] = "";
+int fv_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int fv_hip_fail(hipError_t e, const char* what) { return fv_fail(FV_ERR_HIP, "HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what); }
+
+namespace {
+
+
+const char* VT = "model.vision_tower.vision_tower.model.";
+const char* PJ = "model.mm_projector.";
+const char* LM = "model.";
+
+inline bf16_t host_f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+inline float host_bf2f(bf16_t b) {
+  uint32_t u = ((uint32_t)b) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+struct FFN { float *dw_w = nullptr, *dw_b = nullptr; bf16_t* fc1_w = nullptr; float* fc1_b = nullptr; bf16_t* fc2_w = nullptr; float *fc2_b = nullptr, *ls = nullptr; };
+struct Block {
+  float *mix_w = nullptr, *mix_b = nullptr;                           // RepMixer
+  float *ln_w = nullptr, *ln_b = nullptr; bf16_t *qkv_w = nullptr, *proj_w = nullptr; float *proj_b = nullptr, *ls1 = nullptr;  // attention
+  FFN ffn;
+};
+struct Down { float *lk_w = nullptr, *lk_b = nullptr; bf16_t* pw_w = nullptr; float* pw_b = nullptr; };
+struct Cpe { float *w = nullptr, *b = nullptr; };
+struct Tower {
+  float *stem0_w = nullptr, *stem0_b = nullptr, *stem1_w = nullptr, *stem1_b = nullptr; bf16_t* stem2_w = nullptr; float* stem2_b = nullptr;
+  std::vector<std::vector<Block>> stages; std::vector<Down> downs; std::vector<Cpe> cpes;
+  float *exp_w = nullptr, *exp_b = nullptr, *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr, *se_b2 = nullptr;
+  bf16_t *pj0_w = nullptr, *pj2_w = nullptr; float *pj0_b = nullptr, *pj2_b = nullptr;
+};
+struct DecLayer { float* ln1 = nullptr; bf16_t* qkv_w = nullptr; float* qkv_b = nullptr; bf16_t* o_w = nullptr; float* ln2 = nullptr; bf16_t *gu_w = nullptr, *down_w = nullptr; };
+struct Decoder { bf16_t* embed = nullptr; std::vector<DecLayer> layers; float* norm = nullptr; };
+
+struct WsPlan {
+  size_t bufA, bufB, bufH, se, tower_out, x, xn, qkv, att, act, head_scr, total;
+};
+
+}  // namespace
+
+struct fv_handle {
+  fv_model_desc d;
+  int device = 0;
+  bool loaded = false;
+  std::vector<void*> allocs;
+  Tower tw;
+  Decoder dec;
+  float2* rope = nullptr;
+  int rope_rows = 0;
+  float* norm_scratch = nullptr;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  fv::HeadDims hd;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+int dev_alloc(fv_handle* h, size_t bytes, void** out) {
+  void* p = nullptr;
+  FV_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+  h->allocs.push_back(p);
+  *out = p;
+  return FV_OK;
+}
+
+struct Loader {
+  fv_handle* h;
+  std::map<std::string, const fv_tensor_desc*> idx;
+  int rc = FV_OK;
+
+  bool get(const std::string& name, std::vector<float>& out, std::vector<int64_t>* shape = nullptr) {
+    auto it = idx.find(name);
+    if (it == idx.end()) {
+      if (rc == FV_OK) rc = fv_fail(FV_ERR_MISSING, "missing weight tensor '%s'", name.c_str());
+      return false;
+    }
+    const fv_tensor_desc* t = it->second;
+    size_t n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= (size_t)t->shape[i];
+    out.resize(n);
+    if (t->dtype == FV_F32) memcpy(out.data(), t->data, n * 4);
+    else if (t->dtype == FV_BF16) { const bf16_t* s = static_cast<const bf16_t*>(t->data); for (size_t i = 0; i < n; ++i) out[i] = host_bf2f(s[i]); }
+    else { if (rc == FV_OK) rc = fv_fail(FV_ERR_ARG, "tensor '%s': dtype must be f32 or bf16", name.c_str()); return false; }
+    if (shape) shape->assign(t->shape, t->shape + t->ndim);
+    return true;
+  }
+  bool expect(const std::string& name, std::vector<float>& v, size_t n) {
+    if (!get(name, v)) return false;
+    if (v.size() != n) {
+      if (rc == FV_OK) rc = fv_fail(FV_ERR_ARG, "tensor '%s' has %zu elements, expected %zu", name.c_str(), v.size(), n);
+      return false;
+    }
+    return true;
+  }
+  float* up_f32(const std::vector<float>& v) {
+    void* p = nullptr;
+    if (dev_alloc(h, v.size() * 4, &p) != FV_OK) { if (rc == FV_OK) rc = FV_ERR_HIP; return nullptr; }
+    if (hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { if (rc == FV_OK) rc = fv_fail(FV_ERR_HIP, "hipMemcpy failed"); }
+    return static_cast<float*>(p);
+  }
+  bf16_t* up_bf16(const std::vector<float>& v) {
+    std::vector<bf16_t> b(v.size());
+    for (size_t i = 0; i < v.size(); ++i) b[i] = host_f2bf(v[i]);
+    void* p = nullptr;
+    if (dev_alloc(h, b.size() * 2, &p) != FV_OK) { if (rc == FV_OK) rc = FV_ERR_HIP; return nullptr; }
+    if (hipMemcpy(p, b.data(), b.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { if (rc == FV_OK) rc = fv_fail(FV_ERR_HIP, "hipMemcpy failed"); }
+    return static_cast<bf16_t*>(p);
+  }
+  // f32 vector straight up
+  float* vec(const std::string& name, size_t n) { std::vector<float> v; return expect(name, v, n) ? up_f32(v) : nullptr; }
+  // [N][K] (or [N,K,1,1]) -> bf16
+  bf16_t* mat(const std::string& name, size_t n, size_t k) { std::vector<float> v; return expect(name, v, n * k) ? up_bf16(v) : nullptr; }
+  // depthwise [Cout,1,k,k] -> tap-major [k*k][Cout] f32, optionally scaled per out-channel (BN fold)
+  float* dw(const std::string& name, int cout, int k, const std::vector<float>* scale = nullptr) {
+    std::vector<float> v;
+    if (!expect(name, v, (size_t)cout * k * k)) return nullptr;
+    std::vector<float> o((size_t)cout * k * k);
+    for (int c = 0; c < cout; ++c)
+      for (int t = 0; t < k * k; ++t) o[(size_t)t * cout + c] = v[(size_t)c * k * k + t] * (scale ? (*scale)[c] : 1.0f);
+    return up_f32(o);
+  }
+};
+
+int load_ffn(Loader& L, const std::string& pre, int C, int hidden, float bn_eps, FFN& f, const std::string& ls_name) {
+  std::vector<float> g, b, m, v;
+  if (!L.expect(pre + "conv.bn.weight", g, C) || !L.expect(pre + "conv.bn.bias", b, C) ||
+      !L.expect(pre + "conv.bn.running_mean", m, C) || !L.expect(pre + "conv.bn.running_var", v, C))
+    return L.rc;
+  std::vector<float> sc(C), bias(C);
+  for (int c = 0; c < C; ++c) {
+    sc[c] = g[c] / std::sqrt(v[c] + bn_eps);
+    bias[c] = b[c] - m[c] * sc[c];
+  }
+  f.dw_w = L.dw(pre + "conv.conv.weight", C, 7, &sc);
+  f.dw_b = L.up_f32(bias);
+  f.fc1_w = L.mat(pre + "fc1.weight", hidden, C);
+  f.fc1_b = L.vec(pre + "fc1.bias", hidden);
+  f.fc2_w = L.mat(pre + "fc2.weight", C, hidden);
+  f.fc2_b = L.vec(pre + "fc2.bias", C);
+  f.ls = L.vec(ls_name, C);
+  return L.rc;
+}
+
+WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
+  const fv_model_desc& d = h->d;
+  WsPlan p{};
+  const int mb = (d.tower_microbatch > 0 && d.tower_microbatch < B) ? d.tower_microbatch : B;
+  const size_t S = d.image_size;
+  size_t act = (S / 2) * (S / 2) * (size_t)d.tower_dims[0];  // stem0 output, per image (elements)
+  size_t hid = 0;
+  size_t hw = (S / 4) * (S / 4);
+  for (int i = 0; i < d.tower_stages; ++i) {
+    const size_t C = d.tower_dims[i];
+    act = std::max(act, hw * C);
+    hid = std::max(hid, hw * C * d.tower_mlp_ratio);
+    if (d.tower_is_attn[i]) hid = std::max(hid, hw * C * 3);
+    if (i + 1 < d.tower_stages) {
+      hw /= 4;
+      act = std::max(act, hw * (size_t)d.tower_dims[i + 1]);
+    }
+  }
+  const size_t P = hw;
+  act = std::max(act, P * (size_t)d.tower_out_dim);
+  hid = std::max(hid, P * (size_t)d.llm_hidden);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
+  p.bufA = take(act * mb * 2);
+  p.bufB = take(act * mb * 2);
+  p.bufH = take(hid * mb * 2);
+  p.se = take(((size_t)mb * (2 * d.tower_out_dim + d.tower_se_rd)) * 4);
+  p.tower_out = take((size_t)B * P * d.tower_out_dim * 2);
+  const size_t rows = (size_t)B * (T + (splice ? P : 0));
+  const size_t qkvw = (size_t)(d.llm_heads + 2 * d.llm_kv_heads) * d.llm_head_dim;
+  p.x = take(rows * d.llm_hidden * 4);
+  p.xn = take(rows * d.llm_hidden * 2);
+  p.qkv = take(rows * qkvw * 2);
+  p.att = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2);
+  p.act = take(rows * d.llm_inter * 2);
+  p.head_scr = take(fv::head_bwd_scratch_bytes(h->hd, B));
+  p.total = o;
+  return p;
+}
+
+int check_ready(fv_handle* h, bool need_ws) {
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  if (!h->loaded) return fv_fail(FV_ERR_STATE, "weights not loaded: call fv_load_weights first");
+  if (need_ws && !h->ws) return fv_fail(FV_ERR_STATE, "workspace not bound: call fv_bind_workspace first");
+  return FV_OK;
+}
+
+#define FV_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != FV_OK) return _rc; \
+  } while (0)
+
+int run_ffn(const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t* hid, bf16_t* res_out, int mb, int H, int W, int C,
+            int ratio, hipStream_t s) {
+  // dw_out = dw7x7(x_dw_in) (+BN folded); hid = gelu(fc1(dw_out)); res_out += ls * fc2(hid)
+  FV_TRY(fv::launch_dwconv(x_dw_in, f.dw_w, f.dw_b, dw_out, mb, H, W, C, 7, 1, 1, 0, s));
+  const int M = mb * H * W;
+  fv::GemmArgs g1{dw_out, C, f.fc1_w, M, C * ratio, C, f.fc1_b, nullptr, nullptr, 0, hid, C * ratio, FV_EPI_BIAS_GELU};
+  FV_TRY(fv::launch_gemm(g1, s));
+  fv::GemmArgs g2{hid, C * ratio, f.fc2_w, M, C, C * ratio, f.fc2_b, f.ls, res_out, C, res_out, C, FV_EPI_LS_RES};
+  FV_TRY(fv::launch_gemm(g2, s));
+  return FV_OK;
+}
+
+int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float* img_tokens, const WsPlan& wp,
+               hipStream_t s) {
+  const fv_model_desc& d = h->d;
+  const Tower& tw = h->tw;
+  char* ws = static_cast<char*>(h->ws);
+  bf16_t* cur = reinterpret_cast<bf16_t*>(ws + wp.bufA);
+  bf16_t* oth = reinterpret_cast<bf16_t*>(ws + wp.bufB);
+  bf16_t* hid = reinterpret_cast<bf16_t*>(ws + wp.bufH);
+  float* se = reinterpret_cast<float*>(ws + wp.se);
+  const int S = d.image_size, C0 = d.tower_dims[0];
+  FV_TRY(fv::launch_stem_conv(pix, tw.stem0_w, tw.stem0_b, cur, mb, S, C0, s));
+  FV_TRY(fv::launch_dwconv(cur, tw.stem1_w, tw.stem1_b, oth, mb, S / 2, S / 2, C0, 3, 2, 1, 1, s));
+  int H = S / 4;
+  {
+    fv::GemmArgs g{oth, C0, tw.stem2_w, mb * H * H, C0, C0, tw.stem2_b, nullptr, nullptr, 0, cur, C0, FV_EPI_BIAS_GELU};
+    FV_TRY(fv::launch_gemm(g, s));
+  }
+  for (int i = 0; i < d.tower_stages; ++i) {
+    const int C = d.tower_dims[i];
+    const int M = mb * H * H;
+    if (d.tower_is_attn[i]) {
+      FV_TRY(fv::launch_dwconv(cur, tw.cpes[i].w, tw.cpes[i].b, oth, mb, H, H, C, 7, 1, 1, 0, s));
+      std::swap(cur, oth);
+    }
+    for (const Block& b : tw.stages[i]) {
+      if (!d.tower_is_attn[i]) {
+        FV_TRY(fv::launch_dwconv(cur, b.mix_w, b.mix_b, oth, mb, H, H, C, 3, 1, 1, 0, s));  // x = RepMixer(x) -> oth
+        FV_TRY(run_ffn(b.ffn, oth, cur, hid, oth, mb, H, H, C, d.tower_mlp_ratio, s));        // oth += ls * ffn(oth)
+        std::swap(cur, oth);
+      } else {
+        FV_TRY(fv::launch_layernorm_rows(cur, b.ln_w, b.ln_b, oth, M, C, d.ln_eps, s));
+        fv::GemmArgs gq{oth, C, b.qkv_w, M, 3 * C, C, nullptr, nullptr, nullptr, 0, hid, 3 * C, FV_EPI_BIAS};
+        FV_TRY(fv::launch_gemm(gq, s));
+        const int nh = C / d.tower_head_dim;
+        FV_TRY(fv::launch_attention(hid, hid + C, hid + 2 * C, 3 * C, 3 * C, 3 * C, oth, C, mb, H * H, nh, nh,
+                                    d.tower_head_dim, 0, nullptr, 0, 1.0f / std::sqrt((float)d.tower_head_dim), s));
+        fv::GemmArgs gp{oth, C, b.proj_w, M, C, C, b.proj_b, b.ls1, cur, C, cur, C, FV_EPI_LS_RES};
+        FV_TRY(fv::launch_gemm(gp, s));
+        FV_TRY(run_ffn(b.ffn, cur, oth, hid, cur, mb, H, H, C, d.tower_mlp_ratio, s));
+      }
+    }
+    if (i + 1 < d.tower_stages) {
+      const int C2 = d.tower_dims[i + 1];
+      FV_TRY(fv::launch_dwconv(cur, tw.downs[i].lk_w, tw.downs[i].lk_b, oth, mb, H, H, C, 7, 2, C2 / C, 1, s));
+      H /= 2;
+      fv::GemmArgs g{oth, C2, tw.downs[i].pw_w, mb * H * H, C2, C2, tw.downs[i].pw_b, nullptr, nullptr, 0, cur, C2, FV_EPI_BIAS_GELU};
+      FV_TRY(fv::launch_gemm(g, s));
+    }
+  }
+  const int CL = d.tower_dims[d.tower_stages - 1], CO = d.tower_out_dim, P = H * H;
+  FV_TRY(fv::launch_dwconv(cur, tw.exp_w, tw.exp_b, oth, mb, H, H, CL, 3, 1, CO / CL, 0, s));
+  FV_TRY(fv::launch_se_gelu(oth, tw.se_w1, tw.se_b1, tw.se_w2, tw.se_b2, tower_out, se, mb, P, CO, d.tower_se_rd, s));
+  // mm_projector: Linear + GELU + Linear -> fp32 tokens ([site] fast_vlm/modeling_fast_vlm.py:51-55)
+  fv::GemmArgs p0{tower_out, CO, tw.pj0_w, mb * P, d.llm_hidden, CO, tw.pj0_b, nullptr, nullptr, 0, hid, d.llm_hidden, FV_EPI_BIAS_GELU};
+  FV_TRY(fv::launch_gemm(p0, s));
+  fv::GemmArgs p2{hid, d.llm_hidden, tw.pj2_w, mb * P, d.llm_hidden, d.llm_hidden, tw.pj2_b, nullptr, nullptr, 0, img_tokens, d.llm_hidden, FV_EPI_F32};
+  FV_TRY(fv::launch_gemm(p2, s));
+  return FV_OK;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+const char* fv_version(void) { return "fastvla_hip 0.1 (gfx950)"; }
+const char* fv_last_error(fv_handle*) { return g_err; }
+
+int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
+  if (!desc || !out) return fv_fail(FV_ERR_ARG, "fv_create: null argument");
+  const fv_model_desc& d = *desc;
+  if (d.tower_stages < 1 || d.tower_stages > FV_MAX_STAGES) return fv_fail(FV_ERR_ARG, "tower_stages out of range");
+  if (d.image_size <= 0 || d.image_size % (4 << (d.tower_stages - 1)))
+    return fv_fail(FV_ERR_ARG, "image_size %d must be a positive multiple of %d", d.image_size, 4 << (d.tower_stages - 1));
+  for (int i = 0; i < d.tower_stages; ++i) {
+    if (d.tower_dims[i] % 8 || d.tower_dims[i] <= 0 || d.tower_layers[i] < 0) return fv_fail(FV_ERR_ARG, "tower dims must be positive multiples of 8");
+    if (d.tower_is_attn[i] && d.tower_dims[i] % d.tower_head_dim) return fv_fail(FV_ERR_ARG, "attention stage dim %% head_dim != 0");
+    if (i > 0 && d.tower_dims[i] != 2 * d.tower_dims[i - 1] && d.tower_dims[i] != d.tower_dims[i - 1]) return fv_fail(FV_ERR_UNSUPPORTED, "stage dims must double or stay (grouped 7x7 multiplier 1 or 2)");
+  }
+  if (d.tower_head_dim != 32 && d.tower_head_dim != 64 && d.tower_head_dim != 128) return fv_fail(FV_ERR_UNSUPPORTED, "tower head_dim must be 32/64/128");
+  if (d.llm_head_dim != 32 && d.llm_head_dim != 64 && d.llm_head_dim != 128) return fv_fail(FV_ERR_UNSUPPORTED, "llm head_dim must be 32/64/128");
+  if (d.llm_hidden % 8 || d.llm_inter % 8 || d.llm_heads % d.llm_kv_heads) return fv_fail(FV_ERR_ARG, "llm dims must be multiples of 8 and heads %% kv_heads == 0");
+  if (d.tower_out_dim != 2 * d.tower_dims[d.tower_stages - 1] && d.tower_out_dim != d.tower_dims[d.tower_stages - 1]) return fv_fail(FV_ERR_UNSUPPORTED, "tower_out_dim must be 1x or 2x the last stage dim");
+  if (d.state_dim <= 0 || d.action_dim <= 0 || d.hidden_dim <= 0 || d.fusion_dim <= 0) return fv_fail(FV_ERR_ARG, "head dims must be positive");
+  FV_HIP_CHECK(hipSetDevice(device));
+  fv_handle* h = new fv_handle();
+  h->d = d;
+  h->device = device;
+  h->hd = fv::HeadDims{d.llm_hidden, d.state_dim, d.action_dim, d.hidden_dim, d.fusion_dim};
+  // RoPE table for every position the path can see (text + spliced image tokens)
+  const int P = (d.image_size >> (d.tower_stages + 1)) * (d.image_size >> (d.tower_stages + 1));
+  h->rope_rows = d.max_text_tokens + P + 8;
+  std::vector<float> cs((size_t)h->rope_rows * d.llm_head_dim);
+  fv::rope_table_host(cs.data(), h->rope_rows, d.llm_head_dim, d.rope_theta);
+  void* p = nullptr;
+  int rc = dev_alloc(h, cs.size() * 4, &p);
+  if (rc == FV_OK && hipMemcpy(p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fv_fail(FV_ERR_HIP, "rope table upload failed");
+  h->rope = static_cast<float2*>(p);
+  if (rc == FV_OK) { rc = dev_alloc(h, 64, &p); h->norm_scratch = static_cast<float*>(p); }
+  if (rc != FV_OK) { fv_destroy(h); return rc; }
+  *out = h;
+  return FV_OK;
+}
+
+void fv_destroy(fv_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+}
+
+int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n) {
+  if (!h || !tensors || n <= 0) return fv_fail(FV_ERR_ARG, "fv_load_weights: null argument");
+  if (h->loaded) return fv_fail(FV_ERR_STATE, "weights already loaded");
+  FV_HIP_CHECK(hipSetDevice(h->device));
+  const fv_model_desc& d = h->d;
+  Loader L{h};
+  for (int i = 0; i < n; ++i) {
+    if (!tensors[i].name || !tensors[i].data || tensors[i].ndim < 1 || tensors[i].ndim > 4) return fv_fail(FV_ERR_ARG, "tensor %d: bad descriptor", i);
+    L.idx[tensors[i].name] = &tensors[i];
+  }
+  Tower& tw = h->tw;
+  const std::string vt = VT;
+  const int C0 = d.tower_dims[0];
+  {  // stem: [C0,3,3,3] -> [27][C0] with k = (ky*3+kx)*3+ci
+    std::vector<float> v;
+    if (L.expect(vt + "patch_embed.0.reparam_conv.weight", v, (size_t)C0 * 27)) {
+      std::vector<float> o((size_t)27 * C0);
+      for (int co = 0; co < C0; ++co)
+        for (int ci = 0; ci < 3; ++ci)
+          for (int t = 0; t < 9; ++t) o[(size_t)(t * 3 + ci) * C0 + co] = v[((size_t)co * 3 + ci) * 9 + t];
+      tw.stem0_w = L.up_f32(o);
+    }
+    tw.stem0_b = L.vec(vt + "patch_embed.0.reparam_conv.bias", C0);
+    tw.stem1_w = L.dw(vt + "patch_embed.1.reparam_conv.weight", C0, 3);
+    tw.stem1_b = L.vec(vt + "patch_embed.1.reparam_conv.bias", C0);
+    tw.stem2_w = L.mat(vt + "patch_embed.2.reparam_conv.weight", C0, C0);
+    tw.stem2_b = L.vec(vt + "patch_embed.2.reparam_conv.bias", C0);
+  }
+  tw.stages.resize(d.tower_stages);
+  tw.downs.resize(d.tower_stages);
+  tw.cpes.resize(d.tower_stages);
+  int idx = 0;  // index into mci.py's `network` ModuleList: [RepCPE?] stage [PatchEmbed]
+  for (int i = 0; i < d.tower_stages && L.rc == FV_OK; ++i) {
+    const int C = d.tower_dims[i];
+    if (d.tower_is_attn[i]) {
+      const std::string pre = vt + "network." + std::to_string(idx++) + ".";
+      tw.cpes[i].w = L.dw(pre + "reparam_conv.weight", C, 7);
+      tw.cpes[i].b = L.vec(pre + "reparam_conv.bias", C);
+    }
+    const int sidx = idx++;
+    tw.stages[i].resize(d.tower_layers[i]);
+    for (int j = 0; j < d.tower_layers[i] && L.rc == FV_OK; ++j) {
+      const std::string pre = vt + "network." + std::to_string(sidx) + "." + std::to_string(j) + ".";
+      Block& b = tw.stages[i][j];
+      if (d.tower_is_attn[i]) {
+        b.ln_w = L.vec(pre + "norm.weight", C);
+        b.ln_b = L.vec(pre + "norm.bias", C);
+        b.qkv_w = L.mat(pre + "token_mixer.qkv.weight", 3 * (size_t)C, C);
+        b.proj_w = L.mat(pre + "token_mixer.proj.weight", C, C);
+        b.proj_b = L.vec(pre + "token_mixer.proj.bias", C);
+        b.ls1 = L.vec(pre + "layer_scale_1", C);
+        load_ffn(L, pre + "convffn.", C, C * d.tower_mlp_ratio, d.bn_eps, b.ffn, pre + "layer_scale_2");
+      } else {
+        b.mix_w = L.dw(pre + "token_mixer.reparam_conv.weight", C, 3);
+        b.mix_b = L.vec(pre + "token_mixer.reparam_conv.bias", C);
+        load_ffn(L, pre + "convffn.", C, C * d.tower_mlp_ratio, d.bn_eps, b.ffn, pre + "layer_scale");
+      }
+    }
+    if (i + 1 < d.tower_stages) {
+      const int C2 = d.tower_dims[i + 1];
+      const std::string pre = vt + "network." + std::to_string(idx++) + ".proj.";
+      tw.downs[i].lk_w = L.dw(pre + "0.lkb_reparam.weight", C2, 7);
+      tw.downs[i].lk_b = L.vec(pre + "0.lkb_reparam.bias", C2);
+      tw.downs[i].pw_w = L.mat(pre + "1.reparam_conv.weight", C2, C2);
+      tw.downs[i].pw_b = L.vec(pre + "1.reparam_conv.bias", C2);
+    }
+  }
+  const int CO = d.tower_out_dim, RD = d.tower_se_rd;
+  tw.exp_w = L.dw(vt + "conv_exp.reparam_conv.weight", CO, 3);
+  tw.exp_b = L.vec(vt + "conv_exp.reparam_conv.bias", CO);
+  tw.se_w1 = L.vec(vt + "conv_exp.se.reduce.weight", (size_t)RD * CO);
+  tw.se_b1 = L.vec(vt + "conv_exp.se.reduce.bias", RD);
+  tw.se_w2 = L.vec(vt + "conv_exp.se.expand.weight", (size_t)CO * RD);
+  tw.se_b2 = L.vec(vt + "conv_exp.se.expand.bias", CO);
+  const std::string pj = PJ;
+  tw.pj0_w = L.mat(pj + "0.weight", d.llm_hidden, CO);
+  tw.pj0_b = L.vec(pj + "0.bias", d.llm_hidden);
+  tw.pj2_w = L.mat(pj + "2.weight", d.llm_hidden, d.llm_hidden);
+  tw.pj2_b = L.vec(pj + "2.bias", d.llm_hidden);
+
+  // ---- decoder
+  const std::string lm = LM;
+  const size_t Hd = d.llm_hidden, I = d.llm_inter;
+  const size_t qd = (size_t)d.llm_heads * d.llm_head_dim, kd = (size_t)d.llm_kv_heads * d.llm_head_dim;
+  h->dec.embed = L.mat(lm + "embed_tokens.weight", d.llm_vocab, Hd);
+  h->dec.norm = L.vec(lm + "norm.weight", Hd);
+  h->dec.layers.resize(d.llm_layers);
+  for (int l = 0; l < d.llm_layers && L.rc == FV_OK; ++l) {
+    const std::string pre = lm + "layers." + std::to_string(l) + ".";
+    DecLayer& y = h->dec.layers[l];
+    y.ln1 = L.vec(pre + "input_layernorm.weight", Hd);
+    y.ln2 = L.vec(pre + "post_attention_layernorm.weight", Hd);
+    std::vector<float> q, k, v, qb, kb, vb;
+    if (L.expect(pre + "self_attn.q_proj.weight", q, qd * Hd) && L.expect(pre + "self_attn.k_proj.weight", k, kd * Hd) &&
+        L.expect(pre + "self_attn.v_proj.weight", v, kd * Hd) && L.expect(pre + "self_attn.q_proj.bias", qb, qd) &&
+        L.expect(pre + "self_attn.k_proj.bias", kb, kd) && L.expect(pre + "self_attn.v_proj.bias", vb, kd)) {
+      q.insert(q.end(), k.begin(), k.end());
+      q.insert(q.end(), v.begin(), v.end());
+      qb.insert(qb.end(), kb.begin(), kb.end());
+      qb.insert(qb.end(), vb.begin(), vb.end());
+      y.qkv_w = L.up_bf16(q);
+      y.qkv_b = L.up_f32(qb);
+    }
+    y.o_w = L.mat(pre + "self_attn.o_proj.weight", Hd, qd);
+    std::vector<float> g, u;
+    if (L.expect(pre + "mlp.gate_proj.weight", g, I * Hd) && L.expect(pre + "mlp.up_proj.weight", u, I * Hd)) {
+      std::vector<float> gu(2 * I * Hd);  // rows interleaved [8 gate | 8 up] for the SwiGLU epilogue
+      for (size_t j = 0; j < I; ++j) {
+        memcpy(&gu[((j / 8) * 16 + (j % 8)) * Hd], &g[j * Hd], Hd * 4);
+        memcpy(&gu[((j / 8) * 16 + 8 + (j % 8)) * Hd], &u[j * Hd], Hd * 4);
+      }
+      y.gu_w = L.up_bf16(gu);
+    }
+    y.down_w = L.mat(pre + "mlp.down_proj.weight", Hd, I);
+  }
+  if (L.rc != FV_OK) return L.rc;
+  FV_HIP_CHECK(hipDeviceSynchronize());
+  h->loaded = true;
+  return FV_OK;
+}
+
+int fv_workspace_bytes(fv_handle* h, int B, int T, int splice, size_t* out_bytes) {
+  if (!h || !out_bytes) return fv_fail(FV_ERR_ARG, "fv_workspace_bytes: null argument");
+  if (B <= 0 || T <= 0) return fv_fail(FV_ERR_ARG, "fv_workspace_bytes: B and T must be positive");
+  *out_bytes = plan_ws(h, B, T, splice).total;
+  return FV_OK;
+}
+
+int fv_bind_workspace(fv_handle* h, void* ws, size_t bytes) {
+  if (!h || !ws) return fv_fail(FV_ERR_ARG, "fv_bind_workspace: null argument");
+  if ((uintptr_t)ws & 255) return fv_fail(FV_ERR_ARG, "workspace must be 256-byte aligned");
+  h->ws = ws;
+  h->ws_bytes = bytes;
+  return FV_OK;
+}
+
+int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value,
+                  int resize_with_padding, void* pix_out, fv_stream s) {
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  return fv::launch_letterbox(img, dtype, B, C, Hin, Win, h->d.image_size, pad_value, resize_with_padding,
+                              static_cast<bf16_t*>(pix_out), static_cast<hipStream_t>(s));
+}
+
+int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, fv_stream s) {
+  FV_TRY(check_ready(h, true));
+  if (!pix || !img_tokens || B <= 0) return fv_fail(FV_ERR_ARG, "fv_vision_forward: bad argument");
+  if (B > h->d.max_batch) return fv_fail(FV_ERR_ARG, "fv_vision_forward: B=%d exceeds max_batch=%d", B, h->d.max_batch);
+  const fv_model_desc& d = h->d;
+  // the tower part of the plan does not depend on T / splice
+  const WsPlan wp = plan_ws(h, B, 1, 0);
+  if (wp.x > h->ws_bytes) return fv_fail(FV_ERR_STATE, "workspace too small for B=%d (%zu > %zu)", B, wp.x, h->ws_bytes);
+  const int mb = (d.tower_microbatch > 0 && d.tower_microbatch < B) ? d.tower_microbatch : B;
+  const size_t S = d.image_size;
+  const int Pside = d.image_size >> (d.tower_stages + 1);
+  const size_t P = (size_t)Pside * Pside;
+  bf16_t* tout = tower_out ? static_cast<bf16_t*>(tower_out) : reinterpret_cast<bf16_t*>(static_cast<char*>(h->ws) + wp.tower_out);
+  for (int b0 = 0; b0 < B; b0 += mb) {
+    const int nb = std::min(mb, B - b0);
+    FV_TRY(tower_pass(h, static_cast<const bf16_t*>(pix) + (size_t)b0 * S * S * 4, nb, tout + (size_t)b0 * P * d.tower_out_dim,
+                      static_cast<float*>(img_tokens) + (size_t)b0 * P * d.llm_hidden, wp, static_cast<hipStream_t>(s)));
+  }
+  return FV_OK;
+}
+
+int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens, const void* img_tokens, int Ni, int B,
+                          int T, int pool_mode, void* pooled, fv_stream st) {
+  FV_TRY(check_ready(h, true));
+  if (!ids || !lens || !pooled || B <= 0 || T <= 0 || Ni < 0) return fv_fail(FV_ERR_ARG, "fv_llm_forward_pooled: bad argument");
+  if (Ni > 0 && !img_tokens) return fv_fail(FV_ERR_ARG, "fv_llm_forward_pooled: Ni > 0 without img_tokens");
+  if (!img_tokens) Ni = 0;
+  const fv_model_desc& d = h->d;
+  const int Tt = T + Ni;
+  if (Tt > h->rope_rows) return fv_fail(FV_ERR_ARG, "sequence of %d tokens exceeds the RoPE table (%d)", Tt, h->rope_rows);
+  if (B > d.max_batch) return fv_fail(FV_ERR_ARG, "B=%d exceeds max_batch=%d", B, d.max_batch);
+  const int Pside = d.image_size >> (d.tower_stages + 1);
+  const WsPlan wp = plan_ws(h, B, T, Ni > 0);
+  if (Ni > Pside * Pside || wp.total > h->ws_bytes) return fv_fail(FV_ERR_STATE, "workspace too small (%zu > %zu) or Ni too large", wp.total, h->ws_bytes);
+  hipStream_t s = static_cast<hipStream_t>(st);
+  char* ws = static_cast<char*>(h->ws);
+  float* x = reinterpret_cast<float*>(ws + wp.x);
+  bf16_t* xn = reinterpret_cast<bf16_t*>(ws + wp.xn);
+  bf16_t* qkv = reinterpret_cast<bf16_t*>(ws + wp.qkv);
+  bf16_t* att = reinterpret_cast<bf16_t*>(ws + wp.att);
+  bf16_t* act = reinterpret_cast<bf16_t*>(ws + wp.act);
+  const int rows = B * Tt, Hd = d.llm_hidden, D = d.llm_head_dim;
+  const int qd = d.llm_heads * D, kd = d.llm_kv_heads * D, qkvw = qd + 2 * kd;
+  FV_TRY(fv::launch_embed_gather(ids, h->dec.embed, static_cast<const float*>(img_tokens), x, B, T, Ni, Hd, d.llm_vocab, s));
+  for (const DecLayer& L : h->dec.layers) {
+    FV_TRY(fv::launch_rmsnorm(x, L.ln1, xn, rows, Hd, d.rms_eps, s));
+    fv::GemmArgs gq{xn, Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkv, qkvw, FV_EPI_BIAS};
+    FV_TRY(fv::launch_gemm(gq, s));
+    FV_TRY(fv::launch_rope(qkv, h->rope, qkvw, rows, Tt, d.llm_heads, d.llm_kv_heads, D, s));
+    FV_TRY(fv::launch_attention(qkv, qkv + qd, qkv + qd + kd, qkvw, qkvw, qkvw, att, qd, B, Tt, d.llm_heads, d.llm_kv_heads,
+                                D, 1, lens, Ni, 1.0f / std::sqrt((float)D), s));
+    fv::GemmArgs go{att, qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+    FV_TRY(fv::launch_gemm(go, s));
+    FV_TRY(fv::launch_rmsnorm(x, L.ln2, xn, rows, Hd, d.rms_eps, s));
+    fv::GemmArgs gg{xn, Hd, L.gu_w, rows, 2 * d.llm_inter, Hd, nullptr, nullptr, nullptr, 0, act, d.llm_inter, FV_EPI_SWIGLU};
+    FV_TRY(fv::launch_gemm(gg, s));
+    fv::GemmArgs gd{act, d.llm_inter, L.down_w, rows, Hd, d.llm_inter, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+    FV_TRY(fv::launch_gemm(gd, s));
+  }
+  FV_TRY(fv::launch_pool_norm(x, lens, h->dec.norm, static_cast<float*>(pooled), B, Tt, Ni, Hd, d.rms_eps, pool_mode, s));
+  return FV_OK;
+}
+
+int fv_head_layout(fv_handle* h, int64_t offsets[13]) {
+  if (!h || !offsets) return fv_fail(FV_ERR_ARG, "fv_head_layout: null argument");
+  const fv::HeadOffsets ho = fv::head_offsets(h->hd);
+  for (int i = 0; i < 13; ++i) offsets[i] = ho.o[i];
+  return FV_OK;
+}
+
+int fv_head_saved_bytes(fv_handle* h, int B, size_t* out_bytes) {
+  if (!h || !out_bytes || B <= 0) return fv_fail(FV_ERR_ARG, "fv_head_saved_bytes: bad argument");
+  *out_bytes = fv::head_saved_bytes(h->hd, B);
+  return FV_OK;
+}
+
+int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled, const float* states, int B,
+                    int training, float dropout_p, uint64_t seed, uint64_t offset, float* actions, void* saved,
+                    fv_stream s) {
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  return fv::launch_head_forward(h->hd, flat_params, pooled, states, B, training, dropout_p, seed, offset, actions,
+                                 static_cast<float*>(saved), static_cast<hipStream_t>(s));
+}
+
+int fv_head_mse_backward(fv_handle* h, const float* flat_params, const float* actions, const float* targets, int B,
+                         float dropout_p, const void* saved, float* loss, float* flat_grads, fv_stream s) {
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  if (!h->ws) return fv_fail(FV_ERR_STATE, "workspace not bound: call fv_bind_workspace first");
+  if (B > h->d.max_batch) return fv_fail(FV_ERR_ARG, "B=%d exceeds max_batch=%d", B, h->d.max_batch);
+  const WsPlan wp = plan_ws(h, B, 1, 0);
+  if (wp.total > h->ws_bytes) return fv_fail(FV_ERR_STATE, "workspace too small for head backward");
+  float* scr = reinterpret_cast<float*>(static_cast<char*>(h->ws) + wp.head_scr);
+  return fv::launch_head_backward(h->hd, flat_params, actions, targets, B, dropout_p, static_cast<const float*>(saved),
+                                  loss, flat_grads, scr, static_cast<hipStream_t>(s));
+}
+
+int fv_adamw_clip_step(fv_handle* h, float* flat_params, const float* flat_grads, float* m, float* v, int64_t n,
+                       const fv_adamw_hparams* hp, int64_t step, float* grad_norm_out, fv_stream s) {
+  if (!h || !hp) return fv_fail(FV_ERR_ARG, "fv_adamw_clip_step: null argument");
+  return fv::launch_adamw_clip(flat_params, flat_grads, m, v, n, *hp, step, h->norm_scratch, grad_norm_out,
+                               static_cast<hipStream_t>(s));
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+// gemm_bf16.hip -- out[M,N] = A[M,K] x W[N,K]^T, bf16 operands, fp32 accumulation on MFMA, fused epilogues.
+//
+// Used for every dense contraction of the path: all 1x1 convs of FastViT-HD (NHWC activations make a 1x1 conv a
+// row-major GEMM with M = B*H*W), the MHSA qkv/proj, the mm_projector, and the Qwen2 QKV / O / gate-up / down
+// projections ([site] modeling_qwen2.py:46-48,189-192).
+//
+// Geometry (gfx950): 128x128 block tile, BK = 64, 256 threads = 4 waves in 2(M) x 2(N), 64x64 per wave as 4x4 tiles
+// of v_mfma_f32_16x16x32_bf16.  Both operands are K-contiguous, so every fragment is one ds_read_b128.  Tiles are
+// register-staged (global_load_dwordx4 -> ds_write_b128) into a double-buffered, XOR-swizzled LDS image
+// (chunk ^= row & 7: conflict-free for the b128 fragment reads and for the staging writes); the next tile's global
+// loads are issued before the MFMAs of the current one and written after them, one barrier per K-tile.
+// The epilogue goes through an fp32 LDS image of the 128x128 tile so that bias / GELU / layer-scale+residual /
+// SwiGLU / fp32-residual all run on 8 contiguous columns per lane with 16-byte global accesses.
+// Bounded by the MFMA roof for K >= ~512, by HBM for the K = 96..384 tower shapes (kernel table).
+#include "kernels.h"
+
+namespace fv {
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDC = BN + 4;                       // fp32 epilogue image row stride (floats)
+constexpr int LDS_BYTES = BM * LDC * 4;           // 67,584 B >= 2 * (BM+BN) * BK * 2 = 65,536 B
+constexpr int TILE_ELEMS = BM * BK;               // per operand per buffer
+
+struct Params {
+  const bf16_t* A; const bf16_t* W; const float* bias; const float* scale; const void* res; void* out;
+  int M, N, K, lda, ldr, ldo, epi, tiles_n, nwg;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
+
+__global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);          // [2][BM*BK]
+  bf16_t* sB = sA + 2 * TILE_ELEMS;                      // [2][BN*BK]
+  float* sC = reinterpret_cast<float*>(smem);            // [BM][LDC], reused after the K loop
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int logical = xcd_remap(blockIdx.x, p.nwg);
+  const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
+  const int bm = tm * BM, bn = tn * BN;
+
+  // staging map: 4 chunks (16 B) per operand per thread; chunk id c = tid + 256 i -> row c>>3, k-chunk c&7
+  const int srow = tid >> 3, skc = tid & 7;
+  uint4 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK + skc * 8;
+    const bool kin = k < p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 32 * i;
+      const int gm = bm + r, gn = bn + r;
+      ra[i] = (kin && gm < p.M) ? *reinterpret_cast<const uint4*>(p.A + (size_t)gm * p.lda + k) : make_uint4(0, 0, 0, 0);
+      rb[i] = (kin && gn < p.N) ? *reinterpret_cast<const uint4*>(p.W + (size_t)gn * p.K + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 32 * i;
+      *reinterpret_cast<uint4*>(sA + buf * TILE_ELEMS + lds_off(r, skc)) = ra[i];
+      *reinterpret_cast<uint4*>(sB + buf * TILE_ELEMS + lds_off(r, skc)) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const bf16_t* a_base = sA + cur * TILE_ELEMS;
+    const bf16_t* b_base = sB + cur * TILE_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = ks * 4 + fq;
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ar = wr * 64 + i * 16 + fr;
+        const int br = wc * 64 + i * 16 + fr;
+        fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + lds_off(ar, chunk)));
+        fb[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b_base + lds_off(br, chunk)));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> fp32 LDS image (C/D map: col = lane&15, row = (lane>>4)*4 + reg) ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sC[(wr * 64 + i * 16 + fq * 4 + r) * LDC + wc * 64 + j * 16 + fr] = acc[i][j][r];
+  __syncthreads();
+
+  const int epi = p.epi;
+  if (epi == FV_EPI_SWIGLU) {
+    // W rows are interleaved [8 gate | 8 up]: 16 accumulator columns -> 8 outputs
+    bf16_t* out = static_cast<bf16_t*>(p.out);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 3, pr = c & 7;
+      const int gm = bm + row, gn = bn + pr * 16;
+      if (gm < p.M && gn < p.N) {
+        const float* src = sC + row * LDC + pr * 16;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = silu_f(src[e]) * src[8 + e];
+        *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (gn >> 1)) = pack8(o);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c >> 4, cc = c & 15;
+    const int gm = bm + row, gn = bn + cc * 8;
+    if (gm >= p.M || gn >= p.N) continue;
+    float v[8];
+    {
+      const float4 lo = *reinterpret_cast<const float4*>(sC + row * LDC + cc * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(sC + row * LDC + cc * 8 + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    }
+    if (p.bias) {
+      const float4 lo = *reinterpret_cast<const float4*>(p.bias + gn);
+      const float4 hi = *reinterpret_cast<const float4*>(p.bias + gn + 4);
+      v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+    }
+    if (epi == FV_EPI_BIAS_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    } else if (epi == FV_EPI_LS_RES) {
+      float r[8], sc[8];
+      unpack8(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), r);
+      const float4 lo = *reinterpret_cast<const float4*>(p.scale + gn);
+      const float4 hi = *reinterpret_cast<const float4*>(p.scale + gn + 4);
+      sc[0] = lo.x; sc[1] = lo.y; sc[2] = lo.z; sc[3] = lo.w; sc[4] = hi.x; sc[5] = hi.y; sc[6] = hi.z; sc[7] = hi.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = r[e] + sc[e] * v[e];
+    }
+    if (epi == FV_EPI_RES_F32 || epi == FV_EPI_F32) {
+      float* out = static_cast<float*>(p.out) + (size_t)gm * p.ldo + gn;
+      if (epi == FV_EPI_RES_F32) {
+        const float* rp = static_cast<const float*>(p.res) + (size_t)gm * p.ldr + gn;
+        const float4 lo = *reinterpret_cast<const float4*>(rp);
+        const float4 hi = *reinterpret_cast<const float4*>(rp + 4);
+        v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+      }
+      *reinterpret_cast<float4*>(out) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8(v);
+    }
+  }
+}
+
+}  // namespace
+
+int launch_gemm(const GemmArgs& a, hipStream_t s) {
+  if (!a.A || !a.W || !a.out) return fv_fail(FV_ERR_ARG, "gemm: null operand");
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fv_fail(FV_ERR_ARG, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.K % 8 || a.lda % 8 || a.N % 8) return fv_fail(FV_ERR_ARG, "gemm: K, lda, N must be multiples of 8 (K=%d lda=%d N=%d)", a.K, a.lda, a.N);
+  if (a.lda < a.K) return fv_fail(FV_ERR_ARG, "gemm: lda < K");
+  if (a.epi < FV_EPI_BIAS || a.epi > FV_EPI_F32) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
+  const bool f32out = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
+  const int ncols = a.epi == FV_EPI_SWIGLU ? a.N / 2 : a.N;
+  if (a.epi == FV_EPI_SWIGLU && a.N % 16) return fv_fail(FV_ERR_ARG, "gemm: SwiGLU needs N %% 16 == 0");
+  if (a.ldo < ncols || a.ldo % (f32out ? 4 : 8)) return fv_fail(FV_ERR_ARG, "gemm: bad ldo %d", a.ldo);
+  if (a.epi == FV_EPI_LS_RES && (!a.res || !a.scale || a.ldr % 8 || a.ldr < a.N)) return fv_fail(FV_ERR_ARG, "gemm: LS_RES needs res/scale");
+  if (a.epi == FV_EPI_RES_F32 && (!a.res || a.ldr % 4 || a.ldr < a.N)) return fv_fail(FV_ERR_ARG, "gemm: RES_F32 needs res");
+  if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.bias | (uintptr_t)a.scale) & 15)
+    return fv_fail(FV_ERR_ARG, "gemm: pointers must be 16-byte aligned");
+  Params p;
+  p.A = a.A; p.W = a.W; p.bias = a.bias; p.scale = a.scale; p.res = a.res; p.out = a.out;
+  p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  p.tiles_n = (a.N + BN - 1) / BN;
+  p.nwg = tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(gemm_kernel, dim3(p.nwg), dim3(256), 0, s, p);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+}  // namespace fv

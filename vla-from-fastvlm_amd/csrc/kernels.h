@@ -1,0 +1,65 @@
+// kernels.h -- internal launch API shared by the engine (engine.hip) and the op-level C entry points (ops_api.hip).
+// Every launcher validates the shapes its kernel and grid assume and returns an fv_status; nothing here allocates or
+// synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fastvla_hip.h"
+#include "common.h"
+
+namespace fv {
+
+struct GemmArgs {
+  const bf16_t* A; int lda;     // [M,K] bf16
+  const bf16_t* W;              // [N,K] bf16 (row stride K)
+  int M, N, K;
+  const float* bias;            // [N] or null
+  const float* scale;           // [N] or null (FV_EPI_LS_RES)
+  const void* res; int ldr;     // residual (bf16 for LS_RES, f32 for RES_F32) or null
+  void* out; int ldo;           // bf16 or f32 by epilogue
+  int epi;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox,
+                     bf16_t* pix, hipStream_t s);
+int launch_stem_conv(const bf16_t* pix, const float* w, const float* bias, bf16_t* y, int B, int S, int Cout,
+                     hipStream_t s);
+int launch_dwconv(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,
+                  int stride, int mult, int gelu, hipStream_t s);
+int launch_layernorm_rows(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int C, float eps,
+                          hipStream_t s);
+int launch_se_gelu(const bf16_t* x, const float* w1, const float* b1, const float* w2, const float* b2, bf16_t* y,
+                   float* scratch, int B, int P, int C, int R, hipStream_t s);
+// lens (B) int32 or null; the visible key count of batch row b is clamp(lens[b] + len_add, 1, T)
+int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ldq, int ldk, int ldv, bf16_t* out,
+                     int ldo, int B, int T, int heads, int kv_heads, int D, int causal, const int32_t* lens,
+                     int len_add, float scale, hipStream_t s);
+
+// decoder elementwise
+int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* img_tokens, float* x, int B, int T,
+                        int Ni, int H, int vocab, hipStream_t s);
+int launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int H, float eps, hipStream_t s);
+// table: [>=T][D/2] (cos, sin) pairs built by rope_table_host(); position = row % T
+int launch_rope(bf16_t* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D,
+                hipStream_t s);
+void rope_table_host(float* cos_sin_pairs, int T, int D, float theta);
+int launch_pool_norm(const float* x, const int32_t* lens, const float* w, float* pooled, int B, int Ttot, int Ni,
+                     int H, float eps, int mode, hipStream_t s);
+
+// action expert (all fp32)
+struct HeadDims { int feat, ds, da, hid, fus; };
+struct HeadOffsets { int64_t o[13]; };
+HeadOffsets head_offsets(const HeadDims& d);
+size_t head_saved_bytes(const HeadDims& d, int B);
+int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, const float* states, int B,
+                        int training, float drop_p, uint64_t seed, uint64_t offset, float* actions, float* saved,
+                        hipStream_t s);
+int launch_head_backward(const HeadDims& d, const float* P, const float* actions, const float* targets, int B,
+                         float drop_p, const float* saved, float* loss, float* G, float* scratch, hipStream_t s);
+size_t head_bwd_scratch_bytes(const HeadDims& d, int B);
+int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const fv_adamw_hparams& hp,
+                      int64_t step, float* norm_scratch, float* grad_norm_out, hipStream_t s);
+
+}  // namespace fv

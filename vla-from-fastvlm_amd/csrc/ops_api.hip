@@ -1,0 +1,57 @@
+// ops_api.hip -- op-level C entry points (include/fastvla_hip.h, "op-level entry points"): one kernel each, so the
+// parity tests can check every kernel of the path against the oracle on its own.  No engine state is involved.
+#include <vector>
+
+#include "kernels.h"
+
+extern "C" {
+
+int fv_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const float* scale,
+               const void* res, int ldr, void* out, int ldo, int epilogue, fv_stream s) {
+  fv::GemmArgs g{static_cast<const bf16_t*>(A), lda, static_cast<const bf16_t*>(W), M, N, K, bias, scale, res, ldr, out, ldo, epilogue};
+  return fv::launch_gemm(g, static_cast<hipStream_t>(s));
+}
+
+int fv_op_dwconv(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
+                 int stride, int mult, int gelu, fv_stream s) {
+  return fv::launch_dwconv(static_cast<const bf16_t*>(x), w, bias, static_cast<bf16_t*>(y), B, H, W, C, k, stride, mult, gelu, static_cast<hipStream_t>(s));
+}
+
+int fv_op_stem_conv(const void* pix, const float* w, const float* bias, void* y, int B, int S, int Cout, fv_stream s) {
+  return fv::launch_stem_conv(static_cast<const bf16_t*>(pix), w, bias, static_cast<bf16_t*>(y), B, S, Cout, static_cast<hipStream_t>(s));
+}
+
+int fv_op_layernorm_rows(const void* x, const float* w, const float* b, void* y, int rows, int C, float eps, fv_stream s) {
+  return fv::launch_layernorm_rows(static_cast<const bf16_t*>(x), w, b, static_cast<bf16_t*>(y), rows, C, eps, static_cast<hipStream_t>(s));
+}
+
+int fv_op_attention(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* out, int ldo, int B,
+                    int T, int heads, int kv_heads, int D, int causal, const int32_t* lens, float scale, fv_stream s) {
+  return fv::launch_attention(static_cast<const bf16_t*>(q), static_cast<const bf16_t*>(k), static_cast<const bf16_t*>(v), ldq, ldk,
+                              ldv, static_cast<bf16_t*>(out), ldo, B, T, heads, kv_heads, D, causal, lens, 0, scale, static_cast<hipStream_t>(s));
+}
+
+int fv_op_rmsnorm(const float* x, const float* w, void* y_bf16, int rows, int H, float eps, fv_stream s) {
+  return fv::launch_rmsnorm(x, w, static_cast<bf16_t*>(y_bf16), rows, H, eps, static_cast<hipStream_t>(s));
+}
+
+int fv_op_rope(void* qkv, int ld, int rows, int T, int heads, int kv_heads, int D, float theta, fv_stream s) {
+  if (T <= 0 || D <= 0 || D % 16) return fv_fail(FV_ERR_ARG, "rope: bad T/D");
+  std::vector<float> cs((size_t)T * D);
+  fv::rope_table_host(cs.data(), T, D, theta);
+  float2* tab = nullptr;
+  FV_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tab), cs.size() * 4));
+  hipError_t e = hipMemcpy(tab, cs.data(), cs.size() * 4, hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? fv::launch_rope(static_cast<bf16_t*>(qkv), tab, ld, rows, T, heads, kv_heads, D, static_cast<hipStream_t>(s))
+                           : fv_hip_fail(e, "hipMemcpy(rope table)");
+  (void)hipStreamSynchronize(static_cast<hipStream_t>(s));
+  (void)hipFree(tab);
+  return rc;
+}
+
+int fv_op_se_gelu(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
+                  float* scratch, int B, int P, int C, int R, fv_stream s) {
+  return fv::launch_se_gelu(static_cast<const bf16_t*>(x), w1, b1, w2, b2, static_cast<bf16_t*>(y), scratch, B, P, C, R, static_cast<hipStream_t>(s));
+}
+
+}  // extern "C"

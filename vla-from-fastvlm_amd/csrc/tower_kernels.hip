@@ -1,0 +1,347 @@
+// tower_kernels.hip -- the HBM/VALU-bound pieces of the FastViT-HD tower, NHWC bf16 activations.
+//   letterbox        resize_with_pad semantics (reference model/fastvlm_adapter.py:36-55) on device
+//   stem conv        dense 3x3 s2, 3(+1 pad)->C0, +bias +GELU           (mci.py convolutional_stem[0])
+//   depthwise conv   k in {3,7}, stride {1,2}, channel multiplier {1,2}   (RepMixer, ConvFFN.conv(+BN folded), RepCPE,
+//                    PatchEmbed grouped 7x7 s2, stem dw3x3 s2, conv_exp)
+//   LayerNormChannel per-pixel LN over C                                  (AttentionBlock.norm)
+//   SE + GELU        conv_exp tail
+// All are bounded by HBM streaming or by the fp32 VALU (49 taps/element for the 7x7), never MFMA-shaped; loads and
+// stores are 8 or 16 B per lane with the channel index fastest across lanes.
+#include "kernels.h"
+
+namespace fv {
+namespace {
+
+// ------------------------------------------------------------------------------------------------ letterbox
+struct LbParams {
+  const void* img; bf16_t* pix; int dtype, B, C, Hin, Win, S, rh, rw, pt, pl; float pad, sh, sw;
+};
+
+__device__ __forceinline__ float lb_fetch(const LbParams& p, size_t plane, int y, int x) {
+  const size_t i = plane + (size_t)y * p.Win + x;
+  return p.dtype == FV_U8 ? (float)static_cast<const uint8_t*>(p.img)[i] : static_cast<const float*>(p.img)[i];
+}
+
+__global__ __launch_bounds__(256) void letterbox_kernel(LbParams p) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= p.S) return;
+  float v[3] = {p.pad, p.pad, p.pad};
+  const int dy = y - p.pt, dx = x - p.pl;
+  if (dy >= 0 && dx >= 0 && dy < p.rh && dx < p.rw) {
+    // ATen area_pixel_compute_source_index, align_corners=False: src = max((dst+0.5)*scale-0.5, 0)
+    const float sy = fmaxf((dy + 0.5f) * p.sh - 0.5f, 0.0f), sx = fmaxf((dx + 0.5f) * p.sw - 0.5f, 0.0f);
+    const int y0 = min((int)sy, p.Hin - 1), x0 = min((int)sx, p.Win - 1);
+    const int y1 = min(y0 + 1, p.Hin - 1), x1 = min(x0 + 1, p.Win - 1);
+    const float wy = sy - (float)y0, wx = sx - (float)x0;
+    const int nc = p.C >= 3 ? 3 : 1;
+    for (int c = 0; c < nc; ++c) {
+      const size_t plane = ((size_t)b * p.C + c) * p.Hin * p.Win;
+      const float p00 = lb_fetch(p, plane, y0, x0), p01 = lb_fetch(p, plane, y0, x1);
+      const float p10 = lb_fetch(p, plane, y1, x0), p11 = lb_fetch(p, plane, y1, x1);
+      v[c] = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + wy * ((1.0f - wx) * p10 + wx * p11);
+    }
+    if (nc == 1) v[1] = v[2] = v[0];  // gray -> repeat (fastvlm_adapter.py:445-446)
+  }
+  uint2 o;
+  o.x = pack_bf2(v[0], v[1]);
+  o.y = pack_bf2(v[2], 0.0f);
+  *reinterpret_cast<uint2*>(p.pix + (((size_t)b * p.S + y) * p.S + x) * 4) = o;
+}
+
+// ------------------------------------------------------------------------------------------------ stem conv
+// thread = 4 horizontally adjacent output pixels x 8 output channels; weights [27][Cout] fp32 staged in LDS.
+__global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict__ pix, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, bf16_t* __restrict__ y, int B,
+                                                         int S, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [27][Cout]
+  for (int i = threadIdx.x; i < 27 * Cout; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int So = S >> 1, G = Cout >> 3, WQ = (So + 3) >> 2;
+  const int per_block = 256 / G;
+  const int g = threadIdx.x % G, ql = threadIdx.x / G;
+  if (ql >= per_block) return;
+  long q = (long)blockIdx.x * per_block + ql;
+  const int xq = (int)(q % WQ); q /= WQ;
+  const int oy = (int)(q % So);
+  const int b = (int)(q / So);
+  if (b >= B) return;
+  const int ox0 = xq * 4, co0 = g * 8;
+  float acc[4][8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[r][e] = bias[co0 + e];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+    if (iy < 0 || iy >= S) continue;
+    float xin[9][3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const int ix = ox0 * 2 - 1 + c;
+      if (ix >= 0 && ix < S) {
+        const uint2 u = *reinterpret_cast<const uint2*>(pix + (((size_t)b * S + iy) * S + ix) * 4);
+        xin[c][0] = bf_lo(u.x); xin[c][1] = bf_hi(u.x); xin[c][2] = bf_lo(u.y);
+      } else {
+        xin[c][0] = xin[c][1] = xin[c][2] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        const float* wp = sw + ((ky * 3 + kx) * 3 + ci) * Cout + co0;
+        const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[r][e] += xin[2 * r + kx][ci] * wv[e];
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (ox0 + r >= So) break;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[r][e] = gelu_f(acc[r][e]);
+    *reinterpret_cast<uint4*>(y + (((size_t)b * So + oy) * So + ox0 + r) * Cout + co0) = pack8(acc[r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise conv
+// thread = R=4 outputs along x  x  8 output channels.  Per kernel row the (R-1)*S+K input columns are held in
+// registers as fp32 and every tap's 8 weights are loaded once and used for the R outputs.
+template <int K, int S, int MULT>
+__global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, bf16_t* __restrict__ y, int B,
+                                                      int H, int W, int C, int Ho, int Wo, int gelu) {
+  constexpr int R = 4, NCOL = (R - 1) * S + K, CI = 8 / MULT, PAD = K / 2;
+  const int Cout = C * MULT, G = Cout >> 3, WQ = (Wo + R - 1) / R;
+  long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int g = (int)(t % G); t /= G;
+  const int xq = (int)(t % WQ); t /= WQ;
+  const int oy = (int)(t % Ho);
+  const long b = t / Ho;
+  if (b >= B) return;
+  const int ox0 = xq * R, co0 = g * 8, ci0 = g * CI;
+  float acc[R][8];
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + co0), b1 = *reinterpret_cast<const float4*>(bias + co0 + 4);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      acc[r][0] = b0.x; acc[r][1] = b0.y; acc[r][2] = b0.z; acc[r][3] = b0.w;
+      acc[r][4] = b1.x; acc[r][5] = b1.y; acc[r][6] = b1.z; acc[r][7] = b1.w;
+    }
+  }
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int iy = oy * S - PAD + ky;
+    if (iy < 0 || iy >= H) continue;
+    const bf16_t* rowp = x + ((size_t)b * H + iy) * W * C + ci0;
+    float xin[NCOL][CI];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+      const int ix = ox0 * S - PAD + c;
+      const bool ok = ix >= 0 && ix < W;
+      if (MULT == 1) {
+        const uint4 u = ok ? *reinterpret_cast<const uint4*>(rowp + (size_t)ix * C) : make_uint4(0, 0, 0, 0);
+        unpack8(u, xin[c]);
+      } else {
+        const uint2 u = ok ? *reinterpret_cast<const uint2*>(rowp + (size_t)ix * C) : make_uint2(0, 0);
+        xin[c][0] = bf_lo(u.x); xin[c][1] = bf_hi(u.x); xin[c][2] = bf_lo(u.y); xin[c][3] = bf_hi(u.y);
+      }
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const float* wp = w + (size_t)(ky * K + kx) * Cout + co0;
+      const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[r][e] += xin[r * S + kx][e / MULT] * wv[e];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (ox0 + r >= Wo) break;
+    if (gelu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[r][e] = gelu_f(acc[r][e]);
+    }
+    *reinterpret_cast<uint4*>(y + (((size_t)b * Ho + oy) * Wo + ox0 + r) * Cout + co0) = pack8(acc[r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNormChannel
+// one wave per row (pixel); C <= 2048, C % 8 == 0; two-pass in registers.
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bb, bf16_t* __restrict__ y,
+                                                              int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = C >> 3;
+  float v[4][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      unpack8(*reinterpret_cast<const uint4*>(x + row * C + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * w[ch * 8 + e] + bb[ch * 8 + e];
+      *reinterpret_cast<uint4*>(y + row * C + ch * 8) = pack8(o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ SE + GELU
+__global__ __launch_bounds__(256) void se_pool_kernel(const bf16_t* __restrict__ x, float* __restrict__ pooled, int P,
+                                                       int C) {
+  // grid (C/8/256 ceil, B); thread = 8 channels, loops over the P pixels
+  const int ch = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (ch >= (C >> 3)) return;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = 0; p < P; ++p) {
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)b * P + p) * C + ch * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pooled[(size_t)b * C + ch * 8 + e] = a[e] / (float)P;
+}
+
+// y[b][n] = act(sum_k x[b][k] W[n][k] + bias[n]); one wave per (b, n); act 0 = relu, 1 = sigmoid
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int N,
+                                                     int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += x[(size_t)b * K + k] * W[(size_t)n * K + k];
+  s = wave_sum(s) + bias[n];
+  if (lane == 0) y[(size_t)b * N + n] = act == 0 ? fmaxf(s, 0.f) : sigmoid_f(s);
+}
+
+__global__ __launch_bounds__(256) void se_apply_gelu_kernel(const bf16_t* __restrict__ x, const float* __restrict__ sc,
+                                                             bf16_t* __restrict__ y, int P, int C, long total_chunks) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total_chunks) return;
+  const int nch = C >> 3;
+  const int ch = (int)(i % nch);
+  const long b = i / ((long)nch * P);
+  float v[8];
+  unpack8(*reinterpret_cast<const uint4*>(x + i * 8), v);
+  const float* s = sc + b * C + ch * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e] * s[e]);
+  *reinterpret_cast<uint4*>(y + i * 8) = pack8(v);
+}
+
+}  // namespace
+
+int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox,
+                     bf16_t* pix, hipStream_t s) {
+  if (!img || !pix) return fv_fail(FV_ERR_ARG, "letterbox: null pointer");
+  if (B <= 0 || Hin <= 0 || Win <= 0 || S <= 0) return fv_fail(FV_ERR_ARG, "letterbox: empty shape");
+  if (C != 1 && C != 3 && C != 4) return fv_fail(FV_ERR_ARG, "letterbox: C must be 1, 3 or 4 (got %d)", C);
+  if (dtype != FV_F32 && dtype != FV_U8) return fv_fail(FV_ERR_ARG, "letterbox: dtype must be f32 or u8");
+  LbParams p;
+  p.img = img; p.pix = pix; p.dtype = dtype; p.B = B; p.C = C; p.Hin = Hin; p.Win = Win; p.S = S; p.pad = pad_value;
+  if (letterbox) {
+    // reference: ratio = max(W/S, H/S); resized = int(dim / ratio) in Python double arithmetic
+    const double ratio = ((double)Win / S > (double)Hin / S) ? (double)Win / S : (double)Hin / S;
+    p.rh = (int)((double)Hin / ratio);
+    p.rw = (int)((double)Win / ratio);
+    if (p.rh > S || p.rw > S || p.rh < 1 || p.rw < 1) return fv_fail(FV_ERR_ARG, "letterbox: degenerate resize %dx%d", p.rh, p.rw);
+  } else {
+    p.rh = S; p.rw = S;
+  }
+  p.pt = S - p.rh; p.pl = S - p.rw;
+  p.sh = (float)Hin / (float)p.rh;
+  p.sw = (float)Win / (float)p.rw;
+  hipLaunchKernelGGL(letterbox_kernel, dim3((S + 255) / 256, S, B), dim3(256), 0, s, p);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_stem_conv(const bf16_t* pix, const float* w, const float* bias, bf16_t* y, int B, int S, int Cout,
+                     hipStream_t s) {
+  if (!pix || !w || !bias || !y) return fv_fail(FV_ERR_ARG, "stem_conv: null pointer");
+  if (B <= 0 || S < 2 || (S & 1) || Cout % 8 || Cout < 8 || Cout > 2048) return fv_fail(FV_ERR_ARG, "stem_conv: bad shape S=%d Cout=%d", S, Cout);
+  const int So = S / 2, G = Cout / 8, WQ = (So + 3) / 4, per_block = 256 / G;
+  const long quads = (long)B * So * WQ;
+  const long blocks = (quads + per_block - 1) / per_block;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, pix, w, bias, y, B, S, Cout);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_dwconv(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,
+                  int stride, int mult, int gelu, hipStream_t s) {
+  if (!x || !w || !bias || !y) return fv_fail(FV_ERR_ARG, "dwconv: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C * mult) % 8) return fv_fail(FV_ERR_ARG, "dwconv: bad shape C=%d mult=%d", C, mult);
+  const int pad = k / 2;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int G = C * mult / 8, WQ = (Wo + 3) / 4;
+  const long threads = (long)B * Ho * WQ * G;
+  const dim3 grid((unsigned)((threads + 255) / 256));
+#define FV_DW(K_, S_, M_)                                                                                        \
+  if (k == K_ && stride == S_ && mult == M_) {                                                                   \
+    hipLaunchKernelGGL((dwconv_kernel<K_, S_, M_>), grid, dim3(256), 0, s, x, w, bias, y, B, H, W, C, Ho, Wo, gelu); \
+    FV_HIP_CHECK(hipGetLastError());                                                                             \
+    return FV_OK;                                                                                                \
+  }
+  FV_DW(3, 1, 1) FV_DW(7, 1, 1) FV_DW(3, 2, 1) FV_DW(7, 2, 2) FV_DW(3, 1, 2)
+#undef FV_DW
+  return fv_fail(FV_ERR_UNSUPPORTED, "dwconv: unsupported k=%d stride=%d mult=%d", k, stride, mult);
+}
+
+int launch_layernorm_rows(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int C, float eps,
+                          hipStream_t s) {
+  if (!x || !w || !b || !y) return fv_fail(FV_ERR_ARG, "layernorm_rows: null pointer");
+  if (rows <= 0 || C % 8 || C > 2048 || C <= 0) return fv_fail(FV_ERR_ARG, "layernorm_rows: bad shape rows=%d C=%d", rows, C);
+  hipLaunchKernelGGL(layernorm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows, C, eps);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_se_gelu(const bf16_t* x, const float* w1, const float* b1, const float* w2, const float* b2, bf16_t* y,
+                   float* scratch, int B, int P, int C, int R, hipStream_t s) {
+  if (!x || !w1 || !b1 || !w2 || !b2 || !y || !scratch) return fv_fail(FV_ERR_ARG, "se_gelu: null pointer");
+  if (B <= 0 || P <= 0 || C % 8 || R <= 0) return fv_fail(FV_ERR_ARG, "se_gelu: bad shape");
+  float* pooled = scratch;             // [B][C]
+  float* hid = pooled + (size_t)B * C; // [B][R]
+  float* sc = hid + (size_t)B * R;     // [B][C]
+  hipLaunchKernelGGL(se_pool_kernel, dim3((C / 8 + 255) / 256, B), dim3(256), 0, s, x, pooled, P, C);
+  hipLaunchKernelGGL(se_fc_kernel, dim3((R + 3) / 4, B), dim3(256), 0, s, pooled, w1, b1, hid, R, C, 0);
+  hipLaunchKernelGGL(se_fc_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, hid, w2, b2, sc, C, R, 1);
+  const long chunks = (long)B * P * (C / 8);
+  hipLaunchKernelGGL(se_apply_gelu_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, x, sc, y, P, C, chunks);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+}  // namespace fv

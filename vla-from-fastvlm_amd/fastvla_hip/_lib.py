@@ -1,0 +1,109 @@
+"""ctypes binding of libfastvla_hip.so (include/fastvla_hip.h).  No torch types cross this boundary: pointers are
+plain integers (``tensor.data_ptr()``), the stream is ``torch.cuda.current_stream().cuda_stream``.
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, ``FastVLAHipError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+FV_MAX_STAGES = 8
+FV_F32, FV_BF16, FV_U8, FV_I32 = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_GELU, EPI_LS_RES, EPI_RES_F32, EPI_SWIGLU, EPI_F32 = range(6)
+
+
+class FastVLAHipError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("llm_hidden", C.c_int32), ("llm_layers", C.c_int32), ("llm_heads", C.c_int32), ("llm_kv_heads", C.c_int32),
+        ("llm_head_dim", C.c_int32), ("llm_inter", C.c_int32), ("llm_vocab", C.c_int32),
+        ("rope_theta", C.c_float), ("rms_eps", C.c_float),
+        ("tower_stages", C.c_int32),
+        ("tower_layers", C.c_int32 * FV_MAX_STAGES), ("tower_dims", C.c_int32 * FV_MAX_STAGES),
+        ("tower_is_attn", C.c_int32 * FV_MAX_STAGES),
+        ("tower_mlp_ratio", C.c_int32), ("tower_head_dim", C.c_int32), ("tower_se_rd", C.c_int32),
+        ("tower_out_dim", C.c_int32),
+        ("ln_eps", C.c_float), ("bn_eps", C.c_float),
+        ("image_size", C.c_int32),
+        ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("hidden_dim", C.c_int32), ("fusion_dim", C.c_int32),
+        ("max_batch", C.c_int32), ("max_text_tokens", C.c_int32), ("tower_microbatch", C.c_int32),
+    ]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4)]
+
+
+class AdamWHParams(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("grad_scale", C.c_float)]
+
+
+_vp, _i, _f, _u64, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/fastvla_hip.h
+SIGNATURES = {
+    "fv_create": (_i, [C.POINTER(ModelDesc), _i, C.POINTER(_vp)]),
+    "fv_load_weights": (_i, [_vp, C.POINTER(TensorDesc), _i]),
+    "fv_destroy": (None, [_vp]),
+    "fv_last_error": (C.c_char_p, [_vp]),
+    "fv_version": (C.c_char_p, []),
+    "fv_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_size_t)]),
+    "fv_bind_workspace": (_i, [_vp, _vp, C.c_size_t]),
+    "fv_preprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "fv_vision_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "fv_llm_forward_pooled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "fv_head_layout": (_i, [_vp, C.POINTER(_i64 * 13)]),
+    "fv_head_saved_bytes": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
+    "fv_head_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _u64, _u64, _vp, _vp, _vp]),
+    "fv_head_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "fv_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(AdamWHParams), _i64, _vp, _vp]),
+    "fv_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "fv_op_dwconv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "fv_op_stem_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fv_op_layernorm_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "fv_op_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "fv_op_rmsnorm": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "fv_op_rope": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "fv_op_se_gelu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+}
+
+_LIB = None
+
+
+def library_path() -> Path:
+    env = os.environ.get("FASTVLA_HIP_LIB")
+    return Path(env) if env else Path(__file__).resolve().parent / "libfastvla_hip.so"
+
+
+def load():
+    """dlopen the library and attach prototypes.  Raises FastVLAHipError if it cannot be loaded."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.is_file():
+        raise FastVLAHipError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C vla-from-fastvlm_amd/csrc).  There is no CPU fallback.")
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as exc:  # e.g. libamdhip64 missing
+        raise FastVLAHipError(f"cannot load {path}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().fv_last_error(None)
+        raise FastVLAHipError(f"{what or 'libfastvla_hip'} failed (status {rc}): {msg.decode() if msg else '?'}")

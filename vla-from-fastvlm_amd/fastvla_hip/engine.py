@@ -1,0 +1,225 @@
+"""Host-side wrapper around one fv_handle: torch owns device memory and streams, the library does the arithmetic.
+
+One engine per process / GPU (one process per GPU under torch.distributed).  Everything here is plumbing: allocate
+buffers with torch's caching allocator, hand raw pointers and the current HIP stream to libfastvla_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .arch import ModelConfig
+
+HEAD_KEYS = (
+    "state_projection.0.weight", "state_projection.0.bias", "state_projection.1.weight", "state_projection.1.bias",
+    "fusion.0.weight", "fusion.0.bias", "fusion.1.weight", "fusion.1.bias", "fusion.4.weight", "fusion.4.bias",
+    "action_head.weight", "action_head.bias",
+)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class FastVLAEngine:
+    def __init__(self, model: ModelConfig, *, state_dim: int = 14, action_dim: int = 14, hidden_dim: int = 1024,
+                 fusion_dim: int = 1024, device: Optional[torch.device] = None, max_batch: int = 64,
+                 max_text_tokens: int = 64, tower_microbatch: int = 0):
+        self.lib = _lib.load()  # raises if the HIP library is missing: no fallback
+        if not torch.cuda.is_available():
+            raise _lib.FastVLAHipError("no HIP device visible: the FastVLA HIP path needs an MI355X (no CPU fallback)")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type != "cuda":
+            raise _lib.FastVLAHipError(f"FastVLAEngine needs a cuda (ROCm) device, got {self.device}")
+        self.model = model
+        self.head_dims = dict(feat=model.llm.hidden, ds=state_dim, da=action_dim, hid=hidden_dim, fus=fusion_dim)
+        d = _lib.ModelDesc()
+        l, t = model.llm, model.tower
+        d.llm_hidden, d.llm_layers, d.llm_heads, d.llm_kv_heads = l.hidden, l.layers, l.heads, l.kv_heads
+        d.llm_head_dim, d.llm_inter, d.llm_vocab = l.head_dim, l.inter, l.vocab
+        d.rope_theta, d.rms_eps = l.rope_theta, l.rms_eps
+        d.tower_stages = len(t.layers)
+        for i in range(len(t.layers)):
+            d.tower_layers[i], d.tower_dims[i], d.tower_is_attn[i] = t.layers[i], t.dims[i], int(i in t.attn_stages)
+        d.tower_mlp_ratio, d.tower_head_dim, d.tower_se_rd, d.tower_out_dim = t.mlp_ratio, t.head_dim, t.se_rd, t.out_dim
+        d.ln_eps, d.bn_eps, d.image_size = t.ln_eps, t.bn_eps, t.image_size
+        d.state_dim, d.action_dim, d.hidden_dim, d.fusion_dim = state_dim, action_dim, hidden_dim, fusion_dim
+        d.max_batch, d.max_text_tokens, d.tower_microbatch = max_batch, max_text_tokens, tower_microbatch
+        self.desc = d
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fv_create(C.byref(d), self.device.index or 0, C.byref(h)), "fv_create")
+        self.h = h
+        self._ws: Optional[torch.Tensor] = None
+        offs = (C.c_int64 * 13)()
+        _lib.check(self.lib.fv_head_layout(self.h, C.byref(offs)), "fv_head_layout")
+        self.head_offsets = list(offs)
+        self.loaded = False
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- frozen weights
+    def load_weights(self, state: Dict[str, torch.Tensor]) -> None:
+        keep, descs = [], (_lib.TensorDesc * len(state))()
+        for i, (k, v) in enumerate(state.items()):
+            t = v.detach().to("cpu")
+            if t.dtype not in (torch.float32, torch.bfloat16):
+                t = t.float()
+            t = t.contiguous()
+            keep.append(t)
+            nm = k.encode()
+            keep.append(nm)
+            descs[i].name = nm
+            descs[i].data = t.data_ptr()
+            descs[i].dtype = _lib.FV_F32 if t.dtype == torch.float32 else _lib.FV_BF16
+            descs[i].ndim = max(t.ndim, 1)
+            if t.ndim > 4:
+                raise ValueError(f"{k}: rank > 4")
+            for j, s in enumerate(t.shape if t.ndim else (1,)):
+                descs[i].shape[j] = s
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fv_load_weights(self.h, descs, len(state)), "fv_load_weights")
+        self.loaded = True
+
+    # ---------------------------------------------------------------- workspace
+    def workspace_bytes(self, B: int, T: int, splice: bool) -> int:
+        n = C.c_size_t()
+        _lib.check(self.lib.fv_workspace_bytes(self.h, B, T, int(splice), C.byref(n)), "fv_workspace_bytes")
+        return n.value
+
+    def ensure_workspace(self, B: int, T: int, splice: bool) -> None:
+        need = self.workspace_bytes(B, T, splice)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            base = self._ws.data_ptr()
+            off = (-base) % 256
+            _lib.check(self.lib.fv_bind_workspace(self.h, base + off, self._ws.numel() - off), "fv_bind_workspace")
+
+    # ---------------------------------------------------------------- frozen backbone
+    def preprocess(self, images: torch.Tensor, pad_value: float = 0.0, resize_with_padding: bool = True) -> torch.Tensor:
+        if images.ndim != 4:
+            raise ValueError(f"(B,C,H,W) expected, but got shape {tuple(images.shape)}")
+        if images.dtype == torch.uint8:
+            dt = _lib.FV_U8
+        else:
+            images = images.to(torch.float32)
+            dt = _lib.FV_F32
+        images = images.to(self.device).contiguous()
+        B, Cc, H, W = images.shape
+        S = self.model.tower.image_size
+        pix = torch.empty(B, S, S, 4, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.fv_preprocess(self.h, images.data_ptr(), dt, B, Cc, H, W, float(pad_value),
+                                          int(resize_with_padding), pix.data_ptr(), _stream()), "fv_preprocess")
+        return pix
+
+    def vision_forward(self, pix: torch.Tensor, return_tower_out: bool = False):
+        B = pix.shape[0]
+        t, l = self.model.tower, self.model.llm
+        self.ensure_workspace(B, 1, False)
+        tok = torch.empty(B, t.num_tokens, l.hidden, dtype=torch.float32, device=self.device)
+        tout = torch.empty(B, t.num_tokens, t.out_dim, dtype=torch.bfloat16, device=self.device) if return_tower_out else None
+        _lib.check(self.lib.fv_vision_forward(self.h, pix.data_ptr(), B, tok.data_ptr(), _ptr(tout), _stream()),
+                   "fv_vision_forward")
+        return (tok, tout) if return_tower_out else tok
+
+    def llm_pooled(self, ids: torch.Tensor, lens: torch.Tensor, img_tokens: Optional[torch.Tensor] = None,
+                   pool_mode: int = 0) -> torch.Tensor:
+        B, T = ids.shape
+        ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        lens = lens.to(device=self.device, dtype=torch.int32).contiguous()
+        ni = 0 if img_tokens is None else img_tokens.shape[1]
+        self.ensure_workspace(B, T, img_tokens is not None)
+        pooled = torch.empty(B, self.model.llm.hidden, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.fv_llm_forward_pooled(self.h, ids.data_ptr(), lens.data_ptr(), _ptr(img_tokens), ni, B, T,
+                                                  pool_mode, pooled.data_ptr(), _stream()), "fv_llm_forward_pooled")
+        return pooled
+
+    def backbone(self, images: torch.Tensor, ids: torch.Tensor, lens: torch.Tensor, *, splice: bool = False,
+                 run_tower: bool = True, pad_value: float = 0.0, resize_with_padding: bool = True,
+                 pool_mode: int = 0) -> torch.Tensor:
+        """letterbox -> tower -> projector -> decoder -> pooled (B,H).  splice=False is the literal reference
+        behaviour: the image tokens are computed and not consumed."""
+        B, T = ids.shape
+        self.ensure_workspace(B, T, splice)
+        tok = None
+        if run_tower or splice:
+            pix = self.preprocess(images, pad_value, resize_with_padding)
+            tok = self.vision_forward(pix)
+        return self.llm_pooled(ids, lens, tok if splice else None, pool_mode)
+
+    # ---------------------------------------------------------------- action expert
+    def head_numel(self) -> int:
+        return self.head_offsets[12]
+
+    def head_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """name -> view into the flat buffer (state-dict order, each tensor 16-byte aligned)."""
+        hd = self.head_dims
+        shapes = [(hd["ds"],), (hd["ds"],), (hd["hid"], hd["ds"]), (hd["hid"],), (hd["fus"], hd["feat"] + hd["hid"]),
+                  (hd["fus"],), (hd["fus"],), (hd["fus"],), (hd["fus"], hd["fus"]), (hd["fus"],), (hd["da"], hd["fus"]),
+                  (hd["da"],)]
+        out = {}
+        for k, shp, off in zip(HEAD_KEYS, shapes, self.head_offsets):
+            n = 1
+            for s in shp:
+                n *= s
+            out[k] = flat[off:off + n].view(*shp)
+        return out
+
+    def head_saved(self, B: int) -> torch.Tensor:
+        n = C.c_size_t()
+        _lib.check(self.lib.fv_head_saved_bytes(self.h, B, C.byref(n)), "fv_head_saved_bytes")
+        return torch.empty(n.value // 4, dtype=torch.float32, device=self.device)
+
+    def head_forward(self, flat_params: torch.Tensor, pooled: torch.Tensor, states: torch.Tensor, *, training: bool = False,
+                     dropout_p: float = 0.0, seed: int = 0, offset: int = 0, saved: Optional[torch.Tensor] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+        B = pooled.shape[0]
+        states = states.to(device=self.device, dtype=torch.float32).contiguous()
+        pooled = pooled.contiguous()
+        if states.shape != (B, self.head_dims["ds"]):
+            raise ValueError(f"states must be (B,{self.head_dims['ds']}), got {tuple(states.shape)}")
+        saved = saved if saved is not None else self.head_saved(B)
+        actions = torch.empty(B, self.head_dims["da"], dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.fv_head_forward(self.h, flat_params.data_ptr(), pooled.data_ptr(), states.data_ptr(), B,
+                                            int(training), float(dropout_p), seed, offset, actions.data_ptr(),
+                                            saved.data_ptr(), _stream()), "fv_head_forward")
+        return actions, saved
+
+    def head_backward(self, flat_params: torch.Tensor, actions: torch.Tensor, targets: torch.Tensor, saved: torch.Tensor,
+                      dropout_p: float = 0.0, flat_grads: Optional[torch.Tensor] = None):
+        B = actions.shape[0]
+        self.ensure_workspace(B, 1, False)
+        targets = targets.to(device=self.device, dtype=torch.float32).contiguous()
+        if flat_grads is None:
+            flat_grads = torch.zeros(self.head_numel(), dtype=torch.float32, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.fv_head_mse_backward(self.h, flat_params.data_ptr(), actions.data_ptr(), targets.data_ptr(), B,
+                                                 float(dropout_p), saved.data_ptr(), loss.data_ptr(),
+                                                 flat_grads.data_ptr(), _stream()), "fv_head_mse_backward")
+        return loss, flat_grads
+
+    def adamw_step(self, flat_params, flat_grads, m, v, step: int, *, lr: float, betas=(0.9, 0.95), eps: float = 1e-8,
+                   weight_decay: float = 1e-4, max_grad_norm: float = 1.0, grad_scale: float = 1.0,
+                   grad_norm_out: Optional[torch.Tensor] = None) -> None:
+        hp = _lib.AdamWHParams(lr, betas[0], betas[1], eps, weight_decay, max_grad_norm if max_grad_norm else 0.0,
+                               grad_scale)
+        _lib.check(self.lib.fv_adamw_clip_step(self.h, flat_params.data_ptr(), flat_grads.data_ptr(), m.data_ptr(),
+                                               v.data_ptr(), flat_params.numel(), C.byref(hp), step,
+                                               _ptr(grad_norm_out), _stream()), "fv_adamw_clip_step")
