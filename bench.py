@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- policy steps/s of the MI355X-native FastVLA path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch through img + prompt + state -> action (BASELINE.json configs[1]: FastVLM-0.5B select_action,
+bs=64 per GPU, 336x336 synthetic RGB + 64-token prompt, bf16 MFMA with fp32 accumulation): letterbox to 1024^2 ->
+FastViT-HD -> mm_projector -> Qwen2 decoder -> last-token pool -> action expert, inputs resident in HBM.
+Inference has no exchange step, so N ranks are N replicas on disjoint batches (weak scaling, no collective); the
+data-parallel TRAINING step (B=32/GPU, RCCL all-reduce of the flat head gradient) is timed as well and reported under
+"train_dp" in the same JSON line.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline      dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time, against the 2.5 PFLOP/s dense peak
+  cpu_baseline  the fp32 CPU oracle (oracle/, "port") timed on this box's host cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for _p in (str(ROOT), str(ROOT / "vla-from-fastvlm_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="fastvlm-0.5b")
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch of the inference step")
+    ap.add_argument("--train-batch", type=int, default=32, help="per-GPU batch of the DP training step")
+    ap.add_argument("--tokens", type=int, default=64)
+    ap.add_argument("--image", type=int, default=336)
+    ap.add_argument("--splice", action="store_true", help="splice the 256 projected image tokens into the LLM sequence")
+    ap.add_argument("--microbatch", type=int, default=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--profile-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fastvla_hip import FastVLAEngine, arch, weights
+    model = arch.preset(args.model)
+    B, T = args.batch, args.tokens
+    eng = FastVLAEngine(model, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, device=dev,
+                        max_batch=max(B, args.train_batch), max_text_tokens=T, tower_microbatch=args.microbatch)
+    t0 = time.time()
+    w = weights.init_backbone(model, seed=1234)  # identical on every rank (frozen replica)
+    eng.load_weights(w)
+    t_load = time.time() - t0
+
+    # trainable head: torch.nn default-style init, identical on every rank
+    g = torch.Generator().manual_seed(4321)
+    flat = torch.zeros(eng.head_numel(), dtype=torch.float32, device=dev)
+    for k, v in eng.head_views(flat).items():
+        if v.ndim == 2:
+            bound = 1.0 / (v.shape[1] ** 0.5)
+            v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * bound)
+        elif k in ("state_projection.0.weight", "fusion.1.weight"):
+            v.fill_(1.0)
+        elif k.endswith("bias") and k not in ("state_projection.0.bias", "fusion.1.bias"):
+            v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * 0.02)
+
+    torch.manual_seed(1234 + rank)
+    Bmax = max(B, args.train_batch)
+    images = torch.rand(Bmax, 3, args.image, args.image, device=dev)
+    ids = torch.randint(0, min(151643, model.llm.vocab), (Bmax, T), device=dev, dtype=torch.int32)
+    lens = torch.full((Bmax,), T, dtype=torch.int32, device=dev)
+    states = torch.randn(Bmax, 14, device=dev)
+    targets = torch.randn(Bmax, 14, device=dev)
+
+    def step_infer():
+        pooled = eng.backbone(images[:B], ids[:B], lens[:B], splice=args.splice)
+        act, _ = eng.head_forward(flat, pooled, states[:B])
+        return act
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt)
+        return el
+
+    el = timed(step_infer, args.steps, args.warmup)
+    ms_per_step = 1e3 * el / args.steps
+    value = world * args.steps / el
+
+    # ---- per-kernel-family HIP-event pass (same work, right after the timed region, on the same stream)
+    eng.profile(True)
+    for _ in range(args.profile_steps):
+        step_infer()
+    torch.cuda.synchronize()
+    fams, shapes = eng.profile_read()
+    eng.profile(False)
+    ps = args.profile_steps
+    gem = fams["gemm"]
+    gemm_tflops = gem["flops"] / (gem["ms"] * 1e-3) / 1e12 if gem["ms"] > 0 else 0.0
+    total_flops = sum(f["flops"] for f in fams.values()) / ps
+    roofline = {
+        "bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA 16x16x32, fp32 acc)",
+        "achieved": round(gemm_tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(gemm_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "launches_per_step": gem["launches"] // ps, "gemm_ms_per_step": round(gem["ms"] / ps, 3),
+        "gemm_flops_per_step": gem["flops"] / ps,
+        "step_achieved": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
+        "step_frac": round(total_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+        "source": f"hipEvents around every launch over {ps} steps after the timed region",
+    }
+    families = {k: {"ms_per_step": round(v["ms"] / ps, 3), "launches": v["launches"] // ps,
+                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
+                    "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in fams.items() if v["launches"]}
+    top = sorted(shapes, key=lambda r: -r["ms"])[:12]
+    gemm_shapes = [{"mnk": [r["m"], r["n"], r["k"]], "epi": r["epi"], "ms_per_step": round(r["ms"] / ps, 3),
+                    "n": r["launches"] // ps,
+                    "tflops": round(2.0 * r["m"] * r["n"] * r["k"] * r["launches"] / max(r["ms"], 1e-9) / 1e9, 1)} for r in top]
+
+    # ---- data-parallel training step (C3): forward + MSE + head backward + all-reduce + clip + AdamW
+    train = None
+    if not args.no_train:
+        Bt = args.train_batch
+        m_buf, v_buf = torch.zeros_like(flat), torch.zeros_like(flat)
+        grads = torch.zeros_like(flat)
+        saved = eng.head_saved(Bt)
+        comm = torch.cuda.Stream(device=dev)
+        state = {"step": 0, "ar_ms": 0.0}
+
+        def step_train():
+            state["step"] += 1
+            pooled = eng.backbone(images[:Bt], ids[:Bt], lens[:Bt], splice=args.splice)
+            act, _ = eng.head_forward(flat, pooled, states[:Bt], training=True, dropout_p=0.1, seed=1234 + rank,
+                                      offset=state["step"], saved=saved)
+            eng.head_backward(flat, act, targets[:Bt], saved, dropout_p=0.1, flat_grads=grads)
+            if world > 1:  # one flat 12 MB bucket on a side stream (RCCL over xGMI), then 1/world inside the optimiser
+                comm.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(comm):
+                    dist.all_reduce(grads)
+                torch.cuda.current_stream().wait_stream(comm)
+            eng.adamw_step(flat, grads, m_buf, v_buf, state["step"], lr=1e-4, weight_decay=1e-4, max_grad_norm=1.0,
+                           grad_scale=1.0 / world)
+
+        flat_backup = flat.clone()
+        elt = timed(step_train, max(2, args.steps // 2), max(1, args.warmup // 2))
+        nst = max(2, args.steps // 2)
+        flat.copy_(flat_backup)
+        train = {"value": round(world * nst / elt, 3), "unit": "train steps/s (whole job)", "ms_per_step": round(1e3 * elt / nst, 3),
+                 "global_batch": Bt * world, "parallelism": f"dp{world}", "collective": "rccl all_reduce(flat head grads)" if world > 1 else None,
+                 "grad_bytes": int(flat.numel() * 4)}
+
+    # ---- CPU baseline (rank 0, N=1 only): the fp32 oracle on a bounded sample of the same workload
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import fastvit_hd, head as ohead, policy, qwen2
+        n = args.cpu_sample
+        lc = qwen2.Qwen2Cfg(hidden=model.llm.hidden, layers=model.llm.layers, heads=model.llm.heads, kv_heads=model.llm.kv_heads,
+                            head_dim=model.llm.head_dim, inter=model.llm.inter, vocab=model.llm.vocab)
+        tc = fastvit_hd.TowerCfg(layers=model.tower.layers, dims=model.tower.dims)
+        hp = {k: v.detach().cpu().clone() for k, v in eng.head_views(flat).items()}
+        # the box exposes every host core but grants a 16-CPU share per GPU: size the pool to the share
+        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(share, int(os.environ.get("FASTVLA_CPU_THREADS", "16")))))
+        ci, cids = images[:n].cpu(), ids[:n].cpu().long()
+        cmask = torch.ones(n, T, dtype=torch.long)
+        t = time.perf_counter()
+        with torch.no_grad():
+            ref = policy.policy_forward(w, hp, ci, states[:n].cpu(), cids, cmask, image_size=model.tower.image_size,
+                                        llm_cfg=lc, tower_cfg=tc, splice=args.splice)
+        cel = time.perf_counter() - t
+        got = step_infer()[:n].cpu()
+        err = float((got - ref).norm() / ref.norm())
+        cpu = {"value": round((n / cel) / B, 5), "unit": f"steps/s (bs={B} equivalent)", "cores": torch.get_num_threads(),
+               "kind": "port", "samples_per_s": round(n / cel, 3), "seconds": round(cel, 2),
+               "sample": f"{n} images {args.image}x{args.image} + {T}-token prompts, one forward "
+                         f"(letterbox+tower+projector+decoder+pool+head) of the fp32 torch oracle",
+               "parity_actions_rel_l2": err}
+
+    if rank == 0:
+        out = {
+            "metric": "policy steps/sec (img+prompt->action) FastVLM-0.5B bs=64" if args.model == "fastvlm-0.5b" and B == 64
+                      else f"policy steps/sec (img+prompt->action) {args.model} bs={B}",
+            "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (seeded random weights + inputs; no checkpoint/dataset reachable offline)",
+            "config": {"workload": f"{args.model} select_action: letterbox {args.image}^2->{model.tower.image_size}^2, FastViT-HD, "
+                                   f"projector, Qwen2 decoder ({'256 image tokens + ' if args.splice else 'text-only, reference-literal: '}"
+                                   f"{T}-token prompt), last-token pool, action head",
+                       "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "image": args.image,
+                       "parallelism": f"replicas x{world} (no collective on the inference path)",
+                       "splice_image_tokens": bool(args.splice), "tower_microbatch": args.microbatch},
+            "samples_per_s": round(value * B, 2),
+            "roofline": roofline, "cpu_baseline": cpu, "train_dp": train,
+            "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,11 +119,25 @@ int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled,
  * flat_grads (overwritten, not accumulated). */
 int fv_head_mse_backward(fv_handle* h, const float* flat_params, const float* actions, const float* targets, int B,
                          float dropout_p, const void* saved, float* loss, float* flat_grads, fv_stream s);
+/* generic backward of the head from dL/dactions (B,A) f32 (what autograd hands a custom Function when the loss is
+ * computed outside, e.g. lerobot_fastvla/modeling_fastvla.py:132 + loss.backward()); overwrites flat_grads. */
+int fv_head_backward(fv_handle* h, const float* flat_params, const float* grad_actions, int B, float dropout_p,
+                     const void* saved, float* flat_grads, fv_stream s);
 /* replaces clip_grad_norm_ + AdamW.step (training/trainer.py:60-66,178-180;
  * lerobot_fastvla/configuration_fastvla.py:51-55): fused global-norm clip + decoupled-decay Adam on the flat buffers.
  * step is 1-based.  grad_norm_out (1 f32, device, may be NULL) receives the pre-clip norm. */
 int fv_adamw_clip_step(fv_handle* h, float* flat_params, const float* flat_grads, float* m, float* v, int64_t n,
                        const fv_adamw_hparams* hp, int64_t step, float* grad_norm_out, fv_stream s);
+
+/* ---- optional per-kernel-family HIP-event timing (bench.py roofline numbers) ------------------------------------- */
+enum fv_family { FV_FAM_GEMM = 0, FV_FAM_DWCONV, FV_FAM_STEM, FV_FAM_ATTN, FV_FAM_NORM, FV_FAM_ELT, FV_FAM_HEAD, FV_FAM_COUNT };
+typedef struct fv_profile_entry { double ms, flops, bytes; int64_t launches; } fv_profile_entry;
+typedef struct fv_gemm_profile { int32_t m, n, k, epi; double ms; int64_t launches; } fv_gemm_profile;
+/* enable != 0: every launch the engine issues is bracketed by hipEvents on the caller's stream (algorithmic flops and
+ * bytes recorded beside it).  fv_profile_read synchronises those events, fills fam_out[FV_FAM_COUNT] and up to max_gemm
+ * distinct GEMM shapes, and clears the record list. */
+int fv_profile(fv_handle* h, int enable);
+int fv_profile_read(fv_handle* h, fv_profile_entry* fam_out, fv_gemm_profile* gemm_out, int max_gemm, int* n_gemm);
 
 /* ---- op-level entry points (used by the parity tests to check each kernel on its own) ------------------------- */
 enum fv_gemm_epilogue {

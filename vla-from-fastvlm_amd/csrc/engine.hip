@@ -73,6 +73,19 @@ struct WsPlan {
   size_t bufA, bufB, bufH, se, tower_out, x, xn, qkv, att, act, head_scr, total;
 };
 
+// optional per-launch HIP-event timing on the caller's stream (bench.py's roofline numbers); off by default
+struct ProfRec { int fam; double flops, bytes; int m, n, k, epi; hipEvent_t e0, e1; };
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  hipEvent_t get() {
+    if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+    return pool[used++];
+  }
+};
+
 }  // namespace
 
 struct fv_handle {
@@ -88,6 +101,7 @@ struct fv_handle {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   fv::HeadDims hd;
+  Profiler prof;
 };
 
 namespace {
@@ -233,15 +247,47 @@ int check_ready(fv_handle* h, bool need_ws) {
     if (_rc != FV_OK) return _rc; \
   } while (0)
 
-int run_ffn(const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t* hid, bf16_t* res_out, int mb, int H, int W, int C,
+void prof_begin(fv_handle* h, int fam, double flops, double bytes, hipStream_t s, int m = 0, int n = 0, int k = 0, int epi = 0) {
+  if (!h->prof.on) return;
+  ProfRec r{fam, flops, bytes, m, n, k, epi, h->prof.get(), h->prof.get()};
+  if (!r.e0 || !r.e1) return;
+  (void)hipEventRecord(r.e0, s);
+  h->prof.recs.push_back(r);
+}
+void prof_end(fv_handle* h, hipStream_t s) {
+  if (!h->prof.on || h->prof.recs.empty()) return;
+  (void)hipEventRecord(h->prof.recs.back().e1, s);
+}
+#define FV_P(fam, flops, bytes, call)            \
+  do {                                           \
+    prof_begin(h, fam, flops, bytes, s);         \
+    int _rc = (call);                            \
+    prof_end(h, s);                              \
+    if (_rc != FV_OK) return _rc;                \
+  } while (0)
+
+int gemm_p(fv_handle* h, const fv::GemmArgs& g, hipStream_t s) {
+  const double M = g.M, N = g.N, K = g.K;
+  const bool f32o = g.epi == FV_EPI_RES_F32 || g.epi == FV_EPI_F32;
+  double bytes = (M * K + N * K) * 2 + M * (g.epi == FV_EPI_SWIGLU ? N / 2 : N) * (f32o ? 4 : 2);
+  if (g.epi == FV_EPI_LS_RES) bytes += M * N * 2;
+  if (g.epi == FV_EPI_RES_F32) bytes += M * N * 4;
+  prof_begin(h, FV_FAM_GEMM, 2.0 * M * N * K, bytes, s, g.M, g.N, g.K, g.epi);
+  const int rc = fv::launch_gemm(g, s);
+  prof_end(h, s);
+  return rc;
+}
+double dw_flops(int B, int Ho, int Wo, int Cout, int k) { return 2.0 * B * Ho * Wo * Cout * k * k; }
+
+int run_ffn(fv_handle* h, const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t* hid, bf16_t* res_out, int mb, int H, int W, int C,
             int ratio, hipStream_t s) {
   // dw_out = dw7x7(x_dw_in) (+BN folded); hid = gelu(fc1(dw_out)); res_out += ls * fc2(hid)
-  FV_TRY(fv::launch_dwconv(x_dw_in, f.dw_w, f.dw_b, dw_out, mb, H, W, C, 7, 1, 1, 0, s));
   const int M = mb * H * W;
+  FV_P(FV_FAM_DWCONV, dw_flops(mb, H, W, C, 7), 4.0 * M * C, fv::launch_dwconv(x_dw_in, f.dw_w, f.dw_b, dw_out, mb, H, W, C, 7, 1, 1, 0, s));
   fv::GemmArgs g1{dw_out, C, f.fc1_w, M, C * ratio, C, f.fc1_b, nullptr, nullptr, 0, hid, C * ratio, FV_EPI_BIAS_GELU};
-  FV_TRY(fv::launch_gemm(g1, s));
+  FV_TRY(gemm_p(h, g1, s));
   fv::GemmArgs g2{hid, C * ratio, f.fc2_w, M, C, C * ratio, f.fc2_b, f.ls, res_out, C, res_out, C, FV_EPI_LS_RES};
-  FV_TRY(fv::launch_gemm(g2, s));
+  FV_TRY(gemm_p(h, g2, s));
   return FV_OK;
 }
 
@@ -255,53 +301,57 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float
   bf16_t* hid = reinterpret_cast<bf16_t*>(ws + wp.bufH);
   float* se = reinterpret_cast<float*>(ws + wp.se);
   const int S = d.image_size, C0 = d.tower_dims[0];
-  FV_TRY(fv::launch_stem_conv(pix, tw.stem0_w, tw.stem0_b, cur, mb, S, C0, s));
-  FV_TRY(fv::launch_dwconv(cur, tw.stem1_w, tw.stem1_b, oth, mb, S / 2, S / 2, C0, 3, 2, 1, 1, s));
+  FV_P(FV_FAM_STEM, 2.0 * mb * (S / 2) * (S / 2) * 27 * C0, (double)mb * S * S * 8 + (double)mb * (S / 2) * (S / 2) * C0 * 2,
+       fv::launch_stem_conv(pix, tw.stem0_w, tw.stem0_b, cur, mb, S, C0, s));
+  FV_P(FV_FAM_DWCONV, dw_flops(mb, S / 4, S / 4, C0, 3), (double)mb * (S / 2) * (S / 2) * C0 * 2 * 1.25,
+       fv::launch_dwconv(cur, tw.stem1_w, tw.stem1_b, oth, mb, S / 2, S / 2, C0, 3, 2, 1, 1, s));
   int H = S / 4;
   {
     fv::GemmArgs g{oth, C0, tw.stem2_w, mb * H * H, C0, C0, tw.stem2_b, nullptr, nullptr, 0, cur, C0, FV_EPI_BIAS_GELU};
-    FV_TRY(fv::launch_gemm(g, s));
+    FV_TRY(gemm_p(h, g, s));
   }
   for (int i = 0; i < d.tower_stages; ++i) {
     const int C = d.tower_dims[i];
     const int M = mb * H * H;
     if (d.tower_is_attn[i]) {
-      FV_TRY(fv::launch_dwconv(cur, tw.cpes[i].w, tw.cpes[i].b, oth, mb, H, H, C, 7, 1, 1, 0, s));
+      FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 7), 4.0 * M * C, fv::launch_dwconv(cur, tw.cpes[i].w, tw.cpes[i].b, oth, mb, H, H, C, 7, 1, 1, 0, s));
       std::swap(cur, oth);
     }
     for (const Block& b : tw.stages[i]) {
       if (!d.tower_is_attn[i]) {
-        FV_TRY(fv::launch_dwconv(cur, b.mix_w, b.mix_b, oth, mb, H, H, C, 3, 1, 1, 0, s));  // x = RepMixer(x) -> oth
-        FV_TRY(run_ffn(b.ffn, oth, cur, hid, oth, mb, H, H, C, d.tower_mlp_ratio, s));        // oth += ls * ffn(oth)
+        FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 3), 4.0 * M * C, fv::launch_dwconv(cur, b.mix_w, b.mix_b, oth, mb, H, H, C, 3, 1, 1, 0, s));  // x = RepMixer(x) -> oth
+        FV_TRY(run_ffn(h, b.ffn, oth, cur, hid, oth, mb, H, H, C, d.tower_mlp_ratio, s));        // oth += ls * ffn(oth)
         std::swap(cur, oth);
       } else {
-        FV_TRY(fv::launch_layernorm_rows(cur, b.ln_w, b.ln_b, oth, M, C, d.ln_eps, s));
+        FV_P(FV_FAM_NORM, 8.0 * M * C, 4.0 * M * C, fv::launch_layernorm_rows(cur, b.ln_w, b.ln_b, oth, M, C, d.ln_eps, s));
         fv::GemmArgs gq{oth, C, b.qkv_w, M, 3 * C, C, nullptr, nullptr, nullptr, 0, hid, 3 * C, FV_EPI_BIAS};
-        FV_TRY(fv::launch_gemm(gq, s));
+        FV_TRY(gemm_p(h, gq, s));
         const int nh = C / d.tower_head_dim;
-        FV_TRY(fv::launch_attention(hid, hid + C, hid + 2 * C, 3 * C, 3 * C, 3 * C, oth, C, mb, H * H, nh, nh,
-                                    d.tower_head_dim, 0, nullptr, 0, 1.0f / std::sqrt((float)d.tower_head_dim), s));
+        FV_P(FV_FAM_ATTN, 4.0 * mb * (double)(H * H) * (H * H) * C, 8.0 * M * C,
+             fv::launch_attention(hid, hid + C, hid + 2 * C, 3 * C, 3 * C, 3 * C, oth, C, mb, H * H, nh, nh,
+                                  d.tower_head_dim, 0, nullptr, 0, 1.0f / std::sqrt((float)d.tower_head_dim), s));
         fv::GemmArgs gp{oth, C, b.proj_w, M, C, C, b.proj_b, b.ls1, cur, C, cur, C, FV_EPI_LS_RES};
-        FV_TRY(fv::launch_gemm(gp, s));
-        FV_TRY(run_ffn(b.ffn, cur, oth, hid, cur, mb, H, H, C, d.tower_mlp_ratio, s));
+        FV_TRY(gemm_p(h, gp, s));
+        FV_TRY(run_ffn(h, b.ffn, cur, oth, hid, cur, mb, H, H, C, d.tower_mlp_ratio, s));
       }
     }
     if (i + 1 < d.tower_stages) {
       const int C2 = d.tower_dims[i + 1];
-      FV_TRY(fv::launch_dwconv(cur, tw.downs[i].lk_w, tw.downs[i].lk_b, oth, mb, H, H, C, 7, 2, C2 / C, 1, s));
+      FV_P(FV_FAM_DWCONV, dw_flops(mb, H / 2, H / 2, C2, 7), 2.0 * M * C + 2.0 * (M / 4) * C2,
+           fv::launch_dwconv(cur, tw.downs[i].lk_w, tw.downs[i].lk_b, oth, mb, H, H, C, 7, 2, C2 / C, 1, s));
       H /= 2;
       fv::GemmArgs g{oth, C2, tw.downs[i].pw_w, mb * H * H, C2, C2, tw.downs[i].pw_b, nullptr, nullptr, 0, cur, C2, FV_EPI_BIAS_GELU};
-      FV_TRY(fv::launch_gemm(g, s));
+      FV_TRY(gemm_p(h, g, s));
     }
   }
   const int CL = d.tower_dims[d.tower_stages - 1], CO = d.tower_out_dim, P = H * H;
-  FV_TRY(fv::launch_dwconv(cur, tw.exp_w, tw.exp_b, oth, mb, H, H, CL, 3, 1, CO / CL, 0, s));
-  FV_TRY(fv::launch_se_gelu(oth, tw.se_w1, tw.se_b1, tw.se_w2, tw.se_b2, tower_out, se, mb, P, CO, d.tower_se_rd, s));
+  FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, CO, 3), 2.0 * mb * P * (CL + CO), fv::launch_dwconv(cur, tw.exp_w, tw.exp_b, oth, mb, H, H, CL, 3, 1, CO / CL, 0, s));
+  FV_P(FV_FAM_ELT, 20.0 * mb * P * CO, 6.0 * mb * P * CO, fv::launch_se_gelu(oth, tw.se_w1, tw.se_b1, tw.se_w2, tw.se_b2, tower_out, se, mb, P, CO, d.tower_se_rd, s));
   // mm_projector: Linear + GELU + Linear -> fp32 tokens ([site] fast_vlm/modeling_fast_vlm.py:51-55)
   fv::GemmArgs p0{tower_out, CO, tw.pj0_w, mb * P, d.llm_hidden, CO, tw.pj0_b, nullptr, nullptr, 0, hid, d.llm_hidden, FV_EPI_BIAS_GELU};
-  FV_TRY(fv::launch_gemm(p0, s));
+  FV_TRY(gemm_p(h, p0, s));
   fv::GemmArgs p2{hid, d.llm_hidden, tw.pj2_w, mb * P, d.llm_hidden, d.llm_hidden, tw.pj2_b, nullptr, nullptr, 0, img_tokens, d.llm_hidden, FV_EPI_F32};
-  FV_TRY(fv::launch_gemm(p2, s));
+  FV_TRY(gemm_p(h, p2, s));
   return FV_OK;
 }
 
@@ -353,6 +403,7 @@ void fv_destroy(fv_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   for (void* p : h->allocs) (void)hipFree(p);
+  for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -495,8 +546,13 @@ int fv_bind_workspace(fv_handle* h, void* ws, size_t bytes) {
 int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value,
                   int resize_with_padding, void* pix_out, fv_stream s) {
   if (!h) return fv_fail(FV_ERR_ARG, "null handle");
-  return fv::launch_letterbox(img, dtype, B, C, Hin, Win, h->d.image_size, pad_value, resize_with_padding,
-                              static_cast<bf16_t*>(pix_out), static_cast<hipStream_t>(s));
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const double S = h->d.image_size;
+  prof_begin(h, FV_FAM_ELT, 30.0 * B * S * S, (double)B * C * Hin * Win * (dtype == FV_U8 ? 1 : 4) + B * S * S * 8.0, st);
+  const int rc = fv::launch_letterbox(img, dtype, B, C, Hin, Win, h->d.image_size, pad_value, resize_with_padding,
+                                      static_cast<bf16_t*>(pix_out), st);
+  prof_end(h, st);
+  return rc;
 }
 
 int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, fv_stream s) {
@@ -542,23 +598,24 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
   bf16_t* act = reinterpret_cast<bf16_t*>(ws + wp.act);
   const int rows = B * Tt, Hd = d.llm_hidden, D = d.llm_head_dim;
   const int qd = d.llm_heads * D, kd = d.llm_kv_heads * D, qkvw = qd + 2 * kd;
-  FV_TRY(fv::launch_embed_gather(ids, h->dec.embed, static_cast<const float*>(img_tokens), x, B, T, Ni, Hd, d.llm_vocab, s));
+  FV_P(FV_FAM_ELT, 0.0, 6.0 * rows * Hd, fv::launch_embed_gather(ids, h->dec.embed, static_cast<const float*>(img_tokens), x, B, T, Ni, Hd, d.llm_vocab, s));
   for (const DecLayer& L : h->dec.layers) {
-    FV_TRY(fv::launch_rmsnorm(x, L.ln1, xn, rows, Hd, d.rms_eps, s));
+    FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xn, rows, Hd, d.rms_eps, s));
     fv::GemmArgs gq{xn, Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkv, qkvw, FV_EPI_BIAS};
-    FV_TRY(fv::launch_gemm(gq, s));
-    FV_TRY(fv::launch_rope(qkv, h->rope, qkvw, rows, Tt, d.llm_heads, d.llm_kv_heads, D, s));
-    FV_TRY(fv::launch_attention(qkv, qkv + qd, qkv + qd + kd, qkvw, qkvw, qkvw, att, qd, B, Tt, d.llm_heads, d.llm_kv_heads,
-                                D, 1, lens, Ni, 1.0f / std::sqrt((float)D), s));
+    FV_TRY(gemm_p(h, gq, s));
+    FV_P(FV_FAM_ELT, 3.0 * rows * (qd + kd), 4.0 * rows * (qd + kd), fv::launch_rope(qkv, h->rope, qkvw, rows, Tt, d.llm_heads, d.llm_kv_heads, D, s));
+    FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tt * Tt * qd, 2.0 * rows * (qkvw + qd),
+         fv::launch_attention(qkv, qkv + qd, qkv + qd + kd, qkvw, qkvw, qkvw, att, qd, B, Tt, d.llm_heads, d.llm_kv_heads,
+                              D, 1, lens, Ni, 1.0f / std::sqrt((float)D), s));
     fv::GemmArgs go{att, qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
-    FV_TRY(fv::launch_gemm(go, s));
-    FV_TRY(fv::launch_rmsnorm(x, L.ln2, xn, rows, Hd, d.rms_eps, s));
+    FV_TRY(gemm_p(h, go, s));
+    FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, rows, Hd, d.rms_eps, s));
     fv::GemmArgs gg{xn, Hd, L.gu_w, rows, 2 * d.llm_inter, Hd, nullptr, nullptr, nullptr, 0, act, d.llm_inter, FV_EPI_SWIGLU};
-    FV_TRY(fv::launch_gemm(gg, s));
+    FV_TRY(gemm_p(h, gg, s));
     fv::GemmArgs gd{act, d.llm_inter, L.down_w, rows, Hd, d.llm_inter, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
-    FV_TRY(fv::launch_gemm(gd, s));
+    FV_TRY(gemm_p(h, gd, s));
   }
-  FV_TRY(fv::launch_pool_norm(x, lens, h->dec.norm, static_cast<float*>(pooled), B, Tt, Ni, Hd, d.rms_eps, pool_mode, s));
+  FV_P(FV_FAM_ELT, 4.0 * B * Hd, 8.0 * B * Hd, fv::launch_pool_norm(x, lens, h->dec.norm, static_cast<float*>(pooled), B, Tt, Ni, Hd, d.rms_eps, pool_mode, s));
   return FV_OK;
 }
 
@@ -579,8 +636,12 @@ int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled,
                     int training, float dropout_p, uint64_t seed, uint64_t offset, float* actions, void* saved,
                     fv_stream s) {
   if (!h) return fv_fail(FV_ERR_ARG, "null handle");
-  return fv::launch_head_forward(h->hd, flat_params, pooled, states, B, training, dropout_p, seed, offset, actions,
-                                 static_cast<float*>(saved), static_cast<hipStream_t>(s));
+  hipStream_t st = static_cast<hipStream_t>(s);
+  prof_begin(h, FV_FAM_HEAD, 2.0 * B * fv::head_offsets(h->hd).o[12], 4.0 * fv::head_offsets(h->hd).o[12], st);
+  const int rc = fv::launch_head_forward(h->hd, flat_params, pooled, states, B, training, dropout_p, seed, offset, actions,
+                                         static_cast<float*>(saved), st);
+  prof_end(h, st);
+  return rc;
 }
 
 int fv_head_mse_backward(fv_handle* h, const float* flat_params, const float* actions, const float* targets, int B,
@@ -591,8 +652,56 @@ int fv_head_mse_backward(fv_handle* h, const float* flat_params, const float* ac
   const WsPlan wp = plan_ws(h, B, 1, 0);
   if (wp.total > h->ws_bytes) return fv_fail(FV_ERR_STATE, "workspace too small for head backward");
   float* scr = reinterpret_cast<float*>(static_cast<char*>(h->ws) + wp.head_scr);
-  return fv::launch_head_backward(h->hd, flat_params, actions, targets, B, dropout_p, static_cast<const float*>(saved),
-                                  loss, flat_grads, scr, static_cast<hipStream_t>(s));
+  hipStream_t st = static_cast<hipStream_t>(s);
+  prof_begin(h, FV_FAM_HEAD, 4.0 * B * fv::head_offsets(h->hd).o[12], 8.0 * fv::head_offsets(h->hd).o[12], st);
+  const int rc = fv::launch_head_backward(h->hd, flat_params, nullptr, actions, targets, B, dropout_p,
+                                          static_cast<const float*>(saved), loss, flat_grads, scr, st);
+  prof_end(h, st);
+  return rc;
+}
+
+int fv_head_backward(fv_handle* h, const float* flat_params, const float* grad_actions, int B, float dropout_p,
+                     const void* saved, float* flat_grads, fv_stream s) {
+  if (!h || !grad_actions) return fv_fail(FV_ERR_ARG, "fv_head_backward: null argument");
+  if (!h->ws) return fv_fail(FV_ERR_STATE, "workspace not bound: call fv_bind_workspace first");
+  if (B > h->d.max_batch) return fv_fail(FV_ERR_ARG, "B=%d exceeds max_batch=%d", B, h->d.max_batch);
+  const WsPlan wp = plan_ws(h, B, 1, 0);
+  if (wp.total > h->ws_bytes) return fv_fail(FV_ERR_STATE, "workspace too small for head backward");
+  float* scr = reinterpret_cast<float*>(static_cast<char*>(h->ws) + wp.head_scr);
+  return fv::launch_head_backward(h->hd, flat_params, grad_actions, nullptr, nullptr, B, dropout_p,
+                                  static_cast<const float*>(saved), nullptr, flat_grads, scr, static_cast<hipStream_t>(s));
+}
+
+int fv_profile(fv_handle* h, int enable) {
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  h->prof.on = enable != 0;
+  h->prof.recs.clear();
+  h->prof.used = 0;
+  return FV_OK;
+}
+
+int fv_profile_read(fv_handle* h, fv_profile_entry* fam_out, fv_gemm_profile* gemm_out, int max_gemm, int* n_gemm) {
+  if (!h || !fam_out) return fv_fail(FV_ERR_ARG, "fv_profile_read: null argument");
+  for (int i = 0; i < FV_FAM_COUNT; ++i) fam_out[i] = fv_profile_entry{0.0, 0.0, 0.0, 0};
+  std::map<std::vector<int>, fv_gemm_profile> shapes;
+  for (ProfRec& r : h->prof.recs) {
+    FV_HIP_CHECK(hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    FV_HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+    fv_profile_entry& e = fam_out[r.fam];
+    e.ms += ms; e.flops += r.flops; e.bytes += r.bytes; e.launches += 1;
+    if (r.fam == FV_FAM_GEMM) {
+      fv_gemm_profile& g = shapes[{r.m, r.n, r.k, r.epi}];
+      g.m = r.m; g.n = r.n; g.k = r.k; g.epi = r.epi; g.ms += ms; g.launches += 1;
+    }
+  }
+  int n = 0;
+  if (gemm_out)
+    for (auto& kv : shapes) { if (n >= max_gemm) break; gemm_out[n++] = kv.second; }
+  if (n_gemm) *n_gemm = n;
+  h->prof.recs.clear();
+  h->prof.used = 0;
+  return FV_OK;
 }
 
 int fv_adamw_clip_step(fv_handle* h, float* flat_params, const float* flat_grads, float* m, float* v, int64_t n,

@@ -298,21 +298,27 @@ int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, 
   return FV_OK;
 }
 
-int launch_head_backward(const HeadDims& d, const float* P, const float* actions, const float* targets, int B,
-                         float drop_p, const float* saved, float* loss, float* G, float* scratch, hipStream_t s) {
-  if (!P || !actions || !targets || !saved || !loss || !G || !scratch) return fv_fail(FV_ERR_ARG, "head_backward: null pointer");
+int launch_head_backward(const HeadDims& d, const float* P, const float* grad_actions, const float* actions,
+                         const float* targets, int B, float drop_p, const float* saved, float* loss, float* G,
+                         float* scratch, hipStream_t s) {
+  if (!P || !saved || !G || !scratch) return fv_fail(FV_ERR_ARG, "head_backward: null pointer");
+  if (!grad_actions && (!actions || !targets || !loss)) return fv_fail(FV_ERR_ARG, "head_backward: need grad_actions or (actions, targets, loss)");
   if (B <= 0) return fv_fail(FV_ERR_ARG, "head_backward: B must be positive");
   (void)drop_p;  // the multiplier keep/(1-p) is stored in saved.mask
   const HeadOffsets ho = head_offsets(d);
   const Saved sv = carve(d, B, const_cast<float*>(saved));
   const int cw = d.feat + d.hid;
   const size_t wmax = (size_t)(cw > d.fus ? cw : d.fus);
-  float* ga = scratch;
-  float* g1 = ga + ((size_t)B * d.da + 3) / 4 * 4;
+  float* ga_own = scratch;
+  float* g1 = ga_own + ((size_t)B * d.da + 3) / 4 * 4;
   float* g2 = g1 + (size_t)B * wmax;
   const dim3 blk(256);
   const unsigned b8 = cdiv(B, 8);
-  hipLaunchKernelGGL(mse_kernel, dim3(1), blk, 0, s, actions, targets, loss, ga, B * d.da);
+  const float* ga = grad_actions;
+  if (!ga) {
+    hipLaunchKernelGGL(mse_kernel, dim3(1), blk, 0, s, actions, targets, loss, ga_own, B * d.da);
+    ga = ga_own;
+  }
   // action_head
   hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv(d.fus, 256), d.da), blk, 0, s, ga, sv.a3, d.fus, G + ho.o[10], B, d.da, d.fus);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(d.da, 256)), blk, 0, s, ga, G + ho.o[11], B, d.da);

@@ -56,8 +56,10 @@ size_t head_saved_bytes(const HeadDims& d, int B);
 int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, const float* states, int B,
                         int training, float drop_p, uint64_t seed, uint64_t offset, float* actions, float* saved,
                         hipStream_t s);
-int launch_head_backward(const HeadDims& d, const float* P, const float* actions, const float* targets, int B,
-                         float drop_p, const float* saved, float* loss, float* G, float* scratch, hipStream_t s);
+// grad_actions != null: generic backward from dL/dactions (loss untouched); else fused MSE(actions, targets) + backward
+int launch_head_backward(const HeadDims& d, const float* P, const float* grad_actions, const float* actions,
+                         const float* targets, int B, float drop_p, const float* saved, float* loss, float* G,
+                         float* scratch, hipStream_t s);
 size_t head_bwd_scratch_bytes(const HeadDims& d, int B);
 int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const fv_adamw_hparams& hp,
                       int64_t step, float* norm_scratch, float* grad_norm_out, hipStream_t s);

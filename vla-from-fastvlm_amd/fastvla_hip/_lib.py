@@ -45,6 +45,17 @@ class AdamWHParams(C.Structure):
                 ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("grad_scale", C.c_float)]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", C.c_int64)]
+
+
+class GemmProfile(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("epi", C.c_int32), ("ms", C.c_double),
+                ("launches", C.c_int64)]
+
+
+FAMILIES = ("gemm", "dwconv", "stem", "attention", "norm", "elementwise", "head")
+
 _vp, _i, _f, _u64, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/fastvla_hip.h
@@ -63,6 +74,9 @@ SIGNATURES = {
     "fv_head_saved_bytes": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
     "fv_head_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _u64, _u64, _vp, _vp, _vp]),
     "fv_head_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "fv_head_backward": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
+    "fv_profile": (_i, [_vp, _i]),
+    "fv_profile_read": (_i, [_vp, C.POINTER(ProfileEntry), C.POINTER(GemmProfile), _i, C.POINTER(_i)]),
     "fv_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(AdamWHParams), _i64, _vp, _vp]),
     "fv_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "fv_op_dwconv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -215,6 +215,34 @@ class FastVLAEngine:
                                                  flat_grads.data_ptr(), _stream()), "fv_head_mse_backward")
         return loss, flat_grads
 
+    def head_backward_from_grad(self, flat_params: torch.Tensor, grad_actions: torch.Tensor, saved: torch.Tensor,
+                                dropout_p: float = 0.0, flat_grads: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """generic backward: dL/dactions (B,A) -> all 12 head grads in one flat buffer (overwritten)."""
+        B = grad_actions.shape[0]
+        self.ensure_workspace(B, 1, False)
+        grad_actions = grad_actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if flat_grads is None:
+            flat_grads = torch.zeros(self.head_numel(), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.fv_head_backward(self.h, flat_params.data_ptr(), grad_actions.data_ptr(), B, float(dropout_p),
+                                             saved.data_ptr(), flat_grads.data_ptr(), _stream()), "fv_head_backward")
+        return flat_grads
+
+    # ---------------------------------------------------------------- profiling (bench.py)
+    def profile(self, enable: bool) -> None:
+        _lib.check(self.lib.fv_profile(self.h, int(enable)), "fv_profile")
+
+    def profile_read(self):
+        """-> (families: name -> dict(ms, flops, bytes, launches), gemm shapes: list of dicts).  Synchronises."""
+        fam = (_lib.ProfileEntry * len(_lib.FAMILIES))()
+        gem = (_lib.GemmProfile * 128)()
+        n = C.c_int()
+        _lib.check(self.lib.fv_profile_read(self.h, fam, gem, 128, C.byref(n)), "fv_profile_read")
+        fams = {name: dict(ms=fam[i].ms, flops=fam[i].flops, bytes=fam[i].bytes, launches=fam[i].launches)
+                for i, name in enumerate(_lib.FAMILIES)}
+        shapes = [dict(m=gem[i].m, n=gem[i].n, k=gem[i].k, epi=gem[i].epi, ms=gem[i].ms, launches=gem[i].launches)
+                  for i in range(n.value)]
+        return fams, shapes
+
     def adamw_step(self, flat_params, flat_grads, m, v, step: int, *, lr: float, betas=(0.9, 0.95), eps: float = 1e-8,
                    weight_decay: float = 1e-4, max_grad_norm: float = 1.0, grad_scale: float = 1.0,
                    grad_norm_out: Optional[torch.Tensor] = None) -> None:
