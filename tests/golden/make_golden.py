@@ -10,6 +10,7 @@ What is driven:
   G3 head             FastVLMWithExpert (stub backbone) + FastVLAPolicy.compute_loss -> actions, loss, 12 grads
   G4 task table       FastVLAProcessor.normalize_tasks
   G5 tower-name table FastVLMBackbone._infer_size_from_tower_name
+  G7 config contract  dataclasses.asdict of FastVLAConfig / FastVLMBackboneConfig / TrainingConfig defaults
   G6 train step       clip_grad_norm_ + torch.optim.AdamW exactly as training/trainer.py:60-66,171-182 issues them;
                       Trainer._build_scheduler_lambda
 """
@@ -197,8 +198,22 @@ def g6_schedules():
     (HERE / "g6_trainer_schedule.json").write_text(json.dumps(out, indent=1))
 
 
+def g7_config_contract():
+    """Public config contract: field names + defaults of the dataclasses the mirror must keep verbatim."""
+    import dataclasses
+    from vla_fastvlm.training.trainer import TrainingConfig
+    out = {
+        "FastVLAConfig": dataclasses.asdict(FastVLAConfig()),
+        "FastVLMBackboneConfig": dataclasses.asdict(FastVLMBackboneConfig()),
+        "TrainingConfig": dataclasses.asdict(TrainingConfig()),
+        "to_backbone_config": dataclasses.asdict(FastVLAConfig(vlm_model_name="m", image_size=1024, pad_value=0.5,
+                                                               tokenizer_max_length=48).to_backbone_config()),
+    }
+    (HERE / "g7_config_contract.json").write_text(json.dumps(out, indent=1, default=list))
+
+
 if __name__ == "__main__":
     os.environ.setdefault("HF_HUB_OFFLINE", "1")
     torch.set_num_threads(4)
-    g1_letterbox(); g2_pool(); g3_head(); g4_tasks(); g5_tower_names(); g6_schedules()
+    g1_letterbox(); g2_pool(); g3_head(); g4_tasks(); g5_tower_names(); g6_schedules(); g7_config_contract()
     print("golden fixtures written to", HERE)

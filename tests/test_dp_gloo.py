@@ -1,0 +1,91 @@
+"""CPU, world_size 2 over gloo: the data-parallel exchange of the path (one all-reduce of the flat head gradient, 1/world
+folded into the optimiser, clip on the reduced gradient) gives the same step as the single-process full batch.  The
+oracle stands in for the HIP kernels here (there is no GPU); the product code under test is vla_fastvlm.training.dp."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import head
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = head.head_shapes(24, 6, 5, 16, 20)
+    p = {k: torch.randn(*s, generator=g) * 0.2 + (1.0 if k in ("state_projection.0.weight", "fusion.1.weight") else 0.0)
+         for k, s in shapes.items()}
+    B = 8
+    return p, torch.randn(B, 24, generator=g), torch.randn(B, 6, generator=g), torch.randn(B, 5, generator=g)
+
+
+def _flat(d):
+    return torch.cat([d[k].reshape(-1) for k in head.HEAD_KEYS])
+
+
+def _worker(rank, world, port, out):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for p_ in (str(root), str(root / "vla-from-fastvlm_amd")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    from vla_fastvlm.training.dp import allreduce_flat_grads, shard_batches
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    p, feats, states, tgt = _setup()
+    batches = [slice(0, 4), slice(4, 8)]
+    mine = list(shard_batches(batches, rank, world))
+    assert mine == [batches[rank]]
+    sl = mine[0]
+    pred, cache = head.head_forward(p, feats[sl], states[sl], keep_cache=True)
+    _, grads = head.head_mse_backward(p, cache, pred, tgt[sl])
+    flat = _flat(grads)
+    scale = allreduce_flat_grads(flat)           # product code: SUM across ranks, returns 1/world
+    assert scale == 0.5
+    out[rank] = (flat * scale).clone()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_equals_full_batch():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    p, feats, states, tgt = _setup()
+    pred, cache = head.head_forward(p, feats, states, keep_cache=True)
+    _, grads = head.head_mse_backward(p, cache, pred, tgt)
+    full = _flat(grads)
+    assert torch.allclose(out[0], out[1], atol=0, rtol=0)          # identical on every rank after the exchange
+    assert float((out[0] - full).abs().max()) <= 1e-6 * float(full.abs().max())  # mean of shard grads == full-batch grad
+    # clip on the REDUCED gradient then AdamW: same parameters as the single-process step
+    keys = head.HEAD_KEYS
+    def unflat(v):
+        d, o = {}, 0
+        for k in keys:
+            n = p[k].numel()
+            d[k] = v[o:o + n].view_as(p[k])
+            o += n
+        return d
+    z = {k: torch.zeros_like(v) for k, v in p.items()}
+    a, _ = head.clip_grad_norm(unflat(out[0]), 1.0)
+    b, _ = head.clip_grad_norm(grads, 1.0)
+    pa, _, _ = head.adamw_step(p, a, z, z, 1, 1e-4)
+    pb, _, _ = head.adamw_step(p, b, z, z, 1, 1e-4)
+    for k in keys:
+        assert float((pa[k] - pb[k]).abs().max()) < 1e-7
+
+
+def test_single_process_is_a_noop():
+    from vla_fastvlm.training.dp import allreduce_flat_grads, world_size
+    g = torch.ones(5)
+    assert world_size() == 1 and allreduce_flat_grads(g) == 1.0 and torch.equal(g, torch.ones(5))

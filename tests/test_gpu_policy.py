@@ -1,0 +1,132 @@
+"""-m gpu: the drop-in Python surface (vla_fastvlm.fastvla / lerobot_fastvla) driving the HIP path, against the oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, check_close, rel_l2  # noqa: E402
+from fastvla_hip import HEAD_KEYS, arch, weights  # noqa: E402
+from oracle import fastvit_hd, head, policy, qwen2  # noqa: E402
+from vla_fastvlm.fastvla import FastVLAConfig, FastVLAPolicy  # noqa: E402
+
+
+def _oracle_cfgs(m):
+    return (fastvit_hd.TowerCfg(layers=m.tower.layers, dims=m.tower.dims),
+            qwen2.Qwen2Cfg(hidden=m.llm.hidden, layers=m.llm.layers, heads=m.llm.heads, kv_heads=m.llm.kv_heads,
+                           head_dim=m.llm.head_dim, inter=m.llm.inter, vocab=m.llm.vocab))
+
+
+@pytest.fixture(scope="module")
+def pol():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    torch.manual_seed(21)
+    p = FastVLAPolicy(FastVLAConfig(vlm_model_name="synthetic:tiny:77", hidden_dim=48, fusion_dim=64, dropout=0.0))
+    return p.to(DEV)
+
+
+def _batch(B=3):
+    g = torch.Generator().manual_seed(5)
+    return {"images": torch.rand(B, 2, 3, 72, 96, generator=g), "states": torch.randn(B, 2, 14, generator=g),
+            "actions": torch.randn(B, 14, generator=g), "tasks": ["stack the red block", "open drawer", "x"][:B]}
+
+
+def _oracle_actions(pol, batch, head_p):
+    m = arch.preset("tiny")
+    tc, lc = _oracle_cfgs(m)
+    w = weights.init_backbone(m, seed=77)
+    tasks = policy.normalize_tasks(batch["tasks"], batch["images"].shape[0])
+    tok = pol.model.backbone.tokenizer(tasks, padding="longest", truncation=True, max_length=64)
+    pooled, _ = policy.backbone_features(w, policy.last_timestep(batch["images"], 4), tok["input_ids"], tok["attention_mask"],
+                                         image_size=m.tower.image_size, llm_cfg=lc, tower_cfg=tc)
+    return pooled, policy.last_timestep(batch["states"], 2)
+
+
+def test_compute_loss_and_autograd_backward(pol):
+    batch = _batch()
+    pol.train()
+    head_p = {k: v.detach().cpu().clone() for k, v in zip(HEAD_KEYS, pol.model.head_parameters())}
+    out = pol.compute_loss({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()})
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    pooled, states = _oracle_actions(pol, batch, head_p)
+    pred, cache = head.head_forward(head_p, pooled, states, keep_cache=True)
+    loss, grads = head.head_mse_backward(head_p, cache, pred, batch["actions"])
+    assert abs(float(out["loss"].detach()) - float(loss)) <= 5e-3 * float(loss)
+    assert set(out) == {"loss", "mse"} and not out["mse"].requires_grad
+    for k, p in zip(HEAD_KEYS, pol.model.head_parameters()):
+        assert p.grad is not None and p.grad.shape == p.shape
+        assert rel_l2(p.grad.cpu(), grads[k]) < 2e-2, k
+    fg = pol.model.flat_grads()  # autograd may keep the returned views (one flat buffer) or clone them
+    print("grads stay views of one flat buffer:", fg is not None)
+    # a stock torch optimizer keeps working on the same Parameters
+    before = pol.model.action_head.weight.detach().clone()
+    torch.optim.AdamW(pol.parameters(), lr=1e-2).step()
+    assert not torch.equal(before, pol.model.action_head.weight.detach())
+    views = pol.model._engine().head_views(pol.model._flat)
+    assert views["action_head.weight"].data_ptr() == pol.model.action_head.weight.data_ptr()
+    pol.zero_grad()
+
+
+def test_select_action_and_eval_forward(pol):
+    batch = _batch(1)
+    head_p = {k: v.detach().cpu().clone() for k, v in zip(HEAD_KEYS, pol.model.head_parameters())}
+    act = pol.select_action(batch["images"][0, -1], batch["states"][0, -1], "stack the red block", torch.device(DEV))
+    torch.cuda.synchronize()
+    assert act.shape == (14,) and not pol.training
+    pooled, states = _oracle_actions(pol, {**batch, "tasks": ["stack the red block"]}, head_p)
+    check_close(act.cpu()[None], head.head_forward(head_p, pooled, states), rel=5e-3, amax=2e-2, what="select_action")
+
+
+def test_fused_train_step_matches_oracle_step(pol):
+    batch = _batch()
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    pol.train()
+    head_p = {k: v.detach().cpu().clone() for k, v in zip(HEAD_KEYS, pol.model.head_parameters())}
+    pol._opt_state = None
+    # the pooled feature the HIP backbone produces for this batch (checked against the oracle backbone below); feeding
+    # it to the oracle head isolates the step arithmetic: Adam's first update is lr*sign(g), so bf16 noise in the
+    # feature would flip signs of near-zero gradients
+    tasks = pol.processor.prepare_tasks(batch["tasks"], 3)
+    with torch.no_grad():
+        pooled_hip = pol.model.features(pol.processor.prepare_images(dbatch["images"], torch.device(DEV)), tasks).cpu()
+    out = pol.fused_train_step(dbatch, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    pooled, states = _oracle_actions(pol, batch, head_p)
+    assert rel_l2(pooled_hip, pooled) < 5e-3
+    pred, cache = head.head_forward(head_p, pooled_hip, states, keep_cache=True)
+    loss, grads = head.head_mse_backward(head_p, cache, pred, batch["actions"])
+    clipped, norm = head.clip_grad_norm(grads, 1.0)
+    z = {k: torch.zeros_like(v) for k, v in head_p.items()}
+    newp, _, _ = head.adamw_step(head_p, clipped, z, z, 1, 1e-3, (0.9, 0.95), 1e-8, 0.01)
+    assert abs(float(out["loss"]) - float(loss)) <= 1e-5 * float(loss)
+    assert abs(float(out["grad_norm"]) - float(norm)) <= 1e-4 * float(norm)
+    for k, p in zip(HEAD_KEYS, pol.model.head_parameters()):
+        upd, ref = (p.detach().cpu() - head_p[k]), (newp[k] - head_p[k])
+        solid = clipped[k].abs() > 1e-7  # away from g ~ 0, where lr*g/(|g|+eps) is ill-conditioned
+        assert float((upd - ref)[solid].abs().max()) <= 2e-6, k
+    # second step exercises the stored moments
+    out2 = pol.fused_train_step(dbatch, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    assert float(out2["loss"]) < float(out["loss"])
+
+
+def test_lerobot_wrapper_forward_and_queue():
+    from vla_fastvlm.lerobot_fastvla import FastVLAConfig as LRConfig, FastVLAPolicy as LRPolicy
+    from vla_fastvlm.lerobot_fastvla._lerobot_compat import HAVE_LEROBOT, FeatureType, PolicyFeature
+    if HAVE_LEROBOT:
+        pytest.skip("covered by lerobot's own config machinery")
+    feats = {"observation.images.top": PolicyFeature(FeatureType.VISUAL, (3, 64, 64)),
+             "observation.state": PolicyFeature(FeatureType.STATE, (14,))}
+    cfg = LRConfig(vlm_model_name="synthetic:tiny:77", hidden_dim=32, fusion_dim=32, dropout=0.0, input_features=feats,
+                   output_features={"action": PolicyFeature(FeatureType.ACTION, (14,))})
+    pol = LRPolicy(cfg).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    batch = {"observation.images.top": torch.rand(2, 3, 64, 64, generator=g).to(DEV), "observation.state": torch.randn(2, 14, generator=g).to(DEV),
+             "action": torch.randn(2, 1, 14, generator=g).to(DEV), "task": "push"}
+    loss, info = pol.forward(batch)
+    loss.backward()
+    assert info["loss"] == info["mse"] == pytest.approx(float(loss)) and pol.model.action_head.weight.grad is not None
+    chunk = pol.predict_action_chunk(batch)
+    assert chunk.shape == (2, 1, 14)
+    a = pol.select_action(batch)
+    assert a.shape == (2, 14) and torch.allclose(a, chunk[:, 0])

@@ -1,0 +1,35 @@
+"""LeRobot pre/post-processor pipelines for FastVLA (reference:
+src/vla_fastvlm/lerobot_fastvla/processor_fastvla.py:22-61).  The steps are LeRobot-owned elementwise
+normalisation (out of scope for the HIP path); this module only assembles them, and needs `lerobot` installed."""
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+
+from ._lerobot_compat import HAVE_LEROBOT
+from .configuration_fastvla import FastVLAConfig
+
+
+def make_fastvla_pre_post_processors(config: FastVLAConfig, dataset_stats: dict[str, dict[str, torch.Tensor]] | None = None):
+    if not HAVE_LEROBOT:
+        raise ModuleNotFoundError("make_fastvla_pre_post_processors needs the `lerobot` package (>=0.4.4)")
+    from lerobot.processor import (AddBatchDimensionProcessorStep, DeviceProcessorStep, NormalizerProcessorStep,
+                                   PolicyAction, PolicyProcessorPipeline, RenameObservationsProcessorStep,
+                                   UnnormalizerProcessorStep)
+    from lerobot.processor.converters import policy_action_to_transition, transition_to_policy_action
+    from lerobot.utils.constants import POLICY_POSTPROCESSOR_DEFAULT_NAME, POLICY_PREPROCESSOR_DEFAULT_NAME
+
+    features = {**config.input_features, **config.output_features}
+    pre = PolicyProcessorPipeline[dict[str, Any], dict[str, Any]](
+        steps=[RenameObservationsProcessorStep(rename_map={}), AddBatchDimensionProcessorStep(),
+               DeviceProcessorStep(device=config.device),
+               NormalizerProcessorStep(features=features, norm_map=config.normalization_mapping, stats=dataset_stats,
+                                       device=config.device)],
+        name=POLICY_PREPROCESSOR_DEFAULT_NAME)
+    post = PolicyProcessorPipeline[PolicyAction, PolicyAction](
+        steps=[UnnormalizerProcessorStep(features=config.output_features, norm_map=config.normalization_mapping,
+                                         stats=dataset_stats), DeviceProcessorStep(device="cpu")],
+        name=POLICY_POSTPROCESSOR_DEFAULT_NAME, to_transition=policy_action_to_transition,
+        to_output=transition_to_policy_action)
+    return pre, post

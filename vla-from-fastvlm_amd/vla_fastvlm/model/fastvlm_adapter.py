@@ -1,0 +1,303 @@
+"""FastVLM backbone on the HIP engine: image canonicalisation, tokenisation, VLM call, pooling.
+
+Mirror of the reference's `vla_fastvlm.model.fastvlm_adapter` (src/vla_fastvlm/model/fastvlm_adapter.py):
+  FastVLMBackboneConfig            :58-80    same fields / defaults
+  FastVLMBackbone.expected_size    :143, resolution order :245-278, tower-name parsing :300-335, too-small guard :145-154
+  FastVLMBackbone.output_dim       :107
+  FastVLMBackbone._prepare_images_tensor :479-488  -> here ON DEVICE (fv_preprocess), no D2H/CPU-resize/H2D round trip
+  FastVLMBackbone._prep_text       :361-380
+  FastVLMBackbone.forward          :501-560  -> fv_vision_forward + fv_llm_forward_pooled (pooling fused, :337-359)
+  resize_with_pad                  :36-55
+Errors keep the reference's types: ValueError (shapes, too-small image_size), RuntimeError (tokenizer missing),
+OSError (weights unreachable).  There is no CPU execution path: forward() needs a HIP device.
+"""
+from __future__ import annotations
+
+import os
+import re
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import nn
+
+from fastvla_hip import FastVLAEngine, FastVLAHipError, arch as fv_arch, weights as fv_weights
+
+from ..tokenization import SyntheticTokenizer
+
+Tensor = torch.Tensor
+
+# Hub ids of the checkpoints the reference documents (README.md:27-40, scripts/download_fastvlm.sh:14-22) -> preset
+_KNOWN_MODELS = {
+    "apple/fastvlm-0.5b": "fastvlm-0.5b", "llava-fastvithd_0.5b_stage3": "fastvlm-0.5b", "llava-fastvithd_0.5b_stage2": "fastvlm-0.5b",
+    "apple/fastvlm-7b": "fastvlm-7b", "llava-fastvithd_7b_stage3": "fastvlm-7b", "llava-fastvithd_7b_stage2": "fastvlm-7b",
+}
+
+
+@dataclass
+class FastVLMBackboneConfig:
+    model_id: str = "apple/FastVLM-0.5B"
+    bootstrap_model_id: str = "apple/FastVLM-0.5B"  # kept for config compatibility; the native loader needs no bootstrap
+    freeze_backbone: bool = True
+    image_feature_pool: str = "last_token"  # or "mean_pool"
+    fallback_image_size: int = 512
+    force_image_size: Optional[int] = None
+    normalize_imagenet: bool = False
+    resize_with_padding: bool = True
+    pad_value: float = 0.0
+    tokenizer_max_length: int = 64
+    pad_to_max_length: bool = False
+    tokenizer_padding_side: str = "right"
+    image_key_order: Tuple[str, ...] = ("images", "pixel_values", "pixel_values_vit")
+
+
+class PreparedPixels(torch.Tensor):
+    """(B,S,S,4) bf16 NHWC pixels already letterboxed on device; `_prepare_images_tensor` is idempotent on it, which
+    is what makes the reference's double image prep (fastvla/processor_fastvla.py:35 then fastvlm_adapter.py:513)
+    a no-op here."""
+
+
+def infer_size_from_tower_name(tower_name: Any) -> Optional[int]:
+    """'mobileclip_l_1024' -> 1024, '...patch14-384' -> 384, 'fastvithd' -> None (reference :300-335)."""
+    if not isinstance(tower_name, str):
+        return None
+    name = tower_name.lower()
+    plausible = lambda v: 64 <= v <= 4096  # noqa: E731
+    for pat in (r"(?:^|[_-])(\d{2,4})$", r"patch\d+[-_](\d{2,4})(?:$|[_-])"):
+        hit = re.search(pat, name)
+        if hit and plausible(int(hit.group(1))):
+            return int(hit.group(1))
+    last = None
+    for hit in re.finditer(r"(\d{2,4})", name):
+        if plausible(int(hit.group(1))) and name[hit.end():hit.end() + 1] not in ("m", "b"):
+            last = int(hit.group(1))  # skip model-scale suffixes such as "so400m"
+    return last
+
+
+def canonical_bchw(images) -> Tensor:
+    """PIL / numpy / tensor in BCHW, BHWC, CHW, HWC, HW or a list of those -> (B,C,H,W), float32 (uint8 batches stay
+    uint8: the kernel converts), values untouched (reference `_as_bchw` :384-442)."""
+    def one(x) -> Tensor:
+        if not torch.is_tensor(x):
+            import numpy as np
+            arr = np.asarray(x)
+            if arr.dtype == object or arr.ndim not in (2, 3):
+                raise TypeError(f"Unsupported image type: {type(x)}")
+            x = torch.from_numpy(arr)
+        if x.ndim == 2:
+            return x.unsqueeze(0).float()
+        if x.ndim != 3:
+            raise ValueError(f"Unsupported tensor shape: {tuple(x.shape)}")
+        return (x if x.shape[0] in (1, 3) else x.permute(2, 0, 1)).float()
+
+    if torch.is_tensor(images) and images.ndim == 4:
+        x = images
+        if x.shape[-1] in (1, 3) and x.shape[1] not in (1, 3):
+            x = x.permute(0, 3, 1, 2)
+        return x if x.dtype == torch.uint8 else x.float()
+    if isinstance(images, (list, tuple)):
+        return torch.stack([one(i) for i in images], dim=0)
+    return one(images).unsqueeze(0)
+
+
+_LB_ENGINES: Dict[Tuple[int, int], FastVLAEngine] = {}
+
+
+def _letterbox_engine(device: torch.device, size: int) -> FastVLAEngine:
+    """fv_preprocess only reads image_size from its handle: a minimal weight-less engine serves the bare function."""
+    key = (device.index or 0, size)
+    if key not in _LB_ENGINES:
+        model = fv_arch.ModelConfig("letterbox", fv_arch.LLMConfig(hidden=64, layers=1, heads=2, kv_heads=1, head_dim=32, inter=64, vocab=64),
+                                    fv_arch.TowerConfig(layers=(1,), dims=(32,), attn_stages=(), image_size=size))
+        _LB_ENGINES[key] = FastVLAEngine(model, hidden_dim=32, fusion_dim=32, device=device, max_batch=1, max_text_tokens=8)
+    return _LB_ENGINES[key]
+
+
+def resize_with_pad(img: Tensor, width: int, height: int, pad_value: float = 0.0) -> Tensor:
+    """Aspect-preserving bilinear resize + top/left padding (reference :36-55) by the HIP letterbox kernel.
+    Square targets (the tower is square); img must live on a HIP device.  Returns (B,3,H,W) float32 holding the bf16
+    pixel values the tower consumes."""
+    if img.ndim != 4:
+        raise ValueError(f"(B,C,H,W) expected, but got shape {tuple(img.shape)}")
+    if width != height or width % 4:
+        raise ValueError("the HIP letterbox kernel produces square outputs with a side that is a multiple of 4")
+    if img.device.type != "cuda":
+        raise FastVLAHipError("resize_with_pad runs on the HIP device; move the tensor to cuda first (no CPU path)")
+    pix = _letterbox_engine(img.device, int(width)).preprocess(img, pad_value, True)
+    return pix[..., :3].permute(0, 3, 1, 2).float()
+
+
+class FastVLMBackbone(nn.Module):
+    """Frozen FastVLM feature extractor `(images, tasks) -> (B, hidden)` running on libfastvla_hip.so."""
+
+    def __init__(self, config: FastVLMBackboneConfig | None = None) -> None:
+        super().__init__()
+        self.config = config or FastVLMBackboneConfig()
+        self.arch, self._weights_source = self._resolve_model(self.config.model_id)
+        self.output_dim = int(self.arch.llm.hidden)
+        self.expected_size = self._resolve_expected_image_size()
+        declared, tower = self._resolve_declared_tower_size()
+        if declared is not None and self.config.force_image_size is not None and int(self.expected_size) < int(declared):
+            raise ValueError(
+                "Configured image_size is too small for this FastVLM vision tower. "
+                f"force_image_size={self.expected_size}, tower={tower}, required>={declared}. "
+                "Set image_size to the declared tower size (e.g. 1024) or leave it unset (None) for auto-detection.")
+        gran = 4 << (len(self.arch.tower.layers) - 1)
+        if self.expected_size % gran:
+            raise ValueError(f"image size {self.expected_size} must be a multiple of {gran} for the FastViT-HD tower")
+        if self.config.tokenizer_padding_side != "right":
+            raise ValueError("the HIP decoder masks RIGHT padding; tokenizer_padding_side must be 'right'")
+        if self.config.image_feature_pool not in ("last_token", "mean_pool"):
+            raise ValueError(f"unknown image_feature_pool '{self.config.image_feature_pool}'")
+        if self.config.normalize_imagenet:
+            raise NotImplementedError("normalize_imagenet=True is not plumbed by the reference's public configs and is "
+                                      "not implemented on the HIP path")
+        self.tokenizer = self._load_tokenizer()
+        self.processor = None
+        self.image_processor = None
+        self.splice_image_tokens = os.environ.get("FASTVLA_SPLICE", "0") == "1"
+        self._engine: Optional[FastVLAEngine] = None
+        self._head_dims = dict(state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024)
+        self._max_batch = int(os.environ.get("FASTVLA_MAX_BATCH", "64"))
+        print(f"[FastVLMBackbone] expected (S,S) = ({self.expected_size},{self.expected_size})")
+
+    # ------------------------------------------------------------------ model / weights resolution
+    @staticmethod
+    def _resolve_model(model_id: str):
+        mid = str(model_id)
+        if mid.startswith("synthetic:"):
+            parts = mid.split(":")
+            seed = int(parts[2]) if len(parts) > 2 else 1234
+            return fv_arch.preset(parts[1]), ("synthetic", seed)
+        path = Path(mid)
+        key = (path.name if path.is_dir() else mid).lower()
+        if path.is_dir():
+            for fn in ("fastvla_hip_weights.pt", "fastvla_hip_weights.safetensors"):
+                if (path / fn).is_file() and key in _KNOWN_MODELS:
+                    return fv_arch.preset(_KNOWN_MODELS[key]), ("file", str(path / fn))
+        if key in _KNOWN_MODELS:
+            if os.environ.get("FASTVLA_SYNTHETIC_WEIGHTS", "0") == "1":
+                return fv_arch.preset(_KNOWN_MODELS[key]), ("synthetic", 1234)
+            raise OSError(
+                f"FastVLM checkpoint '{model_id}' is not reachable (offline, nothing cached) and no re-parameterised "
+                "weight file (fastvla_hip_weights.pt) was found.  Set FASTVLA_SYNTHETIC_WEIGHTS=1 to run the same "
+                "architecture with seeded random weights, or use model_id='synthetic:fastvlm-0.5b'.")
+        raise OSError(f"unknown FastVLM model id '{model_id}' (known: {sorted(set(_KNOWN_MODELS))}, or 'synthetic:<preset>')")
+
+    def _load_tokenizer(self):
+        if self._weights_source[0] != "synthetic":
+            try:
+                from transformers import AutoTokenizer
+                tok = AutoTokenizer.from_pretrained(self.config.model_id, trust_remote_code=False, local_files_only=True)
+                tok.padding_side = self.config.tokenizer_padding_side
+                return tok
+            except Exception:
+                pass
+        return SyntheticTokenizer(self.arch.llm.vocab, padding_side=self.config.tokenizer_padding_side)
+
+    def _resolve_expected_image_size(self) -> int:
+        if self.config.force_image_size is not None:
+            return int(self.config.force_image_size)
+        declared, _ = self._resolve_declared_tower_size()
+        if declared is not None:
+            return int(declared)
+        return int(self.config.fallback_image_size)
+
+    def _resolve_declared_tower_size(self):
+        name = self.arch.tower.name
+        size = infer_size_from_tower_name(name)
+        return (size, name) if size is not None else (None, None)
+
+    _infer_size_from_tower_name = staticmethod(infer_size_from_tower_name)
+
+    # ------------------------------------------------------------------ engine
+    def configure_head(self, *, state_dim: int, action_dim: int, hidden_dim: int, fusion_dim: int) -> None:
+        self._head_dims = dict(state_dim=state_dim, action_dim=action_dim, hidden_dim=hidden_dim, fusion_dim=fusion_dim)
+        self._engine = None
+
+    def engine(self, device: torch.device | None = None) -> FastVLAEngine:
+        """Create (once) the HIP engine on `device` and pack the frozen weights into it."""
+        if self._engine is None:
+            dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+            if dev.type != "cuda":
+                raise FastVLAHipError(f"FastVLMBackbone runs on a HIP device only, got '{dev}' (there is no CPU fallback)")
+            if dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            tower = fv_arch.TowerConfig(**{**self.arch.tower.__dict__, "image_size": int(self.expected_size)})
+            model = fv_arch.ModelConfig(self.arch.name, self.arch.llm, tower)
+            eng = FastVLAEngine(model, device=dev, max_batch=self._max_batch, max_text_tokens=self.config.tokenizer_max_length,
+                                tower_microbatch=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")), **self._head_dims)
+            kind, arg = self._weights_source
+            if kind == "synthetic":
+                state = fv_weights.init_backbone(self.arch, seed=arg)
+            else:
+                state = torch.load(arg, map_location="cpu") if arg.endswith(".pt") else _load_safetensors(arg)
+            eng.load_weights(state)
+            self._engine = eng
+        return self._engine
+
+    # ------------------------------------------------------------------ preprocessing
+    def _prepare_images_tensor(self, images, device: torch.device) -> Tensor:
+        if isinstance(images, PreparedPixels):
+            return images
+        x = canonical_bchw(images)
+        if x.shape[1] not in (1, 3) and x.shape[1] <= 3:
+            raise ValueError(f"unsupported channel count {x.shape[1]}")
+        if x.shape[1] > 4:
+            x = x[:, :3]  # reference _normalize_channels :447-448
+        eng = self.engine(device if torch.device(device).type == "cuda" else None)
+        pix = eng.preprocess(x.to(eng.device), self.config.pad_value, self.config.resize_with_padding)
+        return pix.as_subclass(PreparedPixels)
+
+    def _prep_text(self, tasks: List[str], device: torch.device) -> Dict[str, Tensor]:
+        if self.tokenizer is None:
+            raise RuntimeError("Tokenizer is missing; ensure AutoTokenizer/AutoProcessor is available.")
+        try:
+            self.tokenizer.padding_side = self.config.tokenizer_padding_side
+        except Exception:
+            pass
+        tok = self.tokenizer(list(tasks), padding="max_length" if self.config.pad_to_max_length else "longest",
+                             truncation=True, max_length=self.config.tokenizer_max_length, return_tensors="pt")
+        return {k: v.to(device) for k, v in tok.items()}
+
+    @staticmethod
+    def _pool_hidden(hidden: Tensor, attention_mask: Optional[Tensor], mode: str) -> Tensor:
+        """Torch statement of the pooling the decoder kernel fuses (kept for API parity; reference :337-359)."""
+        if mode == "mean_pool":
+            if attention_mask is None:
+                return hidden.mean(dim=1)
+            m = attention_mask.to(hidden.dtype).unsqueeze(-1)
+            return (hidden * m).sum(dim=1) / m.sum(dim=1).clamp_min(1e-6)
+        if attention_mask is None:
+            return hidden[:, -1, :]
+        idx = (attention_mask.long().sum(dim=1) - 1).clamp_min(0)
+        return hidden[torch.arange(hidden.shape[0], device=hidden.device), idx]
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, images, tasks: List[str], device: torch.device | None = None) -> Tensor:
+        eng = self.engine(device if device is not None and torch.device(device).type == "cuda" else None)
+        pix = self._prepare_images_tensor(images, eng.device)
+        text = self._prep_text(tasks, eng.device)
+        return self.forward_ids(pix, text["input_ids"], text["attention_mask"])
+
+    @torch.no_grad()
+    def forward_ids(self, images, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
+        """Pre-tokenised entry (the benchmark bypasses the host tokenizer): -> pooled (B, hidden) f32."""
+        eng = self.engine()
+        pix = self._prepare_images_tensor(images, eng.device)
+        if pix.shape[0] != input_ids.shape[0]:
+            raise ValueError(f"batch mismatch: {pix.shape[0]} images vs {input_ids.shape[0]} prompts")
+        lens = attention_mask.to(torch.int32).sum(dim=1).to(torch.int32)
+        tok = eng.vision_forward(pix)  # computed even when not spliced: the literal reference runs the tower too
+        mode = 0 if self.config.image_feature_pool == "last_token" else 1
+        return eng.llm_pooled(input_ids, lens, tok if self.splice_image_tokens else None, pool_mode=mode)
+
+    def backbone(self, images, tasks, device: Optional[torch.device] = None, **kwargs):
+        return self.forward(images, tasks, device=device)
+
+
+def _load_safetensors(path: str):
+    from safetensors.torch import load_file
+    return load_file(path)

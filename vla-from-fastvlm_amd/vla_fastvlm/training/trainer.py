@@ -1,0 +1,174 @@
+"""Native trainer for the FastVLA head on the HIP path.
+
+Keeps the reference's `TrainingConfig` fields and `Trainer(model, train_dl, eval_dl, config).fit()` surface
+(src/vla_fastvlm/training/trainer.py:20-51,145-166) but not its machinery: there is no `accelerate`; one process per
+GPU under torch.distributed (RCCL), batches sharded round-robin by rank, and the step body of trainer.py:171-182
+(loss -> backward -> clip_grad_norm_ -> AdamW.step -> LambdaLR.step) is ONE call into libfastvla_hip.so
+(`FastVLAPolicy.fused_train_step`): head forward, MSE, head backward, all-reduce of the flat 12 MB gradient on a side
+stream, fused clip + AdamW.  The frozen backbone never sees a gradient (reference fastvlm_adapter.py:501 wraps it in
+no_grad unconditionally), so this IS the whole trainable path.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from dataclasses import asdict, dataclass, field
+from pathlib import Path
+from typing import Dict, Iterable, Optional
+
+import torch
+
+from ..device import move_batch_to_device
+from .dp import shard_batches
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class TrainingConfig:
+    output_dir: str = "outputs/train"
+    num_epochs: int = 10
+    max_steps: int | None = None
+    gradient_accumulation_steps: int = 1
+    learning_rate: float = 3e-4
+    weight_decay: float = 0.01
+    betas: tuple[float, float] = (0.9, 0.95)
+    eps: float = 1e-8
+    warmup_ratio: float = 0.03
+    max_grad_norm: float = 1.0
+    mixed_precision: str | None = "bf16"  # the HIP path is always bf16 MFMA / fp32 accumulate; kept for CLI parity
+    logging_steps: int = 50
+    eval_steps: int = 500
+    save_steps: int = 1000
+    seed: int = 42
+    resume_from: str | None = None
+    gradient_checkpointing: bool = False
+    report_to: list[str] = field(default_factory=lambda: ["tensorboard"])
+
+
+def linear_warmup_decay(step: int, total_steps: int, warmup_ratio: float) -> float:
+    """LR multiplier of reference trainer.py:233-244."""
+    warm = int(total_steps * warmup_ratio)
+    if step < warm:
+        return step / max(1, warm)
+    return max(0.0, (total_steps - step) / max(1, total_steps - warm))
+
+
+class Trainer:
+    def __init__(self, model: torch.nn.Module, train_dataloader: Iterable[Dict], eval_dataloader: Optional[Iterable[Dict]] = None,
+                 config: TrainingConfig | None = None) -> None:
+        import torch.distributed as dist
+        self.config = config or TrainingConfig()
+        if self.config.gradient_accumulation_steps != 1:
+            raise NotImplementedError("the fused HIP train step applies every batch; gradient_accumulation_steps must be 1")
+        torch.manual_seed(self.config.seed)
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+        self.device = torch.device("cuda", self.local_rank)
+        self.model = model
+        self.train_dataloader = train_dataloader
+        self.eval_dataloader = eval_dataloader
+        self.num_training_steps = self._compute_total_training_steps()
+        self.global_step = 0
+        self.epoch = 0
+        self.last_lr = 0.0
+
+    @property
+    def is_main_process(self) -> bool:
+        return self.rank == 0
+
+    def _shard(self, loader):
+        return shard_batches(loader, self.rank, self.world)
+
+    def _compute_total_training_steps(self) -> int:
+        if self.config.max_steps:
+            return self.config.max_steps
+        if hasattr(self.train_dataloader, "__len__") and len(self.train_dataloader) > 0:
+            per_epoch = max(len(self.train_dataloader) // self.world, 1)
+            return per_epoch * self.config.num_epochs
+        raise ValueError("Unable to infer total training steps from dataloader; please set max_steps.")
+
+    def fit(self) -> None:
+        out = Path(self.config.output_dir)
+        if self.is_main_process:
+            (out / "checkpoints").mkdir(parents=True, exist_ok=True)
+            (out / "logs").mkdir(exist_ok=True)
+            (out / "training_config.json").write_text(json.dumps(asdict(self.config), indent=2))
+        if self.config.resume_from:
+            self._load_checkpoint(self.config.resume_from)
+        for epoch in range(self.config.num_epochs):
+            self.epoch = epoch
+            self._train_one_epoch()
+            if self.global_step >= self.num_training_steps:
+                break
+
+    def _train_one_epoch(self) -> None:
+        cfg = self.config
+        self.model.train()
+        for batch in self._shard(self.train_dataloader):
+            batch = move_batch_to_device(batch, self.device)
+            self.last_lr = cfg.learning_rate * linear_warmup_decay(self.global_step, self.num_training_steps, cfg.warmup_ratio)
+            out = self.model.fused_train_step(batch, lr=self.last_lr, betas=cfg.betas, eps=cfg.eps,
+                                              weight_decay=cfg.weight_decay, max_grad_norm=cfg.max_grad_norm)
+            self.global_step += 1
+            if self.is_main_process and self.global_step % cfg.logging_steps == 0:
+                self._log({"train/loss": float(out["loss"]), "train/mse": float(out["mse"]), "train/lr": self.last_lr,
+                           "train/epoch": self.epoch, "train/grad_norm": float(out["grad_norm"])})
+            if self.global_step % cfg.eval_steps == 0 and self.eval_dataloader is not None:
+                metrics = self.evaluate()
+                if self.is_main_process:
+                    self._log(metrics)
+            if self.global_step % cfg.save_steps == 0:
+                self._save_checkpoint(f"step-{self.global_step}")
+            if (cfg.max_steps and self.global_step >= cfg.max_steps) or self.global_step >= self.num_training_steps:
+                break
+
+    def _log(self, metrics: Dict[str, float]) -> None:
+        rec = {"step": self.global_step, **metrics}
+        logger.info(json.dumps(rec))
+        with open(Path(self.config.output_dir) / "logs" / "metrics.jsonl", "a", encoding="utf-8") as f:
+            f.write(json.dumps(rec) + "\n")
+
+    @torch.no_grad()
+    def evaluate(self) -> Dict[str, float]:
+        if self.eval_dataloader is None:
+            return {}
+        self.model.eval()
+        total, count = 0.0, 0
+        for batch in self.eval_dataloader:
+            batch = move_batch_to_device(batch, self.device)
+            n = batch["actions"].shape[0]
+            total += float(self.model.compute_loss(batch)["mse"]) * n
+            count += n
+        self.model.train()
+        return {"eval/mse": total / max(count, 1)}
+
+    def _save_checkpoint(self, suffix: str) -> None:
+        """Same files as reference trainer.py:246-255: policy_config.json + policy_state_dict.pt (head tensors under the
+        reference's `model.*` keys; the frozen backbone lives in the library and is not duplicated)."""
+        if not self.is_main_process:
+            return
+        d = Path(self.config.output_dir) / "checkpoints" / suffix
+        d.mkdir(parents=True, exist_ok=True)
+        (d / "policy_config.json").write_text(json.dumps(asdict(self.model.config), indent=2))
+        torch.save({k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}, d / "policy_state_dict.pt")
+        st = getattr(self.model, "_opt_state", None)
+        if st is not None:
+            torch.save({"m": st["m"].cpu(), "v": st["v"].cpu(), "step": st["step"], "global_step": self.global_step}, d / "optimizer.pt")
+
+    def _load_checkpoint(self, path: str) -> None:
+        p = Path(path)
+        if not p.exists():
+            raise FileNotFoundError(f"Checkpoint path {path} does not exist.")
+        state = torch.load(p / "policy_state_dict.pt", map_location="cpu")
+        own = self.model.state_dict()
+        self.model.load_state_dict({k: v for k, v in state.items() if k in own}, strict=False)
+        if (p / "optimizer.pt").is_file():
+            self._resume_opt = torch.load(p / "optimizer.pt", map_location="cpu")
+            self.global_step = int(self._resume_opt.get("global_step", 0))
