@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--image", type=int, default=336)
     ap.add_argument("--splice", action="store_true", help="splice the 256 projected image tokens into the LLM sequence")
     ap.add_argument("--microbatch", type=int, default=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")))
+    ap.add_argument("--llm-precision", type=int, default=1, choices=(0, 1),
+                    help="1 = split-bf16 decoder operands + fp32 attention (actions within 1e-3 of the fp32 reference; default); "
+                         "0 = plain bf16 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2)
@@ -73,7 +76,8 @@ def main():
     model = arch.preset(args.model)
     B, T = args.batch, args.tokens
     eng = FastVLAEngine(model, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, device=dev,
-                        max_batch=max(B, args.train_batch), max_text_tokens=T, tower_microbatch=args.microbatch)
+                        max_batch=max(B, args.train_batch), max_text_tokens=T, tower_microbatch=args.microbatch,
+                        llm_precision=args.llm_precision)
     t0 = time.time()
     w = weights.init_backbone(model, seed=1234)  # identical on every rank (frozen replica)
     eng.load_weights(w)
@@ -230,7 +234,8 @@ def main():
                                    f"{T}-token prompt), last-token pool, action head",
                        "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "image": args.image,
                        "parallelism": f"replicas x{world} (no collective on the inference path)",
-                       "splice_image_tokens": bool(args.splice), "tower_microbatch": args.microbatch},
+                       "splice_image_tokens": bool(args.splice), "tower_microbatch": args.microbatch,
+                       "llm_precision": "split-bf16 (hi+lo) operands, fp32 attention" if args.llm_precision else "bf16 operands"},
             "samples_per_s": round(value * B, 2),
             "roofline": roofline, "cpu_baseline": cpu, "train_dp": train,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),

@@ -57,6 +57,10 @@ typedef struct fv_model_desc {
   /* capacity */
   int32_t max_batch, max_text_tokens;
   int32_t tower_microbatch; /* images per tower pass (0 = whole batch) */
+  /* decoder arithmetic: 0 = bf16 MFMA operands (fastest; actions ~8e-3 from the fp32 reference at 0.5B),
+   * 1 = split-bf16 activations (hi + lo, two MFMA passes, exact bf16 weights) + fp32 attention: 16 significant bits on
+   * every GEMM operand, actions within 1e-3 of the fp32 reference (the parity bar of north_star).  Tower unaffected. */
+  int32_t llm_precision;
 } fv_model_desc;
 
 typedef struct fv_tensor_desc {

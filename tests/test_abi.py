@@ -43,7 +43,7 @@ def test_structs_match_header_layout():
     assert C.sizeof(_lib.TensorDesc) == 8 + 8 + 4 + 4 + 32
     assert C.sizeof(_lib.AdamWHParams) == 28
     assert C.sizeof(_lib.ProfileEntry) == 32 and C.sizeof(_lib.GemmProfile) == 32
-    assert C.sizeof(_lib.ModelDesc) == 4 * (7 + 2 + 1 + 3 * 8 + 4 + 2 + 1 + 4 + 3)
+    assert C.sizeof(_lib.ModelDesc) == 4 * (7 + 2 + 1 + 3 * 8 + 4 + 2 + 1 + 4 + 4)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -28,16 +28,27 @@ def _cfgs(m):
     return tc, lc
 
 
-@pytest.fixture(scope="module", params=["tiny", "small"])
+@pytest.fixture(scope="module", params=[("tiny", 1), ("tiny", 0), ("small", 1)], ids=lambda p: f"{p[0]}-prec{p[1]}")
 def rig(request):
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a HIP device")
-    m = arch.preset(request.param)
+    name, prec = request.param
+    m = arch.preset(name)
     w = weights.init_backbone(m, seed=77)
-    eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=64, fusion_dim=96, max_batch=8, max_text_tokens=32)
+    eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=64, fusion_dim=96, max_batch=8, max_text_tokens=32,
+                        llm_precision=prec)
     eng.load_weights(w)
     yield m, w, eng
     eng.close()
+
+
+def _tol(eng, splice=False):
+    """decoder-side tolerance: split-bf16 (llm_precision=1) carries 16 significant bits per GEMM operand -> the 1e-3 bar of
+    north_star with margin; plain bf16 operands (llm_precision=0) accumulate ~2^-9 per layer.  Spliced image tokens bring
+    the tower's bf16 rounding with them in either mode."""
+    if eng.llm_precision == 1 and not splice:
+        return 3e-4
+    return 5e-3 if eng.llm_precision == 1 else 8e-3
 
 
 def test_tower_and_projector(rig):
@@ -63,7 +74,8 @@ def test_tower_microbatch_is_identical(rig):
     torch.manual_seed(2)
     pix = eng.preprocess(torch.rand(4, 3, 64, 64).to(DEV))
     a = eng.vision_forward(pix)
-    eng2 = FastVLAEngine(m, hidden_dim=64, fusion_dim=96, max_batch=8, max_text_tokens=32, tower_microbatch=3)
+    eng2 = FastVLAEngine(m, hidden_dim=64, fusion_dim=96, max_batch=8, max_text_tokens=32, tower_microbatch=3,
+                         llm_precision=eng.llm_precision)
     eng2.load_weights(w)
     b = eng2.vision_forward(pix)
     torch.cuda.synchronize()
@@ -89,7 +101,8 @@ def test_decoder_pooled(rig, splice):
         got = eng.llm_pooled(ids, lens, None if tok is None else tok.to(DEV), pool_mode=mode)
         torch.cuda.synchronize()
         ref = qwen2.llm_pooled(w, ids, mask, lc, tok, splice=splice, pool=name)
-        r, _ = check_close(got.cpu(), ref, rel=5e-3, amax=3e-2, what=f"pooled {name} splice={splice}")
+        # identical (fp32) image tokens on both sides here, so the decoder arithmetic alone is measured
+        r, _ = check_close(got.cpu(), ref, rel=_tol(eng), amax=10 * _tol(eng), what=f"pooled {name} splice={splice}")
         print(f"[{m.name}] pooled {name} splice={splice} rel_l2={r:.2e}")
 
 
@@ -200,5 +213,8 @@ def test_policy_end_to_end(rig, splice):
     ref_loss = head.mse(ref_act, tgt)
     rp, ra = rel_l2(pooled.cpu(), ref_pooled), rel_l2(act.cpu(), ref_act)
     rl = abs(float(loss) - float(ref_loss)) / float(ref_loss)
-    print(f"[{m.name}] splice={splice} pooled rel_l2={rp:.2e} actions rel_l2={ra:.2e} loss rel={rl:.2e}")
-    assert rp <= 5e-3 and ra <= 5e-3 and rl <= 5e-3
+    print(f"[{m.name}] prec={eng.llm_precision} splice={splice} pooled rel_l2={rp:.2e} actions rel_l2={ra:.2e} loss rel={rl:.2e}")
+    tol = _tol(eng, splice)
+    assert rp <= tol and ra <= tol and rl <= 2 * tol
+    if eng.llm_precision == 1 and not splice:  # the reference-literal path in parity mode: north_star's 1e-3 bar
+        assert ra <= 1e-3 and rl <= 1e-3

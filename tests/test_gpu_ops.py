@@ -108,7 +108,8 @@ def test_gemm_rejects_bad_shapes():
 @pytest.mark.parametrize("k,stride,mult,gelu,C,H,W", [(3, 1, 1, 0, 96, 20, 24), (7, 1, 1, 0, 64, 19, 33),
                                                        (3, 2, 1, 1, 32, 32, 32), (7, 2, 2, 1, 64, 24, 24),
                                                        (3, 1, 2, 0, 512, 4, 4), (7, 1, 1, 0, 768, 8, 8),
-                                                       (7, 1, 1, 0, 96, 5, 3)])
+                                                       (7, 1, 1, 0, 96, 5, 3), (7, 1, 1, 0, 96, 40, 64), (3, 1, 1, 0, 32, 33, 47),
+                                                       (7, 1, 1, 1, 192, 16, 32)])
 def test_dwconv(k, stride, mult, gelu, C, H, W):
     torch.manual_seed(k * 100 + C)
     B = 2

@@ -37,8 +37,10 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __rest
   }
 }
 
+// y (+ y_lo when given: x ~= y + y_lo to 16 significant bits, the split-bf16 operand of the parity-mode GEMMs)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       bf16_t* __restrict__ y, int rows, int H, float eps) {
+                                                       bf16_t* __restrict__ y, bf16_t* __restrict__ y_lo, int rows, int H,
+                                                       float eps) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -54,7 +56,15 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     const float4 wa = *reinterpret_cast<const float4*>(w + i), wc = *reinterpret_cast<const float4*>(w + i + 4);
     const float o[8] = {wa.x * (a.x * r), wa.y * (a.y * r), wa.z * (a.z * r), wa.w * (a.w * r),
                         wc.x * (c.x * r), wc.y * (c.y * r), wc.z * (c.z * r), wc.w * (c.w * r)};
-    *reinterpret_cast<uint4*>(y + row * H + i) = pack8(o);
+    const uint4 hi = pack8(o);
+    *reinterpret_cast<uint4*>(y + row * H + i) = hi;
+    if (y_lo) {
+      float h8[8], l8[8];
+      unpack8(hi, h8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
+      *reinterpret_cast<uint4*>(y_lo + row * H + i) = pack8(l8);
+    }
   }
 }
 
@@ -83,6 +93,160 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, con
   }
   *reinterpret_cast<uint4*>(p1) = pack8(oa);
   *reinterpret_cast<uint4*>(p2) = pack8(ob);
+}
+
+// fp32 variant of the RoPE for the parity-mode decoder (qkv kept in fp32): thread = (row, head, 4 d of the first half)
+__global__ __launch_bounds__(256) void rope_f32_kernel(float* __restrict__ qkv, const float2* __restrict__ cs, int ld,
+                                                        long rows, int T, int nheads_total, int D) {
+  const int per_head = D / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * nheads_total * per_head) return;
+  const int c = (int)(i % per_head);
+  const int hh = (int)((i / per_head) % nheads_total);
+  const long row = i / ((long)per_head * nheads_total);
+  const int pos = (int)(row % T);
+  float* p1 = qkv + row * ld + hh * D + c * 4;
+  float* p2 = p1 + D / 2;
+  const float4 a = *reinterpret_cast<const float4*>(p1), b = *reinterpret_cast<const float4*>(p2);
+  const float2* t = cs + (size_t)pos * (D / 2) + c * 4;
+  const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  float oa[4], ob[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    oa[e] = av[e] * t[e].x - bv[e] * t[e].y;
+    ob[e] = bv[e] * t[e].x + av[e] * t[e].y;
+  }
+  *reinterpret_cast<float4*>(p1) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+  *reinterpret_cast<float4*>(p2) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+}
+
+// gate/up accumulators (fp32, columns interleaved [8 gate | 8 up]) -> silu(g)*u split into bf16 hi + lo
+__global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restrict__ gu, bf16_t* __restrict__ hi,
+                                                            bf16_t* __restrict__ lo, long rows, int I) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per 8 outputs
+  const int per_row = I / 8;
+  if (i >= rows * per_row) return;
+  const long row = i / per_row;
+  const int c = (int)(i % per_row);
+  const float* src = gu + row * (2L * I) + c * 16;
+  float g[8], u[8], o[8], h8[8], l8[8];
+  *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(src);
+  *reinterpret_cast<float4*>(g + 4) = *reinterpret_cast<const float4*>(src + 4);
+  *reinterpret_cast<float4*>(u) = *reinterpret_cast<const float4*>(src + 8);
+  *reinterpret_cast<float4*>(u + 4) = *reinterpret_cast<const float4*>(src + 12);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.0f + __expf(-g[e])) * u[e];
+  const uint4 hv = pack8(o);
+  unpack8(hv, h8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
+  *reinterpret_cast<uint4*>(hi + row * I + c * 8) = hv;
+  *reinterpret_cast<uint4*>(lo + row * I + c * 8) = pack8(l8);
+}
+
+// fp32 causal GQA attention for the parity-mode decoder (T <= a few hundred; 22 GFLOP per step at T = 64): one thread
+// (or NT = D/DPT adjacent lanes) per (query position, q head); K/V chunks of 64 keys staged in LDS as fp32 and read as
+// wave-wide broadcasts; online softmax over groups of 8 keys; output written as bf16 hi + lo for the o-projection.
+template <int DPT, int NT>
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out_hi,
+                                                             bf16_t* __restrict__ out_lo, const int32_t* __restrict__ lens,
+                                                             int len_add, int ld, int T, int heads, int kv_heads, int QT,
+                                                             float scale) {
+  constexpr int D = DPT * NT;
+  extern __shared__ __attribute__((aligned(16))) float skv[];  // [2][64][D]
+  float* sK = skv;
+  float* sV = skv + 64 * D;
+  const int G = heads / kv_heads;
+  const int qtiles = (T + QT - 1) / QT;
+  int bid = blockIdx.x;
+  const int qt = bid % qtiles; bid /= qtiles;
+  const int hk = bid % kv_heads;
+  const int b = bid / kv_heads;
+  const int tid = threadIdx.x;
+  const int part = tid % NT, rowid = tid / NT;       // rowid in [0, QT*G)
+  const int pos_l = rowid % QT, hl = rowid / QT;
+  const bool active = hl < G;
+  const int pos = qt * QT + pos_l;
+  const int h = hk * G + (active ? hl : 0);
+  int len = lens ? lens[b] + len_add : T;
+  len = max(1, min(len, T));
+  const int qd = heads * D, kd = kv_heads * D;
+  float q[DPT], acc[DPT];
+  {
+    const float* qp = qkv + ((size_t)b * T + min(pos, T - 1)) * ld + h * D + part * DPT;
+#pragma unroll
+    for (int d = 0; d < DPT; d += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(qp + d);
+      q[d] = v.x * scale; q[d + 1] = v.y * scale; q[d + 2] = v.z * scale; q[d + 3] = v.w * scale;
+    }
+#pragma unroll
+    for (int d = 0; d < DPT; ++d) acc[d] = 0.f;
+  }
+  float m_run = -1e30f, l_run = 0.f;
+  const int kend = min(len, qt * QT + QT);   // causal: keys beyond the tile's last query are never visible
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * D / 4; i += 256) {
+      const int key = i / (D / 4), c4 = i % (D / 4);
+      const int krow = min(k0 + key, T - 1);
+      const float* base = qkv + ((size_t)b * T + krow) * ld + qd + hk * D + c4 * 4;
+      *reinterpret_cast<float4*>(sK + key * D + c4 * 4) = *reinterpret_cast<const float4*>(base);
+      *reinterpret_cast<float4*>(sV + key * D + c4 * 4) = *reinterpret_cast<const float4*>(base + kd);
+    }
+    __syncthreads();
+    const int kmax = min(64, kend - k0);
+    for (int j0 = 0; j0 < kmax; j0 += 8) {
+      float sc[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float* kr = sK + (j0 + jj) * D + part * DPT;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < DPT; d += 4) {
+          const float4 kv = *reinterpret_cast<const float4*>(kr + d);
+          s += q[d] * kv.x + q[d + 1] * kv.y + q[d + 2] * kv.z + q[d + 3] * kv.w;
+        }
+        if (NT == 2) s += __shfl_xor(s, 1, 64);
+        const int kg = k0 + j0 + jj;
+        sc[jj] = (kg <= pos && kg < len) ? s : -1e30f;
+      }
+      float gm = sc[0];
+#pragma unroll
+      for (int jj = 1; jj < 8; ++jj) gm = fmaxf(gm, sc[jj]);
+      const float m_new = fmaxf(m_run, gm);
+      const float alpha = __expf(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DPT; ++d) acc[d] *= alpha;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float pv = sc[jj] > -1e29f ? __expf(sc[jj] - m_new) : 0.f;
+        l_run += pv;
+        const float* vr = sV + (j0 + jj) * D + part * DPT;
+#pragma unroll
+        for (int d = 0; d < DPT; d += 4) {
+          const float4 vv = *reinterpret_cast<const float4*>(vr + d);
+          acc[d] += pv * vv.x; acc[d + 1] += pv * vv.y; acc[d + 2] += pv * vv.z; acc[d + 3] += pv * vv.w;
+        }
+      }
+    }
+  }
+  if (!active || pos >= T) return;
+  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  const size_t o = ((size_t)b * T + pos) * qd + h * D + part * DPT;
+#pragma unroll
+  for (int d = 0; d < DPT; d += 8) {
+    float v8[8], h8[8], l8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v8[e] = acc[d + e] * inv;
+    const uint4 hv = pack8(v8);
+    unpack8(hv, h8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) l8[e] = v8[e] - h8[e];
+    *reinterpret_cast<uint4*>(out_hi + o + d) = hv;
+    *reinterpret_cast<uint4*>(out_lo + o + d) = pack8(l8);
+  }
 }
 
 // one block per batch row: final RMSNorm on the pooled row(s).  mode 0 = last_token, 1 = mean over valid rows.
@@ -123,10 +287,49 @@ int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* im
   return FV_OK;
 }
 
-int launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int H, float eps, hipStream_t s) {
+int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int rows, int H, float eps, hipStream_t s) {
   if (!x || !w || !y) return fv_fail(FV_ERR_ARG, "rmsnorm: null pointer");
   if (rows <= 0 || H <= 0 || H % 8) return fv_fail(FV_ERR_ARG, "rmsnorm: bad shape rows=%d H=%d", rows, H);
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, rows, H, eps);
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, rows, H, eps);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D, hipStream_t s) {
+  if (!qkv || !table) return fv_fail(FV_ERR_ARG, "rope_f32: null pointer");
+  if (rows <= 0 || T <= 0 || D % 8 || ld % 4 || ld < (heads + kv_heads) * D) return fv_fail(FV_ERR_ARG, "rope_f32: bad shape");
+  const long total = (long)rows * (heads + kv_heads) * (D / 8);
+  hipLaunchKernelGGL(rope_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, table, ld, (long)rows, T, heads + kv_heads, D);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_swiglu_split(const float* gu, bf16_t* hi, bf16_t* lo, int rows, int I, hipStream_t s) {
+  if (!gu || !hi || !lo) return fv_fail(FV_ERR_ARG, "swiglu_split: null pointer");
+  if (rows <= 0 || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_split: bad shape");
+  const long total = (long)rows * (I / 8);
+  hipLaunchKernelGGL(swiglu_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gu, hi, lo, (long)rows, I);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_attention_f32(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int B, int T, int heads, int kv_heads,
+                         int D, const int32_t* lens, int len_add, float scale, hipStream_t s) {
+  if (!qkv || !out_hi || !out_lo) return fv_fail(FV_ERR_ARG, "attention_f32: null pointer");
+  if (B <= 0 || T <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads || ld % 4 || ld < (heads + 2 * kv_heads) * D)
+    return fv_fail(FV_ERR_ARG, "attention_f32: bad shape");
+  const int G = heads / kv_heads;
+  const int NT = D == 128 ? 2 : 1;
+  if (D != 32 && D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: head_dim %d not in {32,64,128}", D);
+  if (G * NT > 256) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: too many q heads per kv head (%d)", G);
+  int QT = 1;
+  while (QT * 2 * G * NT <= 256) QT *= 2;
+  const long blocks = (long)B * kv_heads * ((T + QT - 1) / QT);
+  const size_t lds = (size_t)2 * 64 * D * sizeof(float);
+  const dim3 grid((unsigned)blocks), blk(256);
+  if (D == 32) hipLaunchKernelGGL((attention_f32_kernel<32, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, T, heads, kv_heads, QT, scale);
+  else if (D == 64) hipLaunchKernelGGL((attention_f32_kernel<64, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, T, heads, kv_heads, QT, scale);
+  else hipLaunchKernelGGL((attention_f32_kernel<64, 2>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, T, heads, kv_heads, QT, scale);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

@@ -70,7 +70,7 @@ struct DecLayer { float* ln1 = nullptr; bf16_t* qkv_w = nullptr; float* qkv_b = 
 struct Decoder { bf16_t* embed = nullptr; std::vector<DecLayer> layers; float* norm = nullptr; };
 
 struct WsPlan {
-  size_t bufA, bufB, bufH, se, tower_out, x, xn, qkv, att, act, head_scr, total;
+  size_t bufA, bufB, bufH, se, tower_out, x, xn, qkv, att, act, xn_lo, att_lo, act_lo, qkvf, guf, head_scr, total;
 };
 
 // optional per-launch HIP-event timing on the caller's stream (bench.py's roofline numbers); off by default
@@ -229,6 +229,13 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
   p.qkv = take(rows * qkvw * 2);
   p.att = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2);
   p.act = take(rows * d.llm_inter * 2);
+  if (d.llm_precision == 1) {
+    p.xn_lo = take(rows * d.llm_hidden * 2);
+    p.att_lo = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2);
+    p.act_lo = take(rows * d.llm_inter * 2);
+    p.qkvf = take(rows * qkvw * 4);
+    p.guf = take(rows * (size_t)d.llm_inter * 2 * 4);
+  }
   p.head_scr = take(fv::head_bwd_scratch_bytes(h->hd, B));
   p.total = o;
   return p;
@@ -378,6 +385,7 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   if (d.llm_head_dim != 32 && d.llm_head_dim != 64 && d.llm_head_dim != 128) return fv_fail(FV_ERR_UNSUPPORTED, "llm head_dim must be 32/64/128");
   if (d.llm_hidden % 8 || d.llm_inter % 8 || d.llm_heads % d.llm_kv_heads) return fv_fail(FV_ERR_ARG, "llm dims must be multiples of 8 and heads %% kv_heads == 0");
   if (d.tower_out_dim != 2 * d.tower_dims[d.tower_stages - 1] && d.tower_out_dim != d.tower_dims[d.tower_stages - 1]) return fv_fail(FV_ERR_UNSUPPORTED, "tower_out_dim must be 1x or 2x the last stage dim");
+  if (d.llm_precision != 0 && d.llm_precision != 1) return fv_fail(FV_ERR_ARG, "llm_precision must be 0 (bf16) or 1 (split-bf16)");
   if (d.state_dim <= 0 || d.action_dim <= 0 || d.hidden_dim <= 0 || d.fusion_dim <= 0) return fv_fail(FV_ERR_ARG, "head dims must be positive");
   FV_HIP_CHECK(hipSetDevice(device));
   fv_handle* h = new fv_handle();
@@ -599,21 +607,57 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
   const int rows = B * Tt, Hd = d.llm_hidden, D = d.llm_head_dim;
   const int qd = d.llm_heads * D, kd = d.llm_kv_heads * D, qkvw = qd + 2 * kd;
   FV_P(FV_FAM_ELT, 0.0, 6.0 * rows * Hd, fv::launch_embed_gather(ids, h->dec.embed, static_cast<const float*>(img_tokens), x, B, T, Ni, Hd, d.llm_vocab, s));
-  for (const DecLayer& L : h->dec.layers) {
-    FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xn, rows, Hd, d.rms_eps, s));
-    fv::GemmArgs gq{xn, Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkv, qkvw, FV_EPI_BIAS};
-    FV_TRY(gemm_p(h, gq, s));
-    FV_P(FV_FAM_ELT, 3.0 * rows * (qd + kd), 4.0 * rows * (qd + kd), fv::launch_rope(qkv, h->rope, qkvw, rows, Tt, d.llm_heads, d.llm_kv_heads, D, s));
-    FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tt * Tt * qd, 2.0 * rows * (qkvw + qd),
-         fv::launch_attention(qkv, qkv + qd, qkv + qd + kd, qkvw, qkvw, qkvw, att, qd, B, Tt, d.llm_heads, d.llm_kv_heads,
-                              D, 1, lens, Ni, 1.0f / std::sqrt((float)D), s));
-    fv::GemmArgs go{att, qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
-    FV_TRY(gemm_p(h, go, s));
-    FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, rows, Hd, d.rms_eps, s));
-    fv::GemmArgs gg{xn, Hd, L.gu_w, rows, 2 * d.llm_inter, Hd, nullptr, nullptr, nullptr, 0, act, d.llm_inter, FV_EPI_SWIGLU};
-    FV_TRY(gemm_p(h, gg, s));
-    fv::GemmArgs gd{act, d.llm_inter, L.down_w, rows, Hd, d.llm_inter, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
-    FV_TRY(gemm_p(h, gd, s));
+  const float att_scale = 1.0f / std::sqrt((float)D);
+  if (d.llm_precision == 0) {
+    for (const DecLayer& L : h->dec.layers) {
+      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xn, nullptr, rows, Hd, d.rms_eps, s));
+      fv::GemmArgs gq{xn, Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkv, qkvw, FV_EPI_BIAS};
+      FV_TRY(gemm_p(h, gq, s));
+      FV_P(FV_FAM_ELT, 3.0 * rows * (qd + kd), 4.0 * rows * (qd + kd), fv::launch_rope(qkv, h->rope, qkvw, rows, Tt, d.llm_heads, d.llm_kv_heads, D, s));
+      FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tt * Tt * qd, 2.0 * rows * (qkvw + qd),
+           fv::launch_attention(qkv, qkv + qd, qkv + qd + kd, qkvw, qkvw, qkvw, att, qd, B, Tt, d.llm_heads, d.llm_kv_heads,
+                                D, 1, lens, Ni, att_scale, s));
+      fv::GemmArgs go{att, qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+      FV_TRY(gemm_p(h, go, s));
+      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, rows, Hd, d.rms_eps, s));
+      fv::GemmArgs gg{xn, Hd, L.gu_w, rows, 2 * d.llm_inter, Hd, nullptr, nullptr, nullptr, 0, act, d.llm_inter, FV_EPI_SWIGLU};
+      FV_TRY(gemm_p(h, gg, s));
+      fv::GemmArgs gd{act, d.llm_inter, L.down_w, rows, Hd, d.llm_inter, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+      FV_TRY(gemm_p(h, gd, s));
+    }
+  } else {
+    // split-bf16 activations: every GEMM operand x is carried as hi + lo (16 significant bits) and multiplied in two
+    // MFMA passes against the exact bf16 weights; qkv / gate-up accumulators and attention stay fp32.
+    bf16_t* xn_lo = reinterpret_cast<bf16_t*>(ws + wp.xn_lo);
+    bf16_t* att_lo = reinterpret_cast<bf16_t*>(ws + wp.att_lo);
+    bf16_t* act_lo = reinterpret_cast<bf16_t*>(ws + wp.act_lo);
+    float* qkvf = reinterpret_cast<float*>(ws + wp.qkvf);
+    float* guf = reinterpret_cast<float*>(ws + wp.guf);
+    const int I2 = 2 * d.llm_inter;
+    for (const DecLayer& L : h->dec.layers) {
+      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xn, xn_lo, rows, Hd, d.rms_eps, s));
+      fv::GemmArgs q1{xn, Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkvf, qkvw, FV_EPI_F32};
+      FV_TRY(gemm_p(h, q1, s));
+      fv::GemmArgs q2{xn_lo, Hd, L.qkv_w, rows, qkvw, Hd, nullptr, nullptr, qkvf, qkvw, qkvf, qkvw, FV_EPI_RES_F32};
+      FV_TRY(gemm_p(h, q2, s));
+      FV_P(FV_FAM_ELT, 3.0 * rows * (qd + kd), 8.0 * rows * (qd + kd), fv::launch_rope_f32(qkvf, h->rope, qkvw, rows, Tt, d.llm_heads, d.llm_kv_heads, D, s));
+      FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tt * Tt * qd, 4.0 * rows * (qkvw + qd),
+           fv::launch_attention_f32(qkvf, qkvw, att, att_lo, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, Ni, att_scale, s));
+      fv::GemmArgs o1{att, qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+      FV_TRY(gemm_p(h, o1, s));
+      fv::GemmArgs o2{att_lo, qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+      FV_TRY(gemm_p(h, o2, s));
+      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, xn_lo, rows, Hd, d.rms_eps, s));
+      fv::GemmArgs g1{xn, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, guf, I2, FV_EPI_F32};
+      FV_TRY(gemm_p(h, g1, s));
+      fv::GemmArgs g2{xn_lo, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, guf, I2, guf, I2, FV_EPI_RES_F32};
+      FV_TRY(gemm_p(h, g2, s));
+      FV_P(FV_FAM_ELT, 8.0 * rows * d.llm_inter, 12.0 * rows * d.llm_inter, fv::launch_swiglu_split(guf, act, act_lo, rows, d.llm_inter, s));
+      fv::GemmArgs d1{act, d.llm_inter, L.down_w, rows, Hd, d.llm_inter, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+      FV_TRY(gemm_p(h, d1, s));
+      fv::GemmArgs d2{act_lo, d.llm_inter, L.down_w, rows, Hd, d.llm_inter, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+      FV_TRY(gemm_p(h, d2, s));
+    }
   }
   FV_P(FV_FAM_ELT, 4.0 * B * Hd, 8.0 * B * Hd, fv::launch_pool_norm(x, lens, h->dec.norm, static_cast<float*>(pooled), B, Tt, Ni, Hd, d.rms_eps, pool_mode, s));
   return FV_OK;

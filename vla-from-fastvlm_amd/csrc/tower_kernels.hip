@@ -109,21 +109,32 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise conv
-// thread = R=4 outputs along x  x  8 output channels.  Per kernel row the (R-1)*S+K input columns are held in
-// registers as fp32 and every tap's 8 weights are loaded once and used for the R outputs.
+// block = 256 threads over (pixel quads) x (a slice of GS <= 16 channel groups of 8); the slice's weights [k*k][GS*8]
+// fp32 are staged in LDS once per block.  thread = R=4 outputs along x  x  8 output channels.  Per kernel row the 7 (or
+// 3) taps' weights sit in registers and the input columns stream through one at a time (load 16 B, convert once, FMA
+// into every output it feeds), which keeps the kernel near 110 VGPRs (4 waves/SIMD) instead of holding a whole
+// (R+K-1)-column window.
 template <int K, int S, int MULT>
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, bf16_t* __restrict__ y, int B,
-                                                      int H, int W, int C, int Ho, int Wo, int gelu) {
+                                                      int H, int W, int C, int Ho, int Wo, int gelu, int GS,
+                                                      int nslices, long nquads) {
   constexpr int R = 4, NCOL = (R - 1) * S + K, CI = 8 / MULT, PAD = K / 2;
-  const int Cout = C * MULT, G = Cout >> 3, WQ = (Wo + R - 1) / R;
-  long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const int g = (int)(t % G); t /= G;
-  const int xq = (int)(t % WQ); t /= WQ;
-  const int oy = (int)(t % Ho);
-  const long b = t / Ho;
-  if (b >= B) return;
-  const int ox0 = xq * R, co0 = g * 8, ci0 = g * CI;
+  __shared__ __attribute__((aligned(16))) float sw[K * K * 16 * 8];
+  const int Cout = C * MULT, WQ = (Wo + R - 1) / R;
+  const int slice = blockIdx.x % nslices;
+  const long qblock = blockIdx.x / nslices;
+  const int sc = GS * 8;  // channels in this slice
+  for (int i = threadIdx.x; i < K * K * sc; i += 256) sw[i] = w[(size_t)(i / sc) * Cout + slice * sc + (i % sc)];
+  __syncthreads();
+  const int qpb = 256 / GS;
+  const int g = threadIdx.x % GS, ql = threadIdx.x / GS;
+  long q = qblock * qpb + ql;
+  if (ql >= qpb || q >= nquads) return;
+  const int xq = (int)(q % WQ); q /= WQ;
+  const int oy = (int)(q % Ho);
+  const long b = q / Ho;
+  const int ox0 = xq * R, co0 = slice * sc + g * 8, ci0 = co0 / MULT;
   float acc[R][8];
   {
     const float4 b0 = *reinterpret_cast<const float4*>(bias + co0), b1 = *reinterpret_cast<const float4*>(bias + co0 + 4);
@@ -133,33 +144,39 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
       acc[r][4] = b1.x; acc[r][5] = b1.y; acc[r][6] = b1.z; acc[r][7] = b1.w;
     }
   }
-#pragma unroll
+#pragma unroll 1
   for (int ky = 0; ky < K; ++ky) {
     const int iy = oy * S - PAD + ky;
     if (iy < 0 || iy >= H) continue;
+    float wr[K][8];
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const float* wp = sw + (ky * K + kx) * sc + g * 8;
+      const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+      wr[kx][0] = w0.x; wr[kx][1] = w0.y; wr[kx][2] = w0.z; wr[kx][3] = w0.w;
+      wr[kx][4] = w1.x; wr[kx][5] = w1.y; wr[kx][6] = w1.z; wr[kx][7] = w1.w;
+    }
     const bf16_t* rowp = x + ((size_t)b * H + iy) * W * C + ci0;
-    float xin[NCOL][CI];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
       const int ix = ox0 * S - PAD + c;
       const bool ok = ix >= 0 && ix < W;
+      float xv[CI];
       if (MULT == 1) {
         const uint4 u = ok ? *reinterpret_cast<const uint4*>(rowp + (size_t)ix * C) : make_uint4(0, 0, 0, 0);
-        unpack8(u, xin[c]);
+        unpack8(u, xv);
       } else {
         const uint2 u = ok ? *reinterpret_cast<const uint2*>(rowp + (size_t)ix * C) : make_uint2(0, 0);
-        xin[c][0] = bf_lo(u.x); xin[c][1] = bf_hi(u.x); xin[c][2] = bf_lo(u.y); xin[c][3] = bf_hi(u.y);
+        xv[0] = bf_lo(u.x); xv[1] = bf_hi(u.x); xv[2] = bf_lo(u.y); xv[3] = bf_hi(u.y);
       }
-    }
 #pragma unroll
-    for (int kx = 0; kx < K; ++kx) {
-      const float* wp = w + (size_t)(ky * K + kx) * Cout + co0;
-      const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      for (int r = 0; r < R; ++r) {
+        const int kx = c - r * S;  // compile-time after unrolling
+        if (kx >= 0 && kx < K) {
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[r][e] += xin[r * S + kx][e / MULT] * wv[e];
+          for (int e = 0; e < 8; ++e) acc[r][e] += xv[e / MULT] * wr[kx][e];
+        }
+      }
     }
   }
 #pragma unroll
@@ -170,6 +187,87 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
       for (int e = 0; e < 8; ++e) acc[r][e] = gelu_f(acc[r][e]);
     }
     *reinterpret_cast<uint4*>(y + (((size_t)b * Ho + oy) * Wo + ox0 + r) * Cout + co0) = pack8(acc[r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise conv, LDS-tiled
+// stride-1 depthwise k x k for the large feature maps (W >= 32): block = 8 x 32 output pixels x 32 channels.  The
+// (8+k-1) x (32+k-1) x 32ch halo tile is staged ONCE into LDS with 64-byte pixel segments (global side: each input
+// element fetched ~2x from L2, ~1x from HBM), and the 17.5 re-reads per output of the 7x7 window come from LDS as
+// ds_read_b128.  LDS image: pixel = 64 B, plus one 64-B pad every 4 pixels, so the four pixel quads of a 16-lane
+// ds_read_b128 group land on four different 64-B bank windows (conflict-free).  thread = 4 outputs along x x 8 ch.
+template <int K>
+__global__ __launch_bounds__(256, 3) void dwconv_tile_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                           int H, int W, int C, int gelu, int tiles_x, int tiles_y,
+                                                           int nslices) {
+  constexpr int TH = 8, TW = 32, CS = 32, PAD = K / 2, IH = TH + K - 1, IW = TW + K - 1;
+  constexpr int ROWB = IW * 64 + ((IW + 3) / 4) * 64;  // bytes per LDS tile row
+  __shared__ __attribute__((aligned(16))) char smem[IH * ROWB + K * K * CS * 4];
+  float* sw = reinterpret_cast<float*>(smem + IH * ROWB);
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int slice = bid % nslices; bid /= nslices;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int tyb = bid % tiles_y;
+  const long b = bid / tiles_y;
+  const int c0 = slice * CS;
+  for (int i = tid; i < K * K * CS; i += 256) sw[i] = w[(size_t)(i / CS) * C + c0 + (i % CS)];
+  for (int i = tid; i < IH * IW * 4; i += 256) {
+    const int chunk = i & 3, pc = i >> 2;
+    const int col = pc % IW, row = pc / IW;
+    const int iy = tyb * TH - PAD + row, ix = tx * TW - PAD + col;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + chunk * 8);
+    *reinterpret_cast<uint4*>(smem + row * ROWB + col * 64 + (col >> 2) * 64 + chunk * 16) = v;
+  }
+  __syncthreads();
+  const int g = tid & 3, qx = (tid >> 2) & 7, r_ = tid >> 5;
+  const int oy = tyb * TH + r_, ox0 = tx * TW + qx * 4;
+  float acc[4][8];
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + c0 + g * 8), b1 = *reinterpret_cast<const float4*>(bias + c0 + g * 8 + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[r][0] = b0.x; acc[r][1] = b0.y; acc[r][2] = b0.z; acc[r][3] = b0.w;
+      acc[r][4] = b1.x; acc[r][5] = b1.y; acc[r][6] = b1.z; acc[r][7] = b1.w;
+    }
+  }
+#pragma unroll 1
+  for (int ky = 0; ky < K; ++ky) {
+    float wr[K][8];
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const float* wp = sw + (ky * K + kx) * CS + g * 8;
+      const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+      wr[kx][0] = w0.x; wr[kx][1] = w0.y; wr[kx][2] = w0.z; wr[kx][3] = w0.w;
+      wr[kx][4] = w1.x; wr[kx][5] = w1.y; wr[kx][6] = w1.z; wr[kx][7] = w1.w;
+    }
+    const char* rowp = smem + (r_ + ky) * ROWB + g * 16;
+#pragma unroll
+    for (int c = 0; c < K + 3; ++c) {
+      const int col = qx * 4 + c;
+      float xv[8];
+      unpack8(*reinterpret_cast<const uint4*>(rowp + col * 64 + (col >> 2) * 64), xv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kx = c - r;
+        if (kx >= 0 && kx < K) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[r][e] += xv[e] * wr[kx][e];
+        }
+      }
+    }
+  }
+  if (oy >= H) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (ox0 + r >= W) break;
+    if (gelu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[r][e] = gelu_f(acc[r][e]);
+    }
+    *reinterpret_cast<uint4*>(y + (((size_t)b * H + oy) * W + ox0 + r) * C + c0 + g * 8) = pack8(acc[r]);
   }
 }
 
@@ -305,12 +403,28 @@ int launch_dwconv(const bf16_t* x, const float* w, const float* bias, bf16_t* y,
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C * mult) % 8) return fv_fail(FV_ERR_ARG, "dwconv: bad shape C=%d mult=%d", C, mult);
   const int pad = k / 2;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (stride == 1 && mult == 1 && (k == 3 || k == 7) && W >= 32 && C % 32 == 0) {  // large maps: LDS-tiled variant
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8, nsl = C / 32;
+    const long nblk = (long)B * tiles_x * tiles_y * nsl;
+    if (nblk > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv: grid too large");
+    if (k == 7) hipLaunchKernelGGL(dwconv_tile_kernel<7>, dim3((unsigned)nblk), dim3(256), 0, s, x, w, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
+    else hipLaunchKernelGGL(dwconv_tile_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, s, x, w, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+  }
   const int G = C * mult / 8, WQ = (Wo + 3) / 4;
-  const long threads = (long)B * Ho * WQ * G;
-  const dim3 grid((unsigned)((threads + 255) / 256));
+  int GS = 1;
+  for (int d = 1; d <= 16; ++d)
+    if (G % d == 0) GS = d;  // largest divisor of G that is <= 16: the block's channel slice
+  const int nslices = G / GS, qpb = 256 / GS;
+  const long nquads = (long)B * Ho * WQ;
+  const long blocks = (nquads + qpb - 1) / qpb * nslices;
+  if (blocks > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv: grid too large");
+  const dim3 grid((unsigned)blocks);
 #define FV_DW(K_, S_, M_)                                                                                        \
   if (k == K_ && stride == S_ && mult == M_) {                                                                   \
-    hipLaunchKernelGGL((dwconv_kernel<K_, S_, M_>), grid, dim3(256), 0, s, x, w, bias, y, B, H, W, C, Ho, Wo, gelu); \
+    hipLaunchKernelGGL((dwconv_kernel<K_, S_, M_>), grid, dim3(256), 0, s, x, w, bias, y, B, H, W, C, Ho, Wo, gelu, \
+                       GS, nslices, nquads);                                                                     \
     FV_HIP_CHECK(hipGetLastError());                                                                             \
     return FV_OK;                                                                                                \
   }

@@ -32,6 +32,7 @@ class ModelDesc(C.Structure):
         ("image_size", C.c_int32),
         ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("hidden_dim", C.c_int32), ("fusion_dim", C.c_int32),
         ("max_batch", C.c_int32), ("max_text_tokens", C.c_int32), ("tower_microbatch", C.c_int32),
+        ("llm_precision", C.c_int32),
     ]
 
 

@@ -31,7 +31,7 @@ def _stream() -> int:
 class FastVLAEngine:
     def __init__(self, model: ModelConfig, *, state_dim: int = 14, action_dim: int = 14, hidden_dim: int = 1024,
                  fusion_dim: int = 1024, device: Optional[torch.device] = None, max_batch: int = 64,
-                 max_text_tokens: int = 64, tower_microbatch: int = 0):
+                 max_text_tokens: int = 64, tower_microbatch: int = 0, llm_precision: int = 1):
         self.lib = _lib.load()  # raises if the HIP library is missing: no fallback
         if not torch.cuda.is_available():
             raise _lib.FastVLAHipError("no HIP device visible: the FastVLA HIP path needs an MI355X (no CPU fallback)")
@@ -52,6 +52,8 @@ class FastVLAEngine:
         d.ln_eps, d.bn_eps, d.image_size = t.ln_eps, t.bn_eps, t.image_size
         d.state_dim, d.action_dim, d.hidden_dim, d.fusion_dim = state_dim, action_dim, hidden_dim, fusion_dim
         d.max_batch, d.max_text_tokens, d.tower_microbatch = max_batch, max_text_tokens, tower_microbatch
+        d.llm_precision = int(llm_precision)
+        self.llm_precision = int(llm_precision)
         self.desc = d
         h = C.c_void_p()
         with torch.cuda.device(self.device):
