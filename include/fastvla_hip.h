@@ -174,6 +174,12 @@ int fv_op_rope(void* qkv, int ld, int rows, int T, int heads, int kv_heads, int 
 int fv_op_se_gelu(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
                   float* scratch, int B, int P, int C, int R, fv_stream s);
 
+/* fused ConvFFN pointwise half: out (M,C) bf16 = res + ls * (fc2(gelu(fc1(x) + b1)) + b2), hidden = 4C never leaves the
+ * chip.  w1 (4C,C) bf16; w2p = fc2 weight (C,4C) re-laid as [4C/32][C][32] with slot 8g+j of each 32-block holding
+ * hidden 16*(j>>2) + 4*g + (j&3).  C in {32,64,96,128,192,384}.  out may alias res, not x. */
+int fv_op_convffn(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2, const float* ls,
+                  const void* res, void* out, int M, int C, fv_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -267,3 +267,33 @@ def test_se_gelu_tail():
                              b2d.data_ptr(), y.data_ptr(), scratch.data_ptr(), B, P, Cc, R, stream()), "se_gelu")
     torch.cuda.synchronize()
     check_close(y.float().cpu(), ref, what="se+gelu")
+
+
+def _pack_w2(w2):
+    """fc2 weight (C, 4C) -> [4C/32][C][32], slot 8g+j of each 32-block = hidden 16*(j>>2) + 4*g + (j&3) (fastvla_hip.h)."""
+    Cc, Hd = w2.shape
+    idx = torch.tensor([16 * (j >> 2) + 4 * g + (j & 3) for g in range(4) for j in range(8)])
+    return w2.view(Cc, Hd // 32, 32)[:, :, idx].permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("Cc,M", [(96, 1000), (192, 300), (384, 130), (32, 520), (64, 77), (128, 256)])
+def test_fused_convffn(Cc, M):
+    torch.manual_seed(Cc + M)
+    Hd = 4 * Cc
+    x, res = bf(torch.randn(M, Cc)), bf(torch.randn(M, Cc))
+    w1, w2 = bf(torch.randn(Hd, Cc) / math.sqrt(Cc)), bf(torch.randn(Cc, Hd) / math.sqrt(Hd))
+    b1, b2, ls = torch.randn(Hd) * 0.1, torch.randn(Cc) * 0.1, torch.rand(Cc) * 0.3 + 0.05
+    hid = bf(F.gelu(x.double() @ w1.double().t() + b1.double()).float())  # the kernel rounds the hidden to bf16 too
+    ref = (res.double() + ls.double() * (hid.double() @ w2.double().t() + b2.double())).float()
+    xd, rd, w1d, w2d = dev_bf16(x), dev_bf16(res), dev_bf16(w1), dev_bf16(_pack_w2(w2))
+    b1d, b2d, lsd = dev_f32(b1), dev_f32(b2), dev_f32(ls)
+    out = torch.full((M, Cc), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_convffn(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
+                             rd.data_ptr(), out.data_ptr(), M, Cc, stream()), "fv_op_convffn")
+    torch.cuda.synchronize()
+    check_close(out.float().cpu(), ref, what=f"fused convffn C={Cc}")
+    # in place on the residual buffer (how the engine calls it)
+    call(lib().fv_op_convffn(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
+                             rd.data_ptr(), rd.data_ptr(), M, Cc, stream()), "fv_op_convffn in place")
+    torch.cuda.synchronize()
+    assert torch.equal(rd, out)

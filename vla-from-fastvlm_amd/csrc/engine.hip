@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -52,7 +53,7 @@ inline float host_bf2f(bf16_t b) {
   return f;
 }
 
-struct FFN { float *dw_w = nullptr, *dw_b = nullptr; bf16_t* fc1_w = nullptr; float* fc1_b = nullptr; bf16_t* fc2_w = nullptr; float *fc2_b = nullptr, *ls = nullptr; };
+struct FFN { float *dw_w = nullptr, *dw_b = nullptr; bf16_t* fc1_w = nullptr; float* fc1_b = nullptr; bf16_t* fc2_w = nullptr; float *fc2_b = nullptr, *ls = nullptr; bf16_t* w2p = nullptr; };
 struct Block {
   float *mix_w = nullptr, *mix_b = nullptr;                           // RepMixer
   float *ln_w = nullptr, *ln_b = nullptr; bf16_t *qkv_w = nullptr, *proj_w = nullptr; float *proj_b = nullptr, *ls1 = nullptr;  // attention
@@ -102,6 +103,7 @@ struct fv_handle {
   size_t ws_bytes = 0;
   fv::HeadDims hd;
   Profiler prof;
+  bool no_fused_ffn = false;  // FASTVLA_NO_FUSED_FFN=1: A/B switch back to the two-GEMM ConvFFN
 };
 
 namespace {
@@ -189,6 +191,14 @@ int load_ffn(Loader& L, const std::string& pre, int C, int hidden, float bn_eps,
   f.fc1_w = L.mat(pre + "fc1.weight", hidden, C);
   f.fc1_b = L.vec(pre + "fc1.bias", hidden);
   f.fc2_w = L.mat(pre + "fc2.weight", C, hidden);
+  if (hidden == 4 * C && fv::convffn_supported(C, 4)) {  // hidden-permuted, chunk-major copy for the fused kernel
+    std::vector<float> w2, w2p;
+    if (L.expect(pre + "fc2.weight", w2, (size_t)C * hidden)) {
+      w2p.resize(w2.size());
+      fv::convffn_pack_w2(w2.data(), w2p.data(), C, hidden);
+      f.w2p = L.up_bf16(w2p);
+    }
+  }
   f.fc2_b = L.vec(pre + "fc2.bias", C);
   f.ls = L.vec(ls_name, C);
   return L.rc;
@@ -291,6 +301,12 @@ int run_ffn(fv_handle* h, const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t*
   // dw_out = dw7x7(x_dw_in) (+BN folded); hid = gelu(fc1(dw_out)); res_out += ls * fc2(hid)
   const int M = mb * H * W;
   FV_P(FV_FAM_DWCONV, dw_flops(mb, H, W, C, 7), 4.0 * M * C, fv::launch_dwconv(x_dw_in, f.dw_w, f.dw_b, dw_out, mb, H, W, C, 7, 1, 1, 0, s));
+  if (f.w2p && !h->no_fused_ffn) {
+    prof_begin(h, FV_FAM_GEMM, 4.0 * M * C * (double)(C * ratio), 6.0 * M * C, s, M, C, C * ratio, 6);
+    const int rc = fv::launch_convffn(dw_out, f.fc1_w, f.fc1_b, f.w2p, f.fc2_b, f.ls, res_out, res_out, M, C, C * ratio, s);
+    prof_end(h, s);
+    return rc;
+  }
   fv::GemmArgs g1{dw_out, C, f.fc1_w, M, C * ratio, C, f.fc1_b, nullptr, nullptr, 0, hid, C * ratio, FV_EPI_BIAS_GELU};
   FV_TRY(gemm_p(h, g1, s));
   fv::GemmArgs g2{hid, C * ratio, f.fc2_w, M, C, C * ratio, f.fc2_b, f.ls, res_out, C, res_out, C, FV_EPI_LS_RES};
@@ -392,6 +408,7 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   h->d = d;
   h->device = device;
   h->hd = fv::HeadDims{d.llm_hidden, d.state_dim, d.action_dim, d.hidden_dim, d.fusion_dim};
+  if (const char* e = getenv("FASTVLA_NO_FUSED_FFN")) h->no_fused_ffn = e[0] == '1';
   // RoPE table for every position the path can see (text + spliced image tokens)
   const int P = (d.image_size >> (d.tower_stages + 1)) * (d.image_size >> (d.tower_stages + 1));
   h->rope_rows = d.max_text_tokens + P + 8;

@@ -22,6 +22,12 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
+// fused ConvFFN pointwise half: out = res + ls * (fc2(gelu(fc1(x) + b1)) + b2); w1 [4C][C] bf16, w2p = convffn_pack_w2 layout
+bool convffn_supported(int C, int ratio);
+void convffn_pack_w2(const float* w2, float* out, int C, int hidden);
+int launch_convffn(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2p, const float* b2, const float* ls,
+                   const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s);
+
 int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox,
                      bf16_t* pix, hipStream_t s);
 int launch_stem_conv(const bf16_t* pix, const float* w, const float* bias, bf16_t* y, int B, int S, int Cout,
