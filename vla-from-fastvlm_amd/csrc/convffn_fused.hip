@@ -34,6 +34,17 @@ __device__ __forceinline__ void mfma_acc_a(f32x4& acc, const bf16x8& a, const bf
 __device__ __forceinline__ void mfma_acc_v(f32x4& acc, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
+// first k-step of a hidden tile: C = 0 as an inline constant, so no VALU-written zero feeds the MFMA
+__device__ __forceinline__ void mfma_init_v(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+}
+// last k-step of a hidden tile: the GELU (VALU) reads this accumulator next -- hipcc pads nothing after inline asm, so the
+// XDL-write -> VALU-read wait states go inside the statement
+__device__ __forceinline__ void mfma_last_v(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 3" : "+v"(acc) : "v"(a), "v"(b));
+}
+// VALU-written B operand (packed GELU output) -> MFMA read: tie the wait states to the operand
+__device__ __forceinline__ void settle_operand(bf16x8& v) { asm volatile("s_nop 3" : "+v"(v)); }
 
 template <int C, int MT>
 __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
@@ -126,10 +137,6 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
 #pragma unroll
     for (int i = 0; i < PD; ++i) ring[i] = FFN_FRAG(i, w1s, w2s);
     f32x4 hacc[2][MT];
-#pragma unroll
-    for (int ht = 0; ht < 2; ++ht)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) hacc[ht][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 hf[MT];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -139,7 +146,12 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
 #endif
       if (i < 2 * KS) {  // H^T[ht] += W1[ht rows, k-step] . x^T
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) mfma_acc_v(hacc[i / KS][mt], a, xf[mt][i % KS]);
+        for (int mt = 0; mt < MT; ++mt) {
+          if (KS == 1) { mfma_init_v(hacc[i / KS][mt], a, xf[mt][0]); asm volatile("s_nop 7\n\ts_nop 3" : "+v"(hacc[i / KS][mt])); }
+          else if (i % KS == 0) mfma_init_v(hacc[i / KS][mt], a, xf[mt][0]);
+          else if (i % KS == KS - 1) mfma_last_v(hacc[i / KS][mt], a, xf[mt][i % KS]);
+          else mfma_acc_v(hacc[i / KS][mt], a, xf[mt][i % KS]);
+        }
         if (i == 2 * KS - 1) {  // bias + GELU in registers -> B operand of the second product
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
@@ -155,8 +167,8 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
             u.w = pack_bf2(FFN_ACT(hacc[1][mt][2] + bB.z), FFN_ACT(hacc[1][mt][3] + bB.w));
 #undef FFN_ACT
             hf[mt] = __builtin_bit_cast(bf16x8, u);
+            settle_operand(hf[mt]);
           }
-          asm volatile("s_nop 4" ::: "memory");  // VALU-written hf -> MFMA SrcB, and MFMA D (hacc) fully drained
         }
       } else {           // out^T[nt] += W2[nt rows, chunk] . H^T
 #pragma unroll
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
 
 #undef FFN_STAGE_LOAD
 #undef FFN_STAGE_STORE
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // last XDL writes of the output accumulators -> VALU reads below
   // ---- epilogue: lane owns pixel (m0 + mt*16 + fr), output channels nt*16 + 4*fg .. +4
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {

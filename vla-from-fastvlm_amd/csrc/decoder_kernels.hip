@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __rest
 
 // y (+ y_lo when given: x ~= y + y_lo to 16 significant bits, the split-bf16 operand of the parity-mode GEMMs)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       bf16_t* __restrict__ y, bf16_t* __restrict__ y_lo, int rows, int H,
-                                                       float eps) {
+                                                       bf16_t* __restrict__ y, bf16_t* __restrict__ y_lo, int ldy, int rows,
+                                                       int H, float eps) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -57,13 +57,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     const float o[8] = {wa.x * (a.x * r), wa.y * (a.y * r), wa.z * (a.z * r), wa.w * (a.w * r),
                         wc.x * (c.x * r), wc.y * (c.y * r), wc.z * (c.z * r), wc.w * (c.w * r)};
     const uint4 hi = pack8(o);
-    *reinterpret_cast<uint4*>(y + row * H + i) = hi;
+    *reinterpret_cast<uint4*>(y + row * ldy + i) = hi;
     if (y_lo) {
       float h8[8], l8[8];
       unpack8(hi, h8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
-      *reinterpret_cast<uint4*>(y_lo + row * H + i) = pack8(l8);
+      *reinterpret_cast<uint4*>(y_lo + row * ldy + i) = pack8(l8);
     }
   }
 }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void rope_f32_kernel(float* __restrict__ qkv, 
 
 // gate/up accumulators (fp32, columns interleaved [8 gate | 8 up]) -> silu(g)*u split into bf16 hi + lo
 __global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restrict__ gu, bf16_t* __restrict__ hi,
-                                                            bf16_t* __restrict__ lo, long rows, int I) {
+                                                            bf16_t* __restrict__ lo, int ldo, long rows, int I) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per 8 outputs
   const int per_row = I / 8;
   if (i >= rows * per_row) return;
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restri
   unpack8(hv, h8);
 #pragma unroll
   for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
-  *reinterpret_cast<uint4*>(hi + row * I + c * 8) = hv;
-  *reinterpret_cast<uint4*>(lo + row * I + c * 8) = pack8(l8);
+  *reinterpret_cast<uint4*>(hi + row * ldo + c * 8) = hv;
+  *reinterpret_cast<uint4*>(lo + row * ldo + c * 8) = pack8(l8);
 }
 
 // fp32 causal GQA attention for the parity-mode decoder (T <= a few hundred; 22 GFLOP per step at T = 64): one thread
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restri
 template <int DPT, int NT>
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out_hi,
                                                              bf16_t* __restrict__ out_lo, const int32_t* __restrict__ lens,
-                                                             int len_add, int ld, int T, int heads, int kv_heads, int QT,
-                                                             float scale) {
+                                                             int len_add, int ld, int ldo, int T, int heads, int kv_heads,
+                                                             int QT, float scale) {
   constexpr int D = DPT * NT;
   extern __shared__ __attribute__((aligned(16))) float skv[];  // [2][64][D]
   float* sK = skv;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
   }
   if (!active || pos >= T) return;
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-  const size_t o = ((size_t)b * T + pos) * qd + h * D + part * DPT;
+  const size_t o = ((size_t)b * T + pos) * ldo + h * D + part * DPT;
 #pragma unroll
   for (int d = 0; d < DPT; d += 8) {
     float v8[8], h8[8], l8[8];
@@ -287,10 +287,10 @@ int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* im
   return FV_OK;
 }
 
-int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int rows, int H, float eps, hipStream_t s) {
+int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s) {
   if (!x || !w || !y) return fv_fail(FV_ERR_ARG, "rmsnorm: null pointer");
-  if (rows <= 0 || H <= 0 || H % 8) return fv_fail(FV_ERR_ARG, "rmsnorm: bad shape rows=%d H=%d", rows, H);
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, rows, H, eps);
+  if (rows <= 0 || H <= 0 || H % 8 || ldy < H || ldy % 8) return fv_fail(FV_ERR_ARG, "rmsnorm: bad shape rows=%d H=%d ldy=%d", rows, H, ldy);
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, ldy, rows, H, eps);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -304,18 +304,19 @@ int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, in
   return FV_OK;
 }
 
-int launch_swiglu_split(const float* gu, bf16_t* hi, bf16_t* lo, int rows, int I, hipStream_t s) {
+int launch_swiglu_split(const float* gu, bf16_t* hi, bf16_t* lo, int ldo, int rows, int I, hipStream_t s) {
   if (!gu || !hi || !lo) return fv_fail(FV_ERR_ARG, "swiglu_split: null pointer");
-  if (rows <= 0 || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_split: bad shape");
+  if (rows <= 0 || I <= 0 || I % 8 || ldo < I || ldo % 8) return fv_fail(FV_ERR_ARG, "swiglu_split: bad shape");
   const long total = (long)rows * (I / 8);
-  hipLaunchKernelGGL(swiglu_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gu, hi, lo, (long)rows, I);
+  hipLaunchKernelGGL(swiglu_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gu, hi, lo, ldo, (long)rows, I);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
 
-int launch_attention_f32(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int B, int T, int heads, int kv_heads,
-                         int D, const int32_t* lens, int len_add, float scale, hipStream_t s) {
+int launch_attention_f32(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
+                         int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s) {
   if (!qkv || !out_hi || !out_lo) return fv_fail(FV_ERR_ARG, "attention_f32: null pointer");
+  if (ldo < heads * D || ldo % 8) return fv_fail(FV_ERR_ARG, "attention_f32: bad ldo");
   if (B <= 0 || T <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads || ld % 4 || ld < (heads + 2 * kv_heads) * D)
     return fv_fail(FV_ERR_ARG, "attention_f32: bad shape");
   const int G = heads / kv_heads;
@@ -327,9 +328,9 @@ int launch_attention_f32(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_l
   const long blocks = (long)B * kv_heads * ((T + QT - 1) / QT);
   const size_t lds = (size_t)2 * 64 * D * sizeof(float);
   const dim3 grid((unsigned)blocks), blk(256);
-  if (D == 32) hipLaunchKernelGGL((attention_f32_kernel<32, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, T, heads, kv_heads, QT, scale);
-  else if (D == 64) hipLaunchKernelGGL((attention_f32_kernel<64, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, T, heads, kv_heads, QT, scale);
-  else hipLaunchKernelGGL((attention_f32_kernel<64, 2>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, T, heads, kv_heads, QT, scale);
+  if (D == 32) hipLaunchKernelGGL((attention_f32_kernel<32, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, QT, scale);
+  else if (D == 64) hipLaunchKernelGGL((attention_f32_kernel<64, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, QT, scale);
+  else hipLaunchKernelGGL((attention_f32_kernel<64, 2>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, QT, scale);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

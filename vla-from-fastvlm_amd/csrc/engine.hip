@@ -240,9 +240,9 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
   p.att = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2);
   p.act = take(rows * d.llm_inter * 2);
   if (d.llm_precision == 1) {
-    p.xn_lo = take(rows * d.llm_hidden * 2);
-    p.att_lo = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2);
-    p.act_lo = take(rows * d.llm_inter * 2);
+    p.xn_lo = take(rows * d.llm_hidden * 2 * 2);                               // [hi | lo] side by side
+    p.att_lo = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2 * 2);
+    p.act_lo = take(rows * d.llm_inter * 2 * 2);
     p.qkvf = take(rows * qkvw * 4);
     p.guf = take(rows * (size_t)d.llm_inter * 2 * 4);
   }
@@ -289,7 +289,8 @@ int gemm_p(fv_handle* h, const fv::GemmArgs& g, hipStream_t s) {
   double bytes = (M * K + N * K) * 2 + M * (g.epi == FV_EPI_SWIGLU ? N / 2 : N) * (f32o ? 4 : 2);
   if (g.epi == FV_EPI_LS_RES) bytes += M * N * 2;
   if (g.epi == FV_EPI_RES_F32) bytes += M * N * 4;
-  prof_begin(h, FV_FAM_GEMM, 2.0 * M * N * K, bytes, s, g.M, g.N, g.K, g.epi);
+  // algorithmic flops (2MNK) even when ksplit executes the K loop twice for the split-bf16 operand
+  prof_begin(h, FV_FAM_GEMM, 2.0 * M * N * K, bytes + (g.ksplit ? M * K * 2 : 0), s, g.M, g.N, g.ksplit ? -g.K : g.K, g.epi);
   const int rc = fv::launch_gemm(g, s);
   prof_end(h, s);
   return rc;
@@ -627,7 +628,7 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
   const float att_scale = 1.0f / std::sqrt((float)D);
   if (d.llm_precision == 0) {
     for (const DecLayer& L : h->dec.layers) {
-      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xn, nullptr, rows, Hd, d.rms_eps, s));
+      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xn, nullptr, Hd, rows, Hd, d.rms_eps, s));
       fv::GemmArgs gq{xn, Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkv, qkvw, FV_EPI_BIAS};
       FV_TRY(gemm_p(h, gq, s));
       FV_P(FV_FAM_ELT, 3.0 * rows * (qd + kd), 4.0 * rows * (qd + kd), fv::launch_rope(qkv, h->rope, qkvw, rows, Tt, d.llm_heads, d.llm_kv_heads, D, s));
@@ -636,7 +637,7 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
                                 D, 1, lens, Ni, att_scale, s));
       fv::GemmArgs go{att, qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
       FV_TRY(gemm_p(h, go, s));
-      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, rows, Hd, d.rms_eps, s));
+      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s));
       fv::GemmArgs gg{xn, Hd, L.gu_w, rows, 2 * d.llm_inter, Hd, nullptr, nullptr, nullptr, 0, act, d.llm_inter, FV_EPI_SWIGLU};
       FV_TRY(gemm_p(h, gg, s));
       fv::GemmArgs gd{act, d.llm_inter, L.down_w, rows, Hd, d.llm_inter, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
@@ -645,35 +646,28 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
   } else {
     // split-bf16 activations: every GEMM operand x is carried as hi + lo (16 significant bits) and multiplied in two
     // MFMA passes against the exact bf16 weights; qkv / gate-up accumulators and attention stay fp32.
-    bf16_t* xn_lo = reinterpret_cast<bf16_t*>(ws + wp.xn_lo);
-    bf16_t* att_lo = reinterpret_cast<bf16_t*>(ws + wp.att_lo);
-    bf16_t* act_lo = reinterpret_cast<bf16_t*>(ws + wp.act_lo);
+    // hi and lo halves sit side by side ([rows][2K]) so each projection is ONE launch with a doubled K loop (ksplit)
+    bf16_t* xs = reinterpret_cast<bf16_t*>(ws + wp.xn_lo);    // [rows][2*Hd]
+    bf16_t* as = reinterpret_cast<bf16_t*>(ws + wp.att_lo);   // [rows][2*qd]
+    bf16_t* cs = reinterpret_cast<bf16_t*>(ws + wp.act_lo);   // [rows][2*I]
     float* qkvf = reinterpret_cast<float*>(ws + wp.qkvf);
     float* guf = reinterpret_cast<float*>(ws + wp.guf);
-    const int I2 = 2 * d.llm_inter;
+    const int I = d.llm_inter, I2 = 2 * I;
     for (const DecLayer& L : h->dec.layers) {
-      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xn, xn_lo, rows, Hd, d.rms_eps, s));
-      fv::GemmArgs q1{xn, Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkvf, qkvw, FV_EPI_F32};
+      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
+      fv::GemmArgs q1{xs, 2 * Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkvf, qkvw, FV_EPI_F32, 1};
       FV_TRY(gemm_p(h, q1, s));
-      fv::GemmArgs q2{xn_lo, Hd, L.qkv_w, rows, qkvw, Hd, nullptr, nullptr, qkvf, qkvw, qkvf, qkvw, FV_EPI_RES_F32};
-      FV_TRY(gemm_p(h, q2, s));
       FV_P(FV_FAM_ELT, 3.0 * rows * (qd + kd), 8.0 * rows * (qd + kd), fv::launch_rope_f32(qkvf, h->rope, qkvw, rows, Tt, d.llm_heads, d.llm_kv_heads, D, s));
       FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tt * Tt * qd, 4.0 * rows * (qkvw + qd),
-           fv::launch_attention_f32(qkvf, qkvw, att, att_lo, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, Ni, att_scale, s));
-      fv::GemmArgs o1{att, qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+           fv::launch_attention_f32(qkvf, qkvw, as, as + qd, 2 * qd, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, Ni, att_scale, s));
+      fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
       FV_TRY(gemm_p(h, o1, s));
-      fv::GemmArgs o2{att_lo, qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
-      FV_TRY(gemm_p(h, o2, s));
-      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, xn_lo, rows, Hd, d.rms_eps, s));
-      fv::GemmArgs g1{xn, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, guf, I2, FV_EPI_F32};
+      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
+      fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, guf, I2, FV_EPI_F32, 1};
       FV_TRY(gemm_p(h, g1, s));
-      fv::GemmArgs g2{xn_lo, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, guf, I2, guf, I2, FV_EPI_RES_F32};
-      FV_TRY(gemm_p(h, g2, s));
-      FV_P(FV_FAM_ELT, 8.0 * rows * d.llm_inter, 12.0 * rows * d.llm_inter, fv::launch_swiglu_split(guf, act, act_lo, rows, d.llm_inter, s));
-      fv::GemmArgs d1{act, d.llm_inter, L.down_w, rows, Hd, d.llm_inter, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
+      FV_P(FV_FAM_ELT, 8.0 * rows * I, 12.0 * rows * I, fv::launch_swiglu_split(guf, cs, cs + I, I2, rows, I, s));
+      fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
       FV_TRY(gemm_p(h, d1, s));
-      fv::GemmArgs d2{act_lo, d.llm_inter, L.down_w, rows, Hd, d.llm_inter, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32};
-      FV_TRY(gemm_p(h, d2, s));
     }
   }
   FV_P(FV_FAM_ELT, 4.0 * B * Hd, 8.0 * B * Hd, fv::launch_pool_norm(x, lens, h->dec.norm, static_cast<float*>(pooled), B, Tt, Ni, Hd, d.rms_eps, pool_mode, s));

@@ -17,22 +17,27 @@
 namespace fv {
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BN = 128, BK = 64;
 constexpr int LDC = BN + 4;                       // fp32 epilogue image row stride (floats)
-constexpr int LDS_BYTES = BM * LDC * 4;           // 67,584 B >= 2 * (BM+BN) * BK * 2 = 65,536 B
-constexpr int TILE_ELEMS = BM * BK;               // per operand per buffer
 
 struct Params {
   const bf16_t* A; const bf16_t* W; const float* bias; const float* scale; const void* res; void* out;
-  int M, N, K, lda, ldr, ldo, epi, tiles_n, nwg;
+  int M, N, K, lda, ldr, ldo, epi, tiles_n, nwg, ksplit;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 
+// BM = 128: 2x2 waves of 64x64.  BM = 64: 2x2 waves of 32x64, for grids that would otherwise leave CUs idle (the
+// M = B*T = 4096 decoder GEMMs) -- twice the blocks, 3 co-resident per CU.
+template <int BM>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
+  constexpr int MI = BM / 32;                             // 16-row MFMA tiles per wave along M
+  constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
+  constexpr int STAGE_BYTES = 2 * (A_ELEMS + B_ELEMS) * 2, EPI_BYTES = BM * LDC * 4;
+  constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);          // [2][BM*BK]
-  bf16_t* sB = sA + 2 * TILE_ELEMS;                      // [2][BN*BK]
+  bf16_t* sB = sA + 2 * A_ELEMS;                         // [2][BN*BK]
   float* sC = reinterpret_cast<float*>(smem);            // [BM][LDC], reused after the K loop
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -43,34 +48,41 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
 
   // staging map: 4 chunks (16 B) per operand per thread; chunk id c = tid + 256 i -> row c>>3, k-chunk c&7
   const int srow = tid >> 3, skc = tid & 7;
-  uint4 ra[4], rb[4];
+  constexpr int NA = BM / 32;
+  uint4 ra[NA], rb[4];
+  // ksplit: A carries [hi | lo] halves of a split-bf16 operand side by side (2K columns); the second half of the K
+  // loop re-reads the same weight columns, so out = (A_hi + A_lo) . W^T in one launch.
+  const int nk1 = (p.K + BK - 1) / BK;
+  const int nk = p.ksplit ? 2 * nk1 : nk1;
   auto load_tile = [&](int kt) {
-    const int k = kt * BK + skc * 8;
-    const bool kin = k < p.K;
+    const bool second = kt >= nk1;
+    const int kw = (second ? kt - nk1 : kt) * BK + skc * 8;   // weight column
+    const int ka = second ? p.K + kw : kw;                      // activation column
+    const bool kin = kw < p.K;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int gm = bm + srow + 32 * i;
+      ra[i] = (kin && gm < p.M) ? *reinterpret_cast<const uint4*>(p.A + (size_t)gm * p.lda + ka) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = srow + 32 * i;
-      const int gm = bm + r, gn = bn + r;
-      ra[i] = (kin && gm < p.M) ? *reinterpret_cast<const uint4*>(p.A + (size_t)gm * p.lda + k) : make_uint4(0, 0, 0, 0);
-      rb[i] = (kin && gn < p.N) ? *reinterpret_cast<const uint4*>(p.W + (size_t)gn * p.K + k) : make_uint4(0, 0, 0, 0);
+      const int gn = bn + srow + 32 * i;
+      rb[i] = (kin && gn < p.N) ? *reinterpret_cast<const uint4*>(p.W + (size_t)gn * p.K + kw) : make_uint4(0, 0, 0, 0);
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = srow + 32 * i;
-      *reinterpret_cast<uint4*>(sA + buf * TILE_ELEMS + lds_off(r, skc)) = ra[i];
-      *reinterpret_cast<uint4*>(sB + buf * TILE_ELEMS + lds_off(r, skc)) = rb[i];
-    }
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(sA + buf * A_ELEMS + lds_off(srow + 32 * i, skc)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sB + buf * B_ELEMS + lds_off(srow + 32 * i, skc)) = rb[i];
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -79,21 +91,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
-    const bf16_t* a_base = sA + cur * TILE_ELEMS;
-    const bf16_t* b_base = sB + cur * TILE_ELEMS;
+    const bf16_t* a_base = sA + cur * A_ELEMS;
+    const bf16_t* b_base = sB + cur * B_ELEMS;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int chunk = ks * 4 + fq;
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[MI], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ar = wr * 64 + i * 16 + fr;
-        const int br = wc * 64 + i * 16 + fr;
-        fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + lds_off(ar, chunk)));
-        fb[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b_base + lds_off(br, chunk)));
-      }
+      for (int i = 0; i < MI; ++i)
+        fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + lds_off(wr * (BM / 2) + i * 16 + fr, chunk)));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
+        fb[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b_base + lds_off(wc * 64 + i * 16 + fr, chunk)));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
@@ -103,12 +114,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
 
   // ---- epilogue: accumulators -> fp32 LDS image (C/D map: col = lane&15, row = (lane>>4)*4 + reg) ----
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        sC[(wr * 64 + i * 16 + fq * 4 + r) * LDC + wc * 64 + j * 16 + fr] = acc[i][j][r];
+        sC[(wr * (BM / 2) + i * 16 + fq * 4 + r) * LDC + wc * 64 + j * 16 + fr] = acc[i][j][r];
   __syncthreads();
 
   const int epi = p.epi;
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
     // W rows are interleaved [8 gate | 8 up]: 16 accumulator columns -> 8 outputs
     bf16_t* out = static_cast<bf16_t*>(p.out);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BM / 32; ++i) {
       const int c = tid + 256 * i;
       const int row = c >> 3, pr = c & 7;
       const int gm = bm + row, gn = bn + pr * 16;
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < BM / 16; ++i) {
     const int c = tid + 256 * i;
     const int row = c >> 4, cc = c & 15;
     const int gm = bm + row, gn = bn + cc * 8;
@@ -194,10 +205,18 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   Params p;
   p.A = a.A; p.W = a.W; p.bias = a.bias; p.scale = a.scale; p.res = a.res; p.out = a.out;
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi;
-  const int tiles_m = (a.M + BM - 1) / BM;
+  p.ksplit = a.ksplit ? 1 : 0;
+  if (a.ksplit && (a.K % BK || a.lda < 2 * a.K)) return fv_fail(FV_ERR_ARG, "gemm: ksplit needs K %% 64 == 0 and lda >= 2K");
   p.tiles_n = (a.N + BN - 1) / BN;
-  p.nwg = tiles_m * p.tiles_n;
-  hipLaunchKernelGGL(gemm_kernel, dim3(p.nwg), dim3(256), 0, s, p);
+  // pick the row-tile height: 64-row tiles when 128-row tiles would give fewer than two blocks per CU
+  const long blocks128 = (long)((a.M + 127) / 128) * p.tiles_n;
+  if (blocks128 >= 512) {
+    p.nwg = (int)blocks128;
+    hipLaunchKernelGGL(gemm_kernel<128>, dim3(p.nwg), dim3(256), 0, s, p);
+  } else {
+    p.nwg = ((a.M + 63) / 64) * p.tiles_n;
+    hipLaunchKernelGGL(gemm_kernel<64>, dim3(p.nwg), dim3(256), 0, s, p);
+  }
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

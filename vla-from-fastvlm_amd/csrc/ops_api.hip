@@ -32,7 +32,7 @@ int fv_op_attention(const void* q, const void* k, const void* v, int ldq, int ld
 }
 
 int fv_op_rmsnorm(const float* x, const float* w, void* y_bf16, int rows, int H, float eps, fv_stream s) {
-  return fv::launch_rmsnorm(x, w, static_cast<bf16_t*>(y_bf16), nullptr, rows, H, eps, static_cast<hipStream_t>(s));
+  return fv::launch_rmsnorm(x, w, static_cast<bf16_t*>(y_bf16), nullptr, H, rows, H, eps, static_cast<hipStream_t>(s));
 }
 
 int fv_op_rope(void* qkv, int ld, int rows, int T, int heads, int kv_heads, int D, float theta, fv_stream s) {
