@@ -174,6 +174,11 @@ int fv_op_rope(void* qkv, int ld, int rows, int T, int heads, int kv_heads, int 
 int fv_op_se_gelu(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
                   float* scratch, int B, int P, int C, int R, fv_stream s);
 
+/* stride-1 depthwise k x k (k in {3,7}) on the matrix cores (v_mfma_f32_4x4x4_16b_bf16, one 4x4 block per channel);
+ * W >= 32, C % 32 == 0.  ttab = bf16 Toeplitz table [C/16][k][NM=(k+6)/4][16 ch][4 i][4 kk] = w[ky][4m + kk - i] (0 outside
+ * the kernel), i.e. the depthwise weights rounded to bf16. */
+int fv_op_dwconv_mfma(const void* x, const void* ttab, const float* bias, void* y, int B, int H, int W, int C, int k, int gelu,
+                      fv_stream s);
 /* fused ConvFFN pointwise half: out (M,C) bf16 = res + ls * (fc2(gelu(fc1(x) + b1)) + b2), hidden = 4C never leaves the
  * chip.  w1 (4C,C) bf16; w2p = fc2 weight (C,4C) re-laid as [4C/32][C][32] with slot 8g+j of each 32-block holding
  * hidden 16*(j>>2) + 4*g + (j&3).  C in {32,64,96,128,192,384}.  out may alias res, not x. */

@@ -297,3 +297,37 @@ def test_fused_convffn(Cc, M):
                              rd.data_ptr(), rd.data_ptr(), M, Cc, stream()), "fv_op_convffn in place")
     torch.cuda.synchronize()
     assert torch.equal(rd, out)
+
+
+def _toeplitz(w, k):
+    """depthwise weights (C,1,k,k) -> bf16 table [C/16][k][NM][16][4 i][4 kk] = w[ky][4m + kk - i] (fastvla_hip.h)."""
+    Cc = w.shape[0]
+    nm = (k + 6) // 4
+    t = torch.zeros(Cc // 16, k, nm, 16, 4, 4)
+    wv = w.view(Cc // 16, 16, k, k)
+    for m in range(nm):
+        for i in range(4):
+            for kk in range(4):
+                kx = 4 * m + kk - i
+                if 0 <= kx < k:
+                    t[:, :, m, :, i, kk] = wv[:, :, :, kx].permute(0, 2, 1)
+    return t
+
+
+@pytest.mark.parametrize("k,C,H,W,gelu", [(7, 32, 8, 32, 0), (7, 96, 40, 64, 0), (3, 64, 33, 47, 0), (7, 64, 19, 33, 1),
+                                          (3, 192, 16, 32, 0), (7, 384, 24, 40, 0)])
+def test_dwconv_mfma(k, C, H, W, gelu):
+    torch.manual_seed(k * 1000 + C + W)
+    B = 2
+    x = bf(torch.randn(B, C, H, W))
+    w = bf(torch.randn(C, 1, k, k) / k)  # the table stores the weights in bf16
+    b = torch.randn(C) * 0.1
+    ref = F.conv2d(x, w, b, padding=k // 2, groups=C)
+    if gelu:
+        ref = F.gelu(ref)
+    xd, td, bd = dev_bf16(x.permute(0, 2, 3, 1)), dev_bf16(_toeplitz(w, k)), dev_f32(b)
+    y = torch.full((B, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_dwconv_mfma(xd.data_ptr(), td.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, C, k, gelu, stream()),
+         "fv_op_dwconv_mfma")
+    torch.cuda.synchronize()
+    check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"dwconv mfma k{k} C{C} {H}x{W}")

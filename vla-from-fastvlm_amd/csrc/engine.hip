@@ -53,14 +53,14 @@ inline float host_bf2f(bf16_t b) {
   return f;
 }
 
-struct FFN { float *dw_w = nullptr, *dw_b = nullptr; bf16_t* fc1_w = nullptr; float* fc1_b = nullptr; bf16_t* fc2_w = nullptr; float *fc2_b = nullptr, *ls = nullptr; bf16_t* w2p = nullptr; };
+struct FFN { float *dw_w = nullptr, *dw_b = nullptr; bf16_t* fc1_w = nullptr; float* fc1_b = nullptr; bf16_t* fc2_w = nullptr; float *fc2_b = nullptr, *ls = nullptr; bf16_t* w2p = nullptr; bf16_t* dw_t = nullptr; };
 struct Block {
-  float *mix_w = nullptr, *mix_b = nullptr;                           // RepMixer
+  float *mix_w = nullptr, *mix_b = nullptr; bf16_t* mix_t = nullptr;  // RepMixer (+ Toeplitz table for the MFMA path)
   float *ln_w = nullptr, *ln_b = nullptr; bf16_t *qkv_w = nullptr, *proj_w = nullptr; float *proj_b = nullptr, *ls1 = nullptr;  // attention
   FFN ffn;
 };
 struct Down { float *lk_w = nullptr, *lk_b = nullptr; bf16_t* pw_w = nullptr; float* pw_b = nullptr; };
-struct Cpe { float *w = nullptr, *b = nullptr; };
+struct Cpe { float *w = nullptr, *b = nullptr; bf16_t* t = nullptr; };
 struct Tower {
   float *stem0_w = nullptr, *stem0_b = nullptr, *stem1_w = nullptr, *stem1_b = nullptr; bf16_t* stem2_w = nullptr; float* stem2_b = nullptr;
   std::vector<std::vector<Block>> stages; std::vector<Down> downs; std::vector<Cpe> cpes;
@@ -104,6 +104,7 @@ struct fv_handle {
   fv::HeadDims hd;
   Profiler prof;
   bool no_fused_ffn = false;  // FASTVLA_NO_FUSED_FFN=1: A/B switch back to the two-GEMM ConvFFN
+  bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
 };
 
 namespace {
@@ -166,17 +167,23 @@ struct Loader {
   // [N][K] (or [N,K,1,1]) -> bf16
   bf16_t* mat(const std::string& name, size_t n, size_t k) { std::vector<float> v; return expect(name, v, n * k) ? up_bf16(v) : nullptr; }
   // depthwise [Cout,1,k,k] -> tap-major [k*k][Cout] f32, optionally scaled per out-channel (BN fold)
-  float* dw(const std::string& name, int cout, int k, const std::vector<float>* scale = nullptr) {
+  // map_w > 0: also builds the bf16 Toeplitz table of the MFMA depthwise kernel when that kernel serves this layer
+  float* dw(const std::string& name, int cout, int k, const std::vector<float>* scale = nullptr, int map_w = 0, bf16_t** ttab = nullptr) {
     std::vector<float> v;
     if (!expect(name, v, (size_t)cout * k * k)) return nullptr;
     std::vector<float> o((size_t)cout * k * k);
     for (int c = 0; c < cout; ++c)
       for (int t = 0; t < k * k; ++t) o[(size_t)t * cout + c] = v[(size_t)c * k * k + t] * (scale ? (*scale)[c] : 1.0f);
+    if (ttab && fv::dwconv_mfma_supported(map_w, cout, k, 1, 1)) {
+      std::vector<float> tt(fv::dwconv_toeplitz_elems(cout, k));
+      fv::dwconv_toeplitz_pack(o.data(), tt.data(), cout, k);
+      *ttab = up_bf16(tt);
+    }
     return up_f32(o);
   }
 };
 
-int load_ffn(Loader& L, const std::string& pre, int C, int hidden, float bn_eps, FFN& f, const std::string& ls_name) {
+int load_ffn(Loader& L, const std::string& pre, int C, int hidden, float bn_eps, FFN& f, const std::string& ls_name, int map_w) {
   std::vector<float> g, b, m, v;
   if (!L.expect(pre + "conv.bn.weight", g, C) || !L.expect(pre + "conv.bn.bias", b, C) ||
       !L.expect(pre + "conv.bn.running_mean", m, C) || !L.expect(pre + "conv.bn.running_var", v, C))
@@ -186,7 +193,7 @@ int load_ffn(Loader& L, const std::string& pre, int C, int hidden, float bn_eps,
     sc[c] = g[c] / std::sqrt(v[c] + bn_eps);
     bias[c] = b[c] - m[c] * sc[c];
   }
-  f.dw_w = L.dw(pre + "conv.conv.weight", C, 7, &sc);
+  f.dw_w = L.dw(pre + "conv.conv.weight", C, 7, &sc, map_w, &f.dw_t);
   f.dw_b = L.up_f32(bias);
   f.fc1_w = L.mat(pre + "fc1.weight", hidden, C);
   f.fc1_b = L.vec(pre + "fc1.bias", hidden);
@@ -297,11 +304,18 @@ int gemm_p(fv_handle* h, const fv::GemmArgs& g, hipStream_t s) {
 }
 double dw_flops(int B, int Ho, int Wo, int Cout, int k) { return 2.0 * B * Ho * Wo * Cout * k * k; }
 
+// stride-1 depthwise conv: MFMA Toeplitz kernel when a table was packed for this layer, VALU kernels otherwise
+int dw_s1(fv_handle* h, const bf16_t* x, const float* w, const bf16_t* ttab, const float* bias, bf16_t* y, int mb, int H, int C,
+          int k, hipStream_t s) {
+  if (ttab && !h->no_mfma_dw) return fv::launch_dwconv_mfma(x, ttab, bias, y, mb, H, H, C, k, 0, s);
+  return fv::launch_dwconv(x, w, bias, y, mb, H, H, C, k, 1, 1, 0, s);
+}
+
 int run_ffn(fv_handle* h, const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t* hid, bf16_t* res_out, int mb, int H, int W, int C,
             int ratio, hipStream_t s) {
   // dw_out = dw7x7(x_dw_in) (+BN folded); hid = gelu(fc1(dw_out)); res_out += ls * fc2(hid)
   const int M = mb * H * W;
-  FV_P(FV_FAM_DWCONV, dw_flops(mb, H, W, C, 7), 4.0 * M * C, fv::launch_dwconv(x_dw_in, f.dw_w, f.dw_b, dw_out, mb, H, W, C, 7, 1, 1, 0, s));
+  FV_P(FV_FAM_DWCONV, dw_flops(mb, H, W, C, 7), 4.0 * M * C, dw_s1(h, x_dw_in, f.dw_w, f.dw_t, f.dw_b, dw_out, mb, H, C, 7, s));
   if (f.w2p && !h->no_fused_ffn) {
     prof_begin(h, FV_FAM_GEMM, 4.0 * M * C * (double)(C * ratio), 6.0 * M * C, s, M, C, C * ratio, 6);
     const int rc = fv::launch_convffn(dw_out, f.fc1_w, f.fc1_b, f.w2p, f.fc2_b, f.ls, res_out, res_out, M, C, C * ratio, s);
@@ -338,12 +352,12 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float
     const int C = d.tower_dims[i];
     const int M = mb * H * H;
     if (d.tower_is_attn[i]) {
-      FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 7), 4.0 * M * C, fv::launch_dwconv(cur, tw.cpes[i].w, tw.cpes[i].b, oth, mb, H, H, C, 7, 1, 1, 0, s));
+      FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 7), 4.0 * M * C, dw_s1(h, cur, tw.cpes[i].w, tw.cpes[i].t, tw.cpes[i].b, oth, mb, H, C, 7, s));
       std::swap(cur, oth);
     }
     for (const Block& b : tw.stages[i]) {
       if (!d.tower_is_attn[i]) {
-        FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 3), 4.0 * M * C, fv::launch_dwconv(cur, b.mix_w, b.mix_b, oth, mb, H, H, C, 3, 1, 1, 0, s));  // x = RepMixer(x) -> oth
+        FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 3), 4.0 * M * C, dw_s1(h, cur, b.mix_w, b.mix_t, b.mix_b, oth, mb, H, C, 3, s));  // x = RepMixer(x) -> oth
         FV_TRY(run_ffn(h, b.ffn, oth, cur, hid, oth, mb, H, H, C, d.tower_mlp_ratio, s));        // oth += ls * ffn(oth)
         std::swap(cur, oth);
       } else {
@@ -410,6 +424,7 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   h->device = device;
   h->hd = fv::HeadDims{d.llm_hidden, d.state_dim, d.action_dim, d.hidden_dim, d.fusion_dim};
   if (const char* e = getenv("FASTVLA_NO_FUSED_FFN")) h->no_fused_ffn = e[0] == '1';
+  if (const char* e = getenv("FASTVLA_NO_MFMA_DW")) h->no_mfma_dw = e[0] == '1';
   // RoPE table for every position the path can see (text + spliced image tokens)
   const int P = (d.image_size >> (d.tower_stages + 1)) * (d.image_size >> (d.tower_stages + 1));
   h->rope_rows = d.max_text_tokens + P + 8;
@@ -467,9 +482,10 @@ int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n) {
   int idx = 0;  // index into mci.py's `network` ModuleList: [RepCPE?] stage [PatchEmbed]
   for (int i = 0; i < d.tower_stages && L.rc == FV_OK; ++i) {
     const int C = d.tower_dims[i];
+    const int map_w = d.image_size >> (2 + i);  // feature-map side at this stage
     if (d.tower_is_attn[i]) {
       const std::string pre = vt + "network." + std::to_string(idx++) + ".";
-      tw.cpes[i].w = L.dw(pre + "reparam_conv.weight", C, 7);
+      tw.cpes[i].w = L.dw(pre + "reparam_conv.weight", C, 7, nullptr, map_w, &tw.cpes[i].t);
       tw.cpes[i].b = L.vec(pre + "reparam_conv.bias", C);
     }
     const int sidx = idx++;
@@ -484,11 +500,11 @@ int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n) {
         b.proj_w = L.mat(pre + "token_mixer.proj.weight", C, C);
         b.proj_b = L.vec(pre + "token_mixer.proj.bias", C);
         b.ls1 = L.vec(pre + "layer_scale_1", C);
-        load_ffn(L, pre + "convffn.", C, C * d.tower_mlp_ratio, d.bn_eps, b.ffn, pre + "layer_scale_2");
+        load_ffn(L, pre + "convffn.", C, C * d.tower_mlp_ratio, d.bn_eps, b.ffn, pre + "layer_scale_2", map_w);
       } else {
-        b.mix_w = L.dw(pre + "token_mixer.reparam_conv.weight", C, 3);
+        b.mix_w = L.dw(pre + "token_mixer.reparam_conv.weight", C, 3, nullptr, map_w, &b.mix_t);
         b.mix_b = L.vec(pre + "token_mixer.reparam_conv.bias", C);
-        load_ffn(L, pre + "convffn.", C, C * d.tower_mlp_ratio, d.bn_eps, b.ffn, pre + "layer_scale");
+        load_ffn(L, pre + "convffn.", C, C * d.tower_mlp_ratio, d.bn_eps, b.ffn, pre + "layer_scale", map_w);
       }
     }
     if (i + 1 < d.tower_stages) {

@@ -35,6 +35,12 @@ int launch_stem_conv(const bf16_t* pix, const float* w, const float* bias, bf16_
                      hipStream_t s);
 int launch_dwconv(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,
                   int stride, int mult, int gelu, hipStream_t s);
+// MFMA (4x4x4, 16 channel blocks) depthwise conv for stride-1 k in {3,7} on maps with W >= 32; ttab from dwconv_toeplitz_pack
+bool dwconv_mfma_supported(int W, int C, int k, int stride, int mult);
+size_t dwconv_toeplitz_elems(int C, int k);
+void dwconv_toeplitz_pack(const float* w_tapmajor, float* out, int C, int k);
+int launch_dwconv_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,
+                       int gelu, hipStream_t s);
 int launch_layernorm_rows(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int C, float eps,
                           hipStream_t s);
 int launch_se_gelu(const bf16_t* x, const float* w1, const float* b1, const float* w2, const float* b2, bf16_t* y,

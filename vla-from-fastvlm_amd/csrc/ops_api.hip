@@ -54,6 +54,12 @@ int fv_op_se_gelu(const void* x, const float* w1, const float* b1, const float* 
   return fv::launch_se_gelu(static_cast<const bf16_t*>(x), w1, b1, w2, b2, static_cast<bf16_t*>(y), scratch, B, P, C, R, static_cast<hipStream_t>(s));
 }
 
+int fv_op_dwconv_mfma(const void* x, const void* ttab, const float* bias, void* y, int B, int H, int W, int C, int k, int gelu,
+                      fv_stream s) {
+  return fv::launch_dwconv_mfma(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(ttab), bias, static_cast<bf16_t*>(y), B, H, W, C, k,
+                                gelu, static_cast<hipStream_t>(s));
+}
+
 int fv_op_convffn(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2, const float* ls,
                   const void* res, void* out, int M, int C, fv_stream s) {
   return fv::launch_convffn(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w1), b1, static_cast<const bf16_t*>(w2p), b2, ls,

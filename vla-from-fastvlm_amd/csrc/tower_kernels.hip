@@ -271,6 +271,129 @@ __global__ __launch_bounds__(256, 3) void dwconv_tile_kernel(const bf16_t* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------ depthwise conv on MFMA
+// The 7x7 depthwise conv is 49 fp32 FMAs per output element on the VALU (157 TFLOP/s chip-wide against 2.5 PFLOP/s of
+// matrix rate), and it was the second largest item of the step.  Per channel a 1-D convolution along x is a banded
+// (Toeplitz) matrix product, and v_mfma_f32_4x4x4_16b_bf16 multiplies SIXTEEN independent 4x4 blocks per instruction,
+// so one instruction serves 16 channels with no cross-channel mixing:
+//     block = channel c;  A_c[i][k] = w_c[ky][4m + k - i]  (Toeplitz piece: 4 outputs i x 4 input columns k, k-block m)
+//                         B_c[k][j] = x[row r0 + j + ky][col 4(q+m) + k][c]     (4 input columns k x 4 rows j)
+//                         D_c[i][j] += A_c B_c                                   (4 output columns i x 4 rows j)
+// 3 k-blocks cover the 10-column window of 4 outputs: 21 MFMAs per (16 ch x 4 rows x 4 cols), 58 % of their MACs
+// useful, still ~2.3x the VALU's peak rate and freeing the VALU.  The price is layout: operands want 4 consecutive
+// PIXELS of one channel per lane, NHWC gives 8 channels of one pixel per 16 B, so the halo tile is transposed through
+// registers (v_perm_b32) on its way into LDS ([row][column quad][channel][4 columns]) and the 8x32x32 output tile goes
+// back through LDS to leave as 16-byte NHWC stores.  Weights arrive as a precomputed bf16 Toeplitz table.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ttab,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                              int H, int W, int C, int gelu, int tiles_x, int tiles_y,
+                                                              int nslices) {
+  constexpr int TH = 8, TW = 32, PAD = K / 2, IH = TH + K - 1, IW = TW + K - 1;
+  constexpr int NQ = (IW + 3) / 4, NM = (K + 3 + 3) / 4;       // column quads in the halo tile; k-blocks per output quad
+  constexpr int RS = NQ * 256 + 64;                            // LDS bytes per halo row (== 64 mod 256: 4 rows, 4 bank windows)
+  constexpr int T_BYTES = 2 * K * NM * 512, X_BYTES = IH * RS;
+  constexpr int ORS = 32 * 64 + 32;                            // output tile row stride (bytes)
+  constexpr int LDSB = T_BYTES + (X_BYTES > TH * ORS ? X_BYTES : TH * ORS);
+  __shared__ __attribute__((aligned(16))) char smem[LDSB];
+  char* sT = smem;
+  char* sX = smem + T_BYTES;
+  char* sO = sX;  // aliases the halo tile once every wave is done reading it
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int bid = blockIdx.x;
+  const int slice = bid % nslices; bid /= nslices;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int tyb = bid % tiles_y;
+  const long b = bid / tiles_y;
+  const int c0 = slice * 32;
+
+  // ---- Toeplitz table slice (two 16-channel groups, contiguous) -> LDS
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(ttab + (size_t)slice * (T_BYTES / 2));
+    for (int i = tid; i < T_BYTES / 16; i += 256) reinterpret_cast<uint4*>(sT)[i] = src[i];
+  }
+  // ---- halo tile: 4 pixels x 8 channels per task, transposed in registers to 8 channels x 4 pixels
+  for (int task = tid; task < IH * NQ * 4; task += 256) {
+    const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;
+    const int iy = tyb * TH - PAD + row, ix0 = tx * TW - PAD + quad * 4;
+    uint4 px[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ix = ix0 + j;
+      px[j] = (iy >= 0 && iy < H && ix >= 0 && ix < W && quad * 4 + j < IW)
+                  ? *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + cg * 8)
+                  : make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t d[4][4] = {{px[0].x, px[0].y, px[0].z, px[0].w}, {px[1].x, px[1].y, px[1].z, px[1].w},
+                              {px[2].x, px[2].y, px[2].z, px[2].w}, {px[3].x, px[3].y, px[3].z, px[3].w}};
+    char* dst = sX + row * RS + quad * 256 + cg * 64;
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {  // dword dd of a pixel holds channels 2dd (low half) and 2dd+1 (high half)
+      uint2 ev, od;
+      ev.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x05040100u);
+      ev.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x05040100u);
+      od.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x07060302u);
+      od.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x07060302u);
+      *reinterpret_cast<uint2*>(dst + (2 * dd) * 8) = ev;
+      *reinterpret_cast<uint2*>(dst + (2 * dd + 1) * 8) = od;
+    }
+  }
+  __syncthreads();
+
+  // ---- compute: wave = (16-channel group gg, 4 output rows rg); lane = (channel bch = lane>>2, row j = lane&3)
+  const int gg = wid & 1, rg = wid >> 1;
+  const int bch = lane >> 2, jr = lane & 3;
+  s16x4 afr[K][NM];
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+      afr[ky][m] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sT + ((gg * K + ky) * NM + m) * 512 + lane * 8));
+  f32x4 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const char* rowp = sX + (rg * 4 + jr + ky) * RS + (gg * 16 + bch) * 8;
+    s16x4 xq[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(rowp + t * 256));
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+        if (q + m < NQ) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[q + m], acc[q], 0, 0, 0);
+  }
+  __syncthreads();  // all waves are done with the halo tile; reuse it for the output tile
+
+  // ---- bias (+GELU) and NHWC re-layout through LDS: lane holds 4 consecutive columns of one channel per quad
+  {
+    const float bv = bias[c0 + gg * 16 + bch];
+    char* orow = sO + (rg * 4 + jr) * ORS + (gg * 16 + bch) * 2;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[q][i] + bv;
+        if (gelu) v = gelu_f(v);
+        *reinterpret_cast<bf16_t*>(orow + (q * 4 + i) * 64) = f2bf(v);
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;                 // 1024 chunks: row (8) x col (32) x 8-channel chunk (4)
+    const int chunk = c & 3, col = (c >> 2) & 31, row = c >> 7;
+    const int oy = tyb * TH + row, ox = tx * TW + col;
+    if (oy < H && ox < W)
+      *reinterpret_cast<uint4*>(y + (((size_t)b * H + oy) * W + ox) * C + c0 + chunk * 8) =
+          *reinterpret_cast<const uint4*>(sO + row * ORS + col * 64 + chunk * 16);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNormChannel
 // one wave per row (pixel); C <= 2048, C % 8 == 0; two-pass in registers.
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
@@ -431,6 +554,38 @@ int launch_dwconv(const bf16_t* x, const float* w, const float* bias, bf16_t* y,
   FV_DW(3, 1, 1) FV_DW(7, 1, 1) FV_DW(3, 2, 1) FV_DW(7, 2, 2) FV_DW(3, 1, 2)
 #undef FV_DW
   return fv_fail(FV_ERR_UNSUPPORTED, "dwconv: unsupported k=%d stride=%d mult=%d", k, stride, mult);
+}
+
+// bf16 Toeplitz table for dwconv_mfma_kernel: [C/16][K][NM][16 ch][4 out cols i][4 in cols k] = w[ky][4m + k - i]
+size_t dwconv_toeplitz_elems(int C, int k) { return (size_t)(C / 16) * k * ((k + 6) / 4) * 256; }
+void dwconv_toeplitz_pack(const float* w_tapmajor, float* out, int C, int k) {
+  const int NM = (k + 6) / 4;
+  for (int g = 0; g < C / 16; ++g)
+    for (int ky = 0; ky < k; ++ky)
+      for (int m = 0; m < NM; ++m)
+        for (int bch = 0; bch < 16; ++bch)
+          for (int i = 0; i < 4; ++i)
+            for (int kk = 0; kk < 4; ++kk) {
+              const int kx = 4 * m + kk - i;
+              out[((((size_t)(g * k + ky) * NM + m) * 16 + bch) * 4 + i) * 4 + kk] =
+                  (kx >= 0 && kx < k) ? w_tapmajor[(size_t)(ky * k + kx) * C + g * 16 + bch] : 0.0f;
+            }
+}
+bool dwconv_mfma_supported(int W, int C, int k, int stride, int mult) {
+  return stride == 1 && mult == 1 && (k == 3 || k == 7) && W >= 32 && C % 32 == 0;
+}
+
+int launch_dwconv_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,
+                       int gelu, hipStream_t s) {
+  if (!x || !ttab || !bias || !y) return fv_fail(FV_ERR_ARG, "dwconv_mfma: null pointer");
+  if (B <= 0 || H <= 0 || !dwconv_mfma_supported(W, C, k, 1, 1)) return fv_fail(FV_ERR_UNSUPPORTED, "dwconv_mfma: unsupported shape W=%d C=%d k=%d", W, C, k);
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8, nsl = C / 32;
+  const long nblk = (long)B * tiles_x * tiles_y * nsl;
+  if (nblk > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv_mfma: grid too large");
+  if (k == 7) hipLaunchKernelGGL(dwconv_mfma_kernel<7>, dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
+  else hipLaunchKernelGGL(dwconv_mfma_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
 }
 
 int launch_layernorm_rows(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int C, float eps,

@@ -86,6 +86,7 @@ SIGNATURES = {
     "fv_op_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "fv_op_rmsnorm": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "fv_op_rope": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "fv_op_dwconv_mfma": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fv_op_convffn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fv_op_se_gelu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
