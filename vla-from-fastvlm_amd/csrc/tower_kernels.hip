@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_tile_kernel(const bf16_t* __res
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 template <int K>
-__global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ttab,
+__global__ __launch_bounds__(256, 3) void dwconv_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ttab,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                               int H, int W, int C, int gelu, int tiles_x, int tiles_y,
                                                               int nslices) {
@@ -296,11 +296,10 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const bf16_t* __res
   constexpr int RS = NQ * 256 + 64;                            // LDS bytes per halo row (== 64 mod 256: 4 rows, 4 bank windows)
   constexpr int T_BYTES = 2 * K * NM * 512, X_BYTES = IH * RS;
   constexpr int ORS = 32 * 64 + 32;                            // output tile row stride (bytes)
-  constexpr int LDSB = T_BYTES + (X_BYTES > TH * ORS ? X_BYTES : TH * ORS);
+  constexpr int LDSB = X_BYTES > TH * ORS ? X_BYTES : TH * ORS;
   __shared__ __attribute__((aligned(16))) char smem[LDSB];
-  char* sT = smem;
-  char* sX = smem + T_BYTES;
-  char* sO = sX;  // aliases the halo tile once every wave is done reading it
+  char* sX = smem;
+  char* sO = smem;  // aliases the halo tile once every wave is done reading it
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int bid = blockIdx.x;
@@ -309,49 +308,57 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const bf16_t* __res
   const int tyb = bid % tiles_y;
   const long b = bid / tiles_y;
   const int c0 = slice * 32;
+  const int gg = wid & 1, rg = wid >> 1;          // wave = (16-channel group, 4 output rows)
+  const int bch = lane >> 2, jr = lane & 3;       // lane = (channel within the group, row within the 4)
 
-  // ---- Toeplitz table slice (two 16-channel groups, contiguous) -> LDS
+  // ---- Toeplitz fragments straight from the (L2-resident) table into registers: 8 B per lane per (ky, m)
+  s16x4 afr[K][NM];
   {
-    const uint4* src = reinterpret_cast<const uint4*>(ttab + (size_t)slice * (T_BYTES / 2));
-    for (int i = tid; i < T_BYTES / 16; i += 256) reinterpret_cast<uint4*>(sT)[i] = src[i];
+    const char* tsrc = reinterpret_cast<const char*>(ttab) + (size_t)slice * T_BYTES + (size_t)gg * K * NM * 512 + lane * 8;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) afr[ky][m] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(tsrc + (ky * NM + m) * 512));
   }
-  // ---- halo tile: 4 pixels x 8 channels per task, transposed in registers to 8 channels x 4 pixels
-  for (int task = tid; task < IH * NQ * 4; task += 256) {
+  // ---- halo tile: 4 pixels x 8 channels per task, transposed in registers to 8 channels x 4 pixels.  All of a
+  // thread's loads are issued before any is consumed (one exposed HBM/L2 latency per block instead of one per task).
+  constexpr int NTASK = IH * NQ * 4, TPT = (NTASK + 255) / 256;
+  uint4 px[TPT][4];
+#pragma unroll
+  for (int tt = 0; tt < TPT; ++tt) {
+    const int task = tid + 256 * tt;
     const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;
     const int iy = tyb * TH - PAD + row, ix0 = tx * TW - PAD + quad * 4;
-    uint4 px[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ix = ix0 + j;
-      px[j] = (iy >= 0 && iy < H && ix >= 0 && ix < W && quad * 4 + j < IW)
-                  ? *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + cg * 8)
-                  : make_uint4(0, 0, 0, 0);
+      px[tt][j] = (task < NTASK && iy >= 0 && iy < H && ix >= 0 && ix < W && quad * 4 + j < IW)
+                      ? *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + cg * 8)
+                      : make_uint4(0, 0, 0, 0);
     }
-    const uint32_t d[4][4] = {{px[0].x, px[0].y, px[0].z, px[0].w}, {px[1].x, px[1].y, px[1].z, px[1].w},
-                              {px[2].x, px[2].y, px[2].z, px[2].w}, {px[3].x, px[3].y, px[3].z, px[3].w}};
-    char* dst = sX + row * RS + quad * 256 + cg * 64;
+  }
 #pragma unroll
-    for (int dd = 0; dd < 4; ++dd) {  // dword dd of a pixel holds channels 2dd (low half) and 2dd+1 (high half)
-      uint2 ev, od;
-      ev.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x05040100u);
-      ev.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x05040100u);
-      od.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x07060302u);
-      od.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x07060302u);
-      *reinterpret_cast<uint2*>(dst + (2 * dd) * 8) = ev;
-      *reinterpret_cast<uint2*>(dst + (2 * dd + 1) * 8) = od;
+  for (int tt = 0; tt < TPT; ++tt) {
+    const int task = tid + 256 * tt;
+    if (task < NTASK) {
+      const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;
+      const uint32_t d[4][4] = {{px[tt][0].x, px[tt][0].y, px[tt][0].z, px[tt][0].w}, {px[tt][1].x, px[tt][1].y, px[tt][1].z, px[tt][1].w},
+                                {px[tt][2].x, px[tt][2].y, px[tt][2].z, px[tt][2].w}, {px[tt][3].x, px[tt][3].y, px[tt][3].z, px[tt][3].w}};
+      char* dst = sX + row * RS + quad * 256 + cg * 64;
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {  // dword dd of a pixel holds channels 2dd (low half) and 2dd+1 (high half)
+        uint2 ev, od;
+        ev.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x05040100u);
+        ev.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x05040100u);
+        od.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x07060302u);
+        od.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x07060302u);
+        *reinterpret_cast<uint2*>(dst + (2 * dd) * 8) = ev;
+        *reinterpret_cast<uint2*>(dst + (2 * dd + 1) * 8) = od;
+      }
     }
   }
   __syncthreads();
 
-  // ---- compute: wave = (16-channel group gg, 4 output rows rg); lane = (channel bch = lane>>2, row j = lane&3)
-  const int gg = wid & 1, rg = wid >> 1;
-  const int bch = lane >> 2, jr = lane & 3;
-  s16x4 afr[K][NM];
-#pragma unroll
-  for (int ky = 0; ky < K; ++ky)
-#pragma unroll
-    for (int m = 0; m < NM; ++m)
-      afr[ky][m] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sT + ((gg * K + ky) * NM + m) * 512 + lane * 8));
   f32x4 acc[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
