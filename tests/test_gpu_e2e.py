@@ -218,3 +218,28 @@ def test_policy_end_to_end(rig, splice):
     assert rp <= tol and ra <= tol and rl <= 2 * tol
     if eng.llm_precision == 1 and not splice:  # the reference-literal path in parity mode: north_star's 1e-3 bar
         assert ra <= 1e-3 and rl <= 1e-3
+
+
+def test_7b_shaped_decoder_layers():
+    """FastVLM-7B decoder geometry (hidden 3584, 28 q / 4 kv heads of 128, inter 18944) on 2 layers and a reduced vocab:
+    exercises the K = 3584 / 18944 GEMM shapes and the head_dim-128 attention paths (BASELINE.json configs[3] shapes)."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    llm = arch.LLMConfig(hidden=3584, layers=2, heads=28, kv_heads=4, head_dim=128, inter=18944, vocab=4096)
+    m = arch.ModelConfig("7b-2layer", llm, arch.preset("tiny").tower)
+    w = weights.init_backbone(m, seed=3)
+    lc = qwen2.Qwen2Cfg(hidden=3584, layers=2, heads=28, kv_heads=4, head_dim=128, inter=18944, vocab=4096)
+    torch.manual_seed(4)
+    B, T = 3, 20
+    ids = torch.randint(0, 4096, (B, T))
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, 13:] = 0
+    ref = qwen2.llm_pooled(w, ids, mask, lc)
+    for prec, tol in ((1, 3e-4), (0, 2e-2)):  # plain bf16 operands at K = 3584..18944: ~1e-2, the reason parity mode exists
+        eng = FastVLAEngine(m, hidden_dim=64, fusion_dim=64, max_batch=4, max_text_tokens=32, llm_precision=prec)
+        eng.load_weights(w)
+        got = eng.llm_pooled(ids, mask.sum(1))
+        torch.cuda.synchronize()
+        r, _ = check_close(got.cpu(), ref, rel=tol, amax=10 * tol, what=f"7B-shaped pooled prec={prec}")
+        print(f"[7b-2layer] prec={prec} pooled rel_l2={r:.2e}")
+        eng.close()
