@@ -178,7 +178,7 @@ def main():
     families = {k: {"ms_per_step": round(v["ms"] / ps, 3), "launches": v["launches"] // ps,
                     "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
                     "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in fams.items() if v["launches"]}
-    top = sorted(shapes, key=lambda r: -r["ms"])[:12]
+    top = sorted(shapes, key=lambda r: -r["ms"])[:30]
     gemm_shapes = [{"mnk": [r["m"], r["n"], r["k"]], "epi": r["epi"], "ms_per_step": round(r["ms"] / ps, 3),
                     "n": r["launches"] // ps,
                     "tflops": round(_fl(r) / max(r["ms"], 1e-9) / 1e9, 1)} for r in top]

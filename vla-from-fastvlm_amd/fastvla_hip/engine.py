@@ -6,6 +6,7 @@ buffers with torch's caching allocator, hand raw pointers and the current HIP st
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -60,6 +61,8 @@ class FastVLAEngine:
             _lib.check(self.lib.fv_create(C.byref(d), self.device.index or 0, C.byref(h)), "fv_create")
         self.h = h
         self._ws: Optional[torch.Tensor] = None
+        self._side: Optional[torch.cuda.Stream] = None
+        self.overlap_streams = os.environ.get("FASTVLA_OVERLAP", "1") == "1"
         offs = (C.c_int64 * 13)()
         _lib.check(self.lib.fv_head_layout(self.h, C.byref(offs)), "fv_head_layout")
         self.head_offsets = list(offs)
@@ -160,11 +163,25 @@ class FastVLAEngine:
         behaviour: the image tokens are computed and not consumed."""
         B, T = ids.shape
         self.ensure_workspace(B, T, splice)
-        tok = None
-        if run_tower or splice:
-            pix = self.preprocess(images, pad_value, resize_with_padding)
-            tok = self.vision_forward(pix)
-        return self.llm_pooled(ids, lens, tok if splice else None, pool_mode)
+        if splice or not run_tower or not self.overlap_streams:
+            tok = None
+            if run_tower or splice:
+                pix = self.preprocess(images, pad_value, resize_with_padding)
+                tok = self.vision_forward(pix)
+            return self.llm_pooled(ids, lens, tok if splice else None, pool_mode)
+        # literal mode: the decoder does not consume the tower's output, so the two run on separate HIP streams (their
+        # workspace regions are disjoint); the small-grid decoder kernels fill the tower kernels' tails.
+        cur = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            pooled = self.llm_pooled(ids, lens, None, pool_mode)
+        pix = self.preprocess(images, pad_value, resize_with_padding)
+        self._tok_keepalive = self.vision_forward(pix)
+        cur.wait_stream(self._side)
+        pooled.record_stream(cur)
+        return pooled
 
     # ---------------------------------------------------------------- action expert
     def head_numel(self) -> int:
