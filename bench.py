@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2)
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to "
+                                                      "rehearse the multi-process path on a one-GPU box)")
     return ap.parse_args()
 
 
@@ -66,11 +68,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % max(ndev, 1)  # > 1 rank per GPU only in gloo rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from fastvla_hip import FastVLAEngine, arch, weights
     model = arch.preset(args.model)
