@@ -160,6 +160,9 @@ int fv_op_dwconv(const void* x, const float* w, const float* bias, void* y, int 
                  int stride, int mult, int gelu, fv_stream s);
 /* dense 3x3 stride-2 stem conv on (B,S,S,4) bf16 -> (B,S/2,S/2,Cout) bf16, + bias + GELU; w f32 [27][Cout] */
 int fv_op_stem_conv(const void* pix, const float* w, const float* bias, void* y, int B, int S, int Cout, fv_stream s);
+/* the same stem as an implicit GEMM on MFMA: wp (Cout,64) bf16 with slot 32*ks + 8*g + e = weight of kernel row
+ * ky = 2*ks + (g>>1), column kx = 2*(g&1) + (e>>2), channel e&3 (0 where ky, kx or channel is 3); Cout % 16 == 0 */
+int fv_op_stem_mfma(const void* pix, const void* wp, const float* bias, void* y, int B, int S, int Cout, fv_stream s);
 /* per-pixel LayerNorm over channels (LayerNormChannel), x,y (rows,C) bf16 */
 int fv_op_layernorm_rows(const void* x, const float* w, const float* b, void* y, int rows, int C, float eps,
                          fv_stream s);

@@ -331,3 +331,27 @@ def test_dwconv_mfma(k, C, H, W, gelu):
          "fv_op_dwconv_mfma")
     torch.cuda.synchronize()
     check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"dwconv mfma k{k} C{C} {H}x{W}")
+
+
+@pytest.mark.parametrize("S,C0", [(64, 32), (96, 96), (40, 16)])
+def test_stem_mfma(S, C0):
+    torch.manual_seed(S + C0)
+    B = 2
+    x = bf(torch.rand(B, 3, S, S))
+    w = bf(torch.randn(C0, 3, 3, 3) / 5)  # the MFMA image stores the stem weights in bf16
+    b = torch.randn(C0) * 0.1
+    ref = F.gelu(F.conv2d(x, w, b, stride=2, padding=1))
+    pix = torch.zeros(B, S, S, 4, dtype=torch.bfloat16, device=DEV)
+    pix[..., :3] = dev_bf16(x.permute(0, 2, 3, 1))
+    wp = torch.zeros(C0, 64)
+    for ks in range(2):
+        for g in range(4):
+            for e in range(8):
+                ky, kx, ch = 2 * ks + (g >> 1), 2 * (g & 1) + (e >> 2), e & 3
+                if ky < 3 and kx < 3 and ch < 3:
+                    wp[:, ks * 32 + g * 8 + e] = w[:, ch, ky, kx]
+    wd, bd = dev_bf16(wp), dev_f32(b)
+    y = torch.full((B, S // 2, S // 2, C0), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_stem_mfma(pix.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, S, C0, stream()), "fv_op_stem_mfma")
+    torch.cuda.synchronize()
+    check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"stem mfma S={S} C0={C0}")

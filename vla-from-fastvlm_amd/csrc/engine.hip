@@ -62,6 +62,7 @@ struct Block {
 struct Down { float *lk_w = nullptr, *lk_b = nullptr; bf16_t* pw_w = nullptr; float* pw_b = nullptr; };
 struct Cpe { float *w = nullptr, *b = nullptr; bf16_t* t = nullptr; };
 struct Tower {
+  bf16_t* stem0_wp = nullptr;  // [C0][64] image for the MFMA stem
   float *stem0_w = nullptr, *stem0_b = nullptr, *stem1_w = nullptr, *stem1_b = nullptr; bf16_t* stem2_w = nullptr; float* stem2_b = nullptr;
   std::vector<std::vector<Block>> stages; std::vector<Down> downs; std::vector<Cpe> cpes;
   float *exp_w = nullptr, *exp_b = nullptr, *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr, *se_b2 = nullptr;
@@ -340,7 +341,8 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float
   float* se = reinterpret_cast<float*>(ws + wp.se);
   const int S = d.image_size, C0 = d.tower_dims[0];
   FV_P(FV_FAM_STEM, 2.0 * mb * (S / 2) * (S / 2) * 27 * C0, (double)mb * S * S * 8 + (double)mb * (S / 2) * (S / 2) * C0 * 2,
-       fv::launch_stem_conv(pix, tw.stem0_w, tw.stem0_b, cur, mb, S, C0, s));
+       tw.stem0_wp ? fv::launch_stem_mfma(pix, tw.stem0_wp, tw.stem0_b, cur, mb, S, C0, s)
+                   : fv::launch_stem_conv(pix, tw.stem0_w, tw.stem0_b, cur, mb, S, C0, s));
   FV_P(FV_FAM_DWCONV, dw_flops(mb, S / 4, S / 4, C0, 3), (double)mb * (S / 2) * (S / 2) * C0 * 2 * 1.25,
        fv::launch_dwconv(cur, tw.stem1_w, tw.stem1_b, oth, mb, S / 2, S / 2, C0, 3, 2, 1, 1, s));
   int H = S / 4;
@@ -469,6 +471,11 @@ int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n) {
         for (int ci = 0; ci < 3; ++ci)
           for (int t = 0; t < 9; ++t) o[(size_t)(t * 3 + ci) * C0 + co] = v[((size_t)co * 3 + ci) * 9 + t];
       tw.stem0_w = L.up_f32(o);
+      if (C0 % 16 == 0 && C0 <= 128) {
+        std::vector<float> wp((size_t)C0 * 64);
+        fv::stem_mfma_pack(o.data(), wp.data(), C0);
+        tw.stem0_wp = L.up_bf16(wp);
+      }
     }
     tw.stem0_b = L.vec(vt + "patch_embed.0.reparam_conv.bias", C0);
     tw.stem1_w = L.dw(vt + "patch_embed.1.reparam_conv.weight", C0, 3);

@@ -33,6 +33,9 @@ int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win,
                      bf16_t* pix, hipStream_t s);
 int launch_stem_conv(const bf16_t* pix, const float* w, const float* bias, bf16_t* y, int B, int S, int Cout,
                      hipStream_t s);
+// implicit-GEMM stem on MFMA; wp = stem_mfma_pack image ([Cout][64] bf16), Cout % 16 == 0
+void stem_mfma_pack(const float* w27, float* out, int Cout);
+int launch_stem_mfma(const bf16_t* pix, const bf16_t* wp, const float* bias, bf16_t* y, int B, int S, int Cout, hipStream_t s);
 int launch_dwconv(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,
                   int stride, int mult, int gelu, hipStream_t s);
 // MFMA (4x4x4, 16 channel blocks) depthwise conv for stride-1 k in {3,7} on maps with W >= 32; ttab from dwconv_toeplitz_pack

@@ -108,6 +108,67 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------ stem conv on MFMA
+// The dense 3x3 stride-2 stem as an implicit GEMM on v_mfma_f32_16x16x32_bf16 with K padded 27 -> 64 so that every
+// operand fragment is contiguous pixel memory: k-slot (kstep, g, e) = kernel row ky = 2*kstep + (g>>1) (ky < 3), pixel
+// pair pp = g&1 (input columns 2ox-1+2pp, +1), e = 4*(pixel in pair) + channel -- i.e. 8 consecutive bf16 of the
+// (B,S,S,4) pixel image.  Operands are swapped (A = weights [cout][k], B = pixels) so D has the pixel on the lane and 4
+// consecutive output channels in its registers (8-byte NHWC stores).  Weights (6 n-tiles x 2 k-steps) stay in
+// registers while the wave walks TPW tiles of 16 output pixels.  27/64 of the MACs are useful and it does not matter:
+// the kernel is bound by its 3.2 GB of output and the 96 GELUs per pixel.
+template <int TPW>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const bf16_t* __restrict__ pix, const bf16_t* __restrict__ wp,
+                                                         const float* __restrict__ bias, bf16_t* __restrict__ y, int B,
+                                                         int S, int Cout, long ntiles) {
+  const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
+  const int So = S >> 1, tiles_per_row = (So + 15) >> 4;
+  const int NTn = Cout >> 4;  // 16-channel tiles (<= 8)
+  bf16x8 wf[8][2];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      wf[nt][ks] = nt < NTn ? __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wp + ((size_t)(nt * 16 + fr) * 64 + ks * 32 + fg * 8)))
+                            : __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int t = 0; t < TPW; ++t) {
+    const long tile = wave * TPW + t;
+    if (tile >= ntiles) break;
+    const int tx = (int)(tile % tiles_per_row);
+    const int oy = (int)((tile / tiles_per_row) % So);
+    const long b = tile / ((long)tiles_per_row * So);
+    const int ox = tx * 16 + fr;
+    // B fragments: 2 pixels x 4 channels per (k-step, g)
+    bf16x8 xf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ky = 2 * ks + (fg >> 1), pp = fg & 1;
+      const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + 2 * pp;
+      uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
+      if (ky < 3 && iy >= 0 && iy < S && ox < So) {
+        const bf16_t* rp = pix + (((size_t)b * S + iy) * S) * 4;
+        if (ix >= 0 && ix < S) lo = *reinterpret_cast<const uint2*>(rp + (size_t)ix * 4);
+        if (ix + 1 >= 0 && ix + 1 < S) hi = *reinterpret_cast<const uint2*>(rp + (size_t)(ix + 1) * 4);
+      }
+      xf[ks] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      if (nt >= NTn) break;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][0], xf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][1], xf[1], acc, 0, 0, 0);
+      if (ox < So) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + nt * 16 + fg * 4);
+        uint2 o;
+        o.x = pack_bf2(gelu_f(acc[0] + bv.x), gelu_f(acc[1] + bv.y));
+        o.y = pack_bf2(gelu_f(acc[2] + bv.z), gelu_f(acc[3] + bv.w));
+        *reinterpret_cast<uint2*>(y + (((size_t)b * So + oy) * So + ox) * Cout + nt * 16 + fg * 4) = o;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ depthwise conv
 // block = 256 threads over (pixel quads) x (a slice of GS <= 16 channel groups of 8); the slice's weights [k*k][GS*8]
 // fp32 are staged in LDS once per block.  thread = R=4 outputs along x  x  8 output channels.  Per kernel row the 7 (or
@@ -523,6 +584,29 @@ int launch_stem_conv(const bf16_t* pix, const float* w, const float* bias, bf16_
   const long quads = (long)B * So * WQ;
   const long blocks = (quads + per_block - 1) / per_block;
   hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)blocks), dim3(256), 27 * Cout * sizeof(float), s, pix, w, bias, y, B, S, Cout);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+// [Cout][64] bf16 image of the stem weights for stem_mfma_kernel from the tap-major [27][Cout] fp32 layout
+void stem_mfma_pack(const float* w27, float* out, int Cout) {
+  for (int co = 0; co < Cout; ++co)
+    for (int ks = 0; ks < 2; ++ks)
+      for (int g = 0; g < 4; ++g)
+        for (int e = 0; e < 8; ++e) {
+          const int ky = 2 * ks + (g >> 1), kx = 2 * (g & 1) + (e >> 2), ch = e & 3;
+          out[(size_t)co * 64 + ks * 32 + g * 8 + e] = (ky < 3 && kx < 3 && ch < 3) ? w27[(size_t)((ky * 3 + kx) * 3 + ch) * Cout + co] : 0.0f;
+        }
+}
+
+int launch_stem_mfma(const bf16_t* pix, const bf16_t* wp, const float* bias, bf16_t* y, int B, int S, int Cout, hipStream_t s) {
+  if (!pix || !wp || !bias || !y) return fv_fail(FV_ERR_ARG, "stem_mfma: null pointer");
+  if (B <= 0 || S < 2 || (S & 1) || Cout % 16 || Cout > 128) return fv_fail(FV_ERR_UNSUPPORTED, "stem_mfma: bad shape S=%d Cout=%d", S, Cout);
+  const int So = S / 2;
+  const long ntiles = (long)B * So * ((So + 15) / 16);
+  constexpr int TPW = 8;
+  const long blocks = (ntiles + 4 * TPW - 1) / (4 * TPW);
+  hipLaunchKernelGGL(stem_mfma_kernel<TPW>, dim3((unsigned)blocks), dim3(256), 0, s, pix, wp, bias, y, B, S, Cout, ntiles);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
