@@ -219,7 +219,7 @@ def main():
         nst = max(2, args.steps // 2)
         flat.copy_(flat_backup)
         train = {"value": round(world * nst / elt, 3), "unit": "train steps/s (whole job)", "ms_per_step": round(1e3 * elt / nst, 3),
-                 "global_batch": Bt * world, "parallelism": f"dp{world}", "collective": "rccl all_reduce(flat head grads)" if world > 1 else None,
+                 "global_batch": Bt * world, "parallelism": f"dp{world}", "collective": f"{args.backend} all_reduce(flat head grads)" if world > 1 else None,
                  "grad_bytes": int(flat.numel() * 4)}
 
     # ---- CPU baseline (rank 0, N=1 only): the fp32 oracle on a bounded sample of the same workload

@@ -150,7 +150,8 @@ enum fv_gemm_epilogue {
   FV_EPI_LS_RES = 2,      /* out bf16 = res_bf16 + scale[n] * (acc + bias[n])       */
   FV_EPI_RES_F32 = 3,     /* out f32  = res_f32 + acc (+ bias)                      */
   FV_EPI_SWIGLU = 4,      /* out bf16[M,N/2] = silu(gate) * up, W rows 8-interleaved */
-  FV_EPI_F32 = 5          /* out f32  = acc + bias                                  */
+  FV_EPI_F32 = 5,         /* out f32  = acc + bias                                  */
+  FV_EPI_SWIGLU_SPLIT = 7 /* out bf16[M,N] = [hi | lo] of silu(gate)*up (split-bf16 operand), W rows 8-interleaved */
 };
 /* out[M,N] = A[M,K] (bf16, row stride lda) x W[N,K]^T (bf16) with fp32 accumulation on MFMA */
 int fv_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const float* scale,

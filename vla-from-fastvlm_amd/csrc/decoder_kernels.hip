@@ -120,30 +120,6 @@ __global__ __launch_bounds__(256) void rope_f32_kernel(float* __restrict__ qkv, 
   *reinterpret_cast<float4*>(p2) = make_float4(ob[0], ob[1], ob[2], ob[3]);
 }
 
-// gate/up accumulators (fp32, columns interleaved [8 gate | 8 up]) -> silu(g)*u split into bf16 hi + lo
-__global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restrict__ gu, bf16_t* __restrict__ hi,
-                                                            bf16_t* __restrict__ lo, int ldo, long rows, int I) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per 8 outputs
-  const int per_row = I / 8;
-  if (i >= rows * per_row) return;
-  const long row = i / per_row;
-  const int c = (int)(i % per_row);
-  const float* src = gu + row * (2L * I) + c * 16;
-  float g[8], u[8], o[8], h8[8], l8[8];
-  *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(src);
-  *reinterpret_cast<float4*>(g + 4) = *reinterpret_cast<const float4*>(src + 4);
-  *reinterpret_cast<float4*>(u) = *reinterpret_cast<const float4*>(src + 8);
-  *reinterpret_cast<float4*>(u + 4) = *reinterpret_cast<const float4*>(src + 12);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.0f + __expf(-g[e])) * u[e];
-  const uint4 hv = pack8(o);
-  unpack8(hv, h8);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
-  *reinterpret_cast<uint4*>(hi + row * ldo + c * 8) = hv;
-  *reinterpret_cast<uint4*>(lo + row * ldo + c * 8) = pack8(l8);
-}
-
 // fp32 causal GQA attention for the parity-mode decoder (T <= a few hundred; 22 GFLOP per step at T = 64): one thread
 // (or NT = D/DPT adjacent lanes) per (query position, q head); K/V chunks of 64 keys staged in LDS as fp32 and read as
 // wave-wide broadcasts; online softmax over groups of 8 keys; output written as bf16 hi + lo for the o-projection.
@@ -300,15 +276,6 @@ int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, in
   if (rows <= 0 || T <= 0 || D % 8 || ld % 4 || ld < (heads + kv_heads) * D) return fv_fail(FV_ERR_ARG, "rope_f32: bad shape");
   const long total = (long)rows * (heads + kv_heads) * (D / 8);
   hipLaunchKernelGGL(rope_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, table, ld, (long)rows, T, heads + kv_heads, D);
-  FV_HIP_CHECK(hipGetLastError());
-  return FV_OK;
-}
-
-int launch_swiglu_split(const float* gu, bf16_t* hi, bf16_t* lo, int ldo, int rows, int I, hipStream_t s) {
-  if (!gu || !hi || !lo) return fv_fail(FV_ERR_ARG, "swiglu_split: null pointer");
-  if (rows <= 0 || I <= 0 || I % 8 || ldo < I || ldo % 8) return fv_fail(FV_ERR_ARG, "swiglu_split: bad shape");
-  const long total = (long)rows * (I / 8);
-  hipLaunchKernelGGL(swiglu_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gu, hi, lo, ldo, (long)rows, I);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

@@ -252,7 +252,7 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
     p.att_lo = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2 * 2);
     p.act_lo = take(rows * d.llm_inter * 2 * 2);
     p.qkvf = take(rows * qkvw * 4);
-    p.guf = take(rows * (size_t)d.llm_inter * 2 * 4);
+    p.guf = 0;  // gate/up accumulators no longer round-trip through memory (SwiGLU + split fused into the GEMM epilogue)
   }
   p.head_scr = take(fv::head_bwd_scratch_bytes(h->hd, B));
   p.total = o;
@@ -294,7 +294,7 @@ void prof_end(fv_handle* h, hipStream_t s) {
 int gemm_p(fv_handle* h, const fv::GemmArgs& g, hipStream_t s) {
   const double M = g.M, N = g.N, K = g.K;
   const bool f32o = g.epi == FV_EPI_RES_F32 || g.epi == FV_EPI_F32;
-  double bytes = (M * K + N * K) * 2 + M * (g.epi == FV_EPI_SWIGLU ? N / 2 : N) * (f32o ? 4 : 2);
+  double bytes = (M * K + N * K) * 2 + M * (g.epi == FV_EPI_SWIGLU ? N / 2 : N) * (f32o ? 4 : 2);  // SPLIT: N bf16 columns
   if (g.epi == FV_EPI_LS_RES) bytes += M * N * 2;
   if (g.epi == FV_EPI_RES_F32) bytes += M * N * 4;
   // algorithmic flops (2MNK) even when ksplit executes the K loop twice for the split-bf16 operand
@@ -674,7 +674,6 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
     bf16_t* as = reinterpret_cast<bf16_t*>(ws + wp.att_lo);   // [rows][2*qd]
     bf16_t* cs = reinterpret_cast<bf16_t*>(ws + wp.act_lo);   // [rows][2*I]
     float* qkvf = reinterpret_cast<float*>(ws + wp.qkvf);
-    float* guf = reinterpret_cast<float*>(ws + wp.guf);
     const int I = d.llm_inter, I2 = 2 * I;
     for (const DecLayer& L : h->dec.layers) {
       FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
@@ -686,9 +685,8 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
       fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
       FV_TRY(gemm_p(h, o1, s));
       FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
-      fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, guf, I2, FV_EPI_F32, 1};
-      FV_TRY(gemm_p(h, g1, s));
-      FV_P(FV_FAM_ELT, 8.0 * rows * I, 12.0 * rows * I, fv::launch_swiglu_split(guf, cs, cs + I, I2, rows, I, s));
+      fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 1};
+      FV_TRY(gemm_p(h, g1, s));  // silu(gate)*up and its hi/lo split happen in the epilogue: no fp32 round trip
       fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
       FV_TRY(gemm_p(h, d1, s));
     }

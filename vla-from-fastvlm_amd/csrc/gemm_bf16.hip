@@ -123,8 +123,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
   __syncthreads();
 
   const int epi = p.epi;
-  if (epi == FV_EPI_SWIGLU) {
-    // W rows are interleaved [8 gate | 8 up]: 16 accumulator columns -> 8 outputs
+  if (epi == FV_EPI_SWIGLU || epi == FV_EPI_SWIGLU_SPLIT) {
+    // W rows are interleaved [8 gate | 8 up]: 16 accumulator columns -> 8 outputs.  SPLIT also writes the bf16
+    // remainder at column offset N/2 (split-bf16 operand of the down projection: out is [M][hi N/2 | lo N/2]).
     bf16_t* out = static_cast<bf16_t*>(p.out);
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {
@@ -136,7 +137,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = silu_f(src[e]) * src[8 + e];
-        *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (gn >> 1)) = pack8(o);
+        const uint4 hv = pack8(o);
+        *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (gn >> 1)) = hv;
+        if (epi == FV_EPI_SWIGLU_SPLIT) {
+          float h8[8], l8[8];
+          unpack8(hv, h8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
+          *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (p.N >> 1) + (gn >> 1)) = pack8(l8);
+        }
       }
     }
     return;
@@ -193,10 +202,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fv_fail(FV_ERR_ARG, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.K % 8 || a.lda % 8 || a.N % 8) return fv_fail(FV_ERR_ARG, "gemm: K, lda, N must be multiples of 8 (K=%d lda=%d N=%d)", a.K, a.lda, a.N);
   if (a.lda < a.K) return fv_fail(FV_ERR_ARG, "gemm: lda < K");
-  if (a.epi < FV_EPI_BIAS || a.epi > FV_EPI_F32) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
+  if (a.epi < FV_EPI_BIAS || (a.epi > FV_EPI_F32 && a.epi != FV_EPI_SWIGLU_SPLIT)) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
   const bool f32out = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
-  const int ncols = a.epi == FV_EPI_SWIGLU ? a.N / 2 : a.N;
-  if (a.epi == FV_EPI_SWIGLU && a.N % 16) return fv_fail(FV_ERR_ARG, "gemm: SwiGLU needs N %% 16 == 0");
+  const bool swiglu = a.epi == FV_EPI_SWIGLU || a.epi == FV_EPI_SWIGLU_SPLIT;
+  const int ncols = a.epi == FV_EPI_SWIGLU ? a.N / 2 : a.N;  // SPLIT: hi and lo halves side by side -> N columns
+  if (swiglu && a.N % 16) return fv_fail(FV_ERR_ARG, "gemm: SwiGLU needs N %% 16 == 0");
   if (a.ldo < ncols || a.ldo % (f32out ? 4 : 8)) return fv_fail(FV_ERR_ARG, "gemm: bad ldo %d", a.ldo);
   if (a.epi == FV_EPI_LS_RES && (!a.res || !a.scale || a.ldr % 8 || a.ldr < a.N)) return fv_fail(FV_ERR_ARG, "gemm: LS_RES needs res/scale");
   if (a.epi == FV_EPI_RES_F32 && (!a.res || a.ldr % 4 || a.ldr < a.N)) return fv_fail(FV_ERR_ARG, "gemm: RES_F32 needs res");

@@ -59,7 +59,6 @@ int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* im
 // y_lo != null: also writes the bf16 remainder (x ~= y + y_lo), the split operand of the parity-mode decoder GEMMs
 int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s);
 int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D, hipStream_t s);
-int launch_swiglu_split(const float* gu, bf16_t* hi, bf16_t* lo, int ldo, int rows, int I, hipStream_t s);
 int launch_attention_f32(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
                          int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s);
 // table: [>=T][D/2] (cos, sin) pairs built by rope_table_host(); position = row % T

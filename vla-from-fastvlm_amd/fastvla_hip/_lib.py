@@ -12,6 +12,7 @@ from pathlib import Path
 FV_MAX_STAGES = 8
 FV_F32, FV_BF16, FV_U8, FV_I32 = 0, 1, 2, 3
 EPI_BIAS, EPI_BIAS_GELU, EPI_LS_RES, EPI_RES_F32, EPI_SWIGLU, EPI_F32 = range(6)
+EPI_SWIGLU_SPLIT = 7
 
 
 class FastVLAHipError(RuntimeError):
