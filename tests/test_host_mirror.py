@@ -153,3 +153,30 @@ def test_checkpoint_roundtrip(tmp_path):
     again = load_policy_from_checkpoint(str(tmp_path))
     for k, v in pol.state_dict().items():
         assert torch.equal(v, again.state_dict()[k])
+
+
+def test_hf_checkpoint_directory_is_resolved(tmp_path):
+    """A local llava_qwen2 directory (config.json + safetensors with canonical inference-form keys) -> architecture and
+    tensors for fv_load_weights; lm_head is dropped."""
+    from safetensors.torch import save_file
+    from fastvla_hip import arch, weights
+    from vla_fastvlm.model.fastvlm_adapter import arch_from_hf_config, load_hf_checkpoint_dir
+    m = arch.preset("tiny")
+    cfg = dict(model_type="llava_qwen2", hidden_size=m.llm.hidden, num_hidden_layers=m.llm.layers, num_attention_heads=m.llm.heads,
+               num_key_value_heads=m.llm.kv_heads, intermediate_size=m.llm.inter, vocab_size=m.llm.vocab, rope_theta=1e6,
+               rms_norm_eps=1e-6, mm_vision_tower="mobileclip_l_1024", torch_dtype="bfloat16")
+    d = tmp_path / "llava-fastvithd_tiny"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(cfg))
+    state = weights.init_backbone(m, seed=1)
+    state["lm_head.weight"] = torch.zeros(4, 4)
+    keys = sorted(state)
+    save_file({k: state[k].contiguous() for k in keys[: len(keys) // 2]}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({k: state[k].contiguous() for k in keys[len(keys) // 2:]}, str(d / "model-00002-of-00002.safetensors"))
+    got = arch_from_hf_config(d / "config.json")
+    assert got.llm == m.llm and got.tower.image_size == 1024 and got.tower.layers == (2, 12, 24, 4, 2)
+    loaded = load_hf_checkpoint_dir(d)
+    assert "lm_head.weight" not in loaded and set(loaded) == set(state) - {"lm_head.weight"}
+    assert torch.equal(loaded["model.norm.weight"], state["model.norm.weight"])
+    bb = FastVLMBackbone(FastVLMBackboneConfig(model_id=str(d)))
+    assert bb.output_dim == m.llm.hidden and bb.expected_size == 1024 and bb._weights_source[0] == "hf_dir"

@@ -176,6 +176,10 @@ class FastVLMBackbone(nn.Module):
             for fn in ("fastvla_hip_weights.pt", "fastvla_hip_weights.safetensors"):
                 if (path / fn).is_file() and key in _KNOWN_MODELS:
                     return fv_arch.preset(_KNOWN_MODELS[key]), ("file", str(path / fn))
+            # a local llava_qwen2 checkpoint directory as Apple ships it (scripts/download_fastvlm.sh of the reference):
+            # config.json + *.safetensors whose keys are the canonical inference-form names this library packs
+            if (path / "config.json").is_file() and list(path.glob("*.safetensors")):
+                return arch_from_hf_config(path / "config.json"), ("hf_dir", str(path))
         if key in _KNOWN_MODELS:
             if os.environ.get("FASTVLA_SYNTHETIC_WEIGHTS", "0") == "1":
                 return fv_arch.preset(_KNOWN_MODELS[key]), ("synthetic", 1234)
@@ -231,6 +235,8 @@ class FastVLMBackbone(nn.Module):
             kind, arg = self._weights_source
             if kind == "synthetic":
                 state = fv_weights.init_backbone(self.arch, seed=arg)
+            elif kind == "hf_dir":
+                state = load_hf_checkpoint_dir(arg)
             else:
                 state = torch.load(arg, map_location="cpu") if arg.endswith(".pt") else _load_safetensors(arg)
             eng.load_weights(state)
@@ -301,3 +307,34 @@ class FastVLMBackbone(nn.Module):
 def _load_safetensors(path: str):
     from safetensors.torch import load_file
     return load_file(path)
+
+
+def arch_from_hf_config(config_json) -> "fv_arch.ModelConfig":
+    """Model geometry from a llava_qwen2 `config.json` (Qwen2 fields + `mm_vision_tower`, e.g. "mobileclip_l_1024").
+    Only the FastViT-HD tower is supported; its constants are architectural (fastvla_hip.arch.TowerConfig)."""
+    import json
+    cfg = json.loads(Path(config_json).read_text())
+    if cfg.get("model_type") not in ("llava_qwen2", "qwen2", None):
+        raise ValueError(f"unsupported model_type '{cfg.get('model_type')}' (expected llava_qwen2)")
+    heads = int(cfg["num_attention_heads"])
+    hidden = int(cfg["hidden_size"])
+    llm = fv_arch.LLMConfig(hidden=hidden, layers=int(cfg["num_hidden_layers"]), heads=heads,
+                            kv_heads=int(cfg.get("num_key_value_heads", heads)), head_dim=int(cfg.get("head_dim", hidden // heads)),
+                            inter=int(cfg["intermediate_size"]), vocab=int(cfg["vocab_size"]),
+                            rope_theta=float(cfg.get("rope_theta", 1e6)), rms_eps=float(cfg.get("rms_norm_eps", 1e-6)))
+    tower_name = str(cfg.get("mm_vision_tower", "mobileclip_l_1024"))
+    size = infer_size_from_tower_name(tower_name) or 1024
+    tower = fv_arch.TowerConfig(image_size=int(size), name=tower_name)
+    return fv_arch.ModelConfig(Path(config_json).parent.name or "hf-checkpoint", llm, tower)
+
+
+def load_hf_checkpoint_dir(path) -> Dict[str, Tensor]:
+    """All tensors of every *.safetensors shard in the directory, keys unchanged; `lm_head.*` is dropped (the path never
+    computes logits).  Missing or mis-shaped tensors are reported by fv_load_weights with the key name."""
+    from safetensors.torch import load_file
+    state: Dict[str, Tensor] = {}
+    for shard in sorted(Path(path).glob("*.safetensors")):
+        for k, v in load_file(str(shard)).items():
+            if not k.startswith("lm_head."):
+                state[k] = v
+    return state
