@@ -20,7 +20,9 @@ struct AttnParams {
   int ldq, ldk, ldv, ldo, B, T, heads, kv_heads, causal, len_add; float scale;
 };
 
-template <int D>
+// MASKED = false: no causal mask, no key-length mask and T % 64 == 0 (the FastViT-HD MHSA): the softmax then costs one
+// FMA (scale * log2e folded in) and one v_exp_f32 per score -- with head_dim 32 this kernel is VALU-bound, not MFMA-bound.
+template <int D, bool MASKED>
 __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
   constexpr int KS = D / 32;        // k-steps of the S^T product
   constexpr int DT = D / 16;        // 16-row tiles of O^T
@@ -90,28 +92,33 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[ks], sacc[kt], 0, 0, 0);
       }
     }
-    // mask + online softmax (per lane: query qg, keys kb*64 + kt*16 + 4*fg + r)
+    // online softmax (per lane: query qg, keys kb*64 + kt*16 + 4*fg + r); scores are kept in the log2 domain
+    const float c2 = p.scale * 1.4426950408889634f;
     float mloc = -1e30f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int kg = kb * 64 + kt * 16 + fg * 4 + r;
-        const bool ok = kg < len && (!p.causal || kg <= qg);
-        const float sv = ok ? sacc[kt][r] * p.scale : -1e30f;
+        float sv = sacc[kt][r] * c2;
+        if (MASKED) {
+          const int kg = kb * 64 + kt * 16 + fg * 4 + r;
+          const bool ok = kg < len && (!p.causal || kg <= qg);
+          sv = ok ? sv : -1e30f;
+        }
         sacc[kt][r] = sv;
         mloc = fmaxf(mloc, sv);
       }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = sacc[kt][r] > -1e29f ? __expf(sacc[kt][r] - m_new) : 0.f;
+        float pv = __builtin_amdgcn_exp2f(sacc[kt][r] - m_new);
+        if (MASKED) pv = sacc[kt][r] > -1e29f ? pv : 0.f;
         sacc[kt][r] = pv;
         psum += pv;
       }
@@ -171,10 +178,15 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ldq,
   const long blocks = (long)B * heads * ((T + 63) / 64);
   if (blocks > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "attention: grid too large");
   const dim3 grid((unsigned)blocks), blk(256);
-  if (D == 32) hipLaunchKernelGGL(attention_kernel<32>, grid, blk, 0, s, p);
-  else if (D == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, blk, 0, s, p);
-  else if (D == 128) hipLaunchKernelGGL(attention_kernel<128>, grid, blk, 0, s, p);
-  else return fv_fail(FV_ERR_UNSUPPORTED, "attention: head_dim %d not in {32,64,128}", D);
+  const bool masked = causal || lens || (T & 63);
+  if (D != 32 && D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention: head_dim %d not in {32,64,128}", D);
+#define FV_ATT(D_)                                                                        \
+  if (D == D_) {                                                                          \
+    if (masked) hipLaunchKernelGGL((attention_kernel<D_, true>), grid, blk, 0, s, p);     \
+    else hipLaunchKernelGGL((attention_kernel<D_, false>), grid, blk, 0, s, p);           \
+  }
+  FV_ATT(32) FV_ATT(64) FV_ATT(128)
+#undef FV_ATT
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
