@@ -142,12 +142,17 @@ def main():
     value = world * args.steps / el
 
     # ---- per-kernel-family HIP-event pass (same work, right after the timed region, on the same stream)
+    # kernels are timed one at a time here: the decoder/tower stream overlap of the timed region would make concurrent
+    # kernels share the chip and inflate each other's durations (the committed rocprofv3 stats use FASTVLA_OVERLAP=0 too)
+    overlap = eng.overlap_streams
+    eng.overlap_streams = False
     eng.profile(True)
     for _ in range(args.profile_steps):
         step_infer()
     torch.cuda.synchronize()
     fams, shapes = eng.profile_read()
     eng.profile(False)
+    eng.overlap_streams = overlap
     ps = args.profile_steps
     gem = fams["gemm"]
     gemm_tflops = gem["flops"] / (gem["ms"] * 1e-3) / 1e12 if gem["ms"] > 0 else 0.0
@@ -179,7 +184,7 @@ def main():
                              "ms_per_step": round(gem["ms"] / ps, 3), "flops_per_step": gem["flops"] / ps},
         "step_achieved": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
         "step_frac": round(total_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-        "source": f"hipEvents around every launch over {ps} steps after the timed region; algorithmic flops "
+        "source": f"hipEvents around every launch over {ps} steps after the timed region (stream overlap off); algorithmic flops "
                   "(2MNK per GEMM, 4*M*C*4C per fused ConvFFN; split-bf16 passes not double-counted)",
     }
     families = {k: {"ms_per_step": round(v["ms"] / ps, 3), "launches": v["launches"] // ps,
@@ -262,6 +267,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "image": args.image,
                        "parallelism": f"replicas x{world} (no collective on the inference path)",
                        "splice_image_tokens": bool(args.splice), "tower_microbatch": args.microbatch,
+                       "stream_overlap": bool(eng.overlap_streams and not args.splice),
                        "llm_precision": "split-bf16 (hi+lo) operands, fp32 attention" if args.llm_precision else "bf16 operands"},
             "samples_per_s": round(value * B, 2),
             "roofline": roofline, "cpu_baseline": cpu, "train_dp": train,
