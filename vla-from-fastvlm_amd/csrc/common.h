@@ -44,6 +44,56 @@ __device__ __forceinline__ float gelu_f(float x) {
   const float e = __builtin_amdgcn_exp2f(xc * t);
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+#define FV_GELU_C0 0.398636314f
+#define FV_GELU_C1 -0.0658484117f
+#define FV_GELU_C2 0.00950338221f
+#define FV_GELU_C3 -0.00101413109f
+#define FV_GELU_C4 7.77420515e-05f
+#define FV_GELU_C5 -4.11762334e-06f
+#define FV_GELU_C6 1.4164305e-07f
+#define FV_GELU_C7 -2.82720812e-09f
+#define FV_GELU_C8 2.47331455e-11f
+// Two GELUs at once with no transcendental: x * clamp(0.5 + xc P(xc^2), 0, 1), xc = clamp(x, -R, R), P a degree-8 minimax fit
+// (LP over [0, R] with the constraint 0.5 + R P(R^2) >= 1 so the clamp makes the tail exact: tools/gelu_fit.py); max |error|
+// 5.1e-5 over all x in fp32.  12 VALU issues per PAIR, 10 of them packed fp32 (v_pk_mul/fma_f32, full rate on gfx950), where
+// gelu_f spends 7 + two quarter-rate transcendentals per element: ~24 cycles per element instead of ~60.  The fused ConvFFN
+// applies it to 23 G hidden activations per step between its two products, with nothing else to issue meanwhile.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// N pairs in lockstep (coefficient-major): one wave per SIMD cannot hide the latency of a dependent VALU chain, so the
+// N independent Horner chains are what keeps the VALU issuing every cycle.
+template <int N>
+__device__ __forceinline__ void gelu2_n(f32x2 (&x)[N]) {
+  const float R = 4.625f;
+  f32x2 xc[N], x2[N], p[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    xc[n].x = __builtin_amdgcn_fmed3f(x[n].x, -R, R);
+    xc[n].y = __builtin_amdgcn_fmed3f(x[n].y, -R, R);
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) x2[n] = xc[n] * xc[n];
+#pragma unroll
+  for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(x2[n], (f32x2){FV_GELU_C8, FV_GELU_C8}, (f32x2){FV_GELU_C7, FV_GELU_C7});
+#define FV_HORNER(c)                                                                        \
+  _Pragma("unroll") for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(p[n], x2[n], (f32x2){c, c});
+  FV_HORNER(FV_GELU_C6) FV_HORNER(FV_GELU_C5) FV_HORNER(FV_GELU_C4) FV_HORNER(FV_GELU_C3)
+  FV_HORNER(FV_GELU_C2) FV_HORNER(FV_GELU_C1) FV_HORNER(FV_GELU_C0)
+#undef FV_HORNER
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    // The VOP3P clamp bit saturates both halves to [0, 1] for free (the compiler spends two v_max on it).  gfx950 wants one
+    // wait state between a packed VALU write and a dependent VALU read; hipcc pads its own packed ops with s_nop 0 but
+    // cannot see into asm, so the statement carries its own on both sides.
+    f32x2 phi;
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0" : "=v"(phi) : "v"(xc[n]), "v"(p[n]));
+    x[n] = x[n] * phi;
+  }
+}
+__device__ __forceinline__ f32x2 gelu2_f(f32x2 x) {
+  f32x2 v[1] = {x};
+  gelu2_n<1>(v);
+  return v[0];
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 

@@ -31,23 +31,37 @@ struct FfnParams {
 __device__ __forceinline__ void mfma_acc_a(f32x4& acc, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ void mfma_acc_v(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+// Hidden-tile accumulators: HA = false keeps them in architectural registers (the GELU reads them directly); HA = true puts
+// them in the accumulator half too.  The 8-row-tile variants need that: with 64 hidden accumulators among the VGPRs hipcc
+// ran out, and its spill copies (v_accvgpr_write of an accumulator right behind one of these opaque asm MFMAs) read stale
+// data -- the XDL-write -> VALU-read wait states are invisible to the compiler here.
+template <bool HA>
+__device__ __forceinline__ void mfma_acc_h(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (HA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 // first k-step of a hidden tile: C = 0 as an inline constant, so no VALU-written zero feeds the MFMA
-__device__ __forceinline__ void mfma_init_v(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+template <bool HA>
+__device__ __forceinline__ void mfma_init_h(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (HA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
 }
-// last k-step of a hidden tile: the GELU (VALU) reads this accumulator next -- hipcc pads nothing after inline asm, so the
-// XDL-write -> VALU-read wait states go inside the statement
-__device__ __forceinline__ void mfma_last_v(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 3" : "+v"(acc) : "v"(a), "v"(b));
+// after the last k-step of a hidden tile the GELU (VALU) reads the accumulator -- hipcc pads nothing after inline asm, so
+// the XDL-write -> VALU-read wait states are spelled out, tied to the accumulator
+template <bool HA>
+__device__ __forceinline__ void settle_acc(f32x4& acc) {
+  if constexpr (HA) asm volatile("s_nop 7\n\ts_nop 3" : "+a"(acc));
+  else asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc));
 }
 // VALU-written B operand (packed GELU output) -> MFMA read: tie the wait states to the operand
 __device__ __forceinline__ void settle_operand(bf16x8& v) { asm volatile("s_nop 3" : "+v"(v)); }
 
 template <int C, int MT>
 __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
+#ifndef FFN_HA
+#define FFN_HA (MT >= 8)
+#endif
+  constexpr bool HA = FFN_HA;          // hidden accumulators in AGPRs (see mfma_acc_h)
   constexpr int KS = C / 32;            // k-steps of the first product
   constexpr int NT = C / 16;            // output-channel tiles of the second product
   constexpr int W1_STRIDE = C * 2 + 32; // bytes per hidden row in LDS
@@ -116,18 +130,17 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
                 : *reinterpret_cast<const uint4*>((W2S) + (((I) - 2 * KS) * 16 + fr) * W2_STRIDE + fg * 16))
   float4 bA_n = *reinterpret_cast<const float4*>(p.b1 + fg * 4), bB_n = *reinterpret_cast<const float4*>(p.b1 + 16 + fg * 4);
   for (int hc = 0; hc < p.nchunks; ++hc) {
-#ifdef FFN_ABLATE_STAGE
-    const int cur = 0;
-#else
     const int cur = hc & 1;
-#endif
     const float4 bA = bA_n, bB = bB_n;
-#ifdef FFN_ABLATE_STAGE  // tools/ffn_micro.hip only: reuse chunk 0, to price the weight stream
-    if (false) {
-#else
+    // the next chunk's weights: NLD global loads spread over the first product's steps, their NLD LDS stores over the
+    // second product's (a burst of 12 loads costs ~800 issue cycles while the L1 path drains 64 B/clk, a burst of 12
+    // ds_write_b128 ~700: in-order issue makes both dead MFMA time unless they are dealt out between the MFMAs).  The
+    // last iteration re-stages the final chunk into the idle slot, which keeps the stream branch-free.
+    const int hn = min(hc + 1, p.nchunks - 1);
+    const bf16_t* g1n = p.w1 + (size_t)hn * 32 * C;
+    const bf16_t* g2n = p.w2p + (size_t)hn * C * 32;
+    char* nbase = smem + (cur ^ 1) * BUF;
     if (hc + 1 < p.nchunks) {
-#endif
-      FFN_STAGE_LOAD(hc + 1)
       bA_n = *reinterpret_cast<const float4*>(p.b1 + (hc + 1) * 32 + fg * 4);
       bB_n = *reinterpret_cast<const float4*>(p.b1 + (hc + 1) * 32 + 16 + fg * 4);
     }
@@ -141,46 +154,56 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i % PD]);
-#ifndef FFN_ABLATE_READS  // tools/ffn_micro.hip only: keep re-using the first PD fragments, to price the LDS reads
       if (i + PD < NR) ring[i % PD] = FFN_FRAG(i + PD, w1s, w2s);
-#endif
       if (i < 2 * KS) {  // H^T[ht] += W1[ht rows, k-step] . x^T
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          if (KS == 1) { mfma_init_v(hacc[i / KS][mt], a, xf[mt][0]); asm volatile("s_nop 7\n\ts_nop 3" : "+v"(hacc[i / KS][mt])); }
-          else if (i % KS == 0) mfma_init_v(hacc[i / KS][mt], a, xf[mt][0]);
-          else if (i % KS == KS - 1) mfma_last_v(hacc[i / KS][mt], a, xf[mt][i % KS]);
-          else mfma_acc_v(hacc[i / KS][mt], a, xf[mt][i % KS]);
+          if (i % KS == 0) mfma_init_h<HA>(hacc[i / KS][mt], a, xf[mt][0]);
+          else mfma_acc_h<HA>(hacc[i / KS][mt], a, xf[mt][i % KS]);
+          if (i % KS == KS - 1) settle_acc<HA>(hacc[i / KS][mt]);
         }
         if (i == 2 * KS - 1) {  // bias + GELU in registers -> B operand of the second product
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             uint4 u;
-#ifdef FFN_ABLATE_GELU  // tools/ffn_micro.hip only: identity activation, to price the GELU
-#define FFN_ACT(v) (v)
-#else
-#define FFN_ACT(v) gelu_f(v)
+            f32x2 g[4] = {{hacc[0][mt][0] + bA.x, hacc[0][mt][1] + bA.y}, {hacc[0][mt][2] + bA.z, hacc[0][mt][3] + bA.w},
+                          {hacc[1][mt][0] + bB.x, hacc[1][mt][1] + bB.y}, {hacc[1][mt][2] + bB.z, hacc[1][mt][3] + bB.w}};
+#ifndef FFN_ABLATE_GELU  // tools/ffn_micro.hip only: identity activation, to price the GELU
+            if (MT >= 8) {  // the 8-row-tile variants have no registers left for four chains' temporaries
+              f32x2 ga[2] = {g[0], g[1]}, gb[2] = {g[2], g[3]};
+              gelu2_n<2>(ga);
+              gelu2_n<2>(gb);
+              g[0] = ga[0]; g[1] = ga[1]; g[2] = gb[0]; g[3] = gb[1];
+            } else {
+              gelu2_n<4>(g);
+            }
 #endif
-            u.x = pack_bf2(FFN_ACT(hacc[0][mt][0] + bA.x), FFN_ACT(hacc[0][mt][1] + bA.y));
-            u.y = pack_bf2(FFN_ACT(hacc[0][mt][2] + bA.z), FFN_ACT(hacc[0][mt][3] + bA.w));
-            u.z = pack_bf2(FFN_ACT(hacc[1][mt][0] + bB.x), FFN_ACT(hacc[1][mt][1] + bB.y));
-            u.w = pack_bf2(FFN_ACT(hacc[1][mt][2] + bB.z), FFN_ACT(hacc[1][mt][3] + bB.w));
-#undef FFN_ACT
+            const f32x2 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+            u.x = pack_bf2(g0.x, g0.y); u.y = pack_bf2(g1.x, g1.y); u.z = pack_bf2(g2.x, g2.y); u.w = pack_bf2(g3.x, g3.y);
             hf[mt] = __builtin_bit_cast(bf16x8, u);
             settle_operand(hf[mt]);
+            __builtin_amdgcn_sched_barrier(0);  // one row tile's GELU at a time: interleaving all MT of them spills
           }
         }
       } else {           // out^T[nt] += W2[nt rows, chunk] . H^T
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) mfma_acc_a(oacc[i - 2 * KS][mt], a, hf[mt]);
       }
+      // NLD == KS == NT/2 for every C: load j is issued after step 2j, store j after step 2KS + 2j
+      static_assert(NLD == KS && 2 * NLD == NT && NLD * 256 == W1_CH + W2_CH, "staging schedule: one whole load / store per two steps");
+      if ((i & 1) == 0) {
+        const int j = (i < 2 * KS ? i : i - 2 * KS) >> 1;
+        const int c = tid + 256 * j, c2 = c - W1_CH;
+        if (i < 2 * KS) {
+          const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)c2 * 8;
+          st[j] = *reinterpret_cast<const uint4*>(src);
+        } else {
+          const int off = c < W1_CH ? (c / (C / 8)) * W1_STRIDE + (c % (C / 8)) * 16 : W1_BYTES + (c2 >> 2) * W2_STRIDE + (c2 & 3) * 16;
+          *reinterpret_cast<uint4*>(nbase + off) = st[j];
+        }
+      }
     }
-#ifndef FFN_ABLATE_STAGE
-    if (hc + 1 < p.nchunks) FFN_STAGE_STORE(cur ^ 1)
-#endif
-#ifndef FFN_ABLATE_BARRIER
     __syncthreads();
-#endif
   }
 #undef FFN_FRAG
 
@@ -244,7 +267,10 @@ int launch_convffn(const bf16_t* x, const bf16_t* w1, const float* b1, const bf1
   switch (C) {
     case 32: return launch_one<32, 8>(p, s);
     case 64: return launch_one<64, 8>(p, s);
-    case 96: return launch_one<96, 8>(p, s);
+#ifndef FFN_MT96
+#define FFN_MT96 4
+#endif
+    case 96: return launch_one<96, FFN_MT96>(p, s);
     case 128: return launch_one<128, 4>(p, s);
     case 192: return launch_one<192, 4>(p, s);
     case 384: return launch_one<384, 2>(p, s);
