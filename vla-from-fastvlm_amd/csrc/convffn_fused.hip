@@ -22,6 +22,9 @@ namespace {
 struct FfnParams {
   const bf16_t* x; const bf16_t* w1; const float* b1; const bf16_t* w2p; const float* b2; const float* ls;
   const bf16_t* res; bf16_t* out; int M, nchunks;
+#ifdef FFN_STAMPS  // tools/ffn_micro.hip diagnostic build: per-block {shader cycles, 100 MHz ticks} around the chunk loop
+  unsigned long long* stamps;
+#endif
 };
 
 // The 192 output accumulators are pinned to the accumulator half of the register file ("+a") and the hidden-tile
@@ -55,6 +58,9 @@ __device__ __forceinline__ void settle_acc(f32x4& acc) {
 }
 // VALU-written B operand (packed GELU output) -> MFMA read: tie the wait states to the operand
 __device__ __forceinline__ void settle_operand(bf16x8& v) { asm volatile("s_nop 3" : "+v"(v)); }
+
+// largest ring depth <= want that divides the chunk's step count (the ring index must line up across chunks)
+constexpr int ring_depth(int nr, int want) { return nr % want == 0 ? want : ring_depth(nr, want - 1); }
 
 template <int C, int MT>
 __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
@@ -116,27 +122,55 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
 
   FFN_STAGE_LOAD(0)
   FFN_STAGE_STORE(0)
+  FFN_STAGE_LOAD(min(1, p.nchunks - 1))   // rides in registers through chunk 0, stored to LDS during it
   __syncthreads();
 
-  // Fragment stream of one chunk: reads 0..2KS-1 are W1 rows (hidden tile ht = i / KS, k-step i % KS), reads 2KS..NR-1
-  // are W2 rows (output tile i - 2KS).  With one wave per SIMD nothing else hides LDS latency, so the reads run PD
-  // steps ahead of the MFMAs that consume them (ring of PD fragments); the first-product bias rides one chunk ahead.
+  // Fragment stream of one chunk: reads 0..2KS-1 are W1 rows (hidden tile ht, k-step kk), reads 2KS..NR-1 are W2 rows
+  // (output tile i - 2KS).  With one wave per SIMD nothing else hides LDS latency, so the reads run PD steps ahead of
+  // the MFMAs that consume them (ring of PD fragments) -- across the chunk boundary too: the chunk's one barrier sits
+  // PD steps before its end, where the last read of this chunk's slot has been issued and every store of the next
+  // chunk's weights is long done, so the ring refills from the next slot behind it and no chunk starts on a cold ring
+  // behind a barrier.  The first-product bias rides one chunk ahead.
 #ifndef FFN_PD
 #define FFN_PD 6
 #endif
-  constexpr int NR = 2 * KS + NT, PD = FFN_PD;
+  constexpr int NR = 2 * KS + NT, PD = ring_depth(NR, FFN_PD < NR / 2 ? FFN_PD : NR / 2);
+  static_assert(NLD == KS && 2 * NLD == NT && NLD * 256 == W1_CH + W2_CH && 2 * NLD <= NR - PD, "staging schedule");
+  static_assert(NR % PD == 0, "fragment f lives in ring[f % PD] across the chunk boundary");
+#ifndef FFN_ORDER_SEQ  // first-product step i -> hidden tile / k-step.  Interleaving the two hidden tiles doubles the distance
+#define FFN_HT(I) ((I) & 1)   // between MFMAs on the same accumulator (MT = 2: from 2 to 4 MFMAs)
+#define FFN_KK(I) ((I) >> 1)
+#else
+#define FFN_HT(I) ((I) / KS)
+#define FFN_KK(I) ((I) % KS)
+#endif
 #define FFN_FRAG(I, W1S, W2S)                                                                                       \
-  ((I) < 2 * KS ? *reinterpret_cast<const uint4*>((W1S) + (((I) / KS) * 16 + fr) * W1_STRIDE + ((I) % KS) * 64 + fg * 16) \
+  ((I) < 2 * KS ? *reinterpret_cast<const uint4*>((W1S) + (FFN_HT(I) * 16 + fr) * W1_STRIDE + FFN_KK(I) * 64 + fg * 16) \
                 : *reinterpret_cast<const uint4*>((W2S) + (((I) - 2 * KS) * 16 + fr) * W2_STRIDE + fg * 16))
   float4 bA_n = *reinterpret_cast<const float4*>(p.b1 + fg * 4), bB_n = *reinterpret_cast<const float4*>(p.b1 + 16 + fg * 4);
+  uint4 ring[PD];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) ring[i] = FFN_FRAG(i, smem, smem + W1_BYTES);
+#ifdef FFN_STAMPS
+  const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
+#ifdef FFN_STAMPS_FINE  // per-phase cycle sums (perturbs the ring: every stamp drains lgkmcnt)
+  unsigned long long tl = t0c, ta[6] = {0, 0, 0, 0, 0, 0};
+#define FFN_STAMP(K) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ta[K] += t_ - tl; tl = t_; }
+#else
+#define FFN_STAMP(K)
+#endif
+#else
+#define FFN_STAMP(K)
+#endif
   for (int hc = 0; hc < p.nchunks; ++hc) {
     const int cur = hc & 1;
     const float4 bA = bA_n, bB = bB_n;
-    // the next chunk's weights: NLD global loads spread over the first product's steps, their NLD LDS stores over the
-    // second product's (a burst of 12 loads costs ~800 issue cycles while the L1 path drains 64 B/clk, a burst of 12
-    // ds_write_b128 ~700: in-order issue makes both dead MFMA time unless they are dealt out between the MFMAs).  The
-    // last iteration re-stages the final chunk into the idle slot, which keeps the stream branch-free.
-    const int hn = min(hc + 1, p.nchunks - 1);
+    // Weight staging, two chunks deep so no store ever waits on its load: during chunk hc the registers loaded during
+    // chunk hc-1 (chunk hc+1's weights) go to the idle LDS slot and are refilled with chunk hc+2's.  One store or one
+    // load per step of the first product: a burst of 12 loads costs ~800 issue cycles while the L1 path drains
+    // 64 B/clk, a burst of 12 ds_write_b128 ~700, and in-order issue makes both dead MFMA time.  Past the last chunk
+    // the final one is staged again into the idle slot, which keeps the stream branch-free.
+    const int hn = min(hc + 2, p.nchunks - 1);
     const bf16_t* g1n = p.w1 + (size_t)hn * 32 * C;
     const bf16_t* g2n = p.w2p + (size_t)hn * C * 32;
     char* nbase = smem + (cur ^ 1) * BUF;
@@ -146,23 +180,33 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
     }
     const char* w1s = smem + cur * BUF;
     const char* w2s = w1s + W1_BYTES;
-    uint4 ring[PD];
-#pragma unroll
-    for (int i = 0; i < PD; ++i) ring[i] = FFN_FRAG(i, w1s, w2s);
     f32x4 hacc[2][MT];
     bf16x8 hf[MT];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
+      if (i == NR - PD) { FFN_STAMP(3) __syncthreads(); FFN_STAMP(4) }
       const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i % PD]);
-      if (i + PD < NR) ring[i % PD] = FFN_FRAG(i + PD, w1s, w2s);
+      ring[i % PD] = i + PD < NR ? FFN_FRAG(i + PD, w1s, w2s) : FFN_FRAG(i + PD - NR, nbase, nbase + W1_BYTES);
       if (i < 2 * KS) {  // H^T[ht] += W1[ht rows, k-step] . x^T
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          if (i % KS == 0) mfma_init_h<HA>(hacc[i / KS][mt], a, xf[mt][0]);
-          else mfma_acc_h<HA>(hacc[i / KS][mt], a, xf[mt][i % KS]);
-          if (i % KS == KS - 1) settle_acc<HA>(hacc[i / KS][mt]);
+          if (FFN_KK(i) == 0) mfma_init_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][0]);
+          else mfma_acc_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][FFN_KK(i)]);
+          if (FFN_KK(i) == KS - 1) settle_acc<HA>(hacc[FFN_HT(i)][mt]);
+        }
+        {  // staging: even steps store register j to the idle slot, odd steps reload it for the chunk after
+          const int j = i >> 1;
+          const int c = tid + 256 * j, c2 = c - W1_CH;
+          if ((i & 1) == 0) {
+            const int off = c < W1_CH ? (c / (C / 8)) * W1_STRIDE + (c % (C / 8)) * 16 : W1_BYTES + (c2 >> 2) * W2_STRIDE + (c2 & 3) * 16;
+            *reinterpret_cast<uint4*>(nbase + off) = st[j];
+          } else {
+            const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)c2 * 8;
+            st[j] = *reinterpret_cast<const uint4*>(src);
+          }
         }
         if (i == 2 * KS - 1) {  // bias + GELU in registers -> B operand of the second product
+          FFN_STAMP(0)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             uint4 u;
@@ -184,48 +228,72 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
             settle_operand(hf[mt]);
             __builtin_amdgcn_sched_barrier(0);  // one row tile's GELU at a time: interleaving all MT of them spills
           }
+          FFN_STAMP(1)
         }
       } else {           // out^T[nt] += W2[nt rows, chunk] . H^T
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) mfma_acc_a(oacc[i - 2 * KS][mt], a, hf[mt]);
       }
-      // NLD == KS == NT/2 for every C: load j is issued after step 2j, store j after step 2KS + 2j
-      static_assert(NLD == KS && 2 * NLD == NT && NLD * 256 == W1_CH + W2_CH, "staging schedule: one whole load / store per two steps");
-      if ((i & 1) == 0) {
-        const int j = (i < 2 * KS ? i : i - 2 * KS) >> 1;
-        const int c = tid + 256 * j, c2 = c - W1_CH;
-        if (i < 2 * KS) {
-          const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)c2 * 8;
-          st[j] = *reinterpret_cast<const uint4*>(src);
-        } else {
-          const int off = c < W1_CH ? (c / (C / 8)) * W1_STRIDE + (c % (C / 8)) * 16 : W1_BYTES + (c2 >> 2) * W2_STRIDE + (c2 & 3) * 16;
-          *reinterpret_cast<uint4*>(nbase + off) = st[j];
-        }
-      }
     }
-    __syncthreads();
+    FFN_STAMP(5)
   }
+#ifdef FFN_STAMPS
+  if (tid == 0 && p.stamps) {
+    p.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+    p.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+#ifdef FFN_STAMPS_FINE
+    if (blockIdx.x == 0) for (int k = 0; k < 6; ++k) p.stamps[2 * gridDim.x + k] = ta[k];
+#endif
+  }
+#endif
 #undef FFN_FRAG
 
 #undef FFN_STAGE_LOAD
 #undef FFN_STAGE_STORE
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // last XDL writes of the output accumulators -> VALU reads below
-  // ---- epilogue: lane owns pixel (m0 + mt*16 + fr), output channels nt*16 + 4*fg .. +4
+  // ---- epilogue.  The accumulator layout (lane = pixel fr, 4 channels per tile) would leave as 8-byte accesses 32 B apart
+  // -- 2 NT of them per row tile, store-issue-bound with nothing to overlap them at one wave per SIMD.  Instead each
+  // wave turns its 16-row tiles through its own corner of the (now idle) weight slots as fp32: layer scale and bias are
+  // applied on the way in (channels fixed per lane), residual add and bf16 rounding on the way out, where a lane owns
+  // 8 consecutive channels and every global access is 16 B of a fully used line.
+  constexpr int ORB = C * 4 + 16;                      // fp32 row + 16 B (conflict-free 16-B column writes)
+  static_assert(4 * 16 * ORB <= 2 * BUF, "epilogue tile must fit in the weight slots");
+  __syncthreads();                                     // every wave is done reading weights
+  char* so = smem + wid * (16 * ORB);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const long m = m0 + mt * 16 + fr;
-    if (m >= p.M) continue;
+    uint4 rr[KS];                                      // residual rows first: their latency hides behind the LDS turn
+#pragma unroll
+    for (int it = 0; it < KS; ++it) {
+      const int ch = it * 64 + lane, row = ch / (C / 8), c8 = ch % (C / 8);
+      const long m = min(m0 + mt * 16 + row, (long)p.M - 1);
+      rr[it] = *reinterpret_cast<const uint4*>(p.res + m * C + c8 * 8);
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = nt * 16 + fg * 4;
       const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + n);
       const float4 ls = *reinterpret_cast<const float4*>(p.ls + n);
-      const uint2 r = *reinterpret_cast<const uint2*>(p.res + m * C + n);
-      uint2 o;
-      o.x = pack_bf2(bf_lo(r.x) + ls.x * (oacc[nt][mt][0] + b2.x), bf_hi(r.x) + ls.y * (oacc[nt][mt][1] + b2.y));
-      o.y = pack_bf2(bf_lo(r.y) + ls.z * (oacc[nt][mt][2] + b2.z), bf_hi(r.y) + ls.w * (oacc[nt][mt][3] + b2.w));
-      *reinterpret_cast<uint2*>(p.out + m * C + n) = o;
+      float4 v;
+      v.x = ls.x * (oacc[nt][mt][0] + b2.x); v.y = ls.y * (oacc[nt][mt][1] + b2.y);
+      v.z = ls.z * (oacc[nt][mt][2] + b2.z); v.w = ls.w * (oacc[nt][mt][3] + b2.w);
+      *reinterpret_cast<float4*>(so + fr * ORB + n * 4) = v;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-local hand-over: LDS serves a wave's accesses in order
+#pragma unroll
+    for (int it = 0; it < KS; ++it) {
+      const int ch = it * 64 + lane, row = ch / (C / 8), c8 = ch % (C / 8);
+      const long m = m0 + mt * 16 + row;
+      const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
+      const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
+      uint4 o;
+      o.x = pack_bf2(bf_lo(rr[it].x) + y0.x, bf_hi(rr[it].x) + y0.y);
+      o.y = pack_bf2(bf_lo(rr[it].y) + y0.z, bf_hi(rr[it].y) + y0.w);
+      o.z = pack_bf2(bf_lo(rr[it].z) + y1.x, bf_hi(rr[it].z) + y1.y);
+      o.w = pack_bf2(bf_lo(rr[it].w) + y1.z, bf_hi(rr[it].w) + y1.w);
+      if (m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + c8 * 8) = o;
+    }
+    asm volatile("" ::: "memory");                      // the next tile's writes stay behind these reads
   }
 }
 
@@ -245,6 +313,9 @@ int launch_one(const FfnParams& p, hipStream_t s) {
 
 }  // namespace
 
+#ifdef FFN_STAMPS
+unsigned long long* g_ffn_stamps = nullptr;
+#endif
 bool convffn_supported(int C, int ratio) { return ratio == 4 && (C == 32 || C == 64 || C == 96 || C == 128 || C == 192 || C == 384); }
 
 // w2 [C][hidden] row-major -> [hidden/32][C][32] with slot (g, j) of each 32-block holding hidden 16*(j>>2) + 4*g + (j&3)
@@ -264,6 +335,9 @@ int launch_convffn(const bf16_t* x, const bf16_t* w1, const float* b1, const bf1
     return fv_fail(FV_ERR_ARG, "convffn: misaligned pointer");
   if (x == out) return fv_fail(FV_ERR_ARG, "convffn: x must not alias out");
   FfnParams p{x, w1, b1, w2p, b2, ls, res, out, M, hidden / 32};
+#ifdef FFN_STAMPS
+  p.stamps = g_ffn_stamps;
+#endif
   switch (C) {
     case 32: return launch_one<32, 8>(p, s);
     case 64: return launch_one<64, 8>(p, s);

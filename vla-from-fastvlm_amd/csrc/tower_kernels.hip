@@ -347,23 +347,30 @@ __global__ __launch_bounds__(256, 3) void dwconv_tile_kernel(const bf16_t* __res
 // back through LDS to leave as 16-byte NHWC stores.  Weights arrive as a precomputed bf16 Toeplitz table.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-template <int K>
-__global__ __launch_bounds__(256, 3) void dwconv_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ttab,
+template <int K, int TH>
+__global__ __launch_bounds__(256, TH == 8 ? 3 : 2) void dwconv_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ttab,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                               int H, int W, int C, int gelu, int tiles_x, int tiles_y,
                                                               int nslices) {
-  constexpr int TH = 8, TW = 32, PAD = K / 2, IH = TH + K - 1, IW = TW + K - 1;
+  constexpr int TW = 32, NP = TH / 8, PAD = K / 2, IH = TH + K - 1, IW = TW + K - 1;
   constexpr int NQ = (IW + 3) / 4, NM = (K + 3 + 3) / 4;       // column quads in the halo tile; k-blocks per output quad
   constexpr int RS = NQ * 256 + 64;                            // LDS bytes per halo row (== 64 mod 256: 4 rows, 4 bank windows)
   constexpr int T_BYTES = 2 * K * NM * 512, X_BYTES = IH * RS;
-  constexpr int ORS = 32 * 64 + 32;                            // output tile row stride (bytes)
-  constexpr int LDSB = X_BYTES > TH * ORS ? X_BYTES : TH * ORS;
-  __shared__ __attribute__((aligned(16))) char smem[LDSB];
-  char* sX = smem;
-  char* sO = smem;  // aliases the halo tile once every wave is done reading it
+  __shared__ __attribute__((aligned(16))) char smem[X_BYTES];
+  // LDS image, input and output alike: [row][column quad][32 channel slots][4 columns] bf16, 256 B per (row, quad) cell,
+  // channel ch in slot ch ^ (2 (quad & 3) | ch >> 4).  Unswizzled, the 16 lanes one ds_write_b64 services together
+  // (4 quads x 4 channel groups, one channel each) hit 2 bank pairs, an 8-way conflict that made the transpose, not HBM,
+  // the bound of this kernel; swizzled they cover all 32 banks.  The MFMA-side accesses only see a per-quad constant.
+  char* sX = smem;  // the output tile reuses it once every wave is done reading the halo tile
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // The channel slices of one pixel tile share 128-B lines and neighbouring tiles share halo rows/columns: keep them on
+  // one XCD (one L2) instead of dealing them round-robin over all eight.
+#ifdef DW_NO_XCD
   int bid = blockIdx.x;
+#else
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+#endif
   const int slice = bid % nslices; bid /= nslices;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int tyb = bid % tiles_y;
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_mfma_kernel(const bf16_t* __res
       const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;
       const uint32_t d[4][4] = {{px[tt][0].x, px[tt][0].y, px[tt][0].z, px[tt][0].w}, {px[tt][1].x, px[tt][1].y, px[tt][1].z, px[tt][1].w},
                                 {px[tt][2].x, px[tt][2].y, px[tt][2].z, px[tt][2].w}, {px[tt][3].x, px[tt][3].y, px[tt][3].z, px[tt][3].w}};
-      char* dst = sX + row * RS + quad * 256 + cg * 64;
+      const uint32_t dst = (uint32_t)(row * RS + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
 #pragma unroll
       for (int dd = 0; dd < 4; ++dd) {  // dword dd of a pixel holds channels 2dd (low half) and 2dd+1 (high half)
         uint2 ev, od;
@@ -413,52 +420,86 @@ __global__ __launch_bounds__(256, 3) void dwconv_mfma_kernel(const bf16_t* __res
         ev.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x05040100u);
         od.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x07060302u);
         od.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x07060302u);
-        *reinterpret_cast<uint2*>(dst + (2 * dd) * 8) = ev;
-        *reinterpret_cast<uint2*>(dst + (2 * dd + 1) * 8) = od;
+        *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd) * 8))) = ev;
+        *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd + 1) * 8))) = od;
       }
     }
   }
   __syncthreads();
 
-  f32x4 acc[8];
+  // lane's four swizzled channel offsets (one per quad & 3) on its first halo row; everything else is an immediate
+  const char* lrow[4];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int v = 0; v < 4; ++v) lrow[v] = sX + (rg * 4 * NP + jr) * RS + (((gg * 16 + bch) ^ ((v << 1) | gg)) << 3);
+  f32x4 acc[NP][8];
 #pragma unroll
-  for (int ky = 0; ky < K; ++ky) {
-    const char* rowp = sX + (rg * 4 + jr + ky) * RS + (gg * 16 + bch) * 8;
-    s16x4 xq[NQ];
+  for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
-    for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(rowp + t * 256));
+    for (int q = 0; q < 8; ++q) acc[pp][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+  for (int pp = 0; pp < NP; ++pp)   // a wave's NP groups of 4 output rows, one after the other
 #pragma unroll
-      for (int m = 0; m < NM; ++m)
-        if (q + m < NQ) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[q + m], acc[q], 0, 0, 0);
-  }
+    for (int ky = 0; ky < K; ++ky) {
+      s16x4 xq[NQ];
+#pragma unroll
+      for (int t = 0; t < NQ; ++t)
+        xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(lrow[t & 3] + (pp * 4 + ky) * RS + t * 256));
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#ifdef DW_ABL_MFMA  // tools/dw_micro.hip only: one MFMA per (ky, q) instead of NM, to price the matrix work
+          if (q + m < NQ && m == 0) acc[pp][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[q + m], acc[pp][q], 0, 0, 0);
+#else
+          if (q + m < NQ) acc[pp][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[q + m], acc[pp][q], 0, 0, 0);
+#endif
+    }
   __syncthreads();  // all waves are done with the halo tile; reuse it for the output tile
 
-  // ---- bias (+GELU) and NHWC re-layout through LDS: lane holds 4 consecutive columns of one channel per quad
+  // ---- bias (+GELU), then back through LDS in the same cell layout: one 8-byte store per quad (4 columns of the lane's
+  // channel); the NHWC transpose is done by the reading side with v_perm, mirroring the load path
   {
     const float bv = bias[c0 + gg * 16 + bch];
-    char* orow = sO + (rg * 4 + jr) * ORS + (gg * 16 + bch) * 2;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = acc[q][i] + bv;
-        if (gelu) v = gelu_f(v);
-        *reinterpret_cast<bf16_t*>(orow + (q * 4 + i) * 64) = f2bf(v);
+      for (int q = 0; q < 8; ++q) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[pp][q][i] + bv;
+          if (gelu) v[i] = gelu_f(v[i]);
+        }
+        uint2 u;
+        u.x = pack_bf2(v[0], v[1]);
+        u.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(const_cast<char*>(lrow[q & 3]) + pp * 4 * RS + q * 256) = u;
       }
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i;                 // 1024 chunks: row (8) x col (32) x 8-channel chunk (4)
-    const int chunk = c & 3, col = (c >> 2) & 31, row = c >> 7;
-    const int oy = tyb * TH + row, ox = tx * TW + col;
-    if (oy < H && ox < W)
-      *reinterpret_cast<uint4*>(y + (((size_t)b * H + oy) * W + ox) * C + c0 + chunk * 8) =
-          *reinterpret_cast<const uint4*>(sO + row * ORS + col * 64 + chunk * 16);
+  for (int ot = 0; ot < NP; ++ot) {
+    const int task = tid + 256 * ot;
+    const int cg = task & 3, quad = (task >> 2) & 7, row = task >> 5;   // TH rows x 8 quads x 4 channel groups
+    const uint32_t src = (uint32_t)(row * RS + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
+    uint2 r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sX + (src ^ (uint32_t)(e * 8)));
+    const int oy = tyb * TH + row, ox0 = tx * TW + quad * 4;
+    if (oy < H) {
+      bf16_t* yp = y + (((size_t)b * H + oy) * W + ox0) * C + c0 + cg * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (ox0 + j < W) {
+          uint4 o;
+          const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+#define FV_PX(A, B) __builtin_amdgcn_perm((j & 2) ? r[B].y : r[B].x, (j & 2) ? r[A].y : r[A].x, sel)
+          o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
+#undef FV_PX
+          *reinterpret_cast<uint4*>(yp + (size_t)j * C) = o;
+        }
+      }
+    }
   }
 }
 
@@ -670,11 +711,18 @@ int launch_dwconv_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, b
                        int gelu, hipStream_t s) {
   if (!x || !ttab || !bias || !y) return fv_fail(FV_ERR_ARG, "dwconv_mfma: null pointer");
   if (B <= 0 || H <= 0 || !dwconv_mfma_supported(W, C, k, 1, 1)) return fv_fail(FV_ERR_UNSUPPORTED, "dwconv_mfma: unsupported shape W=%d C=%d k=%d", W, C, k);
-  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8, nsl = C / 32;
+  // 7x7: 16-row tiles (halo rows 22/16 instead of 14/8 of the tile, 22 % fewer loads and transposes) when the map is
+  // tall enough to still give every CU several blocks; 3x3 keeps 8 rows (its halo is small, occupancy matters more)
+#ifndef DW_TH7
+#define DW_TH7 8
+#endif
+  const int th = (k == 7 && H >= 32) ? DW_TH7 : 8;
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + th - 1) / th, nsl = C / 32;
   const long nblk = (long)B * tiles_x * tiles_y * nsl;
   if (nblk > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv_mfma: grid too large");
-  if (k == 7) hipLaunchKernelGGL(dwconv_mfma_kernel<7>, dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
-  else hipLaunchKernelGGL(dwconv_mfma_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
+  if (k == 7 && th == 16) hipLaunchKernelGGL((dwconv_mfma_kernel<7, 16>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
+  else if (k == 7) hipLaunchKernelGGL((dwconv_mfma_kernel<7, 8>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
+  else hipLaunchKernelGGL((dwconv_mfma_kernel<3, 8>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
