@@ -44,30 +44,22 @@ int main() {
     hipEventElapsedTime(&ms, e0, e1);
     ms /= it;
 #ifdef FFN_STAMPS
-    {  // in-kernel clock and wave cycles per chunk: median over workgroups of one more launch after the warm loop
-      const int nblk = (M + 64 * 8 - 1) / 64;  // upper bound on the grid
+    {  // per-block cycle stamps of the first tile (median over blocks) from one more launch after the warm loop
+      const int nb = 1024;
       unsigned long long* ds;
-      hipMalloc(&ds, (size_t)nblk * 16 + 64);
-      hipMemset(ds, 0, (size_t)nblk * 16 + 64);
+      hipMalloc(&ds, nb * 32);
+      hipMemset(ds, 0, nb * 32);
       fv::g_ffn_stamps = ds;
       fv::launch_convffn(x, w1, b1, w2, b2, ls, res, out, M, C, H, 0);
       hipDeviceSynchronize();
-      std::vector<unsigned long long> hs((size_t)nblk * 2);
+      std::vector<unsigned long long> hs(nb * 4);
       hipMemcpy(hs.data(), ds, hs.size() * 8, hipMemcpyDeviceToHost);
-      std::vector<double> cyc, clk;
-      for (int b = 0; b < nblk; ++b) if (hs[2 * b + 1]) { cyc.push_back((double)hs[2 * b]); clk.push_back((double)hs[2 * b] / hs[2 * b + 1] * 100.0); }
-      std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
-      printf("  blocks %zu: median loop cycles %.0f = %.0f per 32-hidden chunk; in-kernel clock %.0f MHz\n", cyc.size(), cyc[cyc.size() / 2],
-             cyc[cyc.size() / 2] / (H / 32), clk[clk.size() / 2]);
-#ifdef FFN_STAMPS_FINE
-      {
-        unsigned long long fine[6];
-        hipMemcpy(fine, ds + 2 * (cyc.size() - 3), sizeof fine, hipMemcpyDeviceToHost);  // the 6 fine sums sit behind the grid's pairs
-        const double nc = H / 32;
-        printf("  per chunk (block 0 wave 0): first product %.0f  gelu %.0f  second product to barrier %.0f  barrier %.0f  rest of second product %.0f\n",
-               fine[0] / nc, fine[1] / nc, fine[3] / nc, fine[4] / nc, fine[5] / nc);
-      }
-#endif
+      std::vector<double> v[4];
+      for (int b = 0; b < nb; ++b) if (hs[4 * b + 3]) for (int k = 0; k < 4; ++k) v[k].push_back((double)hs[4 * b + k]);
+      for (auto& a : v) std::sort(a.begin(), a.end());
+      const size_t n = v[0].size();
+      if (n) printf("  %zu blocks: prologue %.0f  chunk loop %.0f (= %.0f per chunk)  epilogue %.0f cycles;  in-loop clock %.0f MHz\n", n, v[0][n / 2],
+                    v[1][n / 2], v[1][n / 2] / (H / 32), v[2][n / 2], v[1][n / 2] / v[3][n / 2] * 100.0);
       fv::g_ffn_stamps = nullptr;
       hipFree(ds);
     }

@@ -22,7 +22,7 @@ namespace {
 struct FfnParams {
   const bf16_t* x; const bf16_t* w1; const float* b1; const bf16_t* w2p; const float* b2; const float* ls;
   const bf16_t* res; bf16_t* out; int M, nchunks;
-#ifdef FFN_STAMPS  // tools/ffn_micro.hip diagnostic build: per-block {shader cycles, 100 MHz ticks} around the chunk loop
+#ifdef FFN_STAMPS  // tools/ffn_micro.hip diagnostic build: per block {prologue, first tile's chunk loop, its epilogue} cycles + clock
   unsigned long long* stamps;
 #endif
 };
@@ -49,15 +49,52 @@ __device__ __forceinline__ void mfma_init_h(f32x4& acc, const bf16x8& a, const b
   if constexpr (HA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
   else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
 }
-// after the last k-step of a hidden tile the GELU (VALU) reads the accumulator -- hipcc pads nothing after inline asm, so
-// the XDL-write -> VALU-read wait states are spelled out, tied to the accumulator
-template <bool HA>
-__device__ __forceinline__ void settle_acc(f32x4& acc) {
-  if constexpr (HA) asm volatile("s_nop 7\n\ts_nop 3" : "+a"(acc));
-  else asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc));
+// Hazards hipcc cannot see through the asm MFMAs, each paid ONCE per chunk (an s_nop wait state is 4 clocks, so a settle per
+// tile cost 450 clocks a chunk at MT = 4).  settle_accs sits behind the first product's LAST MFMA and ties every hidden
+// accumulator to it: the GELU's reads are then ordered after all those MFMAs, and the XDL-write -> VALU-read distance
+// (7 wait states for this 4-pass MFMA) is owed only by the last-issued tile; 10 wait states cover it with a margin.
+// settle_operands does the same for the VALU-written B operands (packed GELU output) ahead of the second product.
+template <bool HA, int N>
+__device__ __forceinline__ void settle_accs(f32x4 (&h)[2][N]) {
+  static_assert(N == 2 || N == 4 || N == 8, "row tiles per wave");
+  if constexpr (N == 2) {
+    if constexpr (HA) asm volatile("s_nop 7\n\ts_nop 1" : "+a"(h[0][0]), "+a"(h[0][1]), "+a"(h[1][0]), "+a"(h[1][1]));
+    else asm volatile("s_nop 7\n\ts_nop 1" : "+v"(h[0][0]), "+v"(h[0][1]), "+v"(h[1][0]), "+v"(h[1][1]));
+  } else if constexpr (N == 4) {
+    if constexpr (HA) asm volatile("s_nop 7\n\ts_nop 1" : "+a"(h[0][0]), "+a"(h[0][1]), "+a"(h[0][2]), "+a"(h[0][3]), "+a"(h[1][0]), "+a"(h[1][1]), "+a"(h[1][2]), "+a"(h[1][3]));
+    else asm volatile("s_nop 7\n\ts_nop 1" : "+v"(h[0][0]), "+v"(h[0][1]), "+v"(h[0][2]), "+v"(h[0][3]), "+v"(h[1][0]), "+v"(h[1][1]), "+v"(h[1][2]), "+v"(h[1][3]));
+  } else {
+    if constexpr (HA) asm volatile("s_nop 7\n\ts_nop 1" : "+a"(h[0][0]), "+a"(h[0][1]), "+a"(h[0][2]), "+a"(h[0][3]), "+a"(h[0][4]), "+a"(h[0][5]), "+a"(h[0][6]), "+a"(h[0][7]),
+                                               "+a"(h[1][0]), "+a"(h[1][1]), "+a"(h[1][2]), "+a"(h[1][3]), "+a"(h[1][4]), "+a"(h[1][5]), "+a"(h[1][6]), "+a"(h[1][7]));
+    else asm volatile("s_nop 7\n\ts_nop 1" : "+v"(h[0][0]), "+v"(h[0][1]), "+v"(h[0][2]), "+v"(h[0][3]), "+v"(h[0][4]), "+v"(h[0][5]), "+v"(h[0][6]), "+v"(h[0][7]),
+                                  "+v"(h[1][0]), "+v"(h[1][1]), "+v"(h[1][2]), "+v"(h[1][3]), "+v"(h[1][4]), "+v"(h[1][5]), "+v"(h[1][6]), "+v"(h[1][7]));
+  }
 }
-// VALU-written B operand (packed GELU output) -> MFMA read: tie the wait states to the operand
-__device__ __forceinline__ void settle_operand(bf16x8& v) { asm volatile("s_nop 3" : "+v"(v)); }
+template <int N>
+__device__ __forceinline__ void settle_operands(bf16x8 (&v)[N]) {
+  if constexpr (N == 2) asm volatile("s_nop 3" : "+v"(v[0]), "+v"(v[1]));
+  else if constexpr (N == 4) asm volatile("s_nop 3" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+  else asm volatile("s_nop 3" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+
+// Staging registers as named scalars: an array indexed by the (unrolled) step counter was left in scratch memory once the
+// chunk body was instantiated twice -- a switch over scalars folds to a register whatever the pass order.
+struct StageRegs {
+  uint4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11;
+  __device__ __forceinline__ uint4 get(int j) const {
+    switch (j) {
+      case 0: return r0; case 1: return r1; case 2: return r2; case 3: return r3; case 4: return r4; case 5: return r5;
+      case 6: return r6; case 7: return r7; case 8: return r8; case 9: return r9; case 10: return r10; default: return r11;
+    }
+  }
+  __device__ __forceinline__ void set(int j, const uint4& v) {
+    switch (j) {
+      case 0: r0 = v; break; case 1: r1 = v; break; case 2: r2 = v; break; case 3: r3 = v; break; case 4: r4 = v; break;
+      case 5: r5 = v; break; case 6: r6 = v; break; case 7: r7 = v; break; case 8: r8 = v; break; case 9: r9 = v; break;
+      case 10: r10 = v; break; default: r11 = v; break;
+    }
+  }
+};
 
 // largest ring depth <= want that divides the chunk's step count (the ring index must line up across chunks)
 constexpr int ring_depth(int nr, int want) { return nr % want == 0 ? want : ring_depth(nr, want - 1); }
@@ -75,29 +112,36 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
   constexpr int W1_BYTES = 32 * W1_STRIDE, W2_BYTES = C * W2_STRIDE, BUF = W1_BYTES + W2_BYTES;
   constexpr int W1_CH = 32 * C / 8, W2_CH = C * 4;           // 16-byte chunks per weight chunk
   constexpr int NLD = (W1_CH + W2_CH + 255) / 256;            // staging loads per thread per chunk
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF] weight slots, then b2[C], ls[C] fp32
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const long m0 = (long)blockIdx.x * (64 * MT) + wid * (16 * MT);
+  const int nch = p.nchunks;                                   // C / 8: even, >= 4
+  const int ntiles = (p.M + 64 * MT - 1) / (64 * MT);
 
-  // ---- x fragments: lane holds x[pixel m][32 ks + 8 fg .. +8] for its MT pixel tiles
+  // ---- x fragments: lane holds x[pixel m][32 ks + 8 fg .. +8] for its MT pixel tiles (rows past M clamp to M - 1)
   bf16x8 xf[MT][KS];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const long m = min(m0 + mt * 16 + fr, (long)p.M - 1);
-    const bf16_t* xp = p.x + m * C + fg * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp + ks * 32));
+#define FFN_LOAD_X(TILE)                                                                                     \
+  {                                                                                                          \
+    int lx_ = lane;                                                                                          \
+    asm volatile("" : "+v"(lx_)); /* keeps this address math out of the chunk loop's live registers */       \
+    const long mb_ = (long)(TILE) * (64 * MT) + wid * (16 * MT);                                             \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                      \
+      const long m_ = min(mb_ + mt * 16 + (lx_ & 15), (long)p.M - 1);                                        \
+      const bf16_t* xp_ = p.x + m_ * C + (lx_ >> 4) * 8;                                                     \
+      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                      \
+        xf[mt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp_ + ks * 32));             \
+    }                                                                                                        \
   }
+#ifdef FFN_STAMPS
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+  FFN_LOAD_X(blockIdx.x)
   f32x4 oacc[NT][MT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) oacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- weight-chunk staging (global -> registers -> LDS); every index below is compile-time after unrolling
-  uint4 st[NLD];
+  static_assert(NLD <= 12, "StageRegs holds 12");
+  StageRegs st;
 #define FFN_STAGE_LOAD(HC)                                                                                   \
   {                                                                                                          \
     const bf16_t* g1 = p.w1 + (size_t)(HC) * 32 * C;  /* [32][C] */                                          \
@@ -105,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
       const int c = tid + 256 * i;                                                                           \
       const bf16_t* src = c < W1_CH ? g1 + (size_t)c * 8 : g2 + (size_t)(c - W1_CH) * 8;                     \
-      st[i] = (c < W1_CH + W2_CH) ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);           \
+      st.set(i, *reinterpret_cast<const uint4*>(src));                                                       \
     }                                                                                                        \
   }
 #define FFN_STAGE_STORE(BUFI)                                                                                \
@@ -116,13 +160,13 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
       const int c2 = c - W1_CH;                                                                              \
       const int off = c < W1_CH ? (c / (C / 8)) * W1_STRIDE + (c % (C / 8)) * 16                             \
                                 : W1_BYTES + (c2 >> 2) * W2_STRIDE + (c2 & 3) * 16;                          \
-      if (c < W1_CH + W2_CH) *reinterpret_cast<uint4*>(base + off) = st[i];                                  \
+      *reinterpret_cast<uint4*>(base + off) = st.get(i);                                                     \
     }                                                                                                        \
   }
 
   FFN_STAGE_LOAD(0)
   FFN_STAGE_STORE(0)
-  FFN_STAGE_LOAD(min(1, p.nchunks - 1))   // rides in registers through chunk 0, stored to LDS during it
+  FFN_STAGE_LOAD(1)                       // rides in registers through chunk 0, stored to LDS during it
   __syncthreads();
 
   // Fragment stream of one chunk: reads 0..2KS-1 are W1 rows (hidden tile ht, k-step kk), reads 2KS..NR-1 are W2 rows
@@ -137,13 +181,10 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
   constexpr int NR = 2 * KS + NT, PD = ring_depth(NR, FFN_PD < NR / 2 ? FFN_PD : NR / 2);
   static_assert(NLD == KS && 2 * NLD == NT && NLD * 256 == W1_CH + W2_CH && 2 * NLD <= NR - PD, "staging schedule");
   static_assert(NR % PD == 0, "fragment f lives in ring[f % PD] across the chunk boundary");
-#ifndef FFN_ORDER_SEQ  // first-product step i -> hidden tile / k-step.  Interleaving the two hidden tiles doubles the distance
-#define FFN_HT(I) ((I) & 1)   // between MFMAs on the same accumulator (MT = 2: from 2 to 4 MFMAs)
+  // first-product step i -> hidden tile / k-step: interleaving the two hidden tiles doubles the distance between MFMAs on
+  // the same accumulator (MT = 2: from 2 to 4 MFMAs)
+#define FFN_HT(I) ((I) & 1)
 #define FFN_KK(I) ((I) >> 1)
-#else
-#define FFN_HT(I) ((I) / KS)
-#define FFN_KK(I) ((I) % KS)
-#endif
 #define FFN_FRAG(I, W1S, W2S)                                                                                       \
   ((I) < 2 * KS ? *reinterpret_cast<const uint4*>((W1S) + (FFN_HT(I) * 16 + fr) * W1_STRIDE + FFN_KK(I) * 64 + fg * 16) \
                 : *reinterpret_cast<const uint4*>((W2S) + (((I) - 2 * KS) * 16 + fr) * W2_STRIDE + fg * 16))
@@ -151,150 +192,195 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
   uint4 ring[PD];
 #pragma unroll
   for (int i = 0; i < PD; ++i) ring[i] = FFN_FRAG(i, smem, smem + W1_BYTES);
-#ifdef FFN_STAMPS
-  const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
-#ifdef FFN_STAMPS_FINE  // per-phase cycle sums (perturbs the ring: every stamp drains lgkmcnt)
-  unsigned long long tl = t0c, ta[6] = {0, 0, 0, 0, 0, 0};
-#define FFN_STAMP(K) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ta[K] += t_ - tl; tl = t_; }
-#else
-#define FFN_STAMP(K)
-#endif
-#else
-#define FFN_STAMP(K)
-#endif
-  for (int hc = 0; hc < p.nchunks; ++hc) {
-    const int cur = hc & 1;
-    const float4 bA = bA_n, bB = bB_n;
-    // Weight staging, two chunks deep so no store ever waits on its load: during chunk hc the registers loaded during
-    // chunk hc-1 (chunk hc+1's weights) go to the idle LDS slot and are refilled with chunk hc+2's.  One store or one
-    // load per step of the first product: a burst of 12 loads costs ~800 issue cycles while the L1 path drains
-    // 64 B/clk, a burst of 12 ds_write_b128 ~700, and in-order issue makes both dead MFMA time.  Past the last chunk
-    // the final one is staged again into the idle slot, which keeps the stream branch-free.
-    const int hn = min(hc + 2, p.nchunks - 1);
-    const bf16_t* g1n = p.w1 + (size_t)hn * 32 * C;
-    const bf16_t* g2n = p.w2p + (size_t)hn * C * 32;
-    char* nbase = smem + (cur ^ 1) * BUF;
-    if (hc + 1 < p.nchunks) {
-      bA_n = *reinterpret_cast<const float4*>(p.b1 + (hc + 1) * 32 + fg * 4);
-      bB_n = *reinterpret_cast<const float4*>(p.b1 + (hc + 1) * 32 + 16 + fg * 4);
-    }
-    const char* w1s = smem + cur * BUF;
-    const char* w2s = w1s + W1_BYTES;
-    f32x4 hacc[2][MT];
-    bf16x8 hf[MT];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      if (i == NR - PD) { FFN_STAMP(3) __syncthreads(); FFN_STAMP(4) }
-      const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i % PD]);
-      ring[i % PD] = i + PD < NR ? FFN_FRAG(i + PD, w1s, w2s) : FFN_FRAG(i + PD - NR, nbase, nbase + W1_BYTES);
-      if (i < 2 * KS) {  // H^T[ht] += W1[ht rows, k-step] . x^T
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          if (FFN_KK(i) == 0) mfma_init_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][0]);
-          else mfma_acc_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][FFN_KK(i)]);
-          if (FFN_KK(i) == KS - 1) settle_acc<HA>(hacc[FFN_HT(i)][mt]);
-        }
-        {  // staging: even steps store register j to the idle slot, odd steps reload it for the chunk after
-          const int j = i >> 1;
-          const int c = tid + 256 * j, c2 = c - W1_CH;
-          if ((i & 1) == 0) {
-            const int off = c < W1_CH ? (c / (C / 8)) * W1_STRIDE + (c % (C / 8)) * 16 : W1_BYTES + (c2 >> 2) * W2_STRIDE + (c2 & 3) * 16;
-            *reinterpret_cast<uint4*>(nbase + off) = st[j];
-          } else {
-            const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)c2 * 8;
-            st[j] = *reinterpret_cast<const uint4*>(src);
-          }
-        }
-        if (i == 2 * KS - 1) {  // bias + GELU in registers -> B operand of the second product
-          FFN_STAMP(0)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            uint4 u;
-            f32x2 g[4] = {{hacc[0][mt][0] + bA.x, hacc[0][mt][1] + bA.y}, {hacc[0][mt][2] + bA.z, hacc[0][mt][3] + bA.w},
-                          {hacc[1][mt][0] + bB.x, hacc[1][mt][1] + bB.y}, {hacc[1][mt][2] + bB.z, hacc[1][mt][3] + bB.w}};
-#ifndef FFN_ABLATE_GELU  // tools/ffn_micro.hip only: identity activation, to price the GELU
-            if (MT >= 8) {  // the 8-row-tile variants have no registers left for four chains' temporaries
-              f32x2 ga[2] = {g[0], g[1]}, gb[2] = {g[2], g[3]};
-              gelu2_n<2>(ga);
-              gelu2_n<2>(gb);
-              g[0] = ga[0]; g[1] = ga[1]; g[2] = gb[0]; g[3] = gb[1];
-            } else {
-              gelu2_n<4>(g);
-            }
-#endif
-            const f32x2 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-            u.x = pack_bf2(g0.x, g0.y); u.y = pack_bf2(g1.x, g1.y); u.z = pack_bf2(g2.x, g2.y); u.w = pack_bf2(g3.x, g3.y);
-            hf[mt] = __builtin_bit_cast(bf16x8, u);
-            settle_operand(hf[mt]);
-            __builtin_amdgcn_sched_barrier(0);  // one row tile's GELU at a time: interleaving all MT of them spills
-          }
-          FFN_STAMP(1)
-        }
-      } else {           // out^T[nt] += W2[nt rows, chunk] . H^T
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) mfma_acc_a(oacc[i - 2 * KS][mt], a, hf[mt]);
-      }
-    }
-    FFN_STAMP(5)
-  }
-#ifdef FFN_STAMPS
-  if (tid == 0 && p.stamps) {
-    p.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
-    p.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
-#ifdef FFN_STAMPS_FINE
-    if (blockIdx.x == 0) for (int k = 0; k < 6; ++k) p.stamps[2 * gridDim.x + k] = ta[k];
-#endif
-  }
-#endif
-#undef FFN_FRAG
 
+  // epilogue geometry: one pass turns 16 rows x C/2 channels of fp32 through the wave's quarter of a weight slot
+  constexpr int ORB = C * 2 + 16;                      // fp32 half row + 16 B (conflict-free 16-B column writes)
+  constexpr int RP = (C + 63) / 64;                    // 8-channel chunks per lane per pass (16 rows x C/16 chunks = C)
+  static_assert(16 * ORB <= BUF / 4 && (BUF / 4) % 16 == 0 && NT % 2 == 0, "epilogue pass must fit in a quarter of a weight slot");
+  float* sb2 = reinterpret_cast<float*>(smem + 2 * BUF);   // second-product bias and layer scale, staged once per block
+  float* sls = sb2 + C;
+  for (int i = tid; i < C / 4; i += 256) {
+    reinterpret_cast<float4*>(sb2)[i] = reinterpret_cast<const float4*>(p.b2)[i];
+    reinterpret_cast<float4*>(sls)[i] = reinterpret_cast<const float4*>(p.ls)[i];
+  }
+  uint4 rr[3][RP];                                     // residual rows, fetched two passes ahead (pass q in rr[q % 3])
+#define FFN_LOAD_RES(Q, MB)                                                                                  \
+  {                                                                                                          \
+    int lr_ = lane;                                                                                          \
+    asm volatile("" : "+v"(lr_));                                                                            \
+    _Pragma("unroll") for (int it = 0; it < RP; ++it) {                                                      \
+      const int ch_ = min(it * 64 + lr_, C - 1), row_ = ch_ / (C / 16), c8_ = ch_ % (C / 16);                \
+      const long m_ = min((MB) + ((Q) >> 1) * 16 + row_, (long)p.M - 1);                                     \
+      rr[(Q) % 3][it] = *reinterpret_cast<const uint4*>(p.res + m_ * C + ((Q) & 1) * (C / 2) + c8_ * 8);     \
+    }                                                                                                        \
+  }
+
+  // One chunk of 32 hidden units.  (One instantiation on purpose: a peeled copy of the last chunk gets its own accumulator
+  // registers, and the copies hipcc then inserts behind the opaque asm MFMAs read stale data.)
+#define FFN_CHUNK                                                                                                   \
+  {                                                                                                                 \
+    const int cur = hc & 1;                                                                                         \
+    const float4 bA = bA_n, bB = bB_n;                                                                              \
+    /* Weight staging, two chunks deep so no store ever waits on its load: during chunk hc the registers loaded   */ \
+    /* during chunk hc-1 (chunk hc+1's weights) go to the idle LDS slot and are refilled with chunk hc+2's; the   */ \
+    /* chunk index wraps, so the stream runs on into the next tile.  One store or one load per step of the first  */ \
+    /* product: a burst of 12 loads costs ~800 issue cycles while the L1 path drains 64 B/clk, a burst of 12      */ \
+    /* ds_write_b128 ~700, and in-order issue makes both dead MFMA time.                                          */ \
+    const int hn = hc + 2 - (hc + 2 >= nch ? nch : 0), hb = hc + 1 - (hc + 1 >= nch ? nch : 0);                     \
+    const bf16_t* g1n = p.w1 + (size_t)hn * 32 * C;                                                                 \
+    const bf16_t* g2n = p.w2p + (size_t)hn * C * 32;                                                                \
+    char* nbase = smem + (cur ^ 1) * BUF;                                                                           \
+    bA_n = *reinterpret_cast<const float4*>(p.b1 + hb * 32 + fg * 4);                                               \
+    bB_n = *reinterpret_cast<const float4*>(p.b1 + hb * 32 + 16 + fg * 4);                                          \
+    const char* w1s = smem + cur * BUF;                                                                             \
+    const char* w2s = w1s + W1_BYTES;                                                                               \
+    f32x4 hacc[2][MT];                                                                                              \
+    bf16x8 hf[MT];                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                                \
+      if (i == NR - PD) __syncthreads();                                                                            \
+      const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i % PD]);                                                    \
+      ring[i % PD] = i + PD < NR ? FFN_FRAG(i + PD, w1s, w2s) : FFN_FRAG(i + PD - NR, nbase, nbase + W1_BYTES);     \
+      if (i < 2 * KS) { /* H^T[ht] += W1[ht rows, k-step] . x^T */                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                         \
+          if (FFN_KK(i) == 0) mfma_init_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][0]);                                   \
+          else mfma_acc_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][FFN_KK(i)]);                                           \
+        }                                                                                                           \
+        { /* staging: even steps store register j to the idle slot, odd steps reload it for the chunk after */      \
+          const int j = i >> 1;                                                                                     \
+          const int c = tid + 256 * j, c2 = c - W1_CH;                                                              \
+          if ((i & 1) == 0) {                                                                                       \
+            const int off = c < W1_CH ? (c / (C / 8)) * W1_STRIDE + (c % (C / 8)) * 16                              \
+                                      : W1_BYTES + (c2 >> 2) * W2_STRIDE + (c2 & 3) * 16;                           \
+            *reinterpret_cast<uint4*>(nbase + off) = st.get(j);                                                     \
+          } else {                                                                                                  \
+            const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)c2 * 8;                             \
+            st.set(j, *reinterpret_cast<const uint4*>(src));                                                        \
+          }                                                                                                         \
+        }                                                                                                           \
+        if (i == 2 * KS - 1) { /* bias + GELU in registers -> B operand of the second product */                    \
+          settle_accs<HA, MT>(hacc);                                                                                \
+          _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
+            f32x2 g[4] = {{hacc[0][mt][0] + bA.x, hacc[0][mt][1] + bA.y}, {hacc[0][mt][2] + bA.z, hacc[0][mt][3] + bA.w},  \
+                          {hacc[1][mt][0] + bB.x, hacc[1][mt][1] + bB.y}, {hacc[1][mt][2] + bB.z, hacc[1][mt][3] + bB.w}}; \
+            FFN_GELU(g)                                                                                             \
+            uint4 u;                                                                                                \
+            u.x = pack_bf2(g[0].x, g[0].y); u.y = pack_bf2(g[1].x, g[1].y);                                         \
+            u.z = pack_bf2(g[2].x, g[2].y); u.w = pack_bf2(g[3].x, g[3].y);                                         \
+            hf[mt] = __builtin_bit_cast(bf16x8, u);                                                                 \
+            __builtin_amdgcn_sched_barrier(0); /* one row tile's GELU at a time: interleaving all MT spills */      \
+          }                                                                                                         \
+          settle_operands<MT>(hf);                                                                                  \
+        }                                                                                                           \
+      } else { /* out^T[nt] += W2[nt rows, chunk] . H^T */                                                          \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) mfma_acc_a(oacc[i - 2 * KS][mt], a, hf[mt]);              \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+#ifdef FFN_ABLATE_GELU  // tools/ffn_micro.hip only: identity activation, to price the GELU
+#define FFN_GELU(G)
+#else
+#define FFN_GELU(G)                                                                                            \
+  if (MT >= 8) { /* the 8-row-tile variants have no registers left for four chains' temporaries */             \
+    f32x2 ga[2] = {G[0], G[1]}, gb[2] = {G[2], G[3]};                                                          \
+    gelu2_n<2>(ga);                                                                                            \
+    gelu2_n<2>(gb);                                                                                            \
+    G[0] = ga[0]; G[1] = ga[1]; G[2] = gb[0]; G[3] = gb[1];                                                    \
+  } else {                                                                                                     \
+    gelu2_n<4>(G);                                                                                             \
+  }
+#endif
+
+  // ---- persistent loop over this block's row tiles.  With 512 registers per lane there is one wave per SIMD and nothing
+  // to overlap a tile's input loads, residual loads and output stores with -- except the neighbouring tile's MFMAs.
+  for (int tile = blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+    const long mb = (long)tile * (64 * MT) + wid * (16 * MT);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) oacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef FFN_STAMPS
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime(), t_real = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int hc = 0; hc < nch; ++hc) FFN_CHUNK
+#ifdef FFN_STAMPS
+    const unsigned long long t_epi = __builtin_amdgcn_s_memtime(), t_real2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    __builtin_amdgcn_sched_barrier(0);  // keep the epilogue's loads out of the chunk: hoisted, they spill its registers
+    FFN_LOAD_RES(0, mb)
+    FFN_LOAD_RES(1, mb)
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // last XDL writes of the output accumulators -> VALU reads below
+    __builtin_amdgcn_sched_barrier(0);  // ... and nothing that reads them moves above the wait states
+    // ---- epilogue.  The accumulator layout (lane = pixel fr, 4 channels per tile) would leave as 8-byte accesses 32 B
+    // apart -- 2 NT of them per row tile, store-issue-bound.  Instead each wave turns 16 rows x C/2 channels at a time
+    // through its quarter of the slot the last chunk just released (the other slot already holds the next tile's first
+    // chunk) as raw fp32; on the way out a lane owns 8 consecutive channels of a row: bias, layer scale (both staged in
+    // LDS), residual add and the one bf16 rounding happen there, and every global access is 16 B of a fully used line.
+    // Nobody reads that slot after the last chunk's barrier, so no block-wide sync is needed to start.
+    char* so = smem + ((nch - 1) & 1) * BUF + wid * (BUF / 4);
+    int le = lane;
+    asm volatile("" : "+v"(le));                         // epilogue address math stays out of the chunk loop's registers
+    const int fre = le & 15, fge = le >> 4;
+#pragma unroll
+    for (int q = 0; q < 2 * MT; ++q) {                   // pass q: row tile q / 2, channel half q % 2
+      const int mt = q >> 1, half = q & 1;
+      // the next tile's x fragments fly during the last pass only (rows past M clamp): earlier they would pin C / 4
+      // registers through the whole epilogue, and every residual wait would wait for them too (vmcnt is in order)
+      if (q == 2 * MT - 1) FFN_LOAD_X(tile + (int)gridDim.x)
+#pragma unroll
+      for (int nh = 0; nh < NT / 2; ++nh)
+        *reinterpret_cast<f32x4*>(so + fre * ORB + (nh * 16 + fge * 4) * 4) = oacc[half * (NT / 2) + nh][mt];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-local hand-over: LDS serves a wave's accesses in order
+      uint4 o[RP];
+#pragma unroll
+      for (int it = 0; it < RP; ++it) {
+        const int ch = min(it * 64 + le, C - 1), row = ch / (C / 16), c8 = ch % (C / 16);
+        const int cb = half * (C / 2) + c8 * 8;
+        const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
+        const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
+        const float4 b0 = *reinterpret_cast<const float4*>(sb2 + cb), b1 = *reinterpret_cast<const float4*>(sb2 + cb + 4);
+        const float4 l0 = *reinterpret_cast<const float4*>(sls + cb), l1 = *reinterpret_cast<const float4*>(sls + cb + 4);
+        o[it].x = pack_bf2(bf_lo(rr[q % 3][it].x) + l0.x * (y0.x + b0.x), bf_hi(rr[q % 3][it].x) + l0.y * (y0.y + b0.y));
+        o[it].y = pack_bf2(bf_lo(rr[q % 3][it].y) + l0.z * (y0.z + b0.z), bf_hi(rr[q % 3][it].y) + l0.w * (y0.w + b0.w));
+        o[it].z = pack_bf2(bf_lo(rr[q % 3][it].z) + l1.x * (y1.x + b1.x), bf_hi(rr[q % 3][it].z) + l1.y * (y1.y + b1.y));
+        o[it].w = pack_bf2(bf_lo(rr[q % 3][it].w) + l1.z * (y1.z + b1.z), bf_hi(rr[q % 3][it].w) + l1.w * (y1.w + b1.w));
+      }
+      if (q + 2 < 2 * MT) FFN_LOAD_RES(q + 2, mb)        // residual rows of the pass after next: one pass is shorter than an HBM read
+#pragma unroll
+      for (int it = 0; it < RP; ++it) {
+        const int ch = it * 64 + le, row = ch / (C / 16), c8 = ch % (C / 16);
+        const long m = mb + mt * 16 + row;
+        if (ch < C && m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + half * (C / 2) + c8 * 8) = o[it];
+      }
+      asm volatile("" ::: "memory");                      // the next pass's writes stay behind these reads
+    }
+    __syncthreads();  // the slot is the next tile's staging target again
+#ifdef FFN_STAMPS
+    if (tid == 0 && p.stamps && tile == (int)blockIdx.x) {
+      unsigned long long* d = p.stamps + 4 * blockIdx.x;
+      d[0] = t_loop - t_entry; d[1] = t_epi - t_loop; d[2] = __builtin_amdgcn_s_memtime() - t_epi; d[3] = t_real2 - t_real;
+    }
+#endif
+  }
+#undef FFN_CHUNK
+#undef FFN_GELU
+#undef FFN_LOAD_RES
+#undef FFN_LOAD_X
+#undef FFN_FRAG
+#undef FFN_HT
+#undef FFN_KK
 #undef FFN_STAGE_LOAD
 #undef FFN_STAGE_STORE
-  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // last XDL writes of the output accumulators -> VALU reads below
-  // ---- epilogue.  The accumulator layout (lane = pixel fr, 4 channels per tile) would leave as 8-byte accesses 32 B apart
-  // -- 2 NT of them per row tile, store-issue-bound with nothing to overlap them at one wave per SIMD.  Instead each
-  // wave turns its 16-row tiles through its own corner of the (now idle) weight slots as fp32: layer scale and bias are
-  // applied on the way in (channels fixed per lane), residual add and bf16 rounding on the way out, where a lane owns
-  // 8 consecutive channels and every global access is 16 B of a fully used line.
-  constexpr int ORB = C * 4 + 16;                      // fp32 row + 16 B (conflict-free 16-B column writes)
-  static_assert(4 * 16 * ORB <= 2 * BUF, "epilogue tile must fit in the weight slots");
-  __syncthreads();                                     // every wave is done reading weights
-  char* so = smem + wid * (16 * ORB);
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    uint4 rr[KS];                                      // residual rows first: their latency hides behind the LDS turn
-#pragma unroll
-    for (int it = 0; it < KS; ++it) {
-      const int ch = it * 64 + lane, row = ch / (C / 8), c8 = ch % (C / 8);
-      const long m = min(m0 + mt * 16 + row, (long)p.M - 1);
-      rr[it] = *reinterpret_cast<const uint4*>(p.res + m * C + c8 * 8);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + fg * 4;
-      const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + n);
-      const float4 ls = *reinterpret_cast<const float4*>(p.ls + n);
-      float4 v;
-      v.x = ls.x * (oacc[nt][mt][0] + b2.x); v.y = ls.y * (oacc[nt][mt][1] + b2.y);
-      v.z = ls.z * (oacc[nt][mt][2] + b2.z); v.w = ls.w * (oacc[nt][mt][3] + b2.w);
-      *reinterpret_cast<float4*>(so + fr * ORB + n * 4) = v;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-local hand-over: LDS serves a wave's accesses in order
-#pragma unroll
-    for (int it = 0; it < KS; ++it) {
-      const int ch = it * 64 + lane, row = ch / (C / 8), c8 = ch % (C / 8);
-      const long m = m0 + mt * 16 + row;
-      const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
-      const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
-      uint4 o;
-      o.x = pack_bf2(bf_lo(rr[it].x) + y0.x, bf_hi(rr[it].x) + y0.y);
-      o.y = pack_bf2(bf_lo(rr[it].y) + y0.z, bf_hi(rr[it].y) + y0.w);
-      o.z = pack_bf2(bf_lo(rr[it].z) + y1.x, bf_hi(rr[it].z) + y1.y);
-      o.w = pack_bf2(bf_lo(rr[it].w) + y1.z, bf_hi(rr[it].w) + y1.w);
-      if (m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + c8 * 8) = o;
-    }
-    asm volatile("" ::: "memory");                      // the next tile's writes stay behind these reads
+}
+
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 256;
+    n = prop.multiProcessorCount;
   }
+  return n;
 }
 
 template <int C, int MT>
@@ -302,11 +388,12 @@ int launch_one(const FfnParams& p, hipStream_t s) {
   constexpr int BUF = 32 * (C * 2 + 32) + C * 96;
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in once per kernel
-    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn_kernel<C, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn_kernel<C, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 8 * C));
     attr_set = true;
   }
-  const long blocks = ((long)p.M + 64 * MT - 1) / (64 * MT);
-  hipLaunchKernelGGL((convffn_kernel<C, MT>), dim3((unsigned)blocks), dim3(256), 2 * BUF, s, p);
+  const long tiles = ((long)p.M + 64 * MT - 1) / (64 * MT);
+  const long blocks = tiles < num_cus() ? tiles : num_cus();   // one persistent block per CU, tiles dealt round-robin
+  hipLaunchKernelGGL((convffn_kernel<C, MT>), dim3((unsigned)blocks), dim3(256), 2 * BUF + 8 * C, s, p);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -338,6 +425,7 @@ int launch_convffn(const bf16_t* x, const bf16_t* w1, const float* b1, const bf1
 #ifdef FFN_STAMPS
   p.stamps = g_ffn_stamps;
 #endif
+
   switch (C) {
     case 32: return launch_one<32, 8>(p, s);
     case 64: return launch_one<64, 8>(p, s);
