@@ -15,8 +15,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
+// two RNE conversions in ONE v_cvt_pk_bf16_f32 (the scalar casts above cost two of them plus a shift and an or)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const bf16x2 r = __builtin_convertvector((f32x2){lo, hi}, bf16x2);
+  return __builtin_bit_cast(uint32_t, r);
 }
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -58,7 +62,6 @@ __device__ __forceinline__ float gelu_f(float x) {
 // 5.1e-5 over all x in fp32.  12 VALU issues per PAIR, 10 of them packed fp32 (v_pk_mul/fma_f32, full rate on gfx950), where
 // gelu_f spends 7 + two quarter-rate transcendentals per element: ~24 cycles per element instead of ~60.  The fused ConvFFN
 // applies it to 23 G hidden activations per step between its two products, with nothing else to issue meanwhile.
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 // N pairs in lockstep (coefficient-major): one wave per SIMD cannot hide the latency of a dependent VALU chain, so the
 // N independent Horner chains are what keeps the VALU issuing every cycle.
 template <int N>
