@@ -82,15 +82,23 @@ __device__ __forceinline__ void gelu2_n(f32x2 (&x)[N]) {
   FV_HORNER(FV_GELU_C6) FV_HORNER(FV_GELU_C5) FV_HORNER(FV_GELU_C4) FV_HORNER(FV_GELU_C3)
   FV_HORNER(FV_GELU_C2) FV_HORNER(FV_GELU_C1) FV_HORNER(FV_GELU_C0)
 #undef FV_HORNER
-#pragma unroll
-  for (int n = 0; n < N; ++n) {
-    // The VOP3P clamp bit saturates both halves to [0, 1] for free (the compiler spends two v_max on it).  gfx950 wants one
-    // wait state between a packed VALU write and a dependent VALU read; hipcc pads its own packed ops with s_nop 0 but
-    // cannot see into asm, so the statement carries its own on both sides.
-    f32x2 phi;
-    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0" : "=v"(phi) : "v"(xc[n]), "v"(p[n]));
-    x[n] = x[n] * phi;
+  // The VOP3P clamp bit saturates both halves to [0, 1] for free (the compiler spends two v_max on it).  gfx950 wants one
+  // wait state between a packed VALU write and a dependent VALU read; hipcc pads its own packed ops with s_nop 0 but
+  // cannot see into asm, so the statement carries its own: one in front and one behind the N clamped fmas (inside the
+  // run the producers and consumers are at least one instruction apart already).
+  static_assert(N == 1 || N == 2 || N == 4, "gelu2_n chains");
+  if constexpr (N == 1) {  // phi overwrites xc in place
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %0, %1, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0" : "+v"(xc[0]) : "v"(p[0]));
+  } else if constexpr (N == 2) {
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %0, %2, 0.5 op_sel_hi:[1,1,0] clamp\n\tv_pk_fma_f32 %1, %1, %3, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0"
+        : "+v"(xc[0]), "+v"(xc[1]) : "v"(p[0]), "v"(p[1]));
+  } else {
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %0, %4, 0.5 op_sel_hi:[1,1,0] clamp\n\tv_pk_fma_f32 %1, %1, %5, 0.5 op_sel_hi:[1,1,0] clamp\n\t"
+        "v_pk_fma_f32 %2, %2, %6, 0.5 op_sel_hi:[1,1,0] clamp\n\tv_pk_fma_f32 %3, %3, %7, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0"
+        : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
   }
+#pragma unroll
+  for (int n = 0; n < N; ++n) x[n] = x[n] * xc[n];
 }
 __device__ __forceinline__ f32x2 gelu2_f(f32x2 x) {
   f32x2 v[1] = {x};
