@@ -503,6 +503,178 @@ __global__ __launch_bounds__(256, TH == 8 ? 3 : 2) void dwconv_mfma_kernel(const
   }
 }
 
+// ---- the same conv, marching: one block per (image, 32-column strip, 32-channel slice) walks DOWN the strip in groups of
+// 8 output rows over a 16-row ring of halo rows in LDS.  A tile-per-block 7x7 reads 14 input rows per 8 output rows, and
+// those re-reads (L2 hits or not) go through the same ~10 B/clk a CU can pull: it ran at 2.7 TB/s of algorithmic traffic
+// with the 3x3 at 4.1.  Marching reads every row once (only the 6 halo columns twice), and the next 8 rows are in flight in
+// registers while the current group is in the MFMAs.  Ring row of image row r = (r - PAD) & 15; "unit" u = rows
+// 8u + PAD .. 8u + PAD + 7 occupies ring rows 8 (u & 1) .. + 7; group g needs units g - 1 and g.
+#ifndef DW_MARCH_OCC
+#define DW_MARCH_OCC 2
+#endif
+template <int K>
+__global__ __launch_bounds__(256, DW_MARCH_OCC) void dwconv_march_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ttab,
+                                                               const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                               int H, int W, int C, int gelu, int tiles_x, int nslices) {
+  constexpr int TW = 32, PAD = K / 2, IW = TW + K - 1;
+  constexpr int NQ = (IW + 3) / 4, NM = (K + 3 + 3) / 4;
+  constexpr int RS = NQ * 256 + 64, RSO = 8 * 256 + 64;        // ring / output-tile row strides (== 64 mod 256)
+  constexpr int T_BYTES = 2 * K * NM * 512;
+#if DW_MARCH_OCC >= 3   // the output tile borrows the ring rows unit g - 1 has just vacated (one more barrier per group)
+  __shared__ __attribute__((aligned(16))) char smem[16 * RS];
+#else
+  __shared__ __attribute__((aligned(16))) char smem[16 * RS + 8 * RSO];
+#endif
+  char* sX = smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);     // slices and neighbouring strips of one image on one XCD
+  const int slice = bid % nslices; bid /= nslices;
+  const int tx = bid % tiles_x;
+  const long b = bid / tiles_x;
+  const int c0 = slice * 32;
+  const int gg = wid & 1, rg = wid >> 1;          // wave = (16-channel group, 4 output rows)
+  const int bch = lane >> 2, jr = lane & 3;       // lane = (channel within the group, row within the 4)
+  const int ng = (H + 7) / 8;
+
+  s16x4 afr[K][NM];
+  {
+    const char* tsrc = reinterpret_cast<const char*>(ttab) + (size_t)slice * T_BYTES + (size_t)gg * K * NM * 512 + lane * 8;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) afr[ky][m] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(tsrc + (ky * NM + m) * 512));
+  }
+  const float bv = bias[c0 + gg * 16 + bch];
+
+  // one unit = 8 rows x NQ quads x 4 channel groups of (4 pixels x 8 channels) tasks
+  constexpr int NTASK = 8 * NQ * 4, TPT = (NTASK + 255) / 256;
+  uint4 px[TPT][4];
+#define DW_LOAD_UNIT(U)                                                                                          \
+  {                                                                                                              \
+    _Pragma("unroll") for (int tt = 0; tt < TPT; ++tt) {                                                         \
+      const int task = tid + 256 * tt;                                                                           \
+      const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;                                  \
+      const int iy = 8 * (U) + PAD + row, ix0 = tx * TW - PAD + quad * 4;                                        \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                            \
+        const int ix = ix0 + j;                                                                                  \
+        px[tt][j] = (task < NTASK && iy >= 0 && iy < H && ix >= 0 && ix < W && quad * 4 + j < IW)                \
+                        ? *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + cg * 8)  \
+                        : make_uint4(0, 0, 0, 0);                                                                \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+#define DW_WRITE_UNIT(U)                                                                                         \
+  {                                                                                                              \
+    _Pragma("unroll") for (int tt = 0; tt < TPT; ++tt) {                                                         \
+      const int task = tid + 256 * tt;                                                                           \
+      if (task < NTASK) {                                                                                        \
+        const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;                                \
+        const uint32_t d[4][4] = {{px[tt][0].x, px[tt][0].y, px[tt][0].z, px[tt][0].w},                          \
+                                  {px[tt][1].x, px[tt][1].y, px[tt][1].z, px[tt][1].w},                          \
+                                  {px[tt][2].x, px[tt][2].y, px[tt][2].z, px[tt][2].w},                          \
+                                  {px[tt][3].x, px[tt][3].y, px[tt][3].z, px[tt][3].w}};                         \
+        const uint32_t dst = (uint32_t)((8 * ((U) & 1) + row) * RS + quad * 256 + cg * 64) |                     \
+                             (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);                                   \
+        _Pragma("unroll") for (int dd = 0; dd < 4; ++dd) {                                                       \
+          uint2 ev, od;                                                                                          \
+          ev.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x05040100u);                                         \
+          ev.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x05040100u);                                         \
+          od.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x07060302u);                                         \
+          od.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x07060302u);                                         \
+          *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd) * 8))) = ev;                                 \
+          *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd + 1) * 8))) = od;                             \
+        }                                                                                                        \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+  // lane's four swizzled channel offsets (one per quad & 3)
+  uint32_t sw[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sw[v] = (uint32_t)(((gg * 16 + bch) ^ ((v << 1) | gg)) << 3);
+
+  DW_LOAD_UNIT(-1)
+  DW_WRITE_UNIT(-1)
+  DW_LOAD_UNIT(0)
+  DW_WRITE_UNIT(0)
+  if (ng > 1) DW_LOAD_UNIT(1)
+
+  for (int g = 0; g < ng; ++g) {
+    __syncthreads();   // unit g is in the ring; the previous group's output tile has been read
+    f32x4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rb = 8 * g + rg * 4 + jr - 2 * PAD;   // ring row (mod 16) of the lane's ky = 0 input row
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const uint32_t ro = (uint32_t)((rb + ky) & 15) * RS;
+      s16x4 xq[NQ];
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sX + ro + sw[t & 3] + t * 256));
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q + m < NQ) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[q + m], acc[q], 0, 0, 0);
+    }
+    __syncthreads();   // every wave is done with unit g - 1: its ring rows take unit g + 1
+#if DW_MARCH_OCC >= 3
+    char* sO = sX + 8 * ((g + 1) & 1) * RS;
+#else
+    char* sO = smem + 16 * RS;
+    if (g + 1 < ng) DW_WRITE_UNIT(g + 1)
+    if (g + 2 < ng) DW_LOAD_UNIT(g + 2)
+#endif
+    // ---- bias (+GELU), through the output tile in the same cell layout, NHWC transpose by v_perm on the reading side
+    {
+      char* orow = sO + (rg * 4 + jr) * RSO;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[q][i] + bv;
+          if (gelu) v[i] = gelu_f(v[i]);
+        }
+        uint2 u;
+        u.x = pack_bf2(v[0], v[1]);
+        u.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(orow + sw[q & 3] + q * 256) = u;
+      }
+    }
+    __syncthreads();
+    {
+      const int cg = tid & 3, quad = (tid >> 2) & 7, row = tid >> 5;   // 8 rows x 8 quads x 4 channel groups
+      const uint32_t src = (uint32_t)(row * RSO + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
+      uint2 r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sO + (src ^ (uint32_t)(e * 8)));
+      const int oy = g * 8 + row, ox0 = tx * TW + quad * 4;
+      if (oy < H) {
+        bf16_t* yp = y + (((size_t)b * H + oy) * W + ox0) * C + c0 + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ox0 + j < W) {
+            uint4 o;
+            const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+#define FV_PX(A, B) __builtin_amdgcn_perm((j & 2) ? r[B].y : r[B].x, (j & 2) ? r[A].y : r[A].x, sel)
+            o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
+#undef FV_PX
+            *reinterpret_cast<uint4*>(yp + (size_t)j * C) = o;
+          }
+        }
+      }
+    }
+#if DW_MARCH_OCC >= 3
+    __syncthreads();   // the borrowed rows have been read
+    if (g + 1 < ng) DW_WRITE_UNIT(g + 1)
+    if (g + 2 < ng) DW_LOAD_UNIT(g + 2)
+#endif
+  }
+#undef DW_LOAD_UNIT
+#undef DW_WRITE_UNIT
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNormChannel
 // one wave per row (pixel); C <= 2048, C % 8 == 0; two-pass in registers.
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
@@ -720,6 +892,22 @@ int launch_dwconv_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, b
   const int tiles_x = (W + 31) / 32, tiles_y = (H + th - 1) / th, nsl = C / 32;
   const long nblk = (long)B * tiles_x * tiles_y * nsl;
   if (nblk > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv_mfma: grid too large");
+#ifndef DW_NO_MARCH
+  if (k == 7 && H >= 16) {   // marching strips (see dwconv_march_kernel); short maps keep the tile kernel
+    const long nstrips = (long)B * tiles_x * nsl;
+    hipLaunchKernelGGL((dwconv_march_kernel<7>), dim3((unsigned)nstrips), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, nsl);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+  }
+#ifdef DW_MARCH3
+  if (k == 3 && H >= 16) {
+    const long nstrips = (long)B * tiles_x * nsl;
+    hipLaunchKernelGGL((dwconv_march_kernel<3>), dim3((unsigned)nstrips), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, nsl);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+  }
+#endif
+#endif
   if (k == 7 && th == 16) hipLaunchKernelGGL((dwconv_mfma_kernel<7, 16>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
   else if (k == 7) hipLaunchKernelGGL((dwconv_mfma_kernel<7, 8>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
   else hipLaunchKernelGGL((dwconv_mfma_kernel<3, 8>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
