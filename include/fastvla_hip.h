@@ -164,6 +164,11 @@ int fv_op_stem_conv(const void* pix, const float* w, const float* bias, void* y,
 /* the same stem as an implicit GEMM on MFMA: wp (Cout,64) bf16 with slot 32*ks + 8*g + e = weight of kernel row
  * ky = 2*ks + (g>>1), column kx = 2*(g&1) + (e>>2), channel e&3 (0 where ky, kx or channel is 3); Cout % 16 == 0 */
 int fv_op_stem_mfma(const void* pix, const void* wp, const float* bias, void* y, int B, int S, int Cout, fv_stream s);
+/* the first two stem convolutions fused (conv 3x3 s2 3->96 + GELU, depthwise 3x3 s2 + GELU): pix (B,S,S,4) bf16 ->
+ * y (B,S/4,S/4,96) bf16; wp as for fv_op_stem_mfma, w2 f32 [9][96] tap-major, the half-resolution map stays in LDS
+ * (rounded to bf16 there exactly as the unfused pair rounds it to memory).  Cout must be 96, S % 4 == 0. */
+int fv_op_stem_fused(const void* pix, const void* wp, const float* b1, const float* w2, const float* b2, void* y, int B,
+                     int S, int Cout, fv_stream s);
 /* per-pixel LayerNorm over channels (LayerNormChannel), x,y (rows,C) bf16 */
 int fv_op_layernorm_rows(const void* x, const float* w, const float* b, void* y, int rows, int C, float eps,
                          fv_stream s);

@@ -358,3 +358,33 @@ def test_stem_mfma(S, C0):
     call(lib().fv_op_stem_mfma(pix.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, S, C0, stream()), "fv_op_stem_mfma")
     torch.cuda.synchronize()
     check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"stem mfma S={S} C0={C0}")
+
+
+@pytest.mark.parametrize("S,B", [(64, 2), (136, 1), (1024, 1)])
+def test_stem_fused(S, B):
+    """conv 3x3 s2 + GELU -> (bf16) -> depthwise 3x3 s2 + GELU in one kernel vs the two convolutions on the host."""
+    torch.manual_seed(S)
+    C0 = 96
+    x = bf(torch.rand(B, 3, S, S))
+    w1 = bf(torch.randn(C0, 3, 3, 3) / 5)
+    b1 = torch.randn(C0) * 0.1
+    w2 = torch.randn(C0, 1, 3, 3) / 3
+    b2 = torch.randn(C0) * 0.1
+    mid = bf(F.gelu(F.conv2d(x, w1, b1, stride=2, padding=1)))          # the kernel rounds the half-resolution map to bf16 too
+    ref = F.gelu(F.conv2d(mid, w2, b2, stride=2, padding=1, groups=C0))
+    pix = torch.zeros(B, S, S, 4, dtype=torch.bfloat16, device=DEV)
+    pix[..., :3] = dev_bf16(x.permute(0, 2, 3, 1))
+    wp = torch.zeros(C0, 64)
+    for ks in range(2):
+        for g in range(4):
+            for e in range(8):
+                ky, kx, ch = 2 * ks + (g >> 1), 2 * (g & 1) + (e >> 2), e & 3
+                if ky < 3 and kx < 3 and ch < 3:
+                    wp[:, ks * 32 + g * 8 + e] = w1[:, ch, ky, kx]
+    wd, b1d, b2d = dev_bf16(wp), dev_f32(b1), dev_f32(b2)
+    w2d = dev_f32(w2.view(C0, 9).t().contiguous())                       # tap-major [9][C0]
+    y = torch.full((B, S // 4, S // 4, C0), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_stem_fused(pix.data_ptr(), wd.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), y.data_ptr(), B, S, C0,
+                                stream()), "fv_op_stem_fused")
+    torch.cuda.synchronize()
+    check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"fused stem S={S}")

@@ -340,11 +340,19 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float
   bf16_t* hid = reinterpret_cast<bf16_t*>(ws + wp.bufH);
   float* se = reinterpret_cast<float*>(ws + wp.se);
   const int S = d.image_size, C0 = d.tower_dims[0];
-  FV_P(FV_FAM_STEM, 2.0 * mb * (S / 2) * (S / 2) * 27 * C0, (double)mb * S * S * 8 + (double)mb * (S / 2) * (S / 2) * C0 * 2,
-       tw.stem0_wp ? fv::launch_stem_mfma(pix, tw.stem0_wp, tw.stem0_b, cur, mb, S, C0, s)
-                   : fv::launch_stem_conv(pix, tw.stem0_w, tw.stem0_b, cur, mb, S, C0, s));
-  FV_P(FV_FAM_DWCONV, dw_flops(mb, S / 4, S / 4, C0, 3), (double)mb * (S / 2) * (S / 2) * C0 * 2 * 1.25,
-       fv::launch_dwconv(cur, tw.stem1_w, tw.stem1_b, oth, mb, S / 2, S / 2, C0, 3, 2, 1, 1, s));
+  static const bool fuse_stem = !getenv("FASTVLA_NO_FUSED_STEM");
+  if (fuse_stem && tw.stem0_wp && fv::stem_fused_supported(S, C0)) {
+    // both convolutions in one kernel: the half-resolution 96-channel map (the path's largest tensor) never reaches HBM
+    FV_P(FV_FAM_STEM, 2.0 * mb * (S / 2) * (S / 2) * 27 * C0 + dw_flops(mb, S / 4, S / 4, C0, 3),
+         (double)mb * S * S * 8 + (double)mb * (S / 4) * (S / 4) * C0 * 2,
+         fv::launch_stem_fused(pix, tw.stem0_wp, tw.stem0_b, tw.stem1_w, tw.stem1_b, oth, mb, S, C0, s));
+  } else {
+    FV_P(FV_FAM_STEM, 2.0 * mb * (S / 2) * (S / 2) * 27 * C0, (double)mb * S * S * 8 + (double)mb * (S / 2) * (S / 2) * C0 * 2,
+         tw.stem0_wp ? fv::launch_stem_mfma(pix, tw.stem0_wp, tw.stem0_b, cur, mb, S, C0, s)
+                     : fv::launch_stem_conv(pix, tw.stem0_w, tw.stem0_b, cur, mb, S, C0, s));
+    FV_P(FV_FAM_DWCONV, dw_flops(mb, S / 4, S / 4, C0, 3), (double)mb * (S / 2) * (S / 2) * C0 * 2 * 1.25,
+         fv::launch_dwconv(cur, tw.stem1_w, tw.stem1_b, oth, mb, S / 2, S / 2, C0, 3, 2, 1, 1, s));
+  }
   int H = S / 4;
   {
     fv::GemmArgs g{oth, C0, tw.stem2_w, mb * H * H, C0, C0, tw.stem2_b, nullptr, nullptr, 0, cur, C0, FV_EPI_BIAS_GELU};

@@ -36,6 +36,10 @@ int launch_stem_conv(const bf16_t* pix, const float* w, const float* bias, bf16_
 // implicit-GEMM stem on MFMA; wp = stem_mfma_pack image ([Cout][64] bf16), Cout % 16 == 0
 void stem_mfma_pack(const float* w27, float* out, int Cout);
 int launch_stem_mfma(const bf16_t* pix, const bf16_t* wp, const float* bias, bf16_t* y, int B, int S, int Cout, hipStream_t s);
+// fused stem conv 3x3 s2 + GELU + depthwise 3x3 s2 + GELU: pix (B,S,S,4) -> y (B,S/4,S/4,96); C0 must be 96
+bool stem_fused_supported(int S, int C0);
+int launch_stem_fused(const bf16_t* pix, const bf16_t* wp, const float* b1, const float* w2, const float* b2, bf16_t* y, int B,
+                      int S, int C0, hipStream_t s);
 int launch_dwconv(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,
                   int stride, int mult, int gelu, hipStream_t s);
 // MFMA (4x4x4, 16 channel blocks) depthwise conv for stride-1 k in {3,7} on maps with W >= 32; ttab from dwconv_toeplitz_pack

@@ -24,6 +24,11 @@ int fv_op_stem_conv(const void* pix, const float* w, const float* bias, void* y,
 int fv_op_stem_mfma(const void* pix, const void* wp, const float* bias, void* y, int B, int S, int Cout, fv_stream s) {
   return fv::launch_stem_mfma(static_cast<const bf16_t*>(pix), static_cast<const bf16_t*>(wp), bias, static_cast<bf16_t*>(y), B, S, Cout, static_cast<hipStream_t>(s));
 }
+int fv_op_stem_fused(const void* pix, const void* wp, const float* b1, const float* w2, const float* b2, void* y, int B, int S, int Cout,
+                     fv_stream s) {
+  return fv::launch_stem_fused(static_cast<const bf16_t*>(pix), static_cast<const bf16_t*>(wp), b1, w2, b2, static_cast<bf16_t*>(y), B, S, Cout,
+                               static_cast<hipStream_t>(s));
+}
 
 int fv_op_layernorm_rows(const void* x, const float* w, const float* b, void* y, int rows, int C, float eps, fv_stream s) {
   return fv::launch_layernorm_rows(static_cast<const bf16_t*>(x), w, b, static_cast<bf16_t*>(y), rows, C, eps, static_cast<hipStream_t>(s));

@@ -332,6 +332,119 @@ __global__ __launch_bounds__(256, 3) void dwconv_tile_kernel(const bf16_t* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused stem
+// conv 3x3 s2 (3 -> 96) + GELU and depthwise 3x3 s2 + GELU in one kernel ([UNVENDORED] mci.py convolutional_stem, first two
+// MobileOne blocks after reparameterisation).  Unfused, the 96-channel half-resolution map is the largest tensor of the
+// whole path: at B = 64 it is 3.2 GB written by the first conv and read straight back by the second, 2.5 ms of pure
+// traffic.  Here a block owns 4 x 32 pixels of the quarter-resolution output: it computes the 9 x 65 half-resolution
+// pixels they need on MFMA (implicit GEMM as in stem_mfma_kernel, K 27 -> 64), rounds them to bf16 into LDS exactly as the
+// unfused pair rounds them to HBM, and runs the depthwise conv out of LDS.  The halo recompute costs 14 %; HBM sees the
+// image once and the quarter-resolution map once.  Persistent blocks (one per CU, 8 waves), weights loaded once.
+constexpr int SF_C = 96, SF_TR = 4, SF_TC = 32, SF_R1 = 2 * SF_TR + 1, SF_C1 = 2 * SF_TC + 1, SF_SEG = (SF_C1 + 15) / 16;
+constexpr int SF_PS = SF_C * 2 + 16;                      // bytes per half-resolution pixel in LDS (16-B aligned, 2-way banks)
+constexpr int SF_S1 = SF_R1 * SF_C1 * SF_PS;              // 121,680 B
+constexpr int SF_LDS = SF_S1 + 10 * SF_C * 4;             // + depthwise taps [9][96] and bias [96] fp32
+__global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __restrict__ pix, const bf16_t* __restrict__ wp,
+                                                             const float* __restrict__ b1, const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, bf16_t* __restrict__ y, int B, int S,
+                                                             long ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char sf_smem[];
+  char* s1 = sf_smem;
+  float* sw2 = reinterpret_cast<float*>(sf_smem + SF_S1);   // [9][96] taps, then [96] bias
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int S1 = S >> 1, S2 = S >> 2;                        // half / quarter resolution
+  const int tiles_x = (S2 + SF_TC - 1) / SF_TC, tiles_y = (S2 + SF_TR - 1) / SF_TR;
+  for (int i = tid; i < 10 * SF_C; i += 512) sw2[i] = i < 9 * SF_C ? w2[i] : b2[i - 9 * SF_C];
+  bf16x8 wf[6][2];
+#pragma unroll
+  for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      wf[nt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wp + ((size_t)(nt * 16 + fr) * 64 + ks * 32 + fg * 8)));
+  float4 bv1[6];
+#pragma unroll
+  for (int nt = 0; nt < 6; ++nt) bv1[nt] = *reinterpret_cast<const float4*>(b1 + nt * 16 + fg * 4);
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+    const long b = tile / ((long)tiles_x * tiles_y);
+    const int y1_0 = 2 * ty * SF_TR - 1, x1_0 = 2 * tx * SF_TC - 1;   // half-resolution origin of the halo region
+    __syncthreads();   // the previous tile's depthwise pass is done with s1 (and the taps are staged)
+    // ---- first conv: SF_R1 x SF_SEG segments of 16 half-resolution pixels, dealt to the 8 waves; the next segment's
+    // pixels are fetched while the current one is in the MFMAs and the GELU (nothing else hides that latency here)
+#define SF_FETCH(SEG, XF, LIVE)                                                                                  \
+  {                                                                                                              \
+    const int r1_ = (SEG) / SF_SEG, cs_ = ((SEG) % SF_SEG) * 16 + fr;                                            \
+    const int oy_ = y1_0 + r1_, ox_ = x1_0 + cs_;                                                                \
+    LIVE = (SEG) < SF_R1 * SF_SEG && cs_ < SF_C1 && oy_ >= 0 && oy_ < S1 && ox_ >= 0 && ox_ < S1;               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
+      const int ky = 2 * ks + (fg >> 1), pp = fg & 1;                                                            \
+      const int iy = 2 * oy_ - 1 + ky, ix = 2 * ox_ - 1 + 2 * pp;                                                \
+      uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);                                                        \
+      if (LIVE && ky < 3 && iy >= 0 && iy < S) {                                                                 \
+        const bf16_t* rp = pix + (((size_t)b * S + iy) * S) * 4;                                                 \
+        if (ix >= 0 && ix < S) lo = *reinterpret_cast<const uint2*>(rp + (size_t)ix * 4);                        \
+        if (ix + 1 >= 0 && ix + 1 < S) hi = *reinterpret_cast<const uint2*>(rp + (size_t)(ix + 1) * 4);          \
+      }                                                                                                          \
+      XF[ks] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));                                   \
+    }                                                                                                            \
+  }
+    bf16x8 xf[2], xn[2];
+    bool live, live_n;
+    SF_FETCH(wid, xf, live)   // outside the map: the depthwise conv's zero padding
+    for (int seg = wid; seg < SF_R1 * SF_SEG; seg += 8) {
+      SF_FETCH(seg + 8, xn, live_n)
+      const int r1 = seg / SF_SEG, cs = (seg % SF_SEG) * 16 + fr;     // row / column inside the region
+      char* dst = s1 + (r1 * SF_C1 + cs) * SF_PS + fg * 8;
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][0], xf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][1], xf[1], acc, 0, 0, 0);
+        f32x2 g[2] = {{acc[0] + bv1[nt].x, acc[1] + bv1[nt].y}, {acc[2] + bv1[nt].z, acc[3] + bv1[nt].w}};
+        gelu2_n<2>(g);
+        uint2 o;
+        o.x = live ? pack_bf2(g[0].x, g[0].y) : 0u;
+        o.y = live ? pack_bf2(g[1].x, g[1].y) : 0u;
+        if (cs < SF_C1) *reinterpret_cast<uint2*>(dst + nt * 32) = o;
+      }
+      xf[0] = xn[0]; xf[1] = xn[1]; live = live_n;
+    }
+#undef SF_FETCH
+    __syncthreads();
+    // ---- depthwise 3x3 stride 2 out of LDS: item = (output pixel, 8-channel group), 128 x 12 items over 512 threads
+#pragma unroll
+    for (int it = 0; it < SF_TR * SF_TC * (SF_C / 8) / 512; ++it) {
+      const int item = tid + 512 * it;
+      const int cg = item % (SF_C / 8), p = item / (SF_C / 8), pr = p / SF_TC, pc = p % SF_TC;
+      float acc[8];
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(sw2 + 9 * SF_C + cg * 8), a1 = *reinterpret_cast<const float4*>(sw2 + 9 * SF_C + cg * 8 + 4);
+        acc[0] = a0.x; acc[1] = a0.y; acc[2] = a0.z; acc[3] = a0.w; acc[4] = a1.x; acc[5] = a1.y; acc[6] = a1.z; acc[7] = a1.w;
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          float xv[8];
+          unpack8(*reinterpret_cast<const uint4*>(s1 + ((2 * pr + ky) * SF_C1 + 2 * pc + kx) * SF_PS + cg * 16), xv);
+          const float* wt = sw2 + (ky * 3 + kx) * SF_C + cg * 8;
+          const float4 w0 = *reinterpret_cast<const float4*>(wt), w1 = *reinterpret_cast<const float4*>(wt + 4);
+          acc[0] += xv[0] * w0.x; acc[1] += xv[1] * w0.y; acc[2] += xv[2] * w0.z; acc[3] += xv[3] * w0.w;
+          acc[4] += xv[4] * w1.x; acc[5] += xv[5] * w1.y; acc[6] += xv[6] * w1.z; acc[7] += xv[7] * w1.w;
+        }
+      f32x2 g[4] = {{acc[0], acc[1]}, {acc[2], acc[3]}, {acc[4], acc[5]}, {acc[6], acc[7]}};
+      gelu2_n<4>(g);
+      const int oy = ty * SF_TR + pr, ox = tx * SF_TC + pc;
+      if (oy < S2 && ox < S2) {
+        uint4 o;
+        o.x = pack_bf2(g[0].x, g[0].y); o.y = pack_bf2(g[1].x, g[1].y); o.z = pack_bf2(g[2].x, g[2].y); o.w = pack_bf2(g[3].x, g[3].y);
+        *reinterpret_cast<uint4*>(y + (((size_t)b * S2 + oy) * S2 + ox) * SF_C + cg * 8) = o;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ depthwise conv on MFMA
 // The 7x7 depthwise conv is 49 fp32 FMAs per output element on the VALU (157 TFLOP/s chip-wide against 2.5 PFLOP/s of
 // matrix rate), and it was the second largest item of the step.  Per channel a 1-D convolution along x is a banded
@@ -911,6 +1024,29 @@ int launch_dwconv_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, b
   if (k == 7 && th == 16) hipLaunchKernelGGL((dwconv_mfma_kernel<7, 16>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
   else if (k == 7) hipLaunchKernelGGL((dwconv_mfma_kernel<7, 8>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
   else hipLaunchKernelGGL((dwconv_mfma_kernel<3, 8>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+// pix (B,S,S,4) bf16 -> y (B,S/4,S/4,96) bf16: the first two stem convolutions with their GELUs (see stem_fused_kernel);
+// wp = stem_mfma_pack image of the first, w2 / b2 = tap-major [9][96] fp32 weights and bias of the depthwise second
+bool stem_fused_supported(int S, int C0) { return C0 == SF_C && S >= 8 && S % 4 == 0; }
+int launch_stem_fused(const bf16_t* pix, const bf16_t* wp, const float* b1, const float* w2, const float* b2, bf16_t* y, int B,
+                      int S, int C0, hipStream_t s) {
+  if (!pix || !wp || !b1 || !w2 || !b2 || !y) return fv_fail(FV_ERR_ARG, "stem_fused: null pointer");
+  if (B <= 0 || !stem_fused_supported(S, C0)) return fv_fail(FV_ERR_UNSUPPORTED, "stem_fused: bad shape S=%d C0=%d", S, C0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS));
+    attr_set = true;
+  }
+  const int S2 = S / 4;
+  const long ntiles = (long)B * ((S2 + SF_TC - 1) / SF_TC) * ((S2 + SF_TR - 1) / SF_TR);
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const long blocks = ntiles < cus ? ntiles : cus;
+  hipLaunchKernelGGL(stem_fused_kernel, dim3((unsigned)blocks), dim3(512), SF_LDS, s, pix, wp, b1, w2, b2, y, B, S, ntiles);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

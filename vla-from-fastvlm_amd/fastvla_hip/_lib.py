@@ -84,6 +84,7 @@ SIGNATURES = {
     "fv_op_dwconv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fv_op_stem_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "fv_op_stem_mfma": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fv_op_stem_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "fv_op_layernorm_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "fv_op_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "fv_op_rmsnorm": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
