@@ -38,9 +38,13 @@ __device__ __forceinline__ void mfma_acc_a(f32x4& acc, const bf16x8& a, const bf
 // them in the accumulator half too.  The 8-row-tile variants need that: with 64 hidden accumulators among the VGPRs hipcc
 // ran out, and its spill copies (v_accvgpr_write of an accumulator right behind one of these opaque asm MFMAs) read stale
 // data -- the XDL-write -> VALU-read wait states are invisible to the compiler here.
-template <bool HA>
+// BA: the B operand (an x fragment) lives in the accumulator half of the register file too.  At C >= 192 the x fragments
+// are 96 registers; keeping half of them in AGPRs (MFMA reads A / B from either half) is what leaves room for the
+// staging registers and the GELU stages without spilling -- the 192 output accumulators leave 64 AGPRs unused.
+template <bool HA, bool BA = false>
 __device__ __forceinline__ void mfma_acc_h(f32x4& acc, const bf16x8& a, const bf16x8& b) {
   if constexpr (HA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else if constexpr (BA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
   else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 // first k-step of a hidden tile: C = 0 as an inline constant, so no VALU-written zero feeds the MFMA
@@ -77,24 +81,18 @@ __device__ __forceinline__ void settle_operands(bf16x8 (&v)[N]) {
   else asm volatile("s_nop 3" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 }
 
-// Staging registers as named scalars: an array indexed by the (unrolled) step counter was left in scratch memory once the
-// chunk body was instantiated twice -- a switch over scalars folds to a register whatever the pass order.
-struct StageRegs {
-  uint4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11;
-  __device__ __forceinline__ uint4 get(int j) const {
-    switch (j) {
-      case 0: return r0; case 1: return r1; case 2: return r2; case 3: return r3; case 4: return r4; case 5: return r5;
-      case 6: return r6; case 7: return r7; case 8: return r8; case 9: return r9; case 10: return r10; default: return r11;
-    }
+// Staging registers are twelve named locals picked by select chains on the (unrolled) step counter: an array or a struct
+// indexed by it was left in scratch memory whenever the full unroll came after the last SROA run.
+#define FFN_ST_GET(J)                                                                                              \
+  ((J) == 0 ? st0 : (J) == 1 ? st1 : (J) == 2 ? st2 : (J) == 3 ? st3 : (J) == 4 ? st4 : (J) == 5 ? st5 : (J) == 6 ? st6 \
+   : (J) == 7 ? st7 : (J) == 8 ? st8 : (J) == 9 ? st9 : (J) == 10 ? st10 : st11)
+#define FFN_ST_SET(J, V)                                                                                           \
+  {                                                                                                                \
+    const uint4 v_ = (V);                                                                                          \
+    if ((J) == 0) st0 = v_; else if ((J) == 1) st1 = v_; else if ((J) == 2) st2 = v_; else if ((J) == 3) st3 = v_;  \
+    else if ((J) == 4) st4 = v_; else if ((J) == 5) st5 = v_; else if ((J) == 6) st6 = v_; else if ((J) == 7) st7 = v_; \
+    else if ((J) == 8) st8 = v_; else if ((J) == 9) st9 = v_; else if ((J) == 10) st10 = v_; else st11 = v_;        \
   }
-  __device__ __forceinline__ void set(int j, const uint4& v) {
-    switch (j) {
-      case 0: r0 = v; break; case 1: r1 = v; break; case 2: r2 = v; break; case 3: r3 = v; break; case 4: r4 = v; break;
-      case 5: r5 = v; break; case 6: r6 = v; break; case 7: r7 = v; break; case 8: r8 = v; break; case 9: r9 = v; break;
-      case 10: r10 = v; break; default: r11 = v; break;
-    }
-  }
-};
 
 // largest ring depth <= want that divides the chunk's step count (the ring index must line up across chunks)
 constexpr int ring_depth(int nr, int want) { return nr % want == 0 ? want : ring_depth(nr, want - 1); }
@@ -140,8 +138,9 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
   f32x4 oacc[NT][MT];
 
   // ---- weight-chunk staging (global -> registers -> LDS); every index below is compile-time after unrolling
-  static_assert(NLD <= 12, "StageRegs holds 12");
-  StageRegs st;
+  static_assert(NLD <= 12, "twelve staging registers");
+  uint4 st0, st1, st2, st3, st4, st5, st6, st7, st8, st9, st10, st11;
+  st0 = st1 = st2 = st3 = st4 = st5 = st6 = st7 = st8 = st9 = st10 = st11 = make_uint4(0, 0, 0, 0);
 #define FFN_STAGE_LOAD(HC)                                                                                   \
   {                                                                                                          \
     const bf16_t* g1 = p.w1 + (size_t)(HC) * 32 * C;  /* [32][C] */                                          \
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
       const int c = tid + 256 * i;                                                                           \
       const bf16_t* src = c < W1_CH ? g1 + (size_t)c * 8 : g2 + (size_t)(c - W1_CH) * 8;                     \
-      st.set(i, *reinterpret_cast<const uint4*>(src));                                                       \
+      FFN_ST_SET(i, *reinterpret_cast<const uint4*>(src))                                                    \
     }                                                                                                        \
   }
 #define FFN_STAGE_STORE(BUFI)                                                                                \
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
       const int c2 = c - W1_CH;                                                                              \
       const int off = c < W1_CH ? (c / (C / 8)) * W1_STRIDE + (c % (C / 8)) * 16                             \
                                 : W1_BYTES + (c2 >> 2) * W2_STRIDE + (c2 & 3) * 16;                          \
-      *reinterpret_cast<uint4*>(base + off) = st.get(i);                                                     \
+      *reinterpret_cast<uint4*>(base + off) = FFN_ST_GET(i);                                                 \
     }                                                                                                        \
   }
 
@@ -178,7 +177,9 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
 #ifndef FFN_PD
 #define FFN_PD 6
 #endif
-  constexpr int NR = 2 * KS + NT, PD = ring_depth(NR, FFN_PD < NR / 2 ? FFN_PD : NR / 2);
+  constexpr int NB = NT;                   // second-product steps per chunk
+  constexpr bool XA = !HA && C >= 192;     // upper half of the x fragments in AGPRs (see mfma_acc_h)
+  constexpr int NR = 2 * KS + NB, PD = ring_depth(NR, FFN_PD < NR / 2 ? FFN_PD : NR / 2);
   static_assert(NLD == KS && 2 * NLD == NT && NLD * 256 == W1_CH + W2_CH && 2 * NLD <= NR - PD, "staging schedule");
   static_assert(NR % PD == 0, "fragment f lives in ring[f % PD] across the chunk boundary");
   // first-product step i -> hidden tile / k-step: interleaving the two hidden tiles doubles the distance between MFMAs on
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
       if (i < 2 * KS) { /* H^T[ht] += W1[ht rows, k-step] . x^T */                                                  \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                         \
           if (FFN_KK(i) == 0) mfma_init_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][0]);                                   \
+          else if (XA && FFN_KK(i) >= KS / 2) mfma_acc_h<HA, XA>(hacc[FFN_HT(i)][mt], a, xf[mt][FFN_KK(i) >= KS / 2 ? FFN_KK(i) : KS - 1]); \
           else mfma_acc_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][FFN_KK(i)]);                                           \
         }                                                                                                           \
         { /* staging: even steps store register j to the idle slot, odd steps reload it for the chunk after */      \
@@ -251,10 +253,10 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
           if ((i & 1) == 0) {                                                                                       \
             const int off = c < W1_CH ? (c / (C / 8)) * W1_STRIDE + (c % (C / 8)) * 16                              \
                                       : W1_BYTES + (c2 >> 2) * W2_STRIDE + (c2 & 3) * 16;                           \
-            *reinterpret_cast<uint4*>(nbase + off) = st.get(j);                                                     \
+            *reinterpret_cast<uint4*>(nbase + off) = FFN_ST_GET(j);                                                 \
           } else {                                                                                                  \
             const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)c2 * 8;                             \
-            st.set(j, *reinterpret_cast<const uint4*>(src));                                                        \
+            FFN_ST_SET(j, *reinterpret_cast<const uint4*>(src))                                                     \
           }                                                                                                         \
         }                                                                                                           \
         if (i == 2 * KS - 1) { /* bias + GELU in registers -> B operand of the second product */                    \
@@ -330,27 +332,25 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
       for (int nh = 0; nh < NT / 2; ++nh)
         *reinterpret_cast<f32x4*>(so + fre * ORB + (nh * 16 + fge * 4) * 4) = oacc[half * (NT / 2) + nh][mt];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-local hand-over: LDS serves a wave's accesses in order
-      uint4 o[RP];
 #pragma unroll
       for (int it = 0; it < RP; ++it) {
-        const int ch = min(it * 64 + le, C - 1), row = ch / (C / 16), c8 = ch % (C / 16);
+        const int ch = it * 64 + le, chc = min(ch, C - 1), row = chc / (C / 16), c8 = chc % (C / 16);
         const int cb = half * (C / 2) + c8 * 8;
         const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
         const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
         const float4 b0 = *reinterpret_cast<const float4*>(sb2 + cb), b1 = *reinterpret_cast<const float4*>(sb2 + cb + 4);
         const float4 l0 = *reinterpret_cast<const float4*>(sls + cb), l1 = *reinterpret_cast<const float4*>(sls + cb + 4);
-        o[it].x = pack_bf2(bf_lo(rr[q % 3][it].x) + l0.x * (y0.x + b0.x), bf_hi(rr[q % 3][it].x) + l0.y * (y0.y + b0.y));
-        o[it].y = pack_bf2(bf_lo(rr[q % 3][it].y) + l0.z * (y0.z + b0.z), bf_hi(rr[q % 3][it].y) + l0.w * (y0.w + b0.w));
-        o[it].z = pack_bf2(bf_lo(rr[q % 3][it].z) + l1.x * (y1.x + b1.x), bf_hi(rr[q % 3][it].z) + l1.y * (y1.y + b1.y));
-        o[it].w = pack_bf2(bf_lo(rr[q % 3][it].w) + l1.z * (y1.z + b1.z), bf_hi(rr[q % 3][it].w) + l1.w * (y1.w + b1.w));
+        const uint4 r4 = rr[q % 3][it];
+        uint4 o;
+        o.x = pack_bf2(bf_lo(r4.x) + l0.x * (y0.x + b0.x), bf_hi(r4.x) + l0.y * (y0.y + b0.y));
+        o.y = pack_bf2(bf_lo(r4.y) + l0.z * (y0.z + b0.z), bf_hi(r4.y) + l0.w * (y0.w + b0.w));
+        o.z = pack_bf2(bf_lo(r4.z) + l1.x * (y1.x + b1.x), bf_hi(r4.z) + l1.y * (y1.y + b1.y));
+        o.w = pack_bf2(bf_lo(r4.w) + l1.z * (y1.z + b1.z), bf_hi(r4.w) + l1.w * (y1.w + b1.w));
+        const long m = mb + mt * 16 + row;
+        if (ch < C && m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + half * (C / 2) + c8 * 8) = o;
+        if (it & 1) __builtin_amdgcn_sched_barrier(0);    // two chunks' operands in flight at a time, not all RP of them
       }
       if (q + 2 < 2 * MT) FFN_LOAD_RES(q + 2, mb)        // residual rows of the pass after next: one pass is shorter than an HBM read
-#pragma unroll
-      for (int it = 0; it < RP; ++it) {
-        const int ch = it * 64 + le, row = ch / (C / 16), c8 = ch % (C / 16);
-        const long m = mb + mt * 16 + row;
-        if (ch < C && m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + half * (C / 2) + c8 * 8) = o[it];
-      }
       asm volatile("" ::: "memory");                      // the next pass's writes stay behind these reads
     }
     __syncthreads();  // the slot is the next tile's staging target again
