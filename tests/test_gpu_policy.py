@@ -130,3 +130,32 @@ def test_lerobot_wrapper_forward_and_queue():
     assert chunk.shape == (2, 1, 14)
     a = pol.select_action(batch)
     assert a.shape == (2, 14) and torch.allclose(a, chunk[:, 0])
+
+
+def test_prompt_feature_cache_matches_uncached():
+    """SURVEY 8f rank 1 extension (off by default): cached pooled features and the skipped tower leave the actions
+    bit-identical to the uncached literal path, for hits, misses and mixed batches."""
+    from vla_fastvlm.model.fastvlm_adapter import FastVLMBackbone, FastVLMBackboneConfig
+    torch.manual_seed(5)
+    bb = FastVLMBackbone(FastVLMBackboneConfig(model_id="synthetic:tiny:3"))
+    eng = bb.engine()
+    B, T = 4, 12
+    vocab = eng.model.llm.vocab
+    ids = torch.randint(0, vocab, (B, T), device=eng.device, dtype=torch.int32)
+    mask = torch.ones(B, T, dtype=torch.int32, device=eng.device)
+    mask[1, 7:] = 0
+    images = torch.rand(B, 3, 40, 52)
+    ref = bb.forward_ids(images, ids, mask).clone()
+    bb.cache_prompt_features = True
+    bb.skip_unused_tower = True
+    first = bb.forward_ids(images, ids, mask)           # all misses
+    again = bb.forward_ids(images, ids, mask)           # all hits: no decoder launch
+    ids2 = ids.clone()
+    ids2[2] = torch.randint(0, vocab, (T,), device=eng.device, dtype=torch.int32)
+    mixed = bb.forward_ids(images, ids2, mask)          # one miss among hits
+    torch.cuda.synchronize()
+    assert torch.equal(first, ref) and torch.equal(again, ref)
+    assert torch.equal(mixed[[0, 1, 3]], ref[[0, 1, 3]]) and not torch.equal(mixed[2], ref[2])
+    bb.cache_prompt_features = False
+    bb.skip_unused_tower = False
+    assert torch.equal(bb.forward_ids(images, ids2, mask), mixed)

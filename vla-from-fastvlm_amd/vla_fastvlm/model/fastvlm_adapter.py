@@ -157,6 +157,14 @@ class FastVLMBackbone(nn.Module):
         self.processor = None
         self.image_processor = None
         self.splice_image_tokens = os.environ.get("FASTVLA_SPLICE", "0") == "1"
+        # Extensions of this build, attributes rather than config fields because the config dataclass
+        # is the reference's public contract; both OFF by default so that a step does exactly the reference's work.  In
+        # literal (non-splice) mode the pooled feature depends on the prompt alone, so a policy that is asked the same task
+        # string every env step can keep it (LRU keyed by the prompt's token ids) and skip the decoder ...
+        self.cache_prompt_features = os.environ.get("FASTVLA_PROMPT_CACHE", "0") == "1"
+        self.prompt_cache_size = 256
+        # ... and the tower, whose output the literal reference computes and never consumes
+        self.skip_unused_tower = os.environ.get("FASTVLA_SKIP_UNUSED_TOWER", "0") == "1"
         self._engine: Optional[FastVLAEngine] = None
         self._head_dims = dict(state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024)
         self._max_batch = int(os.environ.get("FASTVLA_MAX_BATCH", "64"))
@@ -296,9 +304,33 @@ class FastVLMBackbone(nn.Module):
         if pix.shape[0] != input_ids.shape[0]:
             raise ValueError(f"batch mismatch: {pix.shape[0]} images vs {input_ids.shape[0]} prompts")
         lens = attention_mask.to(torch.int32).sum(dim=1).to(torch.int32)
-        tok = eng.vision_forward(pix)  # computed even when not spliced: the literal reference runs the tower too
         mode = 0 if self.config.image_feature_pool == "last_token" else 1
+        literal = not self.splice_image_tokens
+        tok = None
+        if not (literal and self.skip_unused_tower):
+            tok = eng.vision_forward(pix)  # computed even when not spliced: the literal reference runs the tower too
+        if literal and self.cache_prompt_features:
+            return self._pooled_through_cache(eng, input_ids, lens, mode)
         return eng.llm_pooled(input_ids, lens, tok if self.splice_image_tokens else None, pool_mode=mode)
+
+    def _pooled_through_cache(self, eng, input_ids: Tensor, lens: Tensor, mode: int) -> Tensor:
+        """Literal mode only: pooled rows by prompt.  Keys are the valid token ids of each row (one small D2H copy per call);
+        the decoder runs once per call over the rows that missed, and not at all when every prompt is known."""
+        cache = self.__dict__.setdefault("_prompt_cache", {})
+        ids_h, lens_h = input_ids.detach().cpu(), lens.detach().cpu()
+        keys = [(mode, ids_h[b, : int(lens_h[b])].numpy().tobytes()) for b in range(ids_h.shape[0])]
+        miss = [b for b, k in enumerate(keys) if k not in cache]
+        if miss:
+            sel = torch.as_tensor(miss, device=input_ids.device)
+            rows = eng.llm_pooled(input_ids.index_select(0, sel).contiguous(), lens.index_select(0, sel).contiguous(), None, pool_mode=mode)
+            for j, b in enumerate(miss):
+                cache[keys[b]] = rows[j].clone()
+            while len(cache) > max(int(self.prompt_cache_size), len(keys)):
+                cache.pop(next(iter(cache)))   # dicts keep insertion order: drop the oldest
+        return torch.stack([cache[k] for k in keys], dim=0)
+
+    def clear_prompt_cache(self) -> None:
+        self.__dict__.get("_prompt_cache", {}).clear()
 
     def backbone(self, images, tasks, device: Optional[torch.device] = None, **kwargs):
         return self.forward(images, tasks, device=device)
