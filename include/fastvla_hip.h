@@ -188,6 +188,11 @@ int fv_op_se_gelu(const void* x, const float* w1, const float* b1, const float* 
  * the kernel), i.e. the depthwise weights rounded to bf16. */
 int fv_op_dwconv_mfma(const void* x, const void* ttab, const float* bias, void* y, int B, int H, int W, int C, int k, int gelu,
                       fv_stream s);
+/* RepMixer pair in one marching kernel: y1 = dw3x3(x) + b3 (the reparameterised token mixer), y2 = dw7x7(y1) + b7 (the
+ * ConvFFN's conv); x, y1, y2 (B,H,W,C) bf16 NHWC, distinct; t3 / t7 Toeplitz tables as for fv_op_dwconv_mfma (k = 3 / 7);
+ * H >= 16, W >= 32, C % 32 == 0. */
+int fv_op_dwconv_pair(const void* x, const void* t3, const float* b3, const void* t7, const float* b7, void* y1, void* y2, int B,
+                      int H, int W, int C, fv_stream s);
 /* fused ConvFFN pointwise half: out (M,C) bf16 = res + ls * (fc2(gelu(fc1(x) + b1)) + b2), hidden = 4C never leaves the
  * chip.  w1 (4C,C) bf16; w2p = fc2 weight (C,4C) re-laid as [4C/32][C][32] with slot 8g+j of each 32-block holding
  * hidden 16*(j>>2) + 4*g + (j&3).  C in {32,64,96,128,192,384}.  out may alias res, not x. */

@@ -388,3 +388,26 @@ def test_stem_fused(S, B):
                                 stream()), "fv_op_stem_fused")
     torch.cuda.synchronize()
     check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"fused stem S={S}")
+
+
+@pytest.mark.parametrize("C,H,W", [(32, 16, 32), (96, 40, 64), (64, 19, 37), (192, 24, 96)])
+def test_dwconv_pair(C, H, W):
+    """x' = dw3x3(x) and t = dw7x7(x') from one marching kernel vs the two convolutions on the host (x' rounded to bf16
+    in between, as both the kernel's LDS ring and the unfused pair's HBM round trip do)."""
+    torch.manual_seed(C + H + W)
+    B = 2
+    x = bf(torch.randn(B, C, H, W))
+    w3, w7 = bf(torch.randn(C, 1, 3, 3) / 3), bf(torch.randn(C, 1, 7, 7) / 7)
+    b3, b7 = torch.randn(C) * 0.1, torch.randn(C) * 0.1
+    ref1 = bf(F.conv2d(x, w3, b3, padding=1, groups=C))
+    ref2 = F.conv2d(ref1, w7, b7, padding=3, groups=C)
+    xd = dev_bf16(x.permute(0, 2, 3, 1))
+    t3, t7 = dev_bf16(_toeplitz(w3, 3)), dev_bf16(_toeplitz(w7, 7))
+    b3d, b7d = dev_f32(b3), dev_f32(b7)
+    y1 = torch.full((B, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y2 = torch.full((B, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_dwconv_pair(xd.data_ptr(), t3.data_ptr(), b3d.data_ptr(), t7.data_ptr(), b7d.data_ptr(), y1.data_ptr(), y2.data_ptr(),
+                                 B, H, W, C, stream()), "fv_op_dwconv_pair")
+    torch.cuda.synchronize()
+    check_close(y1.float().cpu().permute(0, 3, 1, 2), ref1, what=f"dw pair 3x3 C{C} {H}x{W}")
+    check_close(y2.float().cpu().permute(0, 3, 1, 2), ref2, what=f"dw pair 7x7 C{C} {H}x{W}")

@@ -367,8 +367,19 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float
     }
     for (const Block& b : tw.stages[i]) {
       if (!d.tower_is_attn[i]) {
-        FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 3), 4.0 * M * C, dw_s1(h, cur, b.mix_w, b.mix_t, b.mix_b, oth, mb, H, C, 3, s));  // x = RepMixer(x) -> oth
-        FV_TRY(run_ffn(h, b.ffn, oth, cur, hid, oth, mb, H, H, C, d.tower_mlp_ratio, s));        // oth += ls * ffn(oth)
+        static const bool pair_ok = !getenv("FASTVLA_NO_DW_PAIR");
+        if (pair_ok && !h->no_mfma_dw && !h->no_fused_ffn && b.mix_t && b.ffn.dw_t && b.ffn.w2p && fv::dwconv_pair_supported(H, H, C)) {
+          // token mixer and the ConvFFN's 7x7 in one marching kernel: cur -> oth (x') and hid (t); then oth += ls * ffn(t)
+          FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 3) + dw_flops(mb, H, H, C, 7), 6.0 * M * C,
+               fv::launch_dwconv_pair(cur, b.mix_t, b.mix_b, b.ffn.dw_t, b.ffn.dw_b, oth, hid, mb, H, H, C, s));
+          prof_begin(h, FV_FAM_GEMM, 4.0 * M * C * (double)(C * d.tower_mlp_ratio), 6.0 * M * C, s, M, C, C * d.tower_mlp_ratio, 6);
+          const int rc = fv::launch_convffn(hid, b.ffn.fc1_w, b.ffn.fc1_b, b.ffn.w2p, b.ffn.fc2_b, b.ffn.ls, oth, oth, M, C, C * d.tower_mlp_ratio, s);
+          prof_end(h, s);
+          if (rc != FV_OK) return rc;
+        } else {
+          FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 3), 4.0 * M * C, dw_s1(h, cur, b.mix_w, b.mix_t, b.mix_b, oth, mb, H, C, 3, s));  // x = RepMixer(x) -> oth
+          FV_TRY(run_ffn(h, b.ffn, oth, cur, hid, oth, mb, H, H, C, d.tower_mlp_ratio, s));        // oth += ls * ffn(oth)
+        }
         std::swap(cur, oth);
       } else {
         FV_P(FV_FAM_NORM, 8.0 * M * C, 4.0 * M * C, fv::launch_layernorm_rows(cur, b.ln_w, b.ln_b, oth, M, C, d.ln_eps, s));

@@ -68,6 +68,11 @@ int fv_op_dwconv_mfma(const void* x, const void* ttab, const float* bias, void* 
   return fv::launch_dwconv_mfma(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(ttab), bias, static_cast<bf16_t*>(y), B, H, W, C, k,
                                 gelu, static_cast<hipStream_t>(s));
 }
+int fv_op_dwconv_pair(const void* x, const void* t3, const float* b3, const void* t7, const float* b7, void* y1, void* y2, int B,
+                      int H, int W, int C, fv_stream s) {
+  return fv::launch_dwconv_pair(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(t3), b3, static_cast<const bf16_t*>(t7), b7,
+                                static_cast<bf16_t*>(y1), static_cast<bf16_t*>(y2), B, H, W, C, static_cast<hipStream_t>(s));
+}
 
 int fv_op_convffn(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2, const float* ls,
                   const void* res, void* out, int M, int C, fv_stream s) {

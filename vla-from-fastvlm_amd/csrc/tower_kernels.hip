@@ -788,6 +788,231 @@ __global__ __launch_bounds__(256, DW_MARCH_OCC) void dwconv_march_kernel(const b
 #undef DW_WRITE_UNIT
 }
 
+// ---- RepMixer pair, marching: x' = dw3x3(x) (the reparameterised token mixer) and t = dw7x7(x') (the ConvFFN's conv) in
+// ONE walk down the strip.  As two kernels the pair moves 4.5 tensor-passes through the CUs' ~10 B/clk load/store path
+// (3x3: 1.33 in + 1 out, 7x7: 1.19 in + 1 out) and that path, not HBM or the MFMAs, is what bounds them; fused it is 3.2:
+// x is read once (plus the 8 halo columns), x' and t are written once, and x' reaches the 7x7 through LDS in the MFMA
+// operand layout the 3x3 produced it in -- no transposition in between.  Two 16-row rings: x rows (ring row (r - 4) & 15,
+// "x unit" u = rows 8u + 4 .. 8u + 11) and x' rows (ring row (r - 3) & 15, "x' unit" u = rows 8u + 3 .. 8u + 10).  Step g:
+// x' unit g from x units g - 1, g; emit its rows; t rows 8g .. 8g + 7 from x' units g - 1, g; emit them.  x' outside the
+// map is stored as zero (it is the 7x7's zero padding, not the 3x3's response to in-map neighbours).
+// LDS is what sets the occupancy: the x ring is 12 rows (row (r - 4) mod 12; 10 are live), the x' ring 16, and the t tile
+// borrows the x' rows unit g - 1 vacates once group g's 7x7 is done -- 73.5 KB, two blocks per CU (at one, with three
+// barriers a step and nothing else resident, the fused kernel was slower than the two it replaces).
+constexpr int DP_NQ = 10, DP_RS = DP_NQ * 256 + 64, DP_XR = 12;
+constexpr int DP_LDS = (DP_XR + 16) * DP_RS;
+__global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ t3,
+                                                               const float* __restrict__ b3, const bf16_t* __restrict__ t7,
+                                                               const float* __restrict__ b7, bf16_t* __restrict__ y1,
+                                                               bf16_t* __restrict__ y2, int H, int W, int C, int tiles_x,
+                                                               int nslices) {
+  constexpr int TW = 32, NQ = DP_NQ, RS = DP_RS, RSO = DP_RS, XR = DP_XR;
+  extern __shared__ __attribute__((aligned(16))) char dp_smem[];
+  char* sX = dp_smem;                 // x ring (XR rows)
+  char* sP = dp_smem + XR * RS;       // x' ring (16 rows); the t output tile borrows its vacated half
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = bid % nslices; bid /= nslices;
+  const int tx = bid % tiles_x;
+  const long b = bid / tiles_x;
+  const int c0 = slice * 32;
+  const int gg = wid & 1, rg = wid >> 1;          // wave = (16-channel group, 4 rows)
+  const int bch = lane >> 2, jr = lane & 3;       // lane = (channel within the group, row within the 4)
+  const int ng = (H + 7) / 8;
+
+  s16x4 a3[3][2], a7[7][3];
+  {
+    const char* s3 = reinterpret_cast<const char*>(t3) + (size_t)slice * (2 * 3 * 2 * 512) + (size_t)gg * 3 * 2 * 512 + lane * 8;
+    const char* s7 = reinterpret_cast<const char*>(t7) + (size_t)slice * (2 * 7 * 3 * 512) + (size_t)gg * 7 * 3 * 512 + lane * 8;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a3[ky][m] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(s3 + (ky * 2 + m) * 512));
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) a7[ky][m] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(s7 + (ky * 3 + m) * 512));
+  }
+  const float bv3 = b3[c0 + gg * 16 + bch], bv7 = b7[c0 + gg * 16 + bch];
+
+  // one x unit = 8 rows x NQ quads x 4 channel groups of (4 pixels x 8 channels) tasks; x columns start at tx*32 - 4
+  constexpr int NTASK = 8 * NQ * 4, TPT = (NTASK + 255) / 256;
+  uint4 px[TPT][4];
+#define DP_LOAD_XUNIT(U)                                                                                         \
+  {                                                                                                              \
+    _Pragma("unroll") for (int tt = 0; tt < TPT; ++tt) {                                                         \
+      const int task = tid + 256 * tt;                                                                           \
+      const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;                                  \
+      const int iy = 8 * (U) + 4 + row, ix0 = tx * TW - 4 + quad * 4;                                            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                            \
+        const int ix = ix0 + j;                                                                                  \
+        px[tt][j] = (task < NTASK && iy >= 0 && iy < H && ix >= 0 && ix < W)                                     \
+                        ? *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + cg * 8)  \
+                        : make_uint4(0, 0, 0, 0);                                                                \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+#define DP_WRITE_XUNIT(U)                                                                                        \
+  {                                                                                                              \
+    _Pragma("unroll") for (int tt = 0; tt < TPT; ++tt) {                                                         \
+      const int task = tid + 256 * tt;                                                                           \
+      if (task < NTASK) {                                                                                        \
+        const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;                                \
+        const uint32_t d[4][4] = {{px[tt][0].x, px[tt][0].y, px[tt][0].z, px[tt][0].w},                          \
+                                  {px[tt][1].x, px[tt][1].y, px[tt][1].z, px[tt][1].w},                          \
+                                  {px[tt][2].x, px[tt][2].y, px[tt][2].z, px[tt][2].w},                          \
+                                  {px[tt][3].x, px[tt][3].y, px[tt][3].z, px[tt][3].w}};                         \
+        const int xr_ = (((U) + 3) % 3 * 8 + row) % XR; /* (8 U + row) mod 12 for U >= -3 */                     \
+        const uint32_t dst = (uint32_t)(xr_ * RS + quad * 256 + cg * 64) |                                       \
+                             (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);                                   \
+        _Pragma("unroll") for (int dd = 0; dd < 4; ++dd) {                                                       \
+          uint2 ev, od;                                                                                          \
+          ev.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x05040100u);                                         \
+          ev.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x05040100u);                                         \
+          od.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x07060302u);                                         \
+          od.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x07060302u);                                         \
+          *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd) * 8))) = ev;                                 \
+          *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd + 1) * 8))) = od;                             \
+        }                                                                                                        \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+  uint32_t sw[4];   // lane's four swizzled channel offsets (one per quad & 3)
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sw[v] = (uint32_t)(((gg * 16 + bch) ^ ((v << 1) | gg)) << 3);
+
+  DP_LOAD_XUNIT(-2)
+  DP_WRITE_XUNIT(-2)
+  DP_LOAD_XUNIT(-1)
+  DP_WRITE_XUNIT(-1)
+  DP_LOAD_XUNIT(0)
+
+  for (int g = -1; g < ng; ++g) {
+    __syncthreads();   // x unit g is in its ring; the previous step's output tile and x' rows have been read
+    // ---- x' unit g = dw3x3 over x units g - 1, g: lane's row r' = 8g + 3 + rg*4 + jr, 10 quads of columns
+    {
+      f32x4 acc[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int rb = (8 * ((g + 3) % 3) + rg * 4 + jr + 10) % XR;   // x ring row of ky = 0: (r' - 1 - 4) mod 12, kept >= 0
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const uint32_t ro = (uint32_t)((rb + ky) % XR) * RS;
+        s16x4 xq[NQ];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sX + ro + sw[t & 3] + t * 256));
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q + m < NQ) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a3[ky][m], xq[q + m], acc[q], 0, 0, 0);
+      }
+      const int r1 = 8 * g + 3 + rg * 4 + jr;
+      const bool rowok = r1 >= 0 && r1 < H;
+      char* prow = sP + (uint32_t)((8 * (g & 1)) + rg * 4 + jr) * RS;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int col = tx * TW + 4 * q - 3 + i;
+          v[i] = (rowok && col >= 0 && col < W) ? acc[q][i] + bv3 : 0.0f;
+        }
+        uint2 u;
+        u.x = pack_bf2(v[0], v[1]);
+        u.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(prow + sw[q & 3] + q * 256) = u;
+      }
+    }
+    __syncthreads();   // x' unit g is in its ring; every wave is done with x unit g - 1
+    if (g + 1 < ng) DP_WRITE_XUNIT(g + 1)
+    if (g + 2 < ng) DP_LOAD_XUNIT(g + 2)
+    // ---- emit x' rows 8g + 3 .. 8g + 10 (columns of this strip only): 8 rows x 9 quads x 4 channel groups, v_perm transpose
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+      const int task = tid + 256 * et;
+      if (task < 8 * 9 * 4) {
+        const int cg = task & 3, quad = (task >> 2) % 9, row = (task >> 2) / 9;
+        const uint32_t src = (uint32_t)((8 * (g & 1) + row) * RS + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
+        uint2 r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sP + (src ^ (uint32_t)(e * 8)));
+        const int oy = 8 * g + 3 + row;
+        if (oy >= 0 && oy < H) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int lc = 4 * quad - 3 + j, ox = tx * TW + lc;     // column inside the strip / in the map
+            if (lc >= 0 && lc < TW && ox < W) {
+              uint4 o;
+              const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+#define FV_PX(A, B) __builtin_amdgcn_perm((j & 2) ? r[B].y : r[B].x, (j & 2) ? r[A].y : r[A].x, sel)
+              o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
+#undef FV_PX
+              *reinterpret_cast<uint4*>(y1 + (((size_t)b * H + oy) * W + ox) * C + c0 + cg * 8) = o;
+            }
+          }
+        }
+      }
+    }
+    if (g < 0) continue;
+    // ---- t rows 8g .. 8g + 7 = dw7x7 over x' units g - 1, g
+    {
+      f32x4 acc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int rb = 8 * g + rg * 4 + jr - 6;     // x' ring row of ky = 0: (o - 3 - 3) & 15
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const uint32_t ro = (uint32_t)((rb + ky) & 15) * RS;
+        s16x4 xq[NQ];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sP + ro + sw[t & 3] + t * 256));
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (q + m < NQ) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a7[ky][m], xq[q + m], acc[q], 0, 0, 0);
+      }
+      __syncthreads();   // every wave is done with x' unit g - 1: its ring rows carry the t tile out
+      char* orow = sP + (8 * ((g + 1) & 1) + rg * 4 + jr) * RS;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        uint2 u;
+        u.x = pack_bf2(acc[q][0] + bv7, acc[q][1] + bv7);
+        u.y = pack_bf2(acc[q][2] + bv7, acc[q][3] + bv7);
+        *reinterpret_cast<uint2*>(orow + sw[q & 3] + q * 256) = u;
+      }
+    }
+    __syncthreads();
+    {
+      const char* sO = sP + 8 * ((g + 1) & 1) * RS;
+      const int cg = tid & 3, quad = (tid >> 2) & 7, row = tid >> 5;   // 8 rows x 8 quads x 4 channel groups
+      const uint32_t src = (uint32_t)(row * RSO + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
+      uint2 r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sO + (src ^ (uint32_t)(e * 8)));
+      const int oy = g * 8 + row, ox0 = tx * TW + quad * 4;
+      if (oy < H) {
+        bf16_t* yp = y2 + (((size_t)b * H + oy) * W + ox0) * C + c0 + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ox0 + j < W) {
+            uint4 o;
+            const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+#define FV_PX(A, B) __builtin_amdgcn_perm((j & 2) ? r[B].y : r[B].x, (j & 2) ? r[A].y : r[A].x, sel)
+            o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
+#undef FV_PX
+            *reinterpret_cast<uint4*>(yp + (size_t)j * C) = o;
+          }
+        }
+      }
+    }
+  }
+#undef DP_LOAD_XUNIT
+#undef DP_WRITE_XUNIT
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNormChannel
 // one wave per row (pixel); C <= 2048, C % 8 == 0; two-pass in registers.
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
@@ -1047,6 +1272,27 @@ int launch_stem_fused(const bf16_t* pix, const bf16_t* wp, const float* b1, cons
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const long blocks = ntiles < cus ? ntiles : cus;
   hipLaunchKernelGGL(stem_fused_kernel, dim3((unsigned)blocks), dim3(512), SF_LDS, s, pix, wp, b1, w2, b2, y, B, S, ntiles);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+// x (B,H,W,C) -> y1 = dw3x3(x) + b3 and y2 = dw7x7(y1) + b7 in one marching kernel (dwpair_march_kernel); t3 / t7 are the
+// Toeplitz tables of dwconv_toeplitz_pack for k = 3 / 7.  x must not alias y1 or y2.
+bool dwconv_pair_supported(int H, int W, int C) { return H >= 16 && W >= 32 && C % 32 == 0; }
+int launch_dwconv_pair(const bf16_t* x, const bf16_t* t3, const float* b3, const bf16_t* t7, const float* b7, bf16_t* y1, bf16_t* y2,
+                       int B, int H, int W, int C, hipStream_t s) {
+  if (!x || !t3 || !b3 || !t7 || !b7 || !y1 || !y2) return fv_fail(FV_ERR_ARG, "dwconv_pair: null pointer");
+  if (B <= 0 || !dwconv_pair_supported(H, W, C)) return fv_fail(FV_ERR_UNSUPPORTED, "dwconv_pair: unsupported shape H=%d W=%d C=%d", H, W, C);
+  if (x == y1 || x == y2 || y1 == y2) return fv_fail(FV_ERR_ARG, "dwconv_pair: buffers must be distinct");
+  static bool attr_set = false;
+  if (!attr_set) {
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpair_march_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS));
+    attr_set = true;
+  }
+  const int tiles_x = (W + 31) / 32, nsl = C / 32;
+  const long nstrips = (long)B * tiles_x * nsl;
+  if (nstrips > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv_pair: grid too large");
+  hipLaunchKernelGGL(dwpair_march_kernel, dim3((unsigned)nstrips), dim3(256), DP_LDS, s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
