@@ -83,14 +83,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Staging pipeline: the registers loaded during iteration kt - 1 (tile kt + 1) are written to LDS right AFTER iteration
+  // kt's barrier and immediately refilled with tile kt + 2, so a load has a whole K-tile of MFMAs to land before its store
+  // needs it (stored at the end of the same iteration, as before, it had only the MFMAs of its own tile: 512 clk against
+  // >1000 of memory latency).  Still one barrier per K-tile: it publishes tile kt and retires the reads of tile kt - 1,
+  // whose buffer the store then overwrites.
   load_tile(0);
   store_tile(0);
-  __syncthreads();
+  if (nk > 1) load_tile(1);
 
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    __syncthreads();
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    if (kt + 2 < nk) load_tile(kt + 2);
     const bf16_t* a_base = sA + cur * A_ELEMS;
     const bf16_t* b_base = sB + cur * B_ELEMS;
 #pragma unroll
@@ -108,9 +115,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
-    __syncthreads();
   }
+  __syncthreads();  // the last tile's fragment reads are done: the epilogue image reuses the staging buffers
 
   // ---- epilogue: accumulators -> fp32 LDS image (C/D map: col = lane&15, row = (lane>>4)*4 + reg) ----
 #pragma unroll
@@ -167,9 +173,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
       const float4 hi = *reinterpret_cast<const float4*>(p.bias + gn + 4);
       v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
     }
-    if (epi == FV_EPI_BIAS_GELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    if (epi == FV_EPI_BIAS_GELU) {  // packed, transcendental-free form (common.h): half the VALU issues of gelu_f
+      f32x2 g[4] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}};
+      gelu2_n<4>(g);
+      v[0] = g[0].x; v[1] = g[0].y; v[2] = g[1].x; v[3] = g[1].y; v[4] = g[2].x; v[5] = g[2].y; v[6] = g[3].x; v[7] = g[3].y;
     } else if (epi == FV_EPI_LS_RES) {
       float r[8], sc[8];
       unpack8(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), r);
