@@ -204,7 +204,11 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
     reinterpret_cast<float4*>(sb2)[i] = reinterpret_cast<const float4*>(p.b2)[i];
     reinterpret_cast<float4*>(sls)[i] = reinterpret_cast<const float4*>(p.ls)[i];
   }
-  uint4 rr[3][RP];                                     // residual rows, fetched two passes ahead (pass q in rr[q % 3])
+  // residual rows, fetched RD - 1 passes ahead (pass q in rr[q % RD]): the epilogue is bound by how many bytes a wave keeps in
+  // flight towards HBM (one pass = 1 KB per load), not by its instructions, so the small-C variants that have the
+  // registers look further ahead
+  constexpr int RD = RP <= 3 ? 5 : 3;
+  uint4 rr[RD][RP];
 #define FFN_LOAD_RES(Q, MB)                                                                                  \
   {                                                                                                          \
     int lr_ = lane;                                                                                          \
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
     _Pragma("unroll") for (int it = 0; it < RP; ++it) {                                                      \
       const int ch_ = min(it * 64 + lr_, C - 1), row_ = ch_ / (C / 16), c8_ = ch_ % (C / 16);                \
       const long m_ = min((MB) + ((Q) >> 1) * 16 + row_, (long)p.M - 1);                                     \
-      rr[(Q) % 3][it] = *reinterpret_cast<const uint4*>(p.res + m_ * C + ((Q) & 1) * (C / 2) + c8_ * 8);     \
+      rr[(Q) % RD][it] = *reinterpret_cast<const uint4*>(p.res + m_ * C + ((Q) & 1) * (C / 2) + c8_ * 8);     \
     }                                                                                                        \
   }
 
@@ -308,8 +312,8 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
     const unsigned long long t_epi = __builtin_amdgcn_s_memtime(), t_real2 = __builtin_amdgcn_s_memrealtime();
 #endif
     __builtin_amdgcn_sched_barrier(0);  // keep the epilogue's loads out of the chunk: hoisted, they spill its registers
-    FFN_LOAD_RES(0, mb)
-    FFN_LOAD_RES(1, mb)
+#pragma unroll
+    for (int q0 = 0; q0 < RD - 1 && q0 < 2 * MT; ++q0) FFN_LOAD_RES(q0, mb)
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // last XDL writes of the output accumulators -> VALU reads below
     __builtin_amdgcn_sched_barrier(0);  // ... and nothing that reads them moves above the wait states
     // ---- epilogue.  The accumulator layout (lane = pixel fr, 4 channels per tile) would leave as 8-byte accesses 32 B
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
 #pragma unroll
       for (int nh = 0; nh < NT / 2; ++nh)
         *reinterpret_cast<f32x4*>(so + fre * ORB + (nh * 16 + fge * 4) * 4) = oacc[half * (NT / 2) + nh][mt];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-local hand-over: LDS serves a wave's accesses in order
+      asm volatile("" ::: "memory");  // wave-local hand-over: LDS serves a wave's accesses in order, no wait needed
 #pragma unroll
       for (int it = 0; it < RP; ++it) {
         const int ch = it * 64 + le, chc = min(ch, C - 1), row = chc / (C / 16), c8 = chc % (C / 16);
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
         const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
         const float4 b0 = *reinterpret_cast<const float4*>(sb2 + cb), b1 = *reinterpret_cast<const float4*>(sb2 + cb + 4);
         const float4 l0 = *reinterpret_cast<const float4*>(sls + cb), l1 = *reinterpret_cast<const float4*>(sls + cb + 4);
-        const uint4 r4 = rr[q % 3][it];
+        const uint4 r4 = rr[q % RD][it];
         uint4 o;
         o.x = pack_bf2(bf_lo(r4.x) + l0.x * (y0.x + b0.x), bf_hi(r4.x) + l0.y * (y0.y + b0.y));
         o.y = pack_bf2(bf_lo(r4.y) + l0.z * (y0.z + b0.z), bf_hi(r4.y) + l0.w * (y0.w + b0.w));
@@ -348,9 +352,9 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
         o.w = pack_bf2(bf_lo(r4.w) + l1.z * (y1.z + b1.z), bf_hi(r4.w) + l1.w * (y1.w + b1.w));
         const long m = mb + mt * 16 + row;
         if (ch < C && m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + half * (C / 2) + c8 * 8) = o;
-        if (it & 1) __builtin_amdgcn_sched_barrier(0);    // two chunks' operands in flight at a time, not all RP of them
+        if (RP > 3 && (it & 1)) __builtin_amdgcn_sched_barrier(0);   // C = 384: two chunks' operands in flight at a time, not all six
       }
-      if (q + 2 < 2 * MT) FFN_LOAD_RES(q + 2, mb)        // residual rows of the pass after next: one pass is shorter than an HBM read
+      if (q + RD - 1 < 2 * MT) FFN_LOAD_RES(q + RD - 1, mb)   // residual rows RD - 1 passes ahead: one pass is far shorter than an HBM read
       asm volatile("" ::: "memory");                      // the next pass's writes stay behind these reads
     }
     __syncthreads();  // the slot is the next tile's staging target again
