@@ -411,3 +411,17 @@ def test_dwconv_pair(C, H, W):
     torch.cuda.synchronize()
     check_close(y1.float().cpu().permute(0, 3, 1, 2), ref1, what=f"dw pair 3x3 C{C} {H}x{W}")
     check_close(y2.float().cpu().permute(0, 3, 1, 2), ref2, what=f"dw pair 7x7 C{C} {H}x{W}")
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 2048, 192), (8192, 4096, 448)])
+def test_gemm_256_tile_variant(M, N, K):
+    """Shapes the 256 x 256 LDS-DMA kernel takes (M, N multiples of 256, K of 64, >= 512 tiles): all three of its epilogues,
+    plus the asymmetric-operand check that a swapped row/column map cannot pass."""
+    torch.manual_seed(M + N + K)
+    A, W = bf(torch.randn(M, K)), bf(torch.randn(N, K) / math.sqrt(K))
+    b, ls, res = torch.randn(N) * 0.1, torch.rand(N) * 0.3 + 0.05, bf(torch.randn(M, N))
+    ref = A @ W.t() + b                       # fp32 on the host keeps the reference to seconds at this size
+    check_close(_gemm(A, W, _lib.EPI_BIAS, bias=b), ref, what=f"gemm256 bias {M}x{N}x{K}")
+    check_close(_gemm(A, W, _lib.EPI_BIAS_GELU, bias=b), F.gelu(ref), what=f"gemm256 gelu {M}x{N}x{K}")
+    check_close(_gemm(A, W, _lib.EPI_LS_RES, bias=b, scale=ls, res=res), res + ls * ref, what=f"gemm256 ls_res {M}x{N}x{K}")
+    check_close(_gemm(A, W, _lib.EPI_BIAS, bias=b, lda=K + 64), ref, what="gemm256 strided A")
