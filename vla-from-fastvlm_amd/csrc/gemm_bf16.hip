@@ -223,106 +223,124 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 2, wc = wid & 3;            // wave's 128-row M half, 64-column N quarter
   const int fr = lane & 15, fq = lane >> 4;
-  const int logical = xcd_remap(blockIdx.x, p.nwg);
-  const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
-  const int bm = tm * 256, bn = tn * 256;
   const int nk = p.K / BK;
+  const int wslot = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
   // staging: slot s = j * 512 + tid is 16 B of row s >> 3 at LDS position s & 7, filled from k-chunk (s & 7) ^ (row & 7)
-  uint32_t offa[4], offw[4];
+  uint32_t offa[4], offw[4], offa_n[4], offw_n[4];
+  auto tile_offsets = [&](int tile, uint32_t (&oa)[4], uint32_t (&ow)[4], int& bm, int& bn) {
+    const int logical = xcd_remap(tile, p.nwg);
+    bm = (logical / p.tiles_n) * 256;
+    bn = (logical % p.tiles_n) * 256;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int sl = j * 512 + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
-    offa[j] = (uint32_t)(((size_t)(bm + row) * p.lda + chunk * 8) * 2);
-    offw[j] = (uint32_t)(((size_t)(bn + row) * p.K + chunk * 8) * 2);
-  }
-  const int wslot = __builtin_amdgcn_readfirstlane(wid) * 1024;
-  auto stage = [&](int kt, int buf) {
+    for (int j = 0; j < 4; ++j) {
+      const int sl = j * 512 + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
+      oa[j] = (uint32_t)(((size_t)(bm + row) * p.lda + chunk * 8) * 2);
+      ow[j] = (uint32_t)(((size_t)(bn + row) * p.K + chunk * 8) * 2);
+    }
+  };
+  auto stage = [&](const uint32_t (&oa)[4], const uint32_t (&ow)[4], int kt, int buf) {
     const char* ab = reinterpret_cast<const char*>(p.A) + (size_t)kt * BK * 2;
     const char* wb = reinterpret_cast<const char*>(p.W) + (size_t)kt * BK * 2;
     char* la = g2_smem + buf * 65536 + wslot;
     char* lw = la + 32768;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(ab + offa[j]), (lds_ptr_t)(la + j * 8192), 16, 0, 0);
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(ab + oa[j]), (lds_ptr_t)(la + j * 8192), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(wb + offw[j]), (lds_ptr_t)(lw + j * 8192), 16, 0, 0);
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(wb + ow[j]), (lds_ptr_t)(lw + j * 8192), 16, 0, 0);
   };
-
-  f32x4 acc[4][8];   // [n tile][m tile]
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   // lane's fragment offsets: row fr of a 16-row tile, swizzled chunk per k-step
   const uint32_t fo0 = (uint32_t)(fr * 128 + (((0 * 4 + fq) ^ (fr & 7)) << 4));
   const uint32_t fo1 = (uint32_t)(fr * 128 + (((1 * 4 + fq) ^ (fr & 7)) << 4));
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-    const char* la = g2_smem + cur * 65536 + (wr * 128) * 128;
-    const char* lw = g2_smem + cur * 65536 + 32768 + (wc * 64) * 128;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint32_t fo = ks ? fo1 : fo0;
-      bf16x8 fw[4], fa[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lw + j * 2048 + fo));
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + i * 2048 + fo));
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed ...
-    __syncthreads();                                    // ... for everybody, and nobody still reads this one
-  }
 
-  // ---- epilogue: per 16-row tile, 64 columns of fp32 through the wave's 4.25 KB of LDS (the staging buffers are idle)
-  constexpr int ORB = 64 * 4 + 16;
-  char* so = g2_smem + wid * (16 * ORB);
-  const int c8 = lane & 7;                       // the lane's 8 output columns on the way out (same for every row tile)
-  const int gn = bn + wc * 64 + c8 * 8;
-  float bs[8], sc[8];
+  // Persistent: one block per CU walks the tiles; the first K-tile of the NEXT output tile is staged under the last K-tile
+  // of this one, so only the very first tile of a block waits for memory with nothing to do, and the epilogue's stores
+  // drain under the next tile's MFMAs.  pb = LDS buffer holding the current tile's K-tile 0.
+  int tile = blockIdx.x, pb = 0, bm, bn, bm_n = 0, bn_n = 0;
+  if (tile >= p.nwg) return;
+  tile_offsets(tile, offa, offw, bm, bn);
+  stage(offa, offw, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (; tile < p.nwg; tile += (int)gridDim.x) {
+    const int next = tile + (int)gridDim.x;
+    if (next < p.nwg) tile_offsets(next, offa_n, offw_n, bm_n, bn_n);
+    f32x4 acc[4][8];   // [n tile][m tile]
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; }
-  if (p.bias) {
-    const float4 lo = *reinterpret_cast<const float4*>(p.bias + gn), hi = *reinterpret_cast<const float4*>(p.bias + gn + 4);
-    bs[0] = lo.x; bs[1] = lo.y; bs[2] = lo.z; bs[3] = lo.w; bs[4] = hi.x; bs[5] = hi.y; bs[6] = hi.z; bs[7] = hi.w;
-  }
-  if (p.epi == FV_EPI_LS_RES) {
-    const float4 lo = *reinterpret_cast<const float4*>(p.scale + gn), hi = *reinterpret_cast<const float4*>(p.scale + gn + 4);
-    sc[0] = lo.x; sc[1] = lo.y; sc[2] = lo.z; sc[3] = lo.w; sc[4] = hi.x; sc[5] = hi.y; sc[6] = hi.z; sc[7] = hi.w;
-  }
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = (pb + kt) & 1;
+      if (kt + 1 < nk) stage(offa, offw, kt + 1, cur ^ 1);
+      else if (next < p.nwg) stage(offa_n, offw_n, 0, cur ^ 1);
+      const char* la = g2_smem + cur * 65536 + (wr * 128) * 128;
+      const char* lw = g2_smem + cur * 65536 + 32768 + (wc * 64) * 128;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(so + fr * ORB + (j * 16 + fq * 4) * 4) = acc[j][i];
-    asm volatile("" ::: "memory");   // wave-local hand-over: LDS serves a wave's accesses in order
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint32_t fo = ks ? fo1 : fo0;
+        bf16x8 fw[4], fa[8];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = it * 8 + (lane >> 3);
-      const int gm = bm + wr * 128 + i * 16 + row;
-      const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
-      const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
-      float v[8] = {y0.x + bs[0], y0.y + bs[1], y0.z + bs[2], y0.w + bs[3], y1.x + bs[4], y1.y + bs[5], y1.z + bs[6], y1.w + bs[7]};
-      if (p.epi == FV_EPI_BIAS_GELU) {
-        f32x2 g[4] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}};
-        gelu2_n<4>(g);
-        v[0] = g[0].x; v[1] = g[0].y; v[2] = g[1].x; v[3] = g[1].y; v[4] = g[2].x; v[5] = g[2].y; v[6] = g[3].x; v[7] = g[3].y;
-      } else if (p.epi == FV_EPI_LS_RES) {
-        float r[8];
-        unpack8(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), r);
+        for (int j = 0; j < 4; ++j) fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lw + j * 2048 + fo));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = r[e] + sc[e] * v[e];
+        for (int i = 0; i < 8; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + i * 2048 + fo));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
       }
-      *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8(v);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next K-tile has landed ...
+      __syncthreads();                                    // ... for everybody, and nobody still reads this one
     }
-    asm volatile("" ::: "memory");   // the next tile's writes stay behind these reads
+
+    // ---- epilogue: per 16-row tile, 64 columns of fp32 through the wave's 4.25 KB of the buffer the last K-tile just
+    // vacated (the other one already holds the next output tile's first K-tile)
+    constexpr int ORB = 64 * 4 + 16;
+    char* so = g2_smem + ((pb + nk - 1) & 1) * 65536 + wid * (16 * ORB);
+    const int c8 = lane & 7;                       // the lane's 8 output columns on the way out (same for every row tile)
+    const int gn = bn + wc * 64 + c8 * 8;
+    float bs[8], sc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; }
+    if (p.bias) {
+      const float4 lo = *reinterpret_cast<const float4*>(p.bias + gn), hi = *reinterpret_cast<const float4*>(p.bias + gn + 4);
+      bs[0] = lo.x; bs[1] = lo.y; bs[2] = lo.z; bs[3] = lo.w; bs[4] = hi.x; bs[5] = hi.y; bs[6] = hi.z; bs[7] = hi.w;
+    }
+    if (p.epi == FV_EPI_LS_RES) {
+      const float4 lo = *reinterpret_cast<const float4*>(p.scale + gn), hi = *reinterpret_cast<const float4*>(p.scale + gn + 4);
+      sc[0] = lo.x; sc[1] = lo.y; sc[2] = lo.z; sc[3] = lo.w; sc[4] = hi.x; sc[5] = hi.y; sc[6] = hi.z; sc[7] = hi.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(so + fr * ORB + (j * 16 + fq * 4) * 4) = acc[j][i];
+      asm volatile("" ::: "memory");   // wave-local hand-over: LDS serves a wave's accesses in order
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int gm = bm + wr * 128 + i * 16 + row;
+        const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
+        const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
+        float v[8] = {y0.x + bs[0], y0.y + bs[1], y0.z + bs[2], y0.w + bs[3], y1.x + bs[4], y1.y + bs[5], y1.z + bs[6], y1.w + bs[7]};
+        if (p.epi == FV_EPI_BIAS_GELU) {
+          f32x2 g[4] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}};
+          gelu2_n<4>(g);
+          v[0] = g[0].x; v[1] = g[0].y; v[2] = g[1].x; v[3] = g[1].y; v[4] = g[2].x; v[5] = g[2].y; v[6] = g[3].x; v[7] = g[3].y;
+        } else if (p.epi == FV_EPI_LS_RES) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = r[e] + sc[e] * v[e];
+        }
+        *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8(v);
+      }
+      asm volatile("" ::: "memory");   // the next tile's writes stay behind these reads
+    }
+    __syncthreads();   // the scratch buffer becomes a staging target again in the next tile's first iteration
+    pb = (pb + nk) & 1;
+    bm = bm_n; bn = bn_n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { offa[j] = offa_n[j]; offw[j] = offw_n[j]; }
   }
 }
 
@@ -368,7 +386,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     }
     p.tiles_n = a.N / 256;
     p.nwg = (a.M / 256) * p.tiles_n;
-    hipLaunchKernelGGL(gemm256_kernel, dim3(p.nwg), dim3(512), G2_LDS, s, p);
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const int grid = p.nwg < cus ? p.nwg : cus / 8 * 8;   // persistent, one block per CU; a multiple of 8 keeps the XCD remap exact
+    hipLaunchKernelGGL(gemm256_kernel, dim3(grid), dim3(512), G2_LDS, s, p);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
   }
