@@ -156,6 +156,10 @@ enum fv_gemm_epilogue {
 /* out[M,N] = A[M,K] (bf16, row stride lda) x W[N,K]^T (bf16) with fp32 accumulation on MFMA */
 int fv_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const float* scale,
                const void* res, int ldr, void* out, int ldo, int epilogue, fv_stream s);
+/* the split-bf16 form the parity-mode decoder uses: A (M, 2K) carries [hi | lo] halves side by side (lda >= 2K), and
+ * out = (A_hi + A_lo) . W^T in one launch with a doubled K loop; epilogues as fv_op_gemm */
+int fv_op_gemm_ksplit(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr,
+                      void* out, int ldo, int epilogue, fv_stream s);
 /* depthwise / channel-multiplier grouped conv, NHWC bf16: x (B,H,W,C) -> y (B,Ho,Wo,C*mult); w f32 [k*k][C*mult] */
 int fv_op_dwconv(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                  int stride, int mult, int gelu, fv_stream s);

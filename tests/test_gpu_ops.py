@@ -425,3 +425,29 @@ def test_gemm_256_tile_variant(M, N, K):
     check_close(_gemm(A, W, _lib.EPI_BIAS_GELU, bias=b), F.gelu(ref), what=f"gemm256 gelu {M}x{N}x{K}")
     check_close(_gemm(A, W, _lib.EPI_LS_RES, bias=b, scale=ls, res=res), res + ls * ref, what=f"gemm256 ls_res {M}x{N}x{K}")
     check_close(_gemm(A, W, _lib.EPI_BIAS, bias=b, lda=K + 64), ref, what="gemm256 strided A")
+
+
+@pytest.mark.parametrize("M,I,K", [(300, 256, 128), (4096, 5120, 192)])
+def test_gemm_ksplit_swiglu_split(M, I, K):
+    """The parity-mode decoder's gate/up GEMM: split-bf16 activations [hi | lo] against bf16 weights in one launch, SwiGLU in
+    the epilogue, output again split [hi | lo].  The second shape is taken by the 256 x 256 kernel, the first by the 128."""
+    torch.manual_seed(M + I + K)
+    A = torch.randn(M, K)
+    Ah = bf(A)
+    Al = bf(A - Ah)
+    G, U = bf(torch.randn(I, K) / math.sqrt(K)), bf(torch.randn(I, K) / math.sqrt(K))
+    Wi = torch.empty(2 * I, K)
+    j = torch.arange(I)
+    Wi[(j // 8) * 16 + j % 8] = G
+    Wi[(j // 8) * 16 + 8 + j % 8] = U
+    a16 = (Ah + Al).double()                                 # what the kernel multiplies: 16 significant bits
+    ref = (F.silu(a16 @ G.double().t()) * (a16 @ U.double().t())).float()
+    a = torch.cat([dev_bf16(Ah), dev_bf16(Al)], dim=1).contiguous()
+    w = dev_bf16(Wi)
+    out = torch.full((M, 2 * I), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_gemm_ksplit(a.data_ptr(), 2 * K, w.data_ptr(), M, 2 * I, K, None, None, 0, out.data_ptr(), 2 * I,
+                                 _lib.EPI_SWIGLU_SPLIT, stream()), "fv_op_gemm_ksplit")
+    torch.cuda.synchronize()
+    o = out.float().cpu()
+    check_close(o[:, :I] + o[:, I:], ref, rel=2e-5, amax=2e-4, what=f"ksplit swiglu split {M}x{I}x{K}")
+    check_close(o[:, :I], ref, what="hi half alone is the bf16 rounding of the result")

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 2, wc = wid & 3;            // wave's 128-row M half, 64-column N quarter
   const int fr = lane & 15, fq = lane >> 4;
-  const int nk = p.K / BK;
+  const int nk1 = p.K / BK, nk = p.ksplit ? 2 * nk1 : nk1;   // ksplit: A = [hi | lo], the weight columns are walked twice
   const int wslot = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
   // staging: slot s = j * 512 + tid is 16 B of row s >> 3 at LDS position s & 7, filled from k-chunk (s & 7) ^ (row & 7)
@@ -240,8 +240,9 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
     }
   };
   auto stage = [&](const uint32_t (&oa)[4], const uint32_t (&ow)[4], int kt, int buf) {
-    const char* ab = reinterpret_cast<const char*>(p.A) + (size_t)kt * BK * 2;
-    const char* wb = reinterpret_cast<const char*>(p.W) + (size_t)kt * BK * 2;
+    const int kw = kt >= nk1 ? kt - nk1 : kt;
+    const char* ab = reinterpret_cast<const char*>(p.A) + ((size_t)kw * BK + (kt >= nk1 ? p.K : 0)) * 2;
+    const char* wb = reinterpret_cast<const char*>(p.W) + (size_t)kw * BK * 2;
     char* la = g2_smem + buf * 65536 + wslot;
     char* lw = la + 32768;
 #pragma unroll
@@ -315,6 +316,25 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(so + fr * ORB + (j * 16 + fq * 4) * 4) = acc[j][i];
       asm volatile("" ::: "memory");   // wave-local hand-over: LDS serves a wave's accesses in order
+      if (p.epi == FV_EPI_SWIGLU_SPLIT) {
+        // W rows are interleaved [8 gate | 8 up]: a lane takes 16 accumulator columns of one row -> 8 outputs, written as
+        // the bf16 value and, N/2 columns further, its bf16 remainder (split-bf16 operand of the down projection)
+        const int row = lane >> 2, pr = lane & 3;
+        const int gm = bm + wr * 128 + i * 16 + row, go = (bn + wc * 64 + pr * 16) >> 1;
+        const float* src = reinterpret_cast<const float*>(so + row * ORB) + pr * 16;
+        float o8[8], h8[8], l8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = silu_f(src[e]) * src[8 + e];
+        const uint4 hv = pack8(o8);
+        unpack8(hv, h8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l8[e] = o8[e] - h8[e];
+        bf16_t* op = static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + go;
+        *reinterpret_cast<uint4*>(op) = hv;
+        *reinterpret_cast<uint4*>(op + (p.N >> 1)) = pack8(l8);
+        asm volatile("" ::: "memory");
+        continue;
+      }
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int row = it * 8 + (lane >> 3);
@@ -349,8 +369,9 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
 #endif
 bool gemm256_ok(const GemmArgs& a) {
   static const bool off = getenv("FASTVLA_NO_GEMM256") != nullptr;
-  if (off || a.ksplit) return false;
-  if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES) return false;
+  if (off) return false;
+  if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT) return false;
+  if (a.epi == FV_EPI_SWIGLU_SPLIT && a.bias) return false;
   if (a.M % 256 || a.N % 256 || a.K % 64 || a.K < 128) return false;
   const long blocks = (long)(a.M / 256) * (a.N / 256);
   return blocks >= G2_MIN_BLOCKS;

@@ -81,6 +81,7 @@ SIGNATURES = {
     "fv_profile_read": (_i, [_vp, C.POINTER(ProfileEntry), C.POINTER(GemmProfile), _i, C.POINTER(_i)]),
     "fv_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(AdamWHParams), _i64, _vp, _vp]),
     "fv_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "fv_op_gemm_ksplit": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "fv_op_dwconv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fv_op_stem_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "fv_op_stem_mfma": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
