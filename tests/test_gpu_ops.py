@@ -451,3 +451,26 @@ def test_gemm_ksplit_swiglu_split(M, I, K):
     o = out.float().cpu()
     check_close(o[:, :I] + o[:, I:], ref, rel=2e-5, amax=2e-4, what=f"ksplit swiglu split {M}x{I}x{K}")
     check_close(o[:, :I], ref, what="hi half alone is the bf16 rounding of the result")
+
+
+def test_gemm_glds_128_tile_fp32_epilogues():
+    """The decoder's projections at M = 4096 (N = 896: too few 256-tiles) go to the 128 x 128 LDS-DMA variant: fp32 residual
+    stream, fp32 output with bias, and the split-bf16 form of both."""
+    torch.manual_seed(11)
+    M, N, K = 4096, 896, 576
+    A = torch.randn(M, K)
+    Ah = bf(A)
+    Al = bf(A - Ah)
+    W, res, b = bf(torch.randn(N, K) * 0.05), torch.randn(M, N), torch.randn(N)
+    ref = (res.double() + Ah.double() @ W.double().t()).float()
+    check_close(_gemm(Ah, W, _lib.EPI_RES_F32, res=res, out_f32=True), ref, rel=2e-5, amax=2e-5, what="glds128 res_f32")
+    ref = (Ah.double() @ W.double().t() + b.double()).float()
+    check_close(_gemm(Ah, W, _lib.EPI_F32, bias=b, out_f32=True), ref, rel=2e-5, amax=2e-5, what="glds128 f32 out")
+    a = torch.cat([dev_bf16(Ah), dev_bf16(Al)], dim=1).contiguous()
+    w, r = dev_bf16(W), dev_f32(res)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    call(lib().fv_op_gemm_ksplit(a.data_ptr(), 2 * K, w.data_ptr(), M, N, K, None, r.data_ptr(), N, out.data_ptr(), N, _lib.EPI_RES_F32,
+                                 stream()), "fv_op_gemm_ksplit")
+    torch.cuda.synchronize()
+    ref = (res.double() + (Ah + Al).double() @ W.double().t()).float()
+    check_close(out.cpu(), ref, rel=2e-5, amax=2e-5, what="glds128 ksplit res_f32")

@@ -216,12 +216,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
 // columns: the epilogue turns 16 rows x 64 columns through LDS with 16-byte writes and leaves as full 128-byte lines.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
-constexpr int G2_LDS = 2 * 2 * 256 * 128;   // [buffer][A | W][256 rows][128 B]
 
-__global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
+// MI = 16-row tiles per wave along M (the block has 2 waves along M), WN = waves along N (64 columns each):
+// <8, 4> = 256 x 256 with 8 waves (one block per CU), <4, 2> = 128 x 128 with 4 waves (two per CU) for problems with too few
+// 256-tiles to fill the chip (the decoder's N = 896 / 1152 projections at M = 4096).
+template <int MI, int WN>
+__global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Params p) {
+  constexpr int BMT = 32 * MI, BNT = 64 * WN, NTH = 128 * WN, BUFB = (BMT + BNT) * 128, AB = BMT * 128;
+  static_assert(BMT * 8 == 4 * NTH && BNT * 8 == 4 * NTH, "four 16-byte slots per thread and operand");
   extern __shared__ __attribute__((aligned(16))) char g2_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 2, wc = wid & 3;            // wave's 128-row M half, 64-column N quarter
+  const int wr = wid / WN, wc = wid % WN;            // wave's M half, 64-column N slice
   const int fr = lane & 15, fq = lane >> 4;
   const int nk1 = p.K / BK, nk = p.ksplit ? 2 * nk1 : nk1;   // ksplit: A = [hi | lo], the weight columns are walked twice
   const int wslot = __builtin_amdgcn_readfirstlane(wid) * 1024;
@@ -230,11 +235,11 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
   uint32_t offa[4], offw[4], offa_n[4], offw_n[4];
   auto tile_offsets = [&](int tile, uint32_t (&oa)[4], uint32_t (&ow)[4], int& bm, int& bn) {
     const int logical = xcd_remap(tile, p.nwg);
-    bm = (logical / p.tiles_n) * 256;
-    bn = (logical % p.tiles_n) * 256;
+    bm = (logical / p.tiles_n) * BMT;
+    bn = (logical % p.tiles_n) * BNT;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int sl = j * 512 + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
+      const int sl = j * NTH + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
       oa[j] = (uint32_t)(((size_t)(bm + row) * p.lda + chunk * 8) * 2);
       ow[j] = (uint32_t)(((size_t)(bn + row) * p.K + chunk * 8) * 2);
     }
@@ -243,12 +248,12 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
     const int kw = kt >= nk1 ? kt - nk1 : kt;
     const char* ab = reinterpret_cast<const char*>(p.A) + ((size_t)kw * BK + (kt >= nk1 ? p.K : 0)) * 2;
     const char* wb = reinterpret_cast<const char*>(p.W) + (size_t)kw * BK * 2;
-    char* la = g2_smem + buf * 65536 + wslot;
-    char* lw = la + 32768;
+    char* la = g2_smem + buf * BUFB + wslot;
+    char* lw = la + AB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(ab + oa[j]), (lds_ptr_t)(la + j * 8192), 16, 0, 0);
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(ab + oa[j]), (lds_ptr_t)(la + j * (NTH * 16)), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(wb + ow[j]), (lds_ptr_t)(lw + j * 8192), 16, 0, 0);
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(wb + ow[j]), (lds_ptr_t)(lw + j * (NTH * 16)), 16, 0, 0);
   };
   // lane's fragment offsets: row fr of a 16-row tile, swizzled chunk per k-step
   const uint32_t fo0 = (uint32_t)(fr * 128 + (((0 * 4 + fq) ^ (fr & 7)) << 4));
@@ -266,27 +271,27 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
   for (; tile < p.nwg; tile += (int)gridDim.x) {
     const int next = tile + (int)gridDim.x;
     if (next < p.nwg) tile_offsets(next, offa_n, offw_n, bm_n, bn_n);
-    f32x4 acc[4][8];   // [n tile][m tile]
+    f32x4 acc[4][MI];   // [n tile][m tile]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = (pb + kt) & 1;
       if (kt + 1 < nk) stage(offa, offw, kt + 1, cur ^ 1);
       else if (next < p.nwg) stage(offa_n, offw_n, 0, cur ^ 1);
-      const char* la = g2_smem + cur * 65536 + (wr * 128) * 128;
-      const char* lw = g2_smem + cur * 65536 + 32768 + (wc * 64) * 128;
+      const char* la = g2_smem + cur * BUFB + (wr * (16 * MI)) * 128;
+      const char* lw = g2_smem + cur * BUFB + AB + (wc * 64) * 128;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const uint32_t fo = ks ? fo1 : fo0;
-        bf16x8 fw[4], fa[8];
+        bf16x8 fw[4], fa[MI];
 #pragma unroll
         for (int j = 0; j < 4; ++j) fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lw + j * 2048 + fo));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + i * 2048 + fo));
+        for (int i = 0; i < MI; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + i * 2048 + fo));
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
       }
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
     // ---- epilogue: per 16-row tile, 64 columns of fp32 through the wave's 4.25 KB of the buffer the last K-tile just
     // vacated (the other one already holds the next output tile's first K-tile)
     constexpr int ORB = 64 * 4 + 16;
-    char* so = g2_smem + ((pb + nk - 1) & 1) * 65536 + wid * (16 * ORB);
+    char* so = g2_smem + ((pb + nk - 1) & 1) * BUFB + wid * (16 * ORB);
     const int c8 = lane & 7;                       // the lane's 8 output columns on the way out (same for every row tile)
     const int gn = bn + wc * 64 + c8 * 8;
     float bs[8], sc[8];
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
       sc[0] = lo.x; sc[1] = lo.y; sc[2] = lo.z; sc[3] = lo.w; sc[4] = hi.x; sc[5] = hi.y; sc[6] = hi.z; sc[7] = hi.w;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(so + fr * ORB + (j * 16 + fq * 4) * 4) = acc[j][i];
       asm volatile("" ::: "memory");   // wave-local hand-over: LDS serves a wave's accesses in order
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
         // W rows are interleaved [8 gate | 8 up]: a lane takes 16 accumulator columns of one row -> 8 outputs, written as
         // the bf16 value and, N/2 columns further, its bf16 remainder (split-bf16 operand of the down projection)
         const int row = lane >> 2, pr = lane & 3;
-        const int gm = bm + wr * 128 + i * 16 + row, go = (bn + wc * 64 + pr * 16) >> 1;
+        const int gm = bm + wr * (16 * MI) + i * 16 + row, go = (bn + wc * 64 + pr * 16) >> 1;
         const float* src = reinterpret_cast<const float*>(so + row * ORB) + pr * 16;
         float o8[8], h8[8], l8[8];
 #pragma unroll
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int row = it * 8 + (lane >> 3);
-        const int gm = bm + wr * 128 + i * 16 + row;
+        const int gm = bm + wr * (16 * MI) + i * 16 + row;
         const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
         const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
         float v[8] = {y0.x + bs[0], y0.y + bs[1], y0.z + bs[2], y0.w + bs[3], y1.x + bs[4], y1.y + bs[5], y1.z + bs[6], y1.w + bs[7]};
@@ -352,7 +357,18 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = r[e] + sc[e] * v[e];
         }
-        *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8(v);
+        if (p.epi == FV_EPI_RES_F32 || p.epi == FV_EPI_F32) {   // fp32 residual stream / fp32 out (decoder)
+          float* op = static_cast<float*>(p.out) + (size_t)gm * p.ldo + gn;
+          if (p.epi == FV_EPI_RES_F32) {
+            const float* rp = static_cast<const float*>(p.res) + (size_t)gm * p.ldr + gn;
+            const float4 lo = *reinterpret_cast<const float4*>(rp), hi = *reinterpret_cast<const float4*>(rp + 4);
+            v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+          }
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8(v);
+        }
       }
       asm volatile("" ::: "memory");   // the next tile's writes stay behind these reads
     }
@@ -364,17 +380,20 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(Params p) {
   }
 }
 
-#ifndef G2_MIN_BLOCKS
-#define G2_MIN_BLOCKS 320   // one block per CU: fewer tiles than this leave too many CUs idle in the last round
-#endif
-bool gemm256_ok(const GemmArgs& a) {
+// which glds kernel (0 = none, 256 or 128) takes the problem.  256-tiles when there are enough of them to keep one block per
+// CU busy; otherwise 128-tiles (two blocks per CU) if the shape allows.
+int gemm_glds_tile(const GemmArgs& a) {
   static const bool off = getenv("FASTVLA_NO_GEMM256") != nullptr;
-  if (off) return false;
-  if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT) return false;
-  if (a.epi == FV_EPI_SWIGLU_SPLIT && a.bias) return false;
-  if (a.M % 256 || a.N % 256 || a.K % 64 || a.K < 128) return false;
-  const long blocks = (long)(a.M / 256) * (a.N / 256);
-  return blocks >= G2_MIN_BLOCKS;
+  if (off || a.K % 64 || a.K < 128) return 0;
+  const bool f32 = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
+  if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT && !f32) return 0;
+  if (a.epi == FV_EPI_SWIGLU_SPLIT && a.bias) return 0;
+  if (a.M % 256 == 0 && a.N % 256 == 0 && (long)(a.M / 256) * (a.N / 256) >= 320) return 256;
+  // 128-tiles: one wave per SIMD and a K-tile of 32 MFMAs per wave cannot cover a memory latency per K-tile, so a long K
+  // loop (the decoder's down projection, K = 2 x 4864) is slower here than on the 128-tile register-staged kernel at three
+  // blocks per CU; short ones (qkv / o, K <= 1024) are on par
+  if (a.M % 128 == 0 && a.N % 128 == 0 && (long)(a.M / 128) * (a.N / 128) >= 128 && a.K >= 512 && a.K <= 1024) return 128;
+  return 0;
 }
 
 }  // namespace
@@ -399,22 +418,21 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi;
   p.ksplit = a.ksplit ? 1 : 0;
   if (a.ksplit && (a.K % BK || a.lda < 2 * a.K)) return fv_fail(FV_ERR_ARG, "gemm: ksplit needs K %% 64 == 0 and lda >= 2K");
-  if (gemm256_ok(a)) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS));
-      attr_set = true;
-    }
-    p.tiles_n = a.N / 256;
-    p.nwg = (a.M / 256) * p.tiles_n;
+  if (const int gt = gemm_glds_tile(a)) {
     static int cus = 0;
     if (!cus) {
       int dev = 0;
       hipDeviceProp_t prop;
       cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+      FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+      FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
     }
-    const int grid = p.nwg < cus ? p.nwg : cus / 8 * 8;   // persistent, one block per CU; a multiple of 8 keeps the XCD remap exact
-    hipLaunchKernelGGL(gemm256_kernel, dim3(grid), dim3(512), G2_LDS, s, p);
+    p.tiles_n = a.N / gt;
+    p.nwg = (a.M / gt) * p.tiles_n;
+    const int slots = (gt == 256 ? cus : 2 * cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
+    const int grid = p.nwg < slots ? p.nwg : slots;
+    if (gt == 256) hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<4, 2>), dim3(grid), dim3(256), 2 * 256 * 128, s, p);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
   }
