@@ -160,6 +160,11 @@ int fv_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const
  * out = (A_hi + A_lo) . W^T in one launch with a doubled K loop; epilogues as fv_op_gemm */
 int fv_op_gemm_ksplit(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr,
                       void* out, int ldo, int epilogue, fv_stream s);
+/* fv_op_gemm_ksplit (ksplit != 0) or fv_op_gemm with a caller-owned scratch buffer for split-K partial sums: fp32 epilogues
+ * (FV_EPI_RES_F32 / FV_EPI_F32) of problems with few output tiles and a long K are cut along K, one unit per CU, and
+ * summed by a second kernel.  ws may be NULL (then exactly fv_op_gemm / fv_op_gemm_ksplit). */
+int fv_op_gemm_splitk(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr,
+                      void* out, int ldo, int epilogue, int ksplit, void* ws, size_t ws_bytes, fv_stream s);
 /* depthwise / channel-multiplier grouped conv, NHWC bf16: x (B,H,W,C) -> y (B,Ho,Wo,C*mult); w f32 [k*k][C*mult] */
 int fv_op_dwconv(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                  int stride, int mult, int gelu, fv_stream s);

@@ -474,3 +474,29 @@ def test_gemm_glds_128_tile_fp32_epilogues():
     torch.cuda.synchronize()
     ref = (res.double() + (Ah + Al).double() @ W.double().t()).float()
     check_close(out.cpu(), ref, rel=2e-5, amax=2e-5, what="glds128 ksplit res_f32")
+
+
+def test_gemm_splitk_down_projection_shape():
+    """M = 4096, N = 896: 64 output tiles of 256 x 256 (the last column tile padded) cut into K ranges, one unit per CU, summed
+    by the reduce kernel -- plain and split-bf16 operands, against the same GEMM without the scratch buffer."""
+    torch.manual_seed(12)
+    M, N, K = 4096, 896, 2432
+    A = torch.randn(M, K)
+    Ah = bf(A)
+    Al = bf(A - Ah)
+    W, res = bf(torch.randn(N, K) * 0.03), torch.randn(M, N)
+    w, r = dev_bf16(W), dev_f32(res)
+    ws = torch.empty(8 * M * 1024, dtype=torch.float32, device=DEV)
+    for ksplit, a, ref in ((0, dev_bf16(Ah), res.double() + Ah.double() @ W.double().t()),
+                           (1, torch.cat([dev_bf16(Ah), dev_bf16(Al)], dim=1).contiguous(), res.double() + (Ah + Al).double() @ W.double().t())):
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        call(lib().fv_op_gemm_splitk(a.data_ptr(), a.shape[1], w.data_ptr(), M, N, K, None, r.data_ptr(), N, out.data_ptr(), N,
+                                     _lib.EPI_RES_F32, ksplit, ws.data_ptr(), ws.numel() * 4, stream()), "fv_op_gemm_splitk")
+        torch.cuda.synchronize()
+        check_close(out.cpu(), ref.float(), rel=2e-5, amax=2e-5, what=f"split-K res_f32 ksplit={ksplit}")
+    # in place on the residual stream, as the decoder calls it
+    x = r.clone()
+    call(lib().fv_op_gemm_splitk(a.data_ptr(), a.shape[1], w.data_ptr(), M, N, K, None, x.data_ptr(), N, x.data_ptr(), N,
+                                 _lib.EPI_RES_F32, 1, ws.data_ptr(), ws.numel() * 4, stream()), "fv_op_gemm_splitk in place")
+    torch.cuda.synchronize()
+    assert torch.equal(x, out)

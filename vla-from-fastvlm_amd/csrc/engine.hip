@@ -72,7 +72,7 @@ struct DecLayer { float* ln1 = nullptr; bf16_t* qkv_w = nullptr; float* qkv_b = 
 struct Decoder { bf16_t* embed = nullptr; std::vector<DecLayer> layers; float* norm = nullptr; };
 
 struct WsPlan {
-  size_t bufA, bufB, bufH, se, tower_out, x, xn, qkv, att, act, xn_lo, att_lo, act_lo, qkvf, guf, head_scr, total;
+  size_t bufA, bufB, bufH, se, tower_out, x, xn, qkv, att, act, xn_lo, att_lo, act_lo, qkvf, guf, splitk, splitk_bytes, head_scr, total;
 };
 
 // optional per-launch HIP-event timing on the caller's stream (bench.py's roofline numbers); off by default
@@ -254,6 +254,10 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
     p.qkvf = take(rows * qkvw * 4);
     p.guf = 0;  // gate/up accumulators no longer round-trip through memory (SwiGLU + split fused into the GEMM epilogue)
   }
+  // split-K partial sums of the down projection (fp32, up to 4 splits of [rows][hidden padded to 256]); launch_gemm only
+  // uses it when the problem has too few output tiles for the chip
+  p.splitk_bytes = rows % 256 == 0 ? (size_t)4 * rows * ((d.llm_hidden + 255) / 256 * 256) * 4 : 0;
+  p.splitk = take(p.splitk_bytes);
   p.head_scr = take(fv::head_bwd_scratch_bytes(h->hd, B));
   p.total = o;
   return p;
@@ -707,6 +711,8 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
       fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 1};
       FV_TRY(gemm_p(h, g1, s));  // silu(gate)*up and its hi/lo split happen in the epilogue: no fp32 round trip
       fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
+      d1.splitk_ws = wp.splitk_bytes ? reinterpret_cast<float*>(ws + wp.splitk) : nullptr;
+      d1.splitk_bytes = wp.splitk_bytes;
       FV_TRY(gemm_p(h, d1, s));
     }
   }

@@ -24,6 +24,7 @@ constexpr int LDC = BN + 4;                       // fp32 epilogue image row str
 struct Params {
   const bf16_t* A; const bf16_t* W; const float* bias; const float* scale; const void* res; void* out;
   int M, N, K, lda, ldr, ldo, epi, tiles_n, nwg, ksplit;
+  int splits = 1, npad = 0; float* part = nullptr;   // split-K (gemm256 only): units = tiles x splits, partials [split][M][npad]
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
@@ -233,15 +234,17 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 
   // staging: slot s = j * 512 + tid is 16 B of row s >> 3 at LDS position s & 7, filled from k-chunk (s & 7) ^ (row & 7)
   uint32_t offa[4], offw[4], offa_n[4], offw_n[4];
-  auto tile_offsets = [&](int tile, uint32_t (&oa)[4], uint32_t (&ow)[4], int& bm, int& bn) {
-    const int logical = xcd_remap(tile, p.nwg);
+  // a unit = (output tile, K split): split-K (p.splits > 1) gives problems with few output tiles and a long K loop -- the
+  // decoder's down projection at M = 4096 -- one unit per CU; each unit leaves raw fp32 partial sums for splitk_reduce_kernel
+  auto tile_offsets = [&](int unit, uint32_t (&oa)[4], uint32_t (&ow)[4], int& bm, int& bn) {
+    const int logical = xcd_remap(unit, p.nwg) / p.splits;
     bm = (logical / p.tiles_n) * BMT;
     bn = (logical % p.tiles_n) * BNT;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int sl = j * NTH + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
       oa[j] = (uint32_t)(((size_t)(bm + row) * p.lda + chunk * 8) * 2);
-      ow[j] = (uint32_t)(((size_t)(bn + row) * p.K + chunk * 8) * 2);
+      ow[j] = (uint32_t)(((size_t)min(bn + row, p.N - 1) * p.K + chunk * 8) * 2);   // rows past N (padded last tile) repeat the last
     }
   };
   auto stage = [&](const uint32_t (&oa)[4], const uint32_t (&ow)[4], int kt, int buf) {
@@ -265,21 +268,24 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   int tile = blockIdx.x, pb = 0, bm, bn, bm_n = 0, bn_n = 0;
   if (tile >= p.nwg) return;
   tile_offsets(tile, offa, offw, bm, bn);
-  stage(offa, offw, 0, 0);
+  auto k_lo = [&](int unit) { return (xcd_remap(unit, p.nwg) % p.splits) * nk / p.splits; };
+  auto k_hi = [&](int unit) { return (xcd_remap(unit, p.nwg) % p.splits + 1) * nk / p.splits; };
+  stage(offa, offw, k_lo(tile), 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (; tile < p.nwg; tile += (int)gridDim.x) {
     const int next = tile + (int)gridDim.x;
     if (next < p.nwg) tile_offsets(next, offa_n, offw_n, bm_n, bn_n);
+    const int kt0 = k_lo(tile), kt1 = k_hi(tile), kn0 = next < p.nwg ? k_lo(next) : 0;
     f32x4 acc[4][MI];   // [n tile][m tile]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = (pb + kt) & 1;
-      if (kt + 1 < nk) stage(offa, offw, kt + 1, cur ^ 1);
-      else if (next < p.nwg) stage(offa_n, offw_n, 0, cur ^ 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (pb + kt - kt0) & 1;
+      if (kt + 1 < kt1) stage(offa, offw, kt + 1, cur ^ 1);
+      else if (next < p.nwg) stage(offa_n, offw_n, kn0, cur ^ 1);
       const char* la = g2_smem + cur * BUFB + (wr * (16 * MI)) * 128;
       const char* lw = g2_smem + cur * BUFB + AB + (wc * 64) * 128;
 #pragma unroll
@@ -302,13 +308,13 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
     // ---- epilogue: per 16-row tile, 64 columns of fp32 through the wave's 4.25 KB of the buffer the last K-tile just
     // vacated (the other one already holds the next output tile's first K-tile)
     constexpr int ORB = 64 * 4 + 16;
-    char* so = g2_smem + ((pb + nk - 1) & 1) * BUFB + wid * (16 * ORB);
+    char* so = g2_smem + ((pb + kt1 - kt0 - 1) & 1) * BUFB + wid * (16 * ORB);
     const int c8 = lane & 7;                       // the lane's 8 output columns on the way out (same for every row tile)
     const int gn = bn + wc * 64 + c8 * 8;
     float bs[8], sc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; }
-    if (p.bias) {
+    if (p.bias && p.splits == 1) {
       const float4 lo = *reinterpret_cast<const float4*>(p.bias + gn), hi = *reinterpret_cast<const float4*>(p.bias + gn + 4);
       bs[0] = lo.x; bs[1] = lo.y; bs[2] = lo.z; bs[3] = lo.w; bs[4] = hi.x; bs[5] = hi.y; bs[6] = hi.z; bs[7] = hi.w;
     }
@@ -321,6 +327,19 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 #pragma unroll
       for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(so + fr * ORB + (j * 16 + fq * 4) * 4) = acc[j][i];
       asm volatile("" ::: "memory");   // wave-local hand-over: LDS serves a wave's accesses in order
+      if (p.splits > 1) {   // raw partial sums; bias, residual and the column bound are the reducer's business
+        const int sp = xcd_remap(tile, p.nwg) % p.splits;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + (lane >> 3);
+          const int gm = bm + wr * (16 * MI) + i * 16 + row;
+          float* pp = p.part + ((size_t)sp * p.M + gm) * p.npad + gn;
+          *reinterpret_cast<float4*>(pp) = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
+          *reinterpret_cast<float4*>(pp + 4) = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
+        }
+        asm volatile("" ::: "memory");
+        continue;
+      }
       if (p.epi == FV_EPI_SWIGLU_SPLIT) {
         // W rows are interleaved [8 gate | 8 up]: a lane takes 16 accumulator columns of one row -> 8 outputs, written as
         // the bf16 value and, N/2 columns further, its bf16 remainder (split-bf16 operand of the down projection)
@@ -373,11 +392,28 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       asm volatile("" ::: "memory");   // the next tile's writes stay behind these reads
     }
     __syncthreads();   // the scratch buffer becomes a staging target again in the next tile's first iteration
-    pb = (pb + nk) & 1;
+    pb = (pb + kt1 - kt0) & 1;
     bm = bm_n; bn = bn_n;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { offa[j] = offa_n[j]; offw[j] = offw_n[j]; }
   }
+}
+
+// out[m][n] = (res ? res[m][n] : 0) + (bias ? bias[n] : 0) + sum over splits of part[s][m][n], 4 columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, int npad,
+                                                             const float* __restrict__ bias, const float* res, int ldr, float* out,
+                                                             int ldo) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N >> 2;
+  if (i >= (long)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+  float4 acc = res ? *reinterpret_cast<const float4*>(res + (size_t)m * ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + n); acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
+  for (int s = 0; s < splits; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)s * M + m) * npad + n);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = acc;
 }
 
 // which glds kernel (0 = none, 256 or 128) takes the problem.  256-tiles when there are enough of them to keep one block per
@@ -418,15 +454,35 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi;
   p.ksplit = a.ksplit ? 1 : 0;
   if (a.ksplit && (a.K % BK || a.lda < 2 * a.K)) return fv_fail(FV_ERR_ARG, "gemm: ksplit needs K %% 64 == 0 and lda >= 2K");
-  if (const int gt = gemm_glds_tile(a)) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-      FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-      FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
+  }
+  // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
+  static const bool no_splitk = getenv("FASTVLA_NO_SPLITK") != nullptr;
+  if (!no_splitk && a.splitk_ws && f32out && !getenv("FASTVLA_NO_GEMM256") && a.M % 256 == 0 && a.K % 64 == 0 && a.N % 4 == 0) {
+    const int tn = (a.N + 255) / 256, tiles = (a.M / 256) * tn, nkt = (a.ksplit ? 2 : 1) * (a.K / 64);
+    int splits = tiles < cus ? cus / tiles : 1;
+    if (splits > 8) splits = 8;
+    while (splits > 1 && nkt / splits < 16) --splits;
+    const size_t need = (size_t)splits * a.M * (tn * 256) * sizeof(float);
+    if (splits > 1 && need <= a.splitk_bytes) {
+      p.tiles_n = tn;
+      p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
+      p.nwg = tiles * splits;
+      hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(p.nwg < cus ? p.nwg : cus / 8 * 8), dim3(512), 2 * 512 * 128, s, p);
+      const long quads = (long)a.M * (a.N / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, p.npad, a.bias,
+                         a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo);
+      FV_HIP_CHECK(hipGetLastError());
+      return FV_OK;
     }
+  }
+  if (const int gt = gemm_glds_tile(a)) {
     p.tiles_n = a.N / gt;
     p.nwg = (a.M / gt) * p.tiles_n;
     const int slots = (gt == 256 ? cus : 2 * cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact

@@ -20,6 +20,8 @@ struct GemmArgs {
   void* out; int ldo;           // bf16 or f32 by epilogue
   int epi;
   int ksplit = 0;               // 1: A holds [hi | lo] (2K columns, lda >= 2K); out = (hi + lo) . W^T in one launch
+  float* splitk_ws = nullptr;   // optional scratch for split-K partial sums (fp32 epilogues, few output tiles, long K)
+  size_t splitk_bytes = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
