@@ -288,18 +288,31 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       else if (next < p.nwg) stage(offa_n, offw_n, kn0, cur ^ 1);
       const char* la = g2_smem + cur * BUFB + (wr * (16 * MI)) * 128;
       const char* lw = g2_smem + cur * BUFB + AB + (wc * 64) * 128;
+      // Fragment reads run two steps (8 MFMAs, ~130 clk) ahead of their use: left to itself hipcc reads each pair of
+      // fragments right before the MFMAs that need them and waits out the LDS latency every 8 MFMAs.  A step = one
+      // activation fragment (m tile i of k-step ks) against the k-step's four weight fragments.
+      {
+        bf16x8 fwA[4], fwB[4], far[3];
+#define G2_RD_A(T) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + ((T) % MI) * 2048 + ((T) / MI ? fo1 : fo0)))
+#define G2_RD_W(KS, J) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lw + (J) * 2048 + ((KS) ? fo1 : fo0)))
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const uint32_t fo = ks ? fo1 : fo0;
-        bf16x8 fw[4], fa[MI];
+        for (int j = 0; j < 4; ++j) fwA[j] = G2_RD_W(0, j);
+        far[0] = G2_RD_A(0);
+        far[1] = G2_RD_A(1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lw + j * 2048 + fo));
+        for (int t = 0; t < 2 * MI; ++t) {
+          if (t + 2 < 2 * MI) far[(t + 2) % 3] = G2_RD_A(t + 2);
+          if (t == MI - 3) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + i * 2048 + fo));
+            for (int j = 0; j < 4; ++j) fwB[j] = G2_RD_W(1, j);
+          }
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+          for (int j = 0; j < 4; ++j)
+            acc[j][t % MI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t < MI ? fwA[j] : fwB[j], far[t % 3], acc[j][t % MI], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);   // keep the reads where they are dealt (hipcc sinks them back to their use)
+        }
+#undef G2_RD_A
+#undef G2_RD_W
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next K-tile has landed ...
       __syncthreads();                                    // ... for everybody, and nobody still reads this one
