@@ -413,10 +413,11 @@ def test_dwconv_pair(C, H, W):
     check_close(y2.float().cpu().permute(0, 3, 1, 2), ref2, what=f"dw pair 7x7 C{C} {H}x{W}")
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 2048, 192), (8192, 4096, 448)])
+@pytest.mark.parametrize("M,N,K", [(16384, 2048, 192), (8192, 4096, 448), (4096, 5632, 192)])
 def test_gemm_256_tile_variant(M, N, K):
-    """Shapes the 256 x 256 LDS-DMA kernel takes (M, N multiples of 256, K of 64, >= 512 tiles): all three of its epilogues,
-    plus the asymmetric-operand check that a swapped row/column map cannot pass."""
+    """Shapes the 256 x 256 LDS-DMA kernel takes (M, N multiples of 256, K of 64, >= 320 tiles): all three of its epilogues,
+    plus the asymmetric-operand check that a swapped row/column map cannot pass.  The third shape has 352 tiles: a ragged second round of
+    the persistent loop."""
     torch.manual_seed(M + N + K)
     A, W = bf(torch.randn(M, K)), bf(torch.randn(N, K) / math.sqrt(K))
     b, ls, res = torch.randn(N) * 0.1, torch.rand(N) * 0.3 + 0.05, bf(torch.randn(M, N))

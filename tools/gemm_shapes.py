@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Time the policy step's GEMM shapes one by one through the C ABI (development aid, GPU box only).
+
+    python tools/gemm_shapes.py [--batch 64] [--iters 30]
+
+Prints, per shape, the average launch time (HIP events around `iters` back-to-back launches) and the executed TFLOP/s.
+Shapes: the FastViT-HD stage-4/5 and projector GEMMs and the Qwen2-0.5B decoder projections at M = batch x 64 tokens.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vla-from-fastvlm_amd"))
+from fastvla_hip import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=30)
+    a = ap.parse_args()
+    L = _lib.load()
+    dev = torch.device("cuda:0")
+    B = a.batch
+    T = B * 64
+    s = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    shapes = [
+        # name, M, N, K, epilogue, ksplit, f32 out
+        ("tower s4 qkv", B * 256, 2304, 768, _lib.EPI_BIAS, 0, False),
+        ("tower s4 fc1", B * 256, 3072, 768, _lib.EPI_BIAS_GELU, 0, False),
+        ("tower s4 fc2", B * 256, 768, 3072, _lib.EPI_LS_RES, 0, False),
+        ("tower s5 fc1", B * 64, 6144, 1536, _lib.EPI_BIAS_GELU, 0, False),
+        ("tower s5 fc2", B * 64, 1536, 6144, _lib.EPI_LS_RES, 0, False),
+        ("dec qkv", T, 1152, 896, _lib.EPI_F32, 1, True),
+        ("dec o", T, 896, 896, _lib.EPI_RES_F32, 1, True),
+        ("dec gate/up", T, 9728, 896, _lib.EPI_SWIGLU_SPLIT, 1, False),
+        ("dec down", T, 896, 4864, _lib.EPI_RES_F32, 1, True),
+    ]
+    for name, M, N, K, epi, ks, f32 in shapes:
+        lda = (2 if ks else 1) * K
+        A = torch.randn(M, lda, device=dev).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev)
+        scale = torch.rand(N, device=dev)
+        res = torch.randn(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+        bp = None if epi == _lib.EPI_SWIGLU_SPLIT else bias.data_ptr()
+
+        def launch():
+            if ks or f32:
+                rc = L.fv_op_gemm_splitk(A.data_ptr(), lda, W.data_ptr(), M, N, K, bp, res.data_ptr(), N, out.data_ptr(), N, epi, ks,
+                                         ws.data_ptr(), ws.numel() * 4, s)
+            else:
+                rc = L.fv_op_gemm(A.data_ptr(), lda, W.data_ptr(), M, N, K, bp, scale.data_ptr(), res.data_ptr(), N, out.data_ptr(), N,
+                                  epi, s)
+            assert rc == 0, (name, rc)
+
+        for _ in range(3):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        fl = 2.0 * M * N * K * (2 if ks else 1)
+        print(f"{name:14s} M={M:6d} N={N:5d} K={K:5d}{' x2' if ks else '   '}  {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF executed", flush=True)
+
+
+if __name__ == "__main__":
+    main()

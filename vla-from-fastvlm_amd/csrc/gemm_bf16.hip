@@ -222,9 +222,10 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 // <8, 4> = 256 x 256 with 8 waves (one block per CU), <4, 2> = 128 x 128 with 4 waves (two per CU) for problems with too few
 // 256-tiles to fill the chip (the decoder's N = 896 / 1152 projections at M = 4096).
 template <int MI, int WN>
-__global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Params p) {
+__global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Params p) {   // <8,4> 256x256, <4,2> 128x128
   constexpr int BMT = 32 * MI, BNT = 64 * WN, NTH = 128 * WN, BUFB = (BMT + BNT) * 128, AB = BMT * 128;
-  static_assert(BMT * 8 == 4 * NTH && BNT * 8 == 4 * NTH, "four 16-byte slots per thread and operand");
+  constexpr int SA = BMT * 8 / NTH, SW = BNT * 8 / NTH;   // 16-byte staging slots per thread: activations / weights
+  static_assert(SA * NTH == BMT * 8 && SW * NTH == BNT * 8 && SA <= 4 && SW <= 4, "whole slots per thread");
   extern __shared__ __attribute__((aligned(16))) char g2_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid / WN, wc = wid % WN;            // wave's M half, 64-column N slice
@@ -243,8 +244,8 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int sl = j * NTH + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
-      oa[j] = (uint32_t)(((size_t)(bm + row) * p.lda + chunk * 8) * 2);
-      ow[j] = (uint32_t)(((size_t)min(bn + row, p.N - 1) * p.K + chunk * 8) * 2);   // rows past N (padded last tile) repeat the last
+      oa[j] = j < SA ? (uint32_t)(((size_t)(bm + row) * p.lda + chunk * 8) * 2) : 0u;
+      ow[j] = j < SW ? (uint32_t)(((size_t)min(bn + row, p.N - 1) * p.K + chunk * 8) * 2) : 0u;   // rows past N (padded last tile) repeat the last
     }
   };
   auto stage = [&](const uint32_t (&oa)[4], const uint32_t (&ow)[4], int kt, int buf) {
@@ -254,9 +255,9 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
     char* la = g2_smem + buf * BUFB + wslot;
     char* lw = la + AB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(ab + oa[j]), (lds_ptr_t)(la + j * (NTH * 16)), 16, 0, 0);
+    for (int j = 0; j < SA; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(ab + oa[j]), (lds_ptr_t)(la + j * (NTH * 16)), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(wb + ow[j]), (lds_ptr_t)(lw + j * (NTH * 16)), 16, 0, 0);
+    for (int j = 0; j < SW; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(wb + ow[j]), (lds_ptr_t)(lw + j * (NTH * 16)), 16, 0, 0);
   };
   // lane's fragment offsets: row fr of a 16-row tile, swizzled chunk per k-step
   const uint32_t fo0 = (uint32_t)(fr * 128 + (((0 * 4 + fq) ^ (fr & 7)) << 4));
@@ -437,6 +438,8 @@ int gemm_glds_tile(const GemmArgs& a) {
   const bool f32 = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
   if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT && !f32) return 0;
   if (a.epi == FV_EPI_SWIGLU_SPLIT && a.bias) return 0;
+  // (a 128 x 256 variant for shapes whose last round of 256-tiles is mostly idle -- the decoder's gate/up, 608 tiles = 2.4
+  // rounds -- was measured slower, 184 vs 150 us: 64 x 64 per wave reads a third more LDS per MFMA)
   if (a.M % 256 == 0 && a.N % 256 == 0 && (long)(a.M / 256) * (a.N / 256) >= 320) return 256;
   // 128-tiles: one wave per SIMD and a K-tile of 32 MFMAs per wave cannot cover a memory latency per K-tile, so a long K
   // loop (the decoder's down projection, K = 2 x 4864) is slower here than on the 128-tile register-staged kernel at three
@@ -498,7 +501,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (const int gt = gemm_glds_tile(a)) {
     p.tiles_n = a.N / gt;
     p.nwg = (a.M / gt) * p.tiles_n;
-    const int slots = (gt == 256 ? cus : 2 * cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
+    const int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
     const int grid = p.nwg < slots ? p.nwg : slots;
     if (gt == 256) hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<4, 2>), dim3(grid), dim3(256), 2 * 256 * 128, s, p);
