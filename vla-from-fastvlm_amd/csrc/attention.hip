@@ -164,6 +164,131 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
   }
 }
 
+
+// ---- the FastViT-HD MHSA specialisation: head_dim 32, no masks, T % 64 == 0 ------------------------------------------
+// With 8 MFMAs per 64-key tile this shape is bound by the VALU work per score, so that is what is trimmed here:
+//   * the running max is taken on the raw scores (v_max3, two per instruction); scale * log2e and the subtraction fold
+//     into one FMA feeding v_exp_f32
+//   * the row sum comes from the matrix core: a third A operand of ones beside the two V^T tiles sums the same
+//     bf16-rounded P that the numerator uses (every row of that tile is the sum, so no cross-lane reduction either)
+//   * the O rescale is skipped (wave-uniform branch) on tiles where no query's max moved: alpha is exactly 1 there
+//   * V is staged row-major like K (one 16-byte write per thread) and read through ds_read_b64_tr_b16: the group of 16
+//     lanes fg gets rows (keys) 4 fg .. 4 fg + 3 x 16 columns (d) delivered column-major, which is precisely the V^T
+//     fragment of the permuted key order the P accumulators already have.  96-byte V rows keep those reads conflict-free.
+//   * K/V tiles double-buffered in LDS with the next tile's global loads in flight during the products: one barrier/tile
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ float xor_max_32_16(float m) {
+  // max over the four 16-lane rows (lane ^ 16, lane ^ 32) without LDS: swap halves / odd-even rows of two copies
+  const auto a = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+  m = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+  const auto b = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+  return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+}
+
+__global__ __launch_bounds__(256, 2) void attention32_kernel(AttnParams p) {   // (, 2): <= 256 VGPRs, so the MFMAs take VGPR accumulators (no v_accvgpr copies)
+  constexpr int D = 32, KLD = 40, VLD = 48, BUFE = 64 * KLD + 64 * VLD;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BUFE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int qblocks = p.T >> 6;
+  int bid = blockIdx.x;
+  const int qb = bid % qblocks; bid /= qblocks;
+  const int h = bid % p.heads;
+  const int b = bid / p.heads;
+  const int hk = h / (p.heads / p.kv_heads);
+
+  const int qg = qb * 64 + wid * 16 + fr;       // this lane's query (column of S^T / O^T)
+  const bf16x8 fq = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p.q + ((size_t)b * p.T + qg) * p.ldq + h * D + fg * 8));
+
+  f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, osum = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f;                          // raw-score domain
+  const float c2 = p.scale * 1.4426950408889634f;
+  const uint4 ones_u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
+  const int nkb = p.T >> 6;
+  const int skey = tid >> 2, sch = tid & 3;      // staging: this thread's key row and 16-byte chunk of it
+  const bf16_t* kg = p.k + ((size_t)b * p.T + skey) * p.ldk + hk * D + sch * 8;
+  const bf16_t* vg = p.v + ((size_t)b * p.T + skey) * p.ldv + hk * D + sch * 8;
+  const size_t kstep = (size_t)64 * p.ldk, vstep = (size_t)64 * p.ldv;
+  uint4 ku = *reinterpret_cast<const uint4*>(kg), vu = *reinterpret_cast<const uint4*>(vg);
+  *reinterpret_cast<uint4*>(smem + skey * KLD + sch * 8) = ku;
+  *reinterpret_cast<uint4*>(smem + 64 * KLD + skey * VLD + sch * 8) = vu;
+  __syncthreads();
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const bf16_t* sK = smem + (kb & 1) * BUFE;
+    const bf16_t* sV = sK + 64 * KLD;
+    // the next tile's rows, in flight during the products (past the end: the last tile again, written to the idle buffer
+    // and never read -- keeping the loop branch-free lets the wait for these loads sit at the LDS writes below)
+    const int nxt = kb + 1 < nkb ? kb + 1 : kb;
+    ku = *reinterpret_cast<const uint4*>(kg + nxt * kstep);
+    vu = *reinterpret_cast<const uint4*>(vg + nxt * vstep);
+    f32x4 sacc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const bf16x8 fk = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * KLD + fg * 8));
+      sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    float mloc = sacc[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sacc[kt][r]);
+    mloc = xor_max_32_16(mloc);
+    const float m_new = fmaxf(m_run, mloc);
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      osum[0] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = -m_run * c2;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sacc[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][r], c2, mc));
+
+    // O^T += V^T . P^T : two k-steps of 32 keys; slot (fg, j) <-> key tile (2*ks2 + (j>>2))*16 + 4*fg + (j&3)
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      uint4 pu;
+      pu.x = pack_bf2(sacc[2 * ks2][0], sacc[2 * ks2][1]);
+      pu.y = pack_bf2(sacc[2 * ks2][2], sacc[2 * ks2][3]);
+      pu.z = pack_bf2(sacc[2 * ks2 + 1][0], sacc[2 * ks2 + 1][1]);
+      pu.w = pack_bf2(sacc[2 * ks2 + 1][2], sacc[2 * ks2 + 1][3]);
+      const bf16x8 fp = __builtin_bit_cast(bf16x8, pu);
+      osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fp, osum, 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        // lane 4q+p of the 16-lane group addresses row q (key 4 fg + q of the key tile), columns 4p .. 4p+3 of the d tile
+        const bf16_t* vr = sV + ((2 * ks2) * 16 + 4 * fg + (fr >> 2)) * VLD + dt * 16 + 4 * (fr & 3);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vr));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vr + 16 * VLD));
+        const uint2 lu = __builtin_bit_cast(uint2, lo), hu = __builtin_bit_cast(uint2, hi);
+        const bf16x8 fv = __builtin_bit_cast(bf16x8, make_uint4(lu.x, lu.y, hu.x, hu.y));
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fp, o[dt], 0, 0, 0);
+      }
+    }
+    bf16_t* nb = smem + ((kb + 1) & 1) * BUFE;
+    *reinterpret_cast<uint4*>(nb + skey * KLD + sch * 8) = ku;
+    *reinterpret_cast<uint4*>(nb + 64 * KLD + skey * VLD + sch * 8) = vu;
+    __syncthreads();
+  }
+
+  const float inv = osum[0] > 0.f ? 1.0f / osum[0] : 0.f;   // every row of the ones tile holds this query's sum
+  bf16_t* op = p.out + ((size_t)b * p.T + qg) * p.ldo + h * D;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    uint2 u;
+    u.x = pack_bf2(o[dt][0] * inv, o[dt][1] * inv);
+    u.y = pack_bf2(o[dt][2] * inv, o[dt][3] * inv);
+    *reinterpret_cast<uint2*>(op + dt * 16 + fg * 4) = u;
+  }
+}
+
 }  // namespace
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ldq, int ldk, int ldv, bf16_t* out,
@@ -180,6 +305,12 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ldq,
   const dim3 grid((unsigned)blocks), blk(256);
   const bool masked = causal || lens || (T & 63);
   if (D != 32 && D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention: head_dim %d not in {32,64,128}", D);
+  static const bool no32 = getenv("FASTVLA_NO_ATTN32") != nullptr;
+  if (D == 32 && !masked && !no32) {
+    hipLaunchKernelGGL(attention32_kernel, grid, blk, 0, s, p);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+  }
 #define FV_ATT(D_)                                                                        \
   if (D == D_) {                                                                          \
     if (masked) hipLaunchKernelGGL((attention_kernel<D_, true>), grid, blk, 0, s, p);     \
