@@ -225,6 +225,121 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
   }
 }
 
+// The same attention on the fp32 matrix core (v_mfma_f32_16x16x4_f32: fp32 operands, exact products, fp32 accumulation --
+// the VALU kernel above with another summation order), for head_dim 64 / 128.  The VALU form hands every lane whole K and
+// V rows as LDS broadcasts (1 KB of register fill per 64 FMAs) and is bound by that; here a 16-key x 16-query score tile
+// costs D/16 ds_read_b128 + D/4 MFMAs, and its P^T accumulators feed the second product directly:
+//   S^T = K . Q^T   A = K[key fr][d = 16c + 4fg + e] (one b128 read = four MFMAs' A operands), B = the same d of Q[query fr]
+//   O^T += V^T . P^T   B of MFMA r = p[r] (D layout: row 4fg + r = key  <->  k-slot fg), A = V[key 4fg + r][d = 16dt + fr]
+// Block = 4 waves = 64 queries of one (batch, q head); K/V chunks of KCH keys in LDS, rows padded by 4 floats so that both
+// read patterns are conflict-free.  Softmax bookkeeping is ~40 VALU issues per tile against 2 * D/4 MFMAs of 32 cycles.
+template <int D>
+__global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out_hi,
+                                                                     bf16_t* __restrict__ out_lo, const int32_t* __restrict__ lens,
+                                                                     int len_add, int ld, int ldo, int T, int heads, int kv_heads,
+                                                                     float scale) {
+  constexpr int DT = D / 16;               // 16-row tiles of O^T, and 16-float column groups of a K row
+  constexpr int KCH = D == 64 ? 64 : 32;   // keys per LDS chunk
+  constexpr int LDR = D + 4;               // padded row (floats)
+  __shared__ __attribute__((aligned(16))) float sK[KCH * LDR];
+  __shared__ __attribute__((aligned(16))) float sV[KCH * LDR];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int qblocks = (T + 63) >> 6;
+  int bid = blockIdx.x;
+  const int qb = bid % qblocks; bid /= qblocks;
+  const int h = bid % heads;
+  const int b = bid / heads;
+  const int hk = h / (heads / kv_heads);
+  int len = lens ? lens[b] + len_add : T;
+  len = max(1, min(len, T));
+  const int q0 = qb * 64 + wid * 16, qg = q0 + fr;
+  const int qd = heads * D, kd = kv_heads * D;
+
+  float4 fq[DT];
+  {
+    const float* qp = qkv + ((size_t)b * T + min(qg, T - 1)) * ld + h * D + 4 * fg;
+#pragma unroll
+    for (int c = 0; c < DT; ++c) fq[c] = *reinterpret_cast<const float4*>(qp + 16 * c);
+  }
+  f32x4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int kend = min(len, qb * 64 + 64);   // causal: keys beyond the block's last query are never visible
+  for (int k0 = 0; k0 < kend; k0 += KCH) {
+    __syncthreads();
+    for (int i = tid; i < KCH * D / 4; i += 256) {
+      const int key = i / (D / 4), c4 = i % (D / 4);
+      const int krow = min(k0 + key, T - 1);
+      const float* base = qkv + ((size_t)b * T + krow) * ld + qd + hk * D + c4 * 4;
+      *reinterpret_cast<float4*>(sK + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base);
+      *reinterpret_cast<float4*>(sV + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base + kd);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < KCH / 16; ++kt) {
+      const int kb = k0 + kt * 16;
+      if (kb > q0 + 15 || kb >= len) break;   // wave-uniform: the rest of the chunk is above the diagonal / past the prompt
+      f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* kr = sK + (kt * 16 + fr) * LDR + 4 * fg;
+#pragma unroll
+      for (int c = 0; c < DT; ++c) {
+        const float4 kf = *reinterpret_cast<const float4*>(kr + 16 * c);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, fq[c].x, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, fq[c].y, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, fq[c].z, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, fq[c].w, sacc, 0, 0, 0);
+      }
+      float sc[4], mloc = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kg = kb + 4 * fg + r;
+        sc[r] = (kg <= qg && kg < len) ? sacc[r] * scale : -1e30f;
+        mloc = fmaxf(mloc, sc[r]);
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __expf(m_run - m_new);
+      m_run = m_new;
+      float pv[4], psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv[r] = sc[r] > -1e29f ? __expf(sc[r] - m_new) : 0.f;
+        psum += pv[r];
+      }
+      l_run = l_run * alpha + psum;            // per-lane partial; the four key groups are summed at the end
+      const float* vr = sV + (kt * 16 + 4 * fg) * LDR + fr;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[r * LDR + 16 * dt], pv[r], o[dt], 0, 0, 0);
+      }
+    }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (qg >= T) return;
+  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  const size_t ob = ((size_t)b * T + qg) * ldo + h * D + 4 * fg;   // lane: query qg, d = 16 dt + 4 fg + r
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    float v4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v4[r] = o[dt][r] * inv;
+    uint2 hv, lv;
+    hv.x = pack_bf2(v4[0], v4[1]); hv.y = pack_bf2(v4[2], v4[3]);
+    lv.x = pack_bf2(v4[0] - bf_lo(hv.x), v4[1] - bf_hi(hv.x));
+    lv.y = pack_bf2(v4[2] - bf_lo(hv.y), v4[3] - bf_hi(hv.y));
+    *reinterpret_cast<uint2*>(out_hi + ob + 16 * dt) = hv;
+    *reinterpret_cast<uint2*>(out_lo + ob + 16 * dt) = lv;
+  }
+}
+
 // one block per batch row: final RMSNorm on the pooled row(s).  mode 0 = last_token, 1 = mean over valid rows.
 __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
                                                          const float* __restrict__ w, float* __restrict__ pooled,
@@ -289,9 +404,21 @@ int launch_attention_f32(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_l
   const int G = heads / kv_heads;
   const int NT = D == 128 ? 2 : 1;
   if (D != 32 && D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: head_dim %d not in {32,64,128}", D);
+  static const bool no_mfma = getenv("FASTVLA_NO_ATTN_F32_MFMA") != nullptr;
+  if (D >= 64 && !no_mfma) {
+    const long nb = (long)B * heads * ((T + 63) / 64);
+    if (D == 64) hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale);
+    else hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale);
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
+  }
   if (G * NT > 256) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: too many q heads per kv head (%d)", G);
-  int QT = 1;
-  while (QT * 2 * G * NT <= 256) QT *= 2;
+  // queries per block: as many as 256 threads hold (any count, not a power of two: G = 7 leaves 44 % of the lanes idle at
+  // 16), then levelled over the tiles so the causal key ranges of the tiles are balanced
+  int QT = 256 / (G * NT);
+  if (QT > T) QT = T;
+  const int qtiles = (T + QT - 1) / QT;
+  QT = (T + qtiles - 1) / qtiles;
   const long blocks = (long)B * kv_heads * ((T + QT - 1) / QT);
   const size_t lds = (size_t)2 * 64 * D * sizeof(float);
   const dim3 grid((unsigned)blocks), blk(256);
