@@ -343,7 +343,10 @@ __global__ __launch_bounds__(256, 3) void dwconv_tile_kernel(const bf16_t* __res
 constexpr int SF_C = 96, SF_TR = 4, SF_TC = 32, SF_R1 = 2 * SF_TR + 1, SF_C1 = 2 * SF_TC + 1, SF_SEG = (SF_C1 + 15) / 16;
 constexpr int SF_PS = SF_C * 2 + 16;                      // bytes per half-resolution pixel in LDS (16-B aligned, 2-way banks)
 constexpr int SF_S1 = SF_R1 * SF_C1 * SF_PS;              // 121,680 B
-constexpr int SF_LDS = SF_S1 + 10 * SF_C * 4;             // + depthwise taps [9][96] and bias [96] fp32
+constexpr int SF_PR = 4 * SF_TR + 3, SF_PCH = (4 * SF_TC + 4) / 2;   // input patch: 19 rows x 66 16-byte chunks (132 pixels)
+constexpr int SF_PATCH = SF_PR * SF_PCH * 16 + 16;        // 20,064 B + one zero chunk (the last row's unused fourth kernel column reads it)
+constexpr int SF_LDS = SF_S1 + 10 * SF_C * 4 + SF_PATCH;  // + depthwise taps [9][96] and bias [96] fp32 + the pixel patch
+constexpr int SF_PLD = (SF_PR * SF_PCH + 511) / 512;      // 16-byte patch chunks per thread
 __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __restrict__ pix, const bf16_t* __restrict__ wp,
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
                                                              const float* __restrict__ b2, bf16_t* __restrict__ y, int B, int S,
@@ -351,6 +354,7 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
   extern __shared__ __attribute__((aligned(16))) char sf_smem[];
   char* s1 = sf_smem;
   float* sw2 = reinterpret_cast<float*>(sf_smem + SF_S1);   // [9][96] taps, then [96] bias
+  char* spx = sf_smem + SF_S1 + 10 * SF_C * 4;              // the tile's input pixels, [19][132] x 8 B, zero outside the image
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fg = lane >> 4;
   const int S1 = S >> 1, S2 = S >> 2;                        // half / quarter resolution
   const int tiles_x = (S2 + SF_TC - 1) / SF_TC, tiles_y = (S2 + SF_TR - 1) / SF_TR;
@@ -365,29 +369,55 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
 #pragma unroll
   for (int nt = 0; nt < 6; ++nt) bv1[nt] = *reinterpret_cast<const float4*>(b1 + nt * 16 + fg * 4);
 
+  // The tile's input pixels go through LDS: rows 4 ty TR - 3 .. + 18, pixels 4 tx TC - 4 .. + 127 (two pixels per 16-byte
+  // chunk, so a chunk is inside or outside the image as a whole).  The NEXT tile's patch is fetched into registers under
+  // the depthwise pass and written once that pass is over -- fetched per segment from global memory instead, the first conv
+  // stalled on one memory latency per segment (two waves per SIMD cannot hide it).
+  uint4 pre[SF_PLD];
+  auto patch_fetch = [&](long tile) {
+    const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+    const long b = tile / ((long)tiles_x * tiles_y);
+    const int iy0 = 4 * ty * SF_TR - 3, ix0 = 4 * tx * SF_TC - 4;
+#pragma unroll
+    for (int j = 0; j < SF_PLD; ++j) {
+      const int c = tid + 512 * j, r = c / SF_PCH, cc = c % SF_PCH;
+      const int iy = iy0 + r, ix = ix0 + 2 * cc;
+      pre[j] = (c < SF_PR * SF_PCH && iy >= 0 && iy < S && ix >= 0 && ix < S)
+                   ? *reinterpret_cast<const uint4*>(pix + (((size_t)b * S + iy) * S + ix) * 4) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto patch_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < SF_PLD; ++j) {
+      const int c = tid + 512 * j;
+      if (c < SF_PR * SF_PCH) *reinterpret_cast<uint4*>(spx + c * 16) = pre[j];
+    }
+  };
+  if (tid == 0) *reinterpret_cast<uint4*>(spx + SF_PR * SF_PCH * 16) = make_uint4(0, 0, 0, 0);
+  if ((long)blockIdx.x < ntiles) { patch_fetch(blockIdx.x); patch_store(); }
+
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
     const long b = tile / ((long)tiles_x * tiles_y);
     const int y1_0 = 2 * ty * SF_TR - 1, x1_0 = 2 * tx * SF_TC - 1;   // half-resolution origin of the halo region
-    __syncthreads();   // the previous tile's depthwise pass is done with s1 (and the taps are staged)
-    // ---- first conv: SF_R1 x SF_SEG segments of 16 half-resolution pixels, dealt to the 8 waves; the next segment's
-    // pixels are fetched while the current one is in the MFMAs and the GELU (nothing else hides that latency here)
+    __syncthreads();   // the patch is written, the previous tile's depthwise pass is done with s1 (and the taps are staged)
+    // ---- first conv: SF_R1 x SF_SEG segments of 16 half-resolution pixels, dealt to the 8 waves.  Fragment of half-res
+    // pixel (r1, cs): k-slot group fg = (kernel row 2 ks + (fg >> 1), pixel pair fg & 1) -> patch row 2 r1 + ky, pixels
+    // 2 cs + 2 pp + 1 and + 2 (kernel row 3 does not exist: zero operand against zero weights)
 #define SF_FETCH(SEG, XF, LIVE)                                                                                  \
   {                                                                                                              \
-    const int r1_ = (SEG) / SF_SEG, cs_ = ((SEG) % SF_SEG) * 16 + fr;                                            \
+    const int r1_ = min((SEG) / SF_SEG, SF_R1 - 1), cs_ = ((SEG) % SF_SEG) * 16 + fr;                            \
     const int oy_ = y1_0 + r1_, ox_ = x1_0 + cs_;                                                                \
     LIVE = (SEG) < SF_R1 * SF_SEG && cs_ < SF_C1 && oy_ >= 0 && oy_ < S1 && ox_ >= 0 && ox_ < S1;               \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
-      const int ky = 2 * ks + (fg >> 1), pp = fg & 1;                                                            \
-      const int iy = 2 * oy_ - 1 + ky, ix = 2 * ox_ - 1 + 2 * pp;                                                \
-      uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);                                                        \
-      if (LIVE && ky < 3 && iy >= 0 && iy < S) {                                                                 \
-        const bf16_t* rp = pix + (((size_t)b * S + iy) * S) * 4;                                                 \
-        if (ix >= 0 && ix < S) lo = *reinterpret_cast<const uint2*>(rp + (size_t)ix * 4);                        \
-        if (ix + 1 >= 0 && ix + 1 < S) hi = *reinterpret_cast<const uint2*>(rp + (size_t)(ix + 1) * 4);          \
-      }                                                                                                          \
-      XF[ks] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));                                   \
+    const char* pp_ = spx + ((2 * r1_ + (fg >> 1)) * SF_PCH * 2 + 2 * min(cs_, SF_C1 - 1) + 2 * (fg & 1) + 1) * 8; \
+    const uint2 l0_ = *reinterpret_cast<const uint2*>(pp_), h0_ = *reinterpret_cast<const uint2*>(pp_ + 8);      \
+    uint2 l1_ = make_uint2(0, 0), h1_ = make_uint2(0, 0);                                                        \
+    if (fg < 2) {                                                                                                \
+      l1_ = *reinterpret_cast<const uint2*>(pp_ + 2 * SF_PCH * 16);                                              \
+      h1_ = *reinterpret_cast<const uint2*>(pp_ + 2 * SF_PCH * 16 + 8);                                          \
     }                                                                                                            \
+    XF[0] = __builtin_bit_cast(bf16x8, make_uint4(l0_.x, l0_.y, h0_.x, h0_.y));                                  \
+    XF[1] = __builtin_bit_cast(bf16x8, make_uint4(l1_.x, l1_.y, h1_.x, h1_.y));                                  \
   }
     bf16x8 xf[2], xn[2];
     bool live, live_n;
@@ -396,24 +426,37 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
       SF_FETCH(seg + 8, xn, live_n)
       const int r1 = seg / SF_SEG, cs = (seg % SF_SEG) * 16 + fr;     // row / column inside the region
       char* dst = s1 + (r1 * SF_C1 + cs) * SF_PS + fg * 8;
+      // all twelve MFMAs first, then the GELUs four pairs at a time: four Horner chains in lockstep instead of two
+      f32x4 acc[6];
 #pragma unroll
       for (int nt = 0; nt < 6; ++nt) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][0], xf[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][1], xf[1], acc, 0, 0, 0);
-        f32x2 g[2] = {{acc[0] + bv1[nt].x, acc[1] + bv1[nt].y}, {acc[2] + bv1[nt].z, acc[3] + bv1[nt].w}};
-        gelu2_n<2>(g);
-        uint2 o;
-        o.x = live ? pack_bf2(g[0].x, g[0].y) : 0u;
-        o.y = live ? pack_bf2(g[1].x, g[1].y) : 0u;
-        if (cs < SF_C1) *reinterpret_cast<uint2*>(dst + nt * 32) = o;
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][0], xf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][1], xf[1], acc[nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int np = 0; np < 3; ++np) {
+        const int n0 = 2 * np, n1 = 2 * np + 1;
+        f32x2 g[4] = {{acc[n0][0] + bv1[n0].x, acc[n0][1] + bv1[n0].y}, {acc[n0][2] + bv1[n0].z, acc[n0][3] + bv1[n0].w},
+                      {acc[n1][0] + bv1[n1].x, acc[n1][1] + bv1[n1].y}, {acc[n1][2] + bv1[n1].z, acc[n1][3] + bv1[n1].w}};
+        gelu2_n<4>(g);
+        uint2 o0, o1;
+        o0.x = live ? pack_bf2(g[0].x, g[0].y) : 0u;
+        o0.y = live ? pack_bf2(g[1].x, g[1].y) : 0u;
+        o1.x = live ? pack_bf2(g[2].x, g[2].y) : 0u;
+        o1.y = live ? pack_bf2(g[3].x, g[3].y) : 0u;
+        if (cs < SF_C1) {
+          *reinterpret_cast<uint2*>(dst + n0 * 32) = o0;
+          *reinterpret_cast<uint2*>(dst + n1 * 32) = o1;
+        }
       }
       xf[0] = xn[0]; xf[1] = xn[1]; live = live_n;
     }
 #undef SF_FETCH
-    __syncthreads();
+    __syncthreads();   // s1 is complete; nobody reads the patch any more
+    const long tile_n = tile + gridDim.x;
+    if (tile_n < ntiles) patch_fetch(tile_n);   // in flight under the depthwise pass
     // ---- depthwise 3x3 stride 2 out of LDS: item = (output pixel, 8-channel group), 128 x 12 items over 512 threads
-#pragma unroll
+#pragma unroll 1
     for (int it = 0; it < SF_TR * SF_TC * (SF_C / 8) / 512; ++it) {
       const int item = tid + 512 * it;
       const int cg = item % (SF_C / 8), p = item / (SF_C / 8), pr = p / SF_TC, pc = p % SF_TC;
@@ -442,6 +485,7 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
         *reinterpret_cast<uint4*>(y + (((size_t)b * S2 + oy) * S2 + ox) * SF_C + cg * 8) = o;
       }
     }
+    if (tile_n < ntiles) patch_store();
   }
 }
 
