@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256, 3) void dwconv_tile_kernel(const bf16_t* __res
 // pixels they need on MFMA (implicit GEMM as in stem_mfma_kernel, K 27 -> 64), rounds them to bf16 into LDS exactly as the
 // unfused pair rounds them to HBM, and runs the depthwise conv out of LDS.  The halo recompute costs 14 %; HBM sees the
 // image once and the quarter-resolution map once.  Persistent blocks (one per CU, 8 waves), weights loaded once.
-constexpr int SF_C = 96, SF_TR = 4, SF_TC = 32, SF_R1 = 2 * SF_TR + 1, SF_C1 = 2 * SF_TC + 1, SF_SEG = (SF_C1 + 15) / 16;
+constexpr int SF_C = 96, SF_TR = 4, SF_TC = 32, SF_R1 = 2 * SF_TR + 1, SF_C1 = 2 * SF_TC + 1;
+constexpr int SF_NSEG = (SF_R1 * SF_C1 + 15) / 16;           // 37 segments of 16 half-resolution pixels
 constexpr int SF_PS = SF_C * 2 + 16;                      // bytes per half-resolution pixel in LDS (16-B aligned, 2-way banks)
 constexpr int SF_S1 = SF_R1 * SF_C1 * SF_PS;              // 121,680 B
 constexpr int SF_PR = 4 * SF_TR + 3, SF_PCH = (4 * SF_TC + 4) / 2;   // input patch: 19 rows x 66 16-byte chunks (132 pixels)
@@ -401,15 +402,16 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
     const long b = tile / ((long)tiles_x * tiles_y);
     const int y1_0 = 2 * ty * SF_TR - 1, x1_0 = 2 * tx * SF_TC - 1;   // half-resolution origin of the halo region
     __syncthreads();   // the patch is written, the previous tile's depthwise pass is done with s1 (and the taps are staged)
-    // ---- first conv: SF_R1 x SF_SEG segments of 16 half-resolution pixels, dealt to the 8 waves.  Fragment of half-res
+    // ---- first conv: the region's 9 x 65 half-resolution pixels, rows flattened, in SF_NSEG segments of 16 dealt to the 8
+    // waves (per row that would be 5 segments for 65 pixels: 45 instead of 37).  Fragment of half-res
     // pixel (r1, cs): k-slot group fg = (kernel row 2 ks + (fg >> 1), pixel pair fg & 1) -> patch row 2 r1 + ky, pixels
     // 2 cs + 2 pp + 1 and + 2 (kernel row 3 does not exist: zero operand against zero weights)
 #define SF_FETCH(SEG, XF, LIVE)                                                                                  \
   {                                                                                                              \
-    const int r1_ = min((SEG) / SF_SEG, SF_R1 - 1), cs_ = ((SEG) % SF_SEG) * 16 + fr;                            \
+    const int f_ = min((SEG) * 16 + fr, SF_R1 * SF_C1 - 1), r1_ = f_ / SF_C1, cs_ = f_ - r1_ * SF_C1;            \
     const int oy_ = y1_0 + r1_, ox_ = x1_0 + cs_;                                                                \
-    LIVE = (SEG) < SF_R1 * SF_SEG && cs_ < SF_C1 && oy_ >= 0 && oy_ < S1 && ox_ >= 0 && ox_ < S1;               \
-    const char* pp_ = spx + ((2 * r1_ + (fg >> 1)) * SF_PCH * 2 + 2 * min(cs_, SF_C1 - 1) + 2 * (fg & 1) + 1) * 8; \
+    LIVE = oy_ >= 0 && oy_ < S1 && ox_ >= 0 && ox_ < S1;                                                         \
+    const char* pp_ = spx + ((2 * r1_ + (fg >> 1)) * SF_PCH * 2 + 2 * cs_ + 2 * (fg & 1) + 1) * 8;               \
     const uint2 l0_ = *reinterpret_cast<const uint2*>(pp_), h0_ = *reinterpret_cast<const uint2*>(pp_ + 8);      \
     uint2 l1_ = make_uint2(0, 0), h1_ = make_uint2(0, 0);                                                        \
     if (fg < 2) {                                                                                                \
@@ -422,10 +424,10 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
     bf16x8 xf[2], xn[2];
     bool live, live_n;
     SF_FETCH(wid, xf, live)   // outside the map: the depthwise conv's zero padding
-    for (int seg = wid; seg < SF_R1 * SF_SEG; seg += 8) {
+    for (int seg = wid; seg < SF_NSEG; seg += 8) {
       SF_FETCH(seg + 8, xn, live_n)
-      const int r1 = seg / SF_SEG, cs = (seg % SF_SEG) * 16 + fr;     // row / column inside the region
-      char* dst = s1 + (r1 * SF_C1 + cs) * SF_PS + fg * 8;
+      const int f = seg * 16 + fr;                                     // pixel of the region, rows flattened
+      char* dst = s1 + f * SF_PS + fg * 8;
       // all twelve MFMAs first, then the GELUs four pairs at a time: four Horner chains in lockstep instead of two
       f32x4 acc[6];
 #pragma unroll
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
         o0.y = live ? pack_bf2(g[1].x, g[1].y) : 0u;
         o1.x = live ? pack_bf2(g[2].x, g[2].y) : 0u;
         o1.y = live ? pack_bf2(g[3].x, g[3].y) : 0u;
-        if (cs < SF_C1) {
+        if (f < SF_R1 * SF_C1) {
           *reinterpret_cast<uint2*>(dst + n0 * 32) = o0;
           *reinterpret_cast<uint2*>(dst + n1 * 32) = o1;
         }
