@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(AttnParams p) {   /
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int qblocks = p.T >> 6;
-  int bid = blockIdx.x;
+  // the query blocks of one (batch, head) read the same K/V rows: a contiguous run of logical ids per XCD keeps them on one
+  // L2 (dealt round-robin, each of the 8 L2s fetched every K/V tile for itself: 1.5 GB of HBM reads per launch by PMC)
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int qb = bid % qblocks; bid /= qblocks;
   const int h = bid % p.heads;
   const int b = bid / p.heads;
