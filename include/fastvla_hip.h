@@ -197,6 +197,12 @@ int fv_op_se_gelu(const void* x, const float* w1, const float* b1, const float* 
  * the kernel), i.e. the depthwise weights rounded to bf16. */
 int fv_op_dwconv_mfma(const void* x, const void* ttab, const float* bias, void* y, int B, int H, int W, int C, int k, int gelu,
                       fv_stream s);
+/* the PatchEmbed large-kernel conv on the same scheme: 7x7, stride 2, two output channels per input channel (groups = C):
+ * x (B,H,W,C) -> y (B,H/2,W/2,2C) bf16 NHWC; H, W even, W >= 16, C % 32 == 0.  ttab = bf16 Toeplitz table
+ * [C/16][e=2][7][4][16 ch][4 i][4 kk] = w[ky][4m + kk - 2i] of output channel 2 (16 g + ch) + e (0 outside the 7 taps).
+ * Replaces fv_op_dwconv(k=7, stride=2, mult=2) for these shapes (mci.py PatchEmbed, lkb_reparam). */
+int fv_op_dwconv_s2_mfma(const void* x, const void* ttab, const float* bias, void* y, int B, int H, int W, int C, int gelu,
+                         fv_stream s);
 /* RepMixer pair in one marching kernel: y1 = dw3x3(x) + b3 (the reparameterised token mixer), y2 = dw7x7(y1) + b7 (the
  * ConvFFN's conv); x, y1, y2 (B,H,W,C) bf16 NHWC, distinct; t3 / t7 Toeplitz tables as for fv_op_dwconv_mfma (k = 3 / 7);
  * H >= 16, W >= 32, C % 32 == 0. */

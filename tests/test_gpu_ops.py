@@ -336,6 +336,40 @@ def test_dwconv_mfma(k, C, H, W, gelu):
     check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"dwconv mfma k{k} C{C} {H}x{W}")
 
 
+def _toeplitz_s2(w):
+    """[2C,1,7,7] -> the table of fv_op_dwconv_s2_mfma: [C/16][e][ky][m][16 ch][4 i][4 kk] = w[2(16g+ch)+e][ky][4m+kk-2i]."""
+    C = w.shape[0] // 2
+    wv = w.view(C // 16, 16, 2, 7, 7)                       # [g][ch][e][ky][kx]
+    t = torch.zeros(C // 16, 2, 7, 4, 16, 4, 4)
+    for m in range(4):
+        for i in range(4):
+            for kk in range(4):
+                kx = 4 * m + kk - 2 * i
+                if 0 <= kx < 7:
+                    t[:, :, :, m, :, i, kk] = wv[:, :, :, :, kx].permute(0, 2, 3, 1)
+    return t
+
+
+@pytest.mark.parametrize("C,H,W,gelu", [(32, 16, 32, 1), (96, 40, 64, 1), (64, 18, 34, 0), (192, 32, 32, 1), (32, 2, 16, 0)])
+def test_dwconv_s2_mfma(C, H, W, gelu):
+    """PatchEmbed large-kernel conv (7x7, stride 2, groups = C, 2C outputs) on the matrix core against conv2d; ragged tiles
+    (Ho % 8, Wo % 16 != 0) and a map smaller than one tile included."""
+    torch.manual_seed(C + H + W)
+    B = 2
+    x = bf(torch.randn(B, C, H, W))
+    w = bf(torch.randn(2 * C, 1, 7, 7) / 7)  # the table stores the weights in bf16
+    b = torch.randn(2 * C) * 0.1
+    ref = F.conv2d(x, w, b, stride=2, padding=3, groups=C)
+    if gelu:
+        ref = F.gelu(ref)
+    xd, td, bd = dev_bf16(x.permute(0, 2, 3, 1)), dev_bf16(_toeplitz_s2(w)), dev_f32(b)
+    y = torch.full((B, H // 2, W // 2, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_dwconv_s2_mfma(xd.data_ptr(), td.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, C, gelu, stream()),
+         "fv_op_dwconv_s2_mfma")
+    torch.cuda.synchronize()
+    check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"dwconv s2 mfma C{C} {H}x{W}")
+
+
 @pytest.mark.parametrize("S,C0", [(64, 32), (96, 96), (40, 16)])
 def test_stem_mfma(S, C0):
     torch.manual_seed(S + C0)

@@ -59,7 +59,7 @@ struct Block {
   float *ln_w = nullptr, *ln_b = nullptr; bf16_t *qkv_w = nullptr, *proj_w = nullptr; float *proj_b = nullptr, *ls1 = nullptr;  // attention
   FFN ffn;
 };
-struct Down { float *lk_w = nullptr, *lk_b = nullptr; bf16_t* pw_w = nullptr; float* pw_b = nullptr; };
+struct Down { float *lk_w = nullptr, *lk_b = nullptr; bf16_t* lk_t = nullptr; bf16_t* pw_w = nullptr; float* pw_b = nullptr; };
 struct Cpe { float *w = nullptr, *b = nullptr; bf16_t* t = nullptr; };
 struct Tower {
   bf16_t* stem0_wp = nullptr;  // [C0][64] image for the MFMA stem
@@ -169,7 +169,10 @@ struct Loader {
   bf16_t* mat(const std::string& name, size_t n, size_t k) { std::vector<float> v; return expect(name, v, n * k) ? up_bf16(v) : nullptr; }
   // depthwise [Cout,1,k,k] -> tap-major [k*k][Cout] f32, optionally scaled per out-channel (BN fold)
   // map_w > 0: also builds the bf16 Toeplitz table of the MFMA depthwise kernel when that kernel serves this layer
-  float* dw(const std::string& name, int cout, int k, const std::vector<float>* scale = nullptr, int map_w = 0, bf16_t** ttab = nullptr) {
+  // s2_cin > 0: a stride-2 layer with cout / s2_cin outputs per input channel on an s2_map-wide map; builds the table of
+  // dwconv_s2_mfma_kernel when that kernel serves it
+  float* dw(const std::string& name, int cout, int k, const std::vector<float>* scale = nullptr, int map_w = 0, bf16_t** ttab = nullptr,
+            int s2_cin = 0, int s2_map = 0, bf16_t** s2_ttab = nullptr) {
     std::vector<float> v;
     if (!expect(name, v, (size_t)cout * k * k)) return nullptr;
     std::vector<float> o((size_t)cout * k * k);
@@ -179,6 +182,11 @@ struct Loader {
       std::vector<float> tt(fv::dwconv_toeplitz_elems(cout, k));
       fv::dwconv_toeplitz_pack(o.data(), tt.data(), cout, k);
       *ttab = up_bf16(tt);
+    }
+    if (s2_ttab && s2_cin > 0 && cout % s2_cin == 0 && fv::dwconv_s2_mfma_supported(s2_map, s2_map, s2_cin, k, 2, cout / s2_cin)) {
+      std::vector<float> tt(fv::dwconv_s2_toeplitz_elems(s2_cin));
+      fv::dwconv_s2_toeplitz_pack(o.data(), tt.data(), s2_cin);
+      *s2_ttab = up_bf16(tt);
     }
     return up_f32(o);
   }
@@ -401,7 +409,9 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float
     if (i + 1 < d.tower_stages) {
       const int C2 = d.tower_dims[i + 1];
       FV_P(FV_FAM_DWCONV, dw_flops(mb, H / 2, H / 2, C2, 7), 2.0 * M * C + 2.0 * (M / 4) * C2,
-           fv::launch_dwconv(cur, tw.downs[i].lk_w, tw.downs[i].lk_b, oth, mb, H, H, C, 7, 2, C2 / C, 1, s));
+           (tw.downs[i].lk_t && !h->no_mfma_dw)
+               ? fv::launch_dwconv_s2_mfma(cur, tw.downs[i].lk_t, tw.downs[i].lk_b, oth, mb, H, H, C, 1, s)
+               : fv::launch_dwconv(cur, tw.downs[i].lk_w, tw.downs[i].lk_b, oth, mb, H, H, C, 7, 2, C2 / C, 1, s));
       H /= 2;
       fv::GemmArgs g{oth, C2, tw.downs[i].pw_w, mb * H * H, C2, C2, tw.downs[i].pw_b, nullptr, nullptr, 0, cur, C2, FV_EPI_BIAS_GELU};
       FV_TRY(gemm_p(h, g, s));
@@ -540,7 +550,7 @@ int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n) {
     if (i + 1 < d.tower_stages) {
       const int C2 = d.tower_dims[i + 1];
       const std::string pre = vt + "network." + std::to_string(idx++) + ".proj.";
-      tw.downs[i].lk_w = L.dw(pre + "0.lkb_reparam.weight", C2, 7);
+      tw.downs[i].lk_w = L.dw(pre + "0.lkb_reparam.weight", C2, 7, nullptr, 0, nullptr, C, map_w, &tw.downs[i].lk_t);
       tw.downs[i].lk_b = L.vec(pre + "0.lkb_reparam.bias", C2);
       tw.downs[i].pw_w = L.mat(pre + "1.reparam_conv.weight", C2, C2);
       tw.downs[i].pw_b = L.vec(pre + "1.reparam_conv.bias", C2);

@@ -48,6 +48,11 @@ int launch_dwconv(const bf16_t* x, const float* w, const float* bias, bf16_t* y,
 bool dwconv_mfma_supported(int W, int C, int k, int stride, int mult);
 size_t dwconv_toeplitz_elems(int C, int k);
 void dwconv_toeplitz_pack(const float* w_tapmajor, float* out, int C, int k);
+size_t dwconv_s2_toeplitz_elems(int C);
+void dwconv_s2_toeplitz_pack(const float* w_tapmajor, float* out, int C);   // 7x7 stride 2, two outputs per input channel
+bool dwconv_s2_mfma_supported(int H, int W, int C, int k, int stride, int mult);
+int launch_dwconv_s2_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, bf16_t* y, int B, int H, int W, int C, int gelu,
+                          hipStream_t s);
 // x' = dw3x3(x), t = dw7x7(x') in one marching kernel (RepMixer token mixer + ConvFFN conv); tables as for launch_dwconv_mfma
 bool dwconv_pair_supported(int H, int W, int C);
 int launch_dwconv_pair(const bf16_t* x, const bf16_t* t3, const float* b3, const bf16_t* t7, const float* b7, bf16_t* y1, bf16_t* y2,

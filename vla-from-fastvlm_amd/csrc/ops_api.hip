@@ -82,6 +82,10 @@ int fv_op_dwconv_mfma(const void* x, const void* ttab, const float* bias, void* 
   return fv::launch_dwconv_mfma(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(ttab), bias, static_cast<bf16_t*>(y), B, H, W, C, k,
                                 gelu, static_cast<hipStream_t>(s));
 }
+int fv_op_dwconv_s2_mfma(const void* x, const void* ttab, const float* bias, void* y, int B, int H, int W, int C, int gelu, fv_stream s) {
+  return fv::launch_dwconv_s2_mfma(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(ttab), bias, static_cast<bf16_t*>(y), B, H, W, C,
+                                   gelu, static_cast<hipStream_t>(s));
+}
 int fv_op_dwconv_pair(const void* x, const void* t3, const float* b3, const void* t7, const float* b7, void* y1, void* y2, int B,
                       int H, int W, int C, fv_stream s) {
   return fv::launch_dwconv_pair(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(t3), b3, static_cast<const bf16_t*>(t7), b7,

@@ -375,9 +375,11 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
   // the depthwise pass and written once that pass is over -- fetched per segment from global memory instead, the first conv
   // stalled on one memory latency per segment (two waves per SIMD cannot hide it).
   uint4 pre[SF_PLD];
-  auto patch_fetch = [&](long tile) {
-    const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
-    const long b = tile / ((long)tiles_x * tiles_y);
+  // tile arithmetic in 32 bits (the launcher bounds ntiles): 64-bit division is emulated, hundreds of scalar instructions
+  auto patch_fetch = [&](unsigned tile) {
+    const unsigned r_ = tile / (unsigned)tiles_x;
+    const int tx = (int)(tile - r_ * (unsigned)tiles_x), ty = (int)(r_ % (unsigned)tiles_y);
+    const long b = r_ / (unsigned)tiles_y;
     const int iy0 = 4 * ty * SF_TR - 3, ix0 = 4 * tx * SF_TC - 4;
 #pragma unroll
     for (int j = 0; j < SF_PLD; ++j) {
@@ -397,9 +399,10 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
   if (tid == 0) *reinterpret_cast<uint4*>(spx + SF_PR * SF_PCH * 16) = make_uint4(0, 0, 0, 0);
   if ((long)blockIdx.x < ntiles) { patch_fetch(blockIdx.x); patch_store(); }
 
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
-    const long b = tile / ((long)tiles_x * tiles_y);
+  for (unsigned tile = blockIdx.x; tile < (unsigned)ntiles; tile += gridDim.x) {
+    const unsigned r_ = tile / (unsigned)tiles_x;
+    const int tx = (int)(tile - r_ * (unsigned)tiles_x), ty = (int)(r_ % (unsigned)tiles_y);
+    const long b = r_ / (unsigned)tiles_y;
     const int y1_0 = 2 * ty * SF_TR - 1, x1_0 = 2 * tx * SF_TC - 1;   // half-resolution origin of the halo region
     __syncthreads();   // the patch is written, the previous tile's depthwise pass is done with s1 (and the taps are staged)
     // ---- first conv: the region's 9 x 65 half-resolution pixels, rows flattened, in SF_NSEG segments of 16 dealt to the 8
@@ -455,8 +458,8 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
     }
 #undef SF_FETCH
     __syncthreads();   // s1 is complete; nobody reads the patch any more
-    const long tile_n = tile + gridDim.x;
-    if (tile_n < ntiles) patch_fetch(tile_n);   // in flight under the depthwise pass
+    const unsigned tile_n = tile + gridDim.x;
+    if (tile_n < (unsigned)ntiles) patch_fetch(tile_n);   // in flight under the depthwise pass
     // ---- depthwise 3x3 stride 2 out of LDS: item = (output pixel, 8-channel group), 128 x 12 items over 512 threads
 #pragma unroll 1
     for (int it = 0; it < SF_TR * SF_TC * (SF_C / 8) / 512; ++it) {
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
         *reinterpret_cast<uint4*>(y + (((size_t)b * S2 + oy) * S2 + ox) * SF_C + cg * 8) = o;
       }
     }
-    if (tile_n < ntiles) patch_store();
+    if (tile_n < (unsigned)ntiles) patch_store();
   }
 }
 
@@ -659,6 +662,173 @@ __global__ __launch_bounds__(256, TH == 8 ? 3 : 2) void dwconv_mfma_kernel(const
         }
       }
     }
+  }
+}
+
+// ---- the PatchEmbed large-kernel conv (7x7, stride 2, two output channels per input channel) on the same MFMA scheme.
+// For four adjacent outputs ox = 4Q + i of a row the input window is columns 8Q .. 8Q + 12 of the halo tile, i.e. column
+// quads 2Q .. 2Q + 3, and the Toeplitz piece of k-block m is A[i][kk] = w[ky][4m + kk - 2i]; the B operand of output row
+// j is halo row 2j + ky.  The two output channels of an input channel share B: two A tables (e = 0, 1), two accumulators.
+// Block = 8 x 16 outputs x 32 input channels (64 output channels): 21 x 37 halo pixels, 224 MFMAs per wave.  On the VALU
+// this layer was 49 FMAs per output at 0.9 ms for the first (256^2 -> 128^2) map; see dwconv_kernel for the fallback.
+__global__ __launch_bounds__(256, 2) void dwconv_s2_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ttab,
+                                                                 const float* __restrict__ bias, bf16_t* __restrict__ y, int H,
+                                                                 int W, int C, int Ho, int Wo, int gelu, int tiles_x, int tiles_y,
+                                                                 int nslices, int nimg) {
+  constexpr int K = 7, TH = 8, TW = 16, PAD = 3, IH = 2 * TH + K - 2, IW = 2 * TW + K - 2;   // 21 x 37
+  constexpr int NQ = (IW + 3) / 4, NM = 4;                     // 10 column quads; 4 k-blocks per output quad
+  constexpr int RS = NQ * 256 + 64;                            // LDS bytes per halo row (== 64 mod 256)
+  constexpr int X_BYTES = IH * RS;                             // 55,104
+  constexpr int OC = 512 + 16;                                 // output cell (row, quad): 64 channels x 4 columns bf16, padded
+  static_assert(TH * 4 * OC <= X_BYTES, "the output tile reuses the halo tile's LDS");
+  __shared__ __attribute__((aligned(16))) char smem[X_BYTES];
+  char* sX = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // persistent: a block keeps its channel slice (and that slice's Toeplitz fragments) and walks pixel tiles; the next
+  // tile's halo pixels are in flight in registers while the current one is in the MFMAs and the epilogue -- one tile per
+  // block at two blocks per CU left every block's load latency exposed (13 us per tile)
+  // Block -> (XCD, chain, slice): blocks b and b + 8 share an XCD, and a 64-byte channel slice is half a cache line, so the
+  // nslices blocks that walk the same tiles (and the chains working on neighbouring tiles, which share halos) are put on
+  // one XCD: dealt round-robin, every L2 fetched every line for itself.  XCD x owns the tile range [x tpx, (x+1) tpx).
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+  const int slice = lb % nslices, chain = lb / nslices, chains = (int)(gridDim.x >> 3) / nslices;
+  const int ntiles = nimg * tiles_x * tiles_y;   // 32-bit on purpose: 64-bit division is emulated
+  const int tpx = (ntiles + 7) >> 3, t_end = min((xcd + 1) * tpx, ntiles), per_slice = chains;
+  const int c0 = slice * 32;                      // first input channel of the slice
+  const int gg = wid & 1, eo = wid >> 1;          // wave = (16-input-channel group, which of the two outputs per channel)
+  const int bch = lane >> 2, jr = lane & 3;       // lane = (channel within the group, output row within a group of 4)
+
+  // Toeplitz fragments [C/16][e][ky][m][16 ch][4 i][4 kk] straight from the (L2-resident) table
+  s16x4 afr[K][NM];
+  {
+    const char* tsrc = reinterpret_cast<const char*>(ttab) + (size_t)(slice * 2 + gg) * (2 * K * NM * 512) + (size_t)eo * (K * NM * 512) + lane * 8;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) afr[ky][m] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(tsrc + (ky * NM + m) * 512));
+  }
+  // halo tile, transposed in registers to [row][column quad][channel slot][4 columns] (see dwconv_mfma_kernel)
+  constexpr int NTASK = IH * NQ * 4, TPT = (NTASK + 255) / 256;
+  uint4 px[TPT][4];
+  // a task's place in the halo tile does not depend on the tile: decode it once (the per-tile address and bounds work was
+  // most of this kernel's instruction stream when it was redone for every load)
+  int trow[TPT], tcol[TPT], toff[TPT];
+  uint32_t tdst[TPT];
+#pragma unroll
+  for (int tt = 0; tt < TPT; ++tt) {
+    const int task = min(tid + 256 * tt, NTASK - 1);   // surplus threads of the last round repeat the last task
+    const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;
+    trow[tt] = row;
+    tcol[tt] = quad * 4;
+    toff[tt] = (row * W + quad * 4) * C + cg * 8;
+    tdst[tt] = (uint32_t)(row * RS + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
+  }
+  auto fetch = [&](int tx, int tyb, int b) {
+    const int iy0 = 2 * tyb * TH - PAD, ix0 = 2 * tx * TW - PAD;
+    const bf16_t* org = x + ((long)b * H * W + (long)iy0 * W + ix0) * C + c0;   // may lie before the image: only in-range taps are read
+#pragma unroll
+    for (int tt = 0; tt < TPT; ++tt) {
+      const bool rok = (unsigned)(iy0 + trow[tt]) < (unsigned)H;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        px[tt][j] = (rok && (unsigned)(ix0 + tcol[tt] + j) < (unsigned)W) ? *reinterpret_cast<const uint4*>(org + toff[tt] + j * C)
+                                                                         : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto decode = [&](int tile, int& tx, int& tyb, int& b) {
+    const unsigned t = (unsigned)tile, r = t / (unsigned)tiles_x;
+    tx = (int)(t - r * (unsigned)tiles_x);
+    b = (int)(r / (unsigned)tiles_y);
+    tyb = (int)(r - (unsigned)b * (unsigned)tiles_y);
+  };
+  int tile = xcd * tpx + chain, tx = 0, tyb = 0, b = 0, txn = 0, tybn = 0, bn = 0;
+  if (tile < t_end) { decode(tile, tx, tyb, b); fetch(tx, tyb, b); }
+  for (; tile < t_end; tile += per_slice) {
+#pragma unroll
+  for (int tt = 0; tt < TPT; ++tt) {
+    if (tid + 256 * tt < NTASK) {
+      const uint32_t d[4][4] = {{px[tt][0].x, px[tt][0].y, px[tt][0].z, px[tt][0].w}, {px[tt][1].x, px[tt][1].y, px[tt][1].z, px[tt][1].w},
+                                {px[tt][2].x, px[tt][2].y, px[tt][2].z, px[tt][2].w}, {px[tt][3].x, px[tt][3].y, px[tt][3].z, px[tt][3].w}};
+      const uint32_t dst = tdst[tt];
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {
+        uint2 ev, od;
+        ev.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x05040100u);
+        ev.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x05040100u);
+        od.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x07060302u);
+        od.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x07060302u);
+        *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd) * 8))) = ev;
+        *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd + 1) * 8))) = od;
+      }
+    }
+  }
+  __syncthreads();
+  if (tile + per_slice < t_end) { decode(tile + per_slice, txn, tybn, bn); fetch(txn, tybn, bn); }
+
+  const char* lrow[4];   // lane's swizzled channel offset per quad & 3, on halo row 2 jr (row group 0)
+#pragma unroll
+  for (int v = 0; v < 4; ++v) lrow[v] = sX + (2 * jr) * RS + (((gg * 16 + bch) ^ ((v << 1) | gg)) << 3);
+  f32x4 acc[2][4];       // [row group of 4 output rows][output quad]
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[rg][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+      s16x4 xq[NQ];
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(lrow[t & 3] + (rg * 8 + ky) * RS + t * 256));
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) acc[rg][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[2 * q + m], acc[rg][q], 0, 0, 0);
+    }
+  __syncthreads();  // all waves are done with the halo tile; reuse it for the output tile
+
+  // bias (+GELU), then through LDS: cell (row, quad) = 64 output-channel slots x 4 columns, slot = co ^ (row >> 1 & 1): with
+  // the 16-byte cell pad the 16 lanes of a ds_write_b64 (4 channels x 4 rows) cover all 32 banks
+  {
+    const int co = 2 * (gg * 16 + bch) + eo, sig = (jr >> 1) & 1;
+    const float bv = bias[2 * c0 + co];
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x2 g[2] = {{acc[rg][q][0] + bv, acc[rg][q][1] + bv}, {acc[rg][q][2] + bv, acc[rg][q][3] + bv}};
+        if (gelu) gelu2_n<2>(g);
+        uint2 u;
+        u.x = pack_bf2(g[0].x, g[0].y);
+        u.y = pack_bf2(g[1].x, g[1].y);
+        *reinterpret_cast<uint2*>(sX + ((rg * 4 + jr) * 4 + q) * OC + ((co ^ sig) << 3)) = u;
+      }
+  }
+  __syncthreads();
+  {
+    const int cg = tid & 7, quad = (tid >> 3) & 3, row = tid >> 5;   // 8 rows x 4 quads x 8 channel groups of 8
+    const int sig = (row >> 1) & 1;
+    uint2 r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sX + (row * 4 + quad) * OC + (((cg * 8 + e) ^ sig) << 3));
+    const int oy = tyb * TH + row, ox0 = tx * TW + quad * 4;
+    if (oy < Ho) {
+      bf16_t* yp = y + (((size_t)b * Ho + oy) * Wo + ox0) * (2 * C) + 2 * c0 + cg * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (ox0 + j < Wo) {
+          uint4 o;
+          const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+#define FV_PX(A, B) __builtin_amdgcn_perm((j & 2) ? r[B].y : r[B].x, (j & 2) ? r[A].y : r[A].x, sel)
+          o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
+#undef FV_PX
+          *reinterpret_cast<uint4*>(yp + (size_t)j * (2 * C)) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();   // the output tile is read out before the next halo tile is written over it
+  tx = txn; tyb = tybn; b = bn;
   }
 }
 
@@ -1259,6 +1429,50 @@ void dwconv_toeplitz_pack(const float* w_tapmajor, float* out, int C, int k) {
                   (kx >= 0 && kx < k) ? w_tapmajor[(size_t)(ky * k + kx) * C + g * 16 + bch] : 0.0f;
             }
 }
+// bf16 Toeplitz table for dwconv_s2_mfma_kernel: [C/16][e][7][4][16 ch][4 out cols i][4 in cols kk] = w[ky][4m + kk - 2i] of
+// output channel 2 (16 g + ch) + e; w_tapmajor is [49][2C]
+size_t dwconv_s2_toeplitz_elems(int C) { return (size_t)(C / 16) * 2 * 7 * 4 * 256; }
+void dwconv_s2_toeplitz_pack(const float* w_tapmajor, float* out, int C) {
+  for (int g = 0; g < C / 16; ++g)
+    for (int e = 0; e < 2; ++e)
+      for (int ky = 0; ky < 7; ++ky)
+        for (int m = 0; m < 4; ++m)
+          for (int bch = 0; bch < 16; ++bch)
+            for (int i = 0; i < 4; ++i)
+              for (int kk = 0; kk < 4; ++kk) {
+                const int kx = 4 * m + kk - 2 * i;
+                out[(((((size_t)(g * 2 + e) * 7 + ky) * 4 + m) * 16 + bch) * 4 + i) * 4 + kk] =
+                    (kx >= 0 && kx < 7) ? w_tapmajor[(size_t)(ky * 7 + kx) * (2 * C) + 2 * (g * 16 + bch) + e] : 0.0f;
+              }
+}
+bool dwconv_s2_mfma_supported(int H, int W, int C, int k, int stride, int mult) {
+  return k == 7 && stride == 2 && mult == 2 && C % 32 == 0 && H % 2 == 0 && W % 2 == 0 && W >= 16;
+}
+int launch_dwconv_s2_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, bf16_t* y, int B, int H, int W, int C, int gelu,
+                          hipStream_t s) {
+  if (!x || !ttab || !bias || !y) return fv_fail(FV_ERR_ARG, "dwconv_s2_mfma: null pointer");
+  if (B <= 0 || H <= 0 || !dwconv_s2_mfma_supported(H, W, C, 7, 2, 2)) return fv_fail(FV_ERR_UNSUPPORTED, "dwconv_s2_mfma: unsupported shape H=%d W=%d C=%d", H, W, C);
+  const int Ho = H / 2, Wo = W / 2;
+  const int tiles_x = (Wo + 15) / 16, tiles_y = (Ho + 7) / 8, nsl = C / 32;
+  const long nblk = (long)B * tiles_x * tiles_y * nsl;
+  if (nblk > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv_s2_mfma: grid too large");
+  // persistent: two blocks per CU, a whole number of blocks per channel slice
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  // grid = 8 XCDs x chains x slices, about two blocks per CU; a chain walks every chains-th tile of its XCD's tile range
+  const long tiles = nblk / nsl, tpx = (tiles + 7) / 8;
+  long chains = (2L * cus / 8) / nsl;
+  if (chains < 1) chains = 1;
+  if (chains > tpx) chains = tpx;
+  hipLaunchKernelGGL(dwconv_s2_mfma_kernel, dim3((unsigned)(8 * chains * nsl)), dim3(256), 0, s, x, ttab, bias, y, H, W, C, Ho, Wo, gelu, tiles_x, tiles_y, nsl, B);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
 bool dwconv_mfma_supported(int W, int C, int k, int stride, int mult) {
   return stride == 1 && mult == 1 && (k == 3 || k == 7) && W >= 32 && C % 32 == 0;
 }
@@ -1313,6 +1527,7 @@ int launch_stem_fused(const bf16_t* pix, const bf16_t* wp, const float* b1, cons
   }
   const int S2 = S / 4;
   const long ntiles = (long)B * ((S2 + SF_TC - 1) / SF_TC) * ((S2 + SF_TR - 1) / SF_TR);
+  if (ntiles > 0x3fffffffL) return fv_fail(FV_ERR_ARG, "stem_fused: too many tiles");
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
