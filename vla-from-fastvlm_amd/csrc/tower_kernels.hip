@@ -780,10 +780,11 @@ __global__ __launch_bounds__(256, 2) void dwconv_s2_mfma_kernel(const bf16_t* __
       s16x4 xq[NQ];
 #pragma unroll
       for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(lrow[t & 3] + (rg * 8 + ky) * RS + t * 256));
+      // k-block outermost: the four MFMAs of one accumulator are then four instructions apart instead of back to back
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int m = 0; m < NM; ++m)
 #pragma unroll
-        for (int m = 0; m < NM; ++m) acc[rg][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[2 * q + m], acc[rg][q], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) acc[rg][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[2 * q + m], acc[rg][q], 0, 0, 0);
     }
   __syncthreads();  // all waves are done with the halo tile; reuse it for the output tile
 
