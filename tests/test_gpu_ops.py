@@ -447,6 +447,19 @@ def test_dwconv_pair(C, H, W):
     check_close(y2.float().cpu().permute(0, 3, 1, 2), ref2, what=f"dw pair 7x7 C{C} {H}x{W}")
 
 
+@pytest.mark.parametrize("M,C", [(128 * 3, 192), (128 * 800, 96), (128 * 300, 192)])
+def test_gemm_pointwise_square(M, C):
+    """K = N = C in {96, 192}, M % 128 == 0, contiguous rows: the persistent pointwise-conv kernel (weight resident in LDS,
+    rows streamed straight into MFMA operands).  The larger cases have more row tiles than the grid has blocks."""
+    torch.manual_seed(M + C)
+    A, W, b = bf(torch.randn(M, C)), bf(torch.randn(C, C) / math.sqrt(C)), torch.randn(C) * 0.1
+    W[5, 7] += 1.0                                     # asymmetric: a transposed weight cannot pass
+    W = bf(W)
+    ref = A @ W.t() + b
+    check_close(_gemm(A, W, _lib.EPI_BIAS, bias=b), ref, what=f"pwconv bias {M}x{C}")
+    check_close(_gemm(A, W, _lib.EPI_BIAS_GELU, bias=b), F.gelu(ref), what=f"pwconv gelu {M}x{C}")
+
+
 @pytest.mark.parametrize("M,N,K", [(16384, 2048, 192), (8192, 4096, 448), (4096, 5632, 192)])
 def test_gemm_256_tile_variant(M, N, K):
     """Shapes the 256 x 256 LDS-DMA kernel takes (M, N multiples of 256, K of 64, >= 320 tiles): all three of its epilogues,

@@ -430,6 +430,89 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = acc;
 }
 
+// ---- pointwise conv with a small square weight (K = N = C in {96, 192}: the stem's third conv and the first PatchEmbed
+// 1x1), 0.9 ms of HBM-bound work per step that the tiled kernels ran at 2.3-3.1 TB/s: with a K loop of two or three tiles a
+// block is mostly prologue and epilogue.  Here the weight sits in LDS for the life of a persistent block, a wave streams
+// its 32 rows straight from global memory into MFMA B operands (no LDS, no barrier; the next tile's rows are in flight
+// during the products), and the bf16 results leave through a wave-private LDS stage as one contiguous 32 x 2C-byte run.
+template <int C>
+__global__ __launch_bounds__(256, C == 96 ? 3 : 1) void pwconv_kernel(Params p) {
+  constexpr int KS = C / 32, NT = C / 16, WP = C * 2 + 16, OP = C * 2 + 16, CH = C / 8;
+  extern __shared__ __attribute__((aligned(16))) char pw_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  char* sW = pw_smem;
+  char* sO = pw_smem + C * WP + wid * (32 * OP);
+  for (int c = tid; c < C * CH; c += 256) {
+    const int n = c / CH, ch = c % CH;
+    *reinterpret_cast<uint4*>(sW + n * WP + ch * 16) = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.W) + (size_t)n * C + ch * 8);
+  }
+  float4 bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bv[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + j * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+
+  const int ntiles = p.M >> 7;
+  const bf16_t* A = static_cast<const bf16_t*>(p.A);
+  bf16_t* Y = static_cast<bf16_t*>(p.out);
+  uint4 xa[2][KS], xn[2][KS];
+  auto fetch = [&](int tile, uint4 (&d)[2][KS]) {
+    const bf16_t* ap = A + ((size_t)tile * 128 + wid * 32 + fr) * C + fq * 8;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) d[mt][ks] = *reinterpret_cast<const uint4*>(ap + (size_t)mt * 16 * C + ks * 32);
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile, xn);
+  for (; tile < ntiles; tile += (int)gridDim.x) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xa[mt][ks] = xn[mt][ks];
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + (int)gridDim.x, xn);
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) {
+      f32x4 acc[2][2];   // [n tile of the pair][m tile]
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const char* wr = sW + ((2 * jp + jj) * 16 + fr) * WP + fq * 16;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[jj][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 wf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wr + ks * 64));
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc[jj][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xa[mt][ks]), acc[jj][mt], 0, 0, 0);
+        }
+      }
+      // D: column = lane & 15 = row of x, rows 4 fq + r = output channels: four channels of one pixel per lane
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const float4 b0 = bv[2 * jp], b1 = bv[2 * jp + 1];
+        f32x2 g[4] = {{acc[0][mt][0] + b0.x, acc[0][mt][1] + b0.y}, {acc[0][mt][2] + b0.z, acc[0][mt][3] + b0.w},
+                      {acc[1][mt][0] + b1.x, acc[1][mt][1] + b1.y}, {acc[1][mt][2] + b1.z, acc[1][mt][3] + b1.w}};
+        if (p.epi == FV_EPI_BIAS_GELU) gelu2_n<4>(g);
+        uint2 o0, o1;
+        o0.x = pack_bf2(g[0].x, g[0].y); o0.y = pack_bf2(g[1].x, g[1].y);
+        o1.x = pack_bf2(g[2].x, g[2].y); o1.y = pack_bf2(g[3].x, g[3].y);
+        char* dst = sO + (mt * 16 + fr) * OP + (2 * jp * 16 + fq * 4) * 2;
+        *reinterpret_cast<uint2*>(dst) = o0;
+        *reinterpret_cast<uint2*>(dst + 32) = o1;
+      }
+    }
+    asm volatile("" ::: "memory");   // wave-local hand-over: LDS serves a wave's accesses in order
+    bf16_t* yp = Y + ((size_t)tile * 128 + wid * 32) * C;
+#pragma unroll
+    for (int t = 0; t < 32 * CH / 64; ++t) {
+      const int q = lane + 64 * t, row = q / CH, ch = q % CH;
+      *reinterpret_cast<uint4*>(yp + (size_t)row * C + ch * 8) = *reinterpret_cast<const uint4*>(sO + row * OP + ch * 16);
+    }
+    asm volatile("" ::: "memory");   // the next tile's stage writes stay behind these reads
+  }
+}
+
 // which glds kernel (0 = none, 256 or 128) takes the problem.  256-tiles when there are enough of them to keep one block per
 // CU busy; otherwise 128-tiles (two blocks per CU) if the shape allows.
 int gemm_glds_tile(const GemmArgs& a) {
@@ -497,6 +580,24 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       FV_HIP_CHECK(hipGetLastError());
       return FV_OK;
     }
+  }
+  static const bool no_pw = getenv("FASTVLA_NO_PWCONV") != nullptr;
+  if (!no_pw && !a.ksplit && a.N == a.K && (a.K == 96 || a.K == 192) && a.lda == a.K && a.ldo == a.N && a.M % 128 == 0 &&
+      (a.epi == FV_EPI_BIAS || a.epi == FV_EPI_BIAS_GELU)) {
+    const int tiles = a.M / 128;
+    if (a.K == 96) {
+      constexpr int LDS = 96 * (96 * 2 + 16) + 4 * 32 * (96 * 2 + 16);
+      static bool set96 = false;
+      if (!set96) { FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set96 = true; }
+      hipLaunchKernelGGL(pwconv_kernel<96>, dim3(tiles < 3 * cus ? tiles : 3 * cus), dim3(256), LDS, s, p);
+    } else {
+      constexpr int LDS = 192 * (192 * 2 + 16) + 4 * 32 * (192 * 2 + 16);
+      static bool set192 = false;
+      if (!set192) { FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set192 = true; }
+      hipLaunchKernelGGL(pwconv_kernel<192>, dim3(tiles < cus ? tiles : cus), dim3(256), LDS, s, p);
+    }
+    FV_HIP_CHECK(hipGetLastError());
+    return FV_OK;
   }
   if (const int gt = gemm_glds_tile(a)) {
     p.tiles_n = a.N / gt;
