@@ -224,6 +224,7 @@ def _attn_ref(q, k, v, causal, lens, scale):
 
 
 @pytest.mark.parametrize("B,T,heads,kv,D,causal", [(2, 256, 4, 4, 32, 0), (1, 1024, 2, 2, 32, 0), (3, 64, 14, 2, 64, 1),
+                                                   (1, 64, 1, 1, 32, 0), (2, 128, 3, 3, 32, 0), (1, 96, 2, 2, 32, 0),
                                                    (2, 77, 4, 2, 64, 1), (2, 40, 4, 1, 128, 1), (1, 320, 14, 2, 64, 1)])
 def test_attention(B, T, heads, kv, D, causal):
     torch.manual_seed(T + D)
