@@ -53,7 +53,7 @@ def parse():
                          "0 = plain bf16 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=6)   # ~12 s of host work on 16 threads
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to "
                                                       "rehearse the multi-process path on a one-GPU box)")
