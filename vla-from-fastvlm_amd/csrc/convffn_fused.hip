@@ -47,6 +47,12 @@ __device__ __forceinline__ void mfma_acc_h(f32x4& acc, const bf16x8& a, const bf
   else if constexpr (BA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
   else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
+// first k-step of a hidden tile with the first-product bias as the C operand (D layout: row 4 fg + r = hidden unit, so a
+// lane's four accumulator registers take its four biases): the GELU then needs no bias add -- VALU issue slots are what
+// the chunk is short of.  The bias registers come from a global load, not from the VALU: no hazard into the MFMA.
+__device__ __forceinline__ void mfma_init_hb(f32x4& acc, const bf16x8& a, const bf16x8& b, const f32x4& bias) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc) : "v"(a), "v"(b), "v"(bias));
+}
 // first k-step of a hidden tile: C = 0 as an inline constant, so no VALU-written zero feeds the MFMA
 template <bool HA>
 __device__ __forceinline__ void mfma_init_h(f32x4& acc, const bf16x8& a, const bf16x8& b) {
@@ -226,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
   {                                                                                                                 \
     const int cur = hc & 1;                                                                                         \
     const float4 bA = bA_n, bB = bB_n;                                                                              \
+    const f32x4 bAv = f32x4{bA.x, bA.y, bA.z, bA.w}, bBv = f32x4{bB.x, bB.y, bB.z, bB.w};                           \
     /* Weight staging, two chunks deep so no store ever waits on its load: during chunk hc the registers loaded   */ \
     /* during chunk hc-1 (chunk hc+1's weights) go to the idle LDS slot and are refilled with chunk hc+2's; the   */ \
     /* chunk index wraps, so the stream runs on into the next tile.  One store or one load per step of the first  */ \
@@ -247,7 +254,8 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
       ring[i % PD] = i + PD < NR ? FFN_FRAG(i + PD, w1s, w2s) : FFN_FRAG(i + PD - NR, nbase, nbase + W1_BYTES);     \
       if (i < 2 * KS) { /* H^T[ht] += W1[ht rows, k-step] . x^T */                                                  \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                         \
-          if (FFN_KK(i) == 0) mfma_init_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][0]);                                   \
+          if (FFN_KK(i) == 0 && !HA) mfma_init_hb(hacc[FFN_HT(i)][mt], a, xf[mt][0], FFN_HT(i) ? bBv : bAv);        \
+          else if (FFN_KK(i) == 0) mfma_init_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][0]);                              \
           else if (XA && FFN_KK(i) >= KS / 2) mfma_acc_h<HA, XA>(hacc[FFN_HT(i)][mt], a, xf[mt][FFN_KK(i) >= KS / 2 ? FFN_KK(i) : KS - 1]); \
           else mfma_acc_h<HA>(hacc[FFN_HT(i)][mt], a, xf[mt][FFN_KK(i)]);                                           \
         }                                                                                                           \
@@ -266,8 +274,11 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
         if (i == 2 * KS - 1) { /* bias + GELU in registers -> B operand of the second product */                    \
           settle_accs<HA, MT>(hacc);                                                                                \
           _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
-            f32x2 g[4] = {{hacc[0][mt][0] + bA.x, hacc[0][mt][1] + bA.y}, {hacc[0][mt][2] + bA.z, hacc[0][mt][3] + bA.w},  \
-                          {hacc[1][mt][0] + bB.x, hacc[1][mt][1] + bB.y}, {hacc[1][mt][2] + bB.z, hacc[1][mt][3] + bB.w}}; \
+            f32x2 g[4] = {{hacc[0][mt][0], hacc[0][mt][1]}, {hacc[0][mt][2], hacc[0][mt][3]},                       \
+                          {hacc[1][mt][0], hacc[1][mt][1]}, {hacc[1][mt][2], hacc[1][mt][3]}};                      \
+            if constexpr (HA) { /* AGPR accumulators start from the inline 0: the bias is added here */             \
+              g[0] += f32x2{bA.x, bA.y}; g[1] += f32x2{bA.z, bA.w}; g[2] += f32x2{bB.x, bB.y}; g[3] += f32x2{bB.z, bB.w}; \
+            }                                                                                                       \
             FFN_GELU(g)                                                                                             \
             uint4 u;                                                                                                \
             u.x = pack_bf2(g[0].x, g[0].y); u.y = pack_bf2(g[1].x, g[1].y);                                         \
