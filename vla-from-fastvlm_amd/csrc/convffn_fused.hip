@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int nch = p.nchunks;                                   // C / 8: even, >= 4
+  const uint32_t tid16 = (uint32_t)tid * 16u;                  // the lane's byte offset inside a 4 KB group of staging loads
   const int ntiles = (p.M + 64 * MT - 1) / (64 * MT);
 
   // ---- x fragments: lane holds x[pixel m][32 ks + 8 fg .. +8] for its MT pixel tiles (rows past M clamp to M - 1)
@@ -266,9 +267,15 @@ __global__ __launch_bounds__(256, 1) void convffn_kernel(FfnParams p) {
             const int off = c < W1_CH ? (c / (C / 8)) * W1_STRIDE + (c % (C / 8)) * 16                              \
                                       : W1_BYTES + (c2 >> 2) * W2_STRIDE + (c2 & 3) * 16;                           \
             *reinterpret_cast<uint4*>(nbase + off) = FFN_ST_GET(j);                                                 \
-          } else {                                                                                                  \
-            const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)c2 * 8;                             \
-            FFN_ST_SET(j, *reinterpret_cast<const uint4*>(src))                                                     \
+          } else { /* uniform base (W1 or W2 part is decided by j alone when 256 divides W1_CH) + the lane's 16 tid */ \
+            if constexpr (W1_CH % 256 == 0) {                                                                       \
+              const char* sb_ = j * 256 < W1_CH ? reinterpret_cast<const char*>(g1n) + j * 4096                     \
+                                                : reinterpret_cast<const char*>(g2n) + (j * 256 - W1_CH) * 16;      \
+              FFN_ST_SET(j, *reinterpret_cast<const uint4*>(sb_ + tid16))                                           \
+            } else {                                                                                                \
+              const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)c2 * 8;                           \
+              FFN_ST_SET(j, *reinterpret_cast<const uint4*>(src))                                                   \
+            }                                                                                                       \
           }                                                                                                         \
         }                                                                                                           \
         if (i == 2 * KS - 1) { /* bias + GELU in registers -> B operand of the second product */                    \
