@@ -65,11 +65,22 @@ typedef struct fv_model_desc {
 
 typedef struct fv_tensor_desc {
   const char* name;   /* canonical checkpoint key, e.g. "model.layers.0.self_attn.q_proj.weight" */
-  const void* data;   /* HOST pointer, contiguous */
+  const void* data;   /* contiguous; HOST pointer unless device != 0 */
   int32_t dtype;      /* FV_F32 or FV_BF16 */
   int32_t ndim;
   int64_t shape[4];
+  int32_t device;     /* != 0: data is a pointer into the handle's device memory space (copied device-to-device) */
+  int32_t reserved;
 } fv_tensor_desc;
+
+/* fv_load_weights_cb: called once per tensor the packer needs, in packing order; fills *out (name may stay NULL) and
+ * returns 0, or returns non-zero when the checkpoint has no such key.  out->data must stay valid until the next call of
+ * the provider (or the end of fv_load_weights_cb): the host side can materialise one tensor at a time (a 7B checkpoint
+ * never exists as one 30 GB fp32 dict). */
+typedef int (*fv_tensor_provider)(void* user, const char* name, fv_tensor_desc* out);
+
+/* opaque RCCL unique id (ncclUniqueId): made by rank 0 (fv_comm_unique_id), carried to the other ranks by the host side */
+typedef struct fv_rccl_id { char internal[128]; } fv_rccl_id;
 
 typedef struct fv_adamw_hparams {
   float lr, beta1, beta2, eps, weight_decay;
@@ -82,8 +93,13 @@ typedef struct fv_adamw_hparams {
 int fv_create(const fv_model_desc* desc, int device, fv_handle** out);
 /* ... and pack/fold the frozen weights (BN folding, gate/up interleave, qkv concat, bf16) into library memory. */
 int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n);
+/* the same packing with the tensors pulled one at a time through `provider` (streaming load; bf16 sources, on the host
+ * or on the device, reach the packed layouts without an fp32 round trip). */
+int fv_load_weights_cb(fv_handle* h, fv_tensor_provider provider, void* user);
 void fv_destroy(fv_handle* h);
-const char* fv_last_error(fv_handle* h); /* h may be NULL: last error of fv_create */
+/* last error of a call made on h (per handle); h == NULL: last error raised on the calling thread by fv_create or by a
+ * handle-less fv_op_* entry point */
+const char* fv_last_error(fv_handle* h);
 const char* fv_version(void);
 
 /* bytes of caller-owned scratch needed for batch B, T text tokens (+ image tokens when splice != 0) */
@@ -100,6 +116,11 @@ int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hi
  * pix (B,S,S,4) bf16 -> img_tokens (B, (S/64)^2, llm_hidden) f32.  tower_out (B,(S/64)^2,tower_out_dim) bf16 may be
  * NULL. */
 int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, fv_stream s);
+/* fv_vision_forward that also copies intermediate activation maps out (parity tests name the failing stage with them):
+ * taps[0] <- stem output (B,S/4,S/4,dims[0]), taps[1+i] <- output of stage i (B, S/(4<<i), S/(4<<i), dims[i]), bf16 NHWC
+ * device buffers; NULL entries are skipped; n_taps <= tower_stages + 1.  The mirror of the oracle's `taps=` argument. */
+int fv_vision_forward_taps(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, void* const* taps,
+                           int n_taps, fv_stream s);
 /* replaces embed_tokens + L x Qwen2DecoderLayer + final RMSNorm + FastVLMBackbone._pool_hidden
  * (fastvlm_adapter.py:533,551-559,337-359): ids (B,T) int32 right-padded, lens (B) int32,
  * img_tokens NULL (literal reference: text-only sequence) or (B,Ni,H) f32 spliced in front of the text.
@@ -132,6 +153,21 @@ int fv_head_backward(fv_handle* h, const float* flat_params, const float* grad_a
  * step is 1-based.  grad_norm_out (1 f32, device, may be NULL) receives the pre-clip norm. */
 int fv_adamw_clip_step(fv_handle* h, float* flat_params, const float* flat_grads, float* m, float* v, int64_t n,
                        const fv_adamw_hparams* hp, int64_t step, float* grad_norm_out, fv_stream s);
+
+/* gradient accumulation (training/trainer.py:96,171: accelerate sums micro-batch gradients before the optimiser step):
+ * acc += grads over n floats; both 16-byte aligned flat head buffers. */
+int fv_grad_accumulate(fv_handle* h, float* acc, const float* grads, int64_t n, fv_stream s);
+/* grads *= *scale_dev (a device scalar, e.g. the upstream dL/dloss autograd hands compute_loss's backward) */
+int fv_grad_scale(fv_handle* h, float* grads, int64_t n, const float* scale_dev, fv_stream s);
+
+/* ---- data-parallel exchange (replaces accelerate/DDP's gradient all-reduce, training/trainer.py:68-78,175) ---------- */
+/* One RCCL communicator per rank over xGMI.  rank 0 calls fv_comm_unique_id, the host side carries the 128 bytes to every
+ * rank (torch.distributed store / broadcast), every rank calls fv_comm_init.  comm is an ncclComm_t. */
+int fv_comm_unique_id(fv_handle* h, fv_rccl_id* id_out);
+int fv_comm_init(fv_handle* h, const fv_rccl_id* id, int rank, int world, void** comm_out);
+int fv_comm_destroy(fv_handle* h, void* comm);
+/* ONE all-reduce (sum, in place) of the flat head gradient on stream s; the 1/world average is fv_adamw_hparams.grad_scale */
+int fv_allreduce_grads(fv_handle* h, void* comm, float* flat_grads, int64_t n, fv_stream s);
 
 /* ---- optional per-kernel-family HIP-event timing (bench.py roofline numbers) ------------------------------------- */
 enum fv_family { FV_FAM_GEMM = 0, FV_FAM_DWCONV, FV_FAM_STEM, FV_FAM_ATTN, FV_FAM_NORM, FV_FAM_ELT, FV_FAM_HEAD, FV_FAM_COUNT };

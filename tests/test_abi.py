@@ -40,7 +40,7 @@ def test_version_and_error_string_without_gpu():
 
 def test_structs_match_header_layout():
     import ctypes as C
-    assert C.sizeof(_lib.TensorDesc) == 8 + 8 + 4 + 4 + 32
+    assert C.sizeof(_lib.TensorDesc) == 8 + 8 + 4 + 4 + 32 + 4 + 4 and C.sizeof(_lib.RcclId) == 128
     assert C.sizeof(_lib.AdamWHParams) == 28
     assert C.sizeof(_lib.ProfileEntry) == 32 and C.sizeof(_lib.GemmProfile) == 32
     assert C.sizeof(_lib.ModelDesc) == 4 * (7 + 2 + 1 + 3 * 8 + 4 + 2 + 1 + 4 + 4)

@@ -9,6 +9,8 @@
 //   FastVLMWithExpert head, MSE, backward, optimiser fastvla/fastvlm_with_expert.py:50-54, trainer.py:171-182 -> fv_head_*
 // Work the reference does and this path deliberately does not: lm_head logits, retained per-layer hidden states,
 // KV-cache write-back, the D2H -> CPU resize -> H2D round trip.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -22,12 +24,17 @@
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------------ error plumbing
+// fv_fail() formats into a thread-local staging buffer (what fv_last_error(NULL) returns: errors of fv_create and of the
+// handle-less op-level entry points) and, when the failing call was made on a handle, into that handle's own buffer:
+// fv_last_error(h) is per handle, as the header promises.
 static thread_local char g_err[768] = "";
+static thread_local char* g_err_handle = nullptr;  // err[] of the handle whose entry point is executing on this thread
 int fv_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+  if (g_err_handle) memcpy(g_err_handle, g_err, sizeof(g_err));
   return code;
 }
 int fv_hip_fail(hipError_t e, const char* what) { return fv_fail(FV_ERR_HIP, "HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what); }
@@ -90,6 +97,15 @@ struct Profiler {
 
 }  // namespace
 
+struct fv_handle;
+namespace {
+struct HandleScope {  // first statement of every entry point that takes a handle
+  char* prev;
+  explicit HandleScope(fv_handle* h);
+  ~HandleScope() { g_err_handle = prev; }
+};
+}  // namespace
+
 struct fv_handle {
   fv_model_desc d;
   int device = 0;
@@ -104,11 +120,18 @@ struct fv_handle {
   size_t ws_bytes = 0;
   fv::HeadDims hd;
   Profiler prof;
+  char err[768] = "";         // last error of a call made on THIS handle (fv_last_error(h)); fv_fail's thread-local
+                              // buffer is only the staging area
+  void* const* taps = nullptr;  // fv_vision_forward_taps: per-stage copies of the activation map (parity tests)
+  int n_taps = 0;
+  void* rccl = nullptr;       // dlopen handle of librccl (fv_comm_* / fv_allreduce_grads), resolved on first use
   bool no_fused_ffn = false;  // FASTVLA_NO_FUSED_FFN=1: A/B switch back to the two-GEMM ConvFFN
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
 };
 
 namespace {
+
+HandleScope::HandleScope(fv_handle* h) : prev(g_err_handle) { g_err_handle = h ? h->err : nullptr; }
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -122,51 +145,119 @@ int dev_alloc(fv_handle* h, size_t bytes, void** out) {
 
 struct Loader {
   fv_handle* h;
-  std::map<std::string, const fv_tensor_desc*> idx;
+  std::map<std::string, const fv_tensor_desc*> idx;   // fv_load_weights: every tensor up front
+  fv_tensor_provider prov = nullptr;                   // fv_load_weights_cb: one tensor at a time, on demand
+  void* user = nullptr;
+  fv_tensor_desc cur{};
+  std::vector<char> stage;                             // host staging of a device-resident tensor that needs host packing
   int rc = FV_OK;
 
-  bool get(const std::string& name, std::vector<float>& out, std::vector<int64_t>* shape = nullptr) {
-    auto it = idx.find(name);
-    if (it == idx.end()) {
-      if (rc == FV_OK) rc = fv_fail(FV_ERR_MISSING, "missing weight tensor '%s'", name.c_str());
-      return false;
-    }
-    const fv_tensor_desc* t = it->second;
+  static size_t count(const fv_tensor_desc* t) {
     size_t n = 1;
     for (int i = 0; i < t->ndim; ++i) n *= (size_t)t->shape[i];
+    return n;
+  }
+  // the descriptor of `name` (valid until the next need()), or null with rc set
+  const fv_tensor_desc* need(const std::string& name) {
+    const fv_tensor_desc* t = nullptr;
+    if (prov) {
+      memset(&cur, 0, sizeof(cur));
+      if (prov(user, name.c_str(), &cur) == 0 && cur.data) t = &cur;
+    } else {
+      auto it = idx.find(name);
+      if (it != idx.end()) t = it->second;
+    }
+    if (!t) {
+      if (rc == FV_OK) rc = fv_fail(FV_ERR_MISSING, "missing weight tensor '%s'", name.c_str());
+      return nullptr;
+    }
+    if ((t->dtype != FV_F32 && t->dtype != FV_BF16) || t->ndim < 1 || t->ndim > 4) {
+      if (rc == FV_OK) rc = fv_fail(FV_ERR_ARG, "tensor '%s': dtype must be f32 or bf16 and rank 1..4", name.c_str());
+      return nullptr;
+    }
+    return t;
+  }
+  const fv_tensor_desc* need_n(const std::string& name, size_t n) {
+    const fv_tensor_desc* t = need(name);
+    if (t && count(t) != n) {
+      if (rc == FV_OK) rc = fv_fail(FV_ERR_ARG, "tensor '%s' has %zu elements, expected %zu", name.c_str(), count(t), n);
+      return nullptr;
+    }
+    return t;
+  }
+  bool to_f32(const fv_tensor_desc* t, std::vector<float>& out) {
+    const size_t n = count(t), esz = t->dtype == FV_F32 ? 4 : 2;
+    const void* src = t->data;
+    if (t->device) {
+      stage.resize(n * esz);
+      if (hipMemcpy(stage.data(), t->data, n * esz, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (rc == FV_OK) rc = fv_fail(FV_ERR_HIP, "hipMemcpy (device tensor -> host) failed");
+        return false;
+      }
+      src = stage.data();
+    }
     out.resize(n);
-    if (t->dtype == FV_F32) memcpy(out.data(), t->data, n * 4);
-    else if (t->dtype == FV_BF16) { const bf16_t* s = static_cast<const bf16_t*>(t->data); for (size_t i = 0; i < n; ++i) out[i] = host_bf2f(s[i]); }
-    else { if (rc == FV_OK) rc = fv_fail(FV_ERR_ARG, "tensor '%s': dtype must be f32 or bf16", name.c_str()); return false; }
+    if (t->dtype == FV_F32) memcpy(out.data(), src, n * 4);
+    else { const bf16_t* b = static_cast<const bf16_t*>(src); for (size_t i = 0; i < n; ++i) out[i] = host_bf2f(b[i]); }
+    return true;
+  }
+  bool get(const std::string& name, std::vector<float>& out, std::vector<int64_t>* shape = nullptr) {
+    const fv_tensor_desc* t = need(name);
+    if (!t || !to_f32(t, out)) return false;
     if (shape) shape->assign(t->shape, t->shape + t->ndim);
     return true;
   }
   bool expect(const std::string& name, std::vector<float>& v, size_t n) {
-    if (!get(name, v)) return false;
-    if (v.size() != n) {
-      if (rc == FV_OK) rc = fv_fail(FV_ERR_ARG, "tensor '%s' has %zu elements, expected %zu", name.c_str(), v.size(), n);
-      return false;
-    }
-    return true;
+    const fv_tensor_desc* t = need_n(name, n);
+    return t && to_f32(t, v);
+  }
+  void* alloc(size_t bytes) {
+    void* p = nullptr;
+    if (dev_alloc(h, bytes, &p) != FV_OK) { if (rc == FV_OK) rc = FV_ERR_HIP; return nullptr; }
+    return p;
   }
   float* up_f32(const std::vector<float>& v) {
-    void* p = nullptr;
-    if (dev_alloc(h, v.size() * 4, &p) != FV_OK) { if (rc == FV_OK) rc = FV_ERR_HIP; return nullptr; }
-    if (hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { if (rc == FV_OK) rc = fv_fail(FV_ERR_HIP, "hipMemcpy failed"); }
+    void* p = alloc(v.size() * 4);
+    if (p && hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { if (rc == FV_OK) rc = fv_fail(FV_ERR_HIP, "hipMemcpy failed"); }
     return static_cast<float*>(p);
   }
   bf16_t* up_bf16(const std::vector<float>& v) {
     std::vector<bf16_t> b(v.size());
     for (size_t i = 0; i < v.size(); ++i) b[i] = host_f2bf(v[i]);
-    void* p = nullptr;
-    if (dev_alloc(h, b.size() * 2, &p) != FV_OK) { if (rc == FV_OK) rc = FV_ERR_HIP; return nullptr; }
-    if (hipMemcpy(p, b.data(), b.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { if (rc == FV_OK) rc = fv_fail(FV_ERR_HIP, "hipMemcpy failed"); }
+    void* p = alloc(b.size() * 2);
+    if (p && hipMemcpy(p, b.data(), b.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { if (rc == FV_OK) rc = fv_fail(FV_ERR_HIP, "hipMemcpy failed"); }
     return static_cast<bf16_t*>(p);
+  }
+  // rows x row_elems bf16 of tensor t into dst with a destination pitch (elements): the building block of the packed
+  // layouts (qkv concatenation, gate/up interleave).  bf16 sources (host or device) are copied as they are -- a 7B
+  // checkpoint streams through without an fp32 round trip; f32 sources are rounded on the host first.
+  bool put_rows(const fv_tensor_desc* t, bf16_t* dst, size_t dst_pitch, size_t row_elems, size_t rows, size_t src_pitch) {
+    std::vector<bf16_t> tmp;
+    const void* src = t->data;
+    hipMemcpyKind kind = t->device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (t->dtype == FV_F32) {
+      std::vector<float> v;
+      if (!to_f32(t, v)) return false;
+      tmp.resize(v.size());
+      for (size_t i = 0; i < v.size(); ++i) tmp[i] = host_f2bf(v[i]);
+      src = tmp.data();
+      kind = hipMemcpyHostToDevice;
+    }
+    if (hipMemcpy2D(dst, dst_pitch * 2, src, src_pitch * 2, row_elems * 2, rows, kind) != hipSuccess) {
+      if (rc == FV_OK) rc = fv_fail(FV_ERR_HIP, "hipMemcpy2D (weight packing) failed");
+      return false;
+    }
+    return true;
   }
   // f32 vector straight up
   float* vec(const std::string& name, size_t n) { std::vector<float> v; return expect(name, v, n) ? up_f32(v) : nullptr; }
   // [N][K] (or [N,K,1,1]) -> bf16
-  bf16_t* mat(const std::string& name, size_t n, size_t k) { std::vector<float> v; return expect(name, v, n * k) ? up_bf16(v) : nullptr; }
+  bf16_t* mat(const std::string& name, size_t n, size_t k) {
+    const fv_tensor_desc* t = need_n(name, n * k);
+    if (!t) return nullptr;
+    bf16_t* p = static_cast<bf16_t*>(alloc(n * k * 2));
+    return p && put_rows(t, p, n * k, n * k, 1, n * k) ? p : nullptr;
+  }
   // depthwise [Cout,1,k,k] -> tap-major [k*k][Cout] f32, optionally scaled per out-channel (BN fold)
   // map_w > 0: also builds the bf16 Toeplitz table of the MFMA depthwise kernel when that kernel serves this layer
   // s2_cin > 0: a stride-2 layer with cout / s2_cin outputs per input channel on an s2_map-wide map; builds the table of
@@ -342,7 +433,15 @@ int run_ffn(fv_handle* h, const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t*
   return FV_OK;
 }
 
-int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float* img_tokens, const WsPlan& wp,
+// parity-test hook: copy the activation map (NHWC bf16) of tap `t` for images [b0, b0 + mb) out of the ping-pong buffer
+int tap_copy(fv_handle* h, int t, const bf16_t* src, int b0, int mb, size_t per_image, hipStream_t s) {
+  if (!h->taps || t >= h->n_taps || !h->taps[t]) return FV_OK;
+  bf16_t* dst = static_cast<bf16_t*>(h->taps[t]) + (size_t)b0 * per_image;
+  FV_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)mb * per_image * 2, hipMemcpyDeviceToDevice, s));
+  return FV_OK;
+}
+
+int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_out, float* img_tokens, const WsPlan& wp,
                hipStream_t s) {
   const fv_model_desc& d = h->d;
   const Tower& tw = h->tw;
@@ -370,6 +469,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float
     fv::GemmArgs g{oth, C0, tw.stem2_w, mb * H * H, C0, C0, tw.stem2_b, nullptr, nullptr, 0, cur, C0, FV_EPI_BIAS_GELU};
     FV_TRY(gemm_p(h, g, s));
   }
+  FV_TRY(tap_copy(h, 0, cur, b0, mb, (size_t)H * H * C0, s));
   for (int i = 0; i < d.tower_stages; ++i) {
     const int C = d.tower_dims[i];
     const int M = mb * H * H;
@@ -406,6 +506,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float
         FV_TRY(run_ffn(h, b.ffn, cur, oth, hid, cur, mb, H, H, C, d.tower_mlp_ratio, s));
       }
     }
+    FV_TRY(tap_copy(h, 1 + i, cur, b0, mb, (size_t)H * H * C, s));
     if (i + 1 < d.tower_stages) {
       const int C2 = d.tower_dims[i + 1];
       FV_P(FV_FAM_DWCONV, dw_flops(mb, H / 2, H / 2, C2, 7), 2.0 * M * C + 2.0 * (M / 4) * C2,
@@ -434,7 +535,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int mb, bf16_t* tower_out, float
 extern "C" {
 
 const char* fv_version(void) { return "fastvla_hip 0.1 (gfx950)"; }
-const char* fv_last_error(fv_handle*) { return g_err; }
+const char* fv_last_error(fv_handle* h) { return h ? h->err : g_err; }
 
 int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   if (!desc || !out) return fv_fail(FV_ERR_ARG, "fv_create: null argument");
@@ -483,16 +584,33 @@ void fv_destroy(fv_handle* h) {
   delete h;
 }
 
+static int load_impl(fv_handle* h, Loader& L);
+
 int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n) {
+  HandleScope _hs(h);
   if (!h || !tensors || n <= 0) return fv_fail(FV_ERR_ARG, "fv_load_weights: null argument");
   if (h->loaded) return fv_fail(FV_ERR_STATE, "weights already loaded");
-  FV_HIP_CHECK(hipSetDevice(h->device));
-  const fv_model_desc& d = h->d;
   Loader L{h};
   for (int i = 0; i < n; ++i) {
     if (!tensors[i].name || !tensors[i].data || tensors[i].ndim < 1 || tensors[i].ndim > 4) return fv_fail(FV_ERR_ARG, "tensor %d: bad descriptor", i);
     L.idx[tensors[i].name] = &tensors[i];
   }
+  return load_impl(h, L);
+}
+
+int fv_load_weights_cb(fv_handle* h, fv_tensor_provider provider, void* user) {
+  HandleScope _hs(h);
+  if (!h || !provider) return fv_fail(FV_ERR_ARG, "fv_load_weights_cb: null argument");
+  if (h->loaded) return fv_fail(FV_ERR_STATE, "weights already loaded");
+  Loader L{h};
+  L.prov = provider;
+  L.user = user;
+  return load_impl(h, L);
+}
+
+static int load_impl(fv_handle* h, Loader& L) {
+  FV_HIP_CHECK(hipSetDevice(h->device));
+  const fv_model_desc& d = h->d;
   Tower& tw = h->tw;
   const std::string vt = VT;
   const int C0 = d.tower_dims[0];
@@ -581,26 +699,27 @@ int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n) {
     DecLayer& y = h->dec.layers[l];
     y.ln1 = L.vec(pre + "input_layernorm.weight", Hd);
     y.ln2 = L.vec(pre + "post_attention_layernorm.weight", Hd);
-    std::vector<float> q, k, v, qb, kb, vb;
-    if (L.expect(pre + "self_attn.q_proj.weight", q, qd * Hd) && L.expect(pre + "self_attn.k_proj.weight", k, kd * Hd) &&
-        L.expect(pre + "self_attn.v_proj.weight", v, kd * Hd) && L.expect(pre + "self_attn.q_proj.bias", qb, qd) &&
-        L.expect(pre + "self_attn.k_proj.bias", kb, kd) && L.expect(pre + "self_attn.v_proj.bias", vb, kd)) {
-      q.insert(q.end(), k.begin(), k.end());
-      q.insert(q.end(), v.begin(), v.end());
-      qb.insert(qb.end(), kb.begin(), kb.end());
-      qb.insert(qb.end(), vb.begin(), vb.end());
-      y.qkv_w = L.up_bf16(q);
-      y.qkv_b = L.up_f32(qb);
+    {  // q | k | v rows concatenated into one [qd + 2 kd][Hd] matrix, biases likewise
+      y.qkv_w = static_cast<bf16_t*>(L.alloc((qd + 2 * kd) * Hd * 2));
+      const char* nm[3] = {"q_proj", "k_proj", "v_proj"};
+      const size_t rows[3] = {qd, kd, kd};
+      size_t r0 = 0;
+      std::vector<float> qb, part;
+      for (int j = 0; j < 3 && L.rc == FV_OK; ++j) {
+        const fv_tensor_desc* t = L.need_n(pre + "self_attn." + nm[j] + ".weight", rows[j] * Hd);
+        if (t && y.qkv_w) L.put_rows(t, y.qkv_w + r0 * Hd, rows[j] * Hd, rows[j] * Hd, 1, rows[j] * Hd);
+        r0 += rows[j];
+        if (L.expect(pre + "self_attn." + nm[j] + ".bias", part, rows[j])) qb.insert(qb.end(), part.begin(), part.end());
+      }
+      if (L.rc == FV_OK) y.qkv_b = L.up_f32(qb);
     }
     y.o_w = L.mat(pre + "self_attn.o_proj.weight", Hd, qd);
-    std::vector<float> g, u;
-    if (L.expect(pre + "mlp.gate_proj.weight", g, I * Hd) && L.expect(pre + "mlp.up_proj.weight", u, I * Hd)) {
-      std::vector<float> gu(2 * I * Hd);  // rows interleaved [8 gate | 8 up] for the SwiGLU epilogue
-      for (size_t j = 0; j < I; ++j) {
-        memcpy(&gu[((j / 8) * 16 + (j % 8)) * Hd], &g[j * Hd], Hd * 4);
-        memcpy(&gu[((j / 8) * 16 + 8 + (j % 8)) * Hd], &u[j * Hd], Hd * 4);
-      }
-      y.gu_w = L.up_bf16(gu);
+    {  // gate / up rows interleaved [8 gate | 8 up] so SwiGLU is a GEMM epilogue
+      y.gu_w = static_cast<bf16_t*>(L.alloc(2 * I * Hd * 2));
+      const fv_tensor_desc* g = L.need_n(pre + "mlp.gate_proj.weight", I * Hd);
+      if (g && y.gu_w) L.put_rows(g, y.gu_w, 16 * Hd, 8 * Hd, I / 8, 8 * Hd);
+      const fv_tensor_desc* u = L.need_n(pre + "mlp.up_proj.weight", I * Hd);
+      if (u && y.gu_w) L.put_rows(u, y.gu_w + 8 * Hd, 16 * Hd, 8 * Hd, I / 8, 8 * Hd);
     }
     y.down_w = L.mat(pre + "mlp.down_proj.weight", Hd, I);
   }
@@ -611,6 +730,7 @@ int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n) {
 }
 
 int fv_workspace_bytes(fv_handle* h, int B, int T, int splice, size_t* out_bytes) {
+  HandleScope _hs(h);
   if (!h || !out_bytes) return fv_fail(FV_ERR_ARG, "fv_workspace_bytes: null argument");
   if (B <= 0 || T <= 0) return fv_fail(FV_ERR_ARG, "fv_workspace_bytes: B and T must be positive");
   *out_bytes = plan_ws(h, B, T, splice).total;
@@ -618,6 +738,7 @@ int fv_workspace_bytes(fv_handle* h, int B, int T, int splice, size_t* out_bytes
 }
 
 int fv_bind_workspace(fv_handle* h, void* ws, size_t bytes) {
+  HandleScope _hs(h);
   if (!h || !ws) return fv_fail(FV_ERR_ARG, "fv_bind_workspace: null argument");
   if ((uintptr_t)ws & 255) return fv_fail(FV_ERR_ARG, "workspace must be 256-byte aligned");
   h->ws = ws;
@@ -627,6 +748,7 @@ int fv_bind_workspace(fv_handle* h, void* ws, size_t bytes) {
 
 int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value,
                   int resize_with_padding, void* pix_out, fv_stream s) {
+  HandleScope _hs(h);
   if (!h) return fv_fail(FV_ERR_ARG, "null handle");
   hipStream_t st = static_cast<hipStream_t>(s);
   const double S = h->d.image_size;
@@ -638,6 +760,7 @@ int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hi
 }
 
 int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, fv_stream s) {
+  HandleScope _hs(h);
   FV_TRY(check_ready(h, true));
   if (!pix || !img_tokens || B <= 0) return fv_fail(FV_ERR_ARG, "fv_vision_forward: bad argument");
   if (B > h->d.max_batch) return fv_fail(FV_ERR_ARG, "fv_vision_forward: B=%d exceeds max_batch=%d", B, h->d.max_batch);
@@ -652,14 +775,28 @@ int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, vo
   bf16_t* tout = tower_out ? static_cast<bf16_t*>(tower_out) : reinterpret_cast<bf16_t*>(static_cast<char*>(h->ws) + wp.tower_out);
   for (int b0 = 0; b0 < B; b0 += mb) {
     const int nb = std::min(mb, B - b0);
-    FV_TRY(tower_pass(h, static_cast<const bf16_t*>(pix) + (size_t)b0 * S * S * 4, nb, tout + (size_t)b0 * P * d.tower_out_dim,
+    FV_TRY(tower_pass(h, static_cast<const bf16_t*>(pix) + (size_t)b0 * S * S * 4, b0, nb, tout + (size_t)b0 * P * d.tower_out_dim,
                       static_cast<float*>(img_tokens) + (size_t)b0 * P * d.llm_hidden, wp, static_cast<hipStream_t>(s)));
   }
   return FV_OK;
 }
 
+int fv_vision_forward_taps(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, void* const* taps,
+                           int n_taps, fv_stream s) {
+  HandleScope _hs(h);
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  if (n_taps < 0 || n_taps > FV_MAX_STAGES + 1 || (n_taps && !taps)) return fv_fail(FV_ERR_ARG, "fv_vision_forward_taps: bad taps");
+  h->taps = taps;
+  h->n_taps = n_taps;
+  const int rc = fv_vision_forward(h, pix, B, img_tokens, tower_out, s);
+  h->taps = nullptr;
+  h->n_taps = 0;
+  return rc;
+}
+
 int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens, const void* img_tokens, int Ni, int B,
                           int T, int pool_mode, void* pooled, fv_stream st) {
+  HandleScope _hs(h);
   FV_TRY(check_ready(h, true));
   if (!ids || !lens || !pooled || B <= 0 || T <= 0 || Ni < 0) return fv_fail(FV_ERR_ARG, "fv_llm_forward_pooled: bad argument");
   if (Ni > 0 && !img_tokens) return fv_fail(FV_ERR_ARG, "fv_llm_forward_pooled: Ni > 0 without img_tokens");
@@ -731,6 +868,7 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
 }
 
 int fv_head_layout(fv_handle* h, int64_t offsets[13]) {
+  HandleScope _hs(h);
   if (!h || !offsets) return fv_fail(FV_ERR_ARG, "fv_head_layout: null argument");
   const fv::HeadOffsets ho = fv::head_offsets(h->hd);
   for (int i = 0; i < 13; ++i) offsets[i] = ho.o[i];
@@ -738,6 +876,7 @@ int fv_head_layout(fv_handle* h, int64_t offsets[13]) {
 }
 
 int fv_head_saved_bytes(fv_handle* h, int B, size_t* out_bytes) {
+  HandleScope _hs(h);
   if (!h || !out_bytes || B <= 0) return fv_fail(FV_ERR_ARG, "fv_head_saved_bytes: bad argument");
   *out_bytes = fv::head_saved_bytes(h->hd, B);
   return FV_OK;
@@ -746,6 +885,7 @@ int fv_head_saved_bytes(fv_handle* h, int B, size_t* out_bytes) {
 int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled, const float* states, int B,
                     int training, float dropout_p, uint64_t seed, uint64_t offset, float* actions, void* saved,
                     fv_stream s) {
+  HandleScope _hs(h);
   if (!h) return fv_fail(FV_ERR_ARG, "null handle");
   hipStream_t st = static_cast<hipStream_t>(s);
   prof_begin(h, FV_FAM_HEAD, 2.0 * B * fv::head_offsets(h->hd).o[12], 4.0 * fv::head_offsets(h->hd).o[12], st);
@@ -757,6 +897,7 @@ int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled,
 
 int fv_head_mse_backward(fv_handle* h, const float* flat_params, const float* actions, const float* targets, int B,
                          float dropout_p, const void* saved, float* loss, float* flat_grads, fv_stream s) {
+  HandleScope _hs(h);
   if (!h) return fv_fail(FV_ERR_ARG, "null handle");
   if (!h->ws) return fv_fail(FV_ERR_STATE, "workspace not bound: call fv_bind_workspace first");
   if (B > h->d.max_batch) return fv_fail(FV_ERR_ARG, "B=%d exceeds max_batch=%d", B, h->d.max_batch);
@@ -773,6 +914,7 @@ int fv_head_mse_backward(fv_handle* h, const float* flat_params, const float* ac
 
 int fv_head_backward(fv_handle* h, const float* flat_params, const float* grad_actions, int B, float dropout_p,
                      const void* saved, float* flat_grads, fv_stream s) {
+  HandleScope _hs(h);
   if (!h || !grad_actions) return fv_fail(FV_ERR_ARG, "fv_head_backward: null argument");
   if (!h->ws) return fv_fail(FV_ERR_STATE, "workspace not bound: call fv_bind_workspace first");
   if (B > h->d.max_batch) return fv_fail(FV_ERR_ARG, "B=%d exceeds max_batch=%d", B, h->d.max_batch);
@@ -784,6 +926,7 @@ int fv_head_backward(fv_handle* h, const float* flat_params, const float* grad_a
 }
 
 int fv_profile(fv_handle* h, int enable) {
+  HandleScope _hs(h);
   if (!h) return fv_fail(FV_ERR_ARG, "null handle");
   h->prof.on = enable != 0;
   h->prof.recs.clear();
@@ -792,6 +935,7 @@ int fv_profile(fv_handle* h, int enable) {
 }
 
 int fv_profile_read(fv_handle* h, fv_profile_entry* fam_out, fv_gemm_profile* gemm_out, int max_gemm, int* n_gemm) {
+  HandleScope _hs(h);
   if (!h || !fam_out) return fv_fail(FV_ERR_ARG, "fv_profile_read: null argument");
   for (int i = 0; i < FV_FAM_COUNT; ++i) fam_out[i] = fv_profile_entry{0.0, 0.0, 0.0, 0};
   std::map<std::vector<int>, fv_gemm_profile> shapes;
@@ -817,9 +961,94 @@ int fv_profile_read(fv_handle* h, fv_profile_entry* fam_out, fv_gemm_profile* ge
 
 int fv_adamw_clip_step(fv_handle* h, float* flat_params, const float* flat_grads, float* m, float* v, int64_t n,
                        const fv_adamw_hparams* hp, int64_t step, float* grad_norm_out, fv_stream s) {
+  HandleScope _hs(h);
   if (!h || !hp) return fv_fail(FV_ERR_ARG, "fv_adamw_clip_step: null argument");
   return fv::launch_adamw_clip(flat_params, flat_grads, m, v, n, *hp, step, h->norm_scratch, grad_norm_out,
                                static_cast<hipStream_t>(s));
+}
+
+
+// ---- gradient accumulation helpers (training/trainer.py:96,171: accelerate's accumulate() sums micro-batch gradients)
+int fv_grad_accumulate(fv_handle* h, float* acc, const float* grads, int64_t n, fv_stream s) {
+  HandleScope _hs(h);
+  if (!h || !acc || !grads || n <= 0) return fv_fail(FV_ERR_ARG, "fv_grad_accumulate: bad argument");
+  return fv::launch_axpy(acc, grads, n, nullptr, static_cast<hipStream_t>(s));
+}
+
+int fv_grad_scale(fv_handle* h, float* grads, int64_t n, const float* scale_dev, fv_stream s) {
+  HandleScope _hs(h);
+  if (!h || !grads || !scale_dev || n <= 0) return fv_fail(FV_ERR_ARG, "fv_grad_scale: bad argument");
+  return fv::launch_axpy(grads, nullptr, n, scale_dev, static_cast<hipStream_t>(s));
+}
+
+// ---- data-parallel exchange on RCCL, without torch in between.  librccl is resolved at first use with
+// dlopen -- the copy the process already holds (torch ships one) when there is one -- so the library itself carries no link
+// dependency on it and single-GPU users never load it.
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, fv_rccl_id, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return FV_OK;
+  const char* names[] = {"librccl.so", "librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* n : names) if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);   // already in the process (torch's)
+  for (const char* n : names) if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return fv_fail(FV_ERR_UNSUPPORTED, "librccl.so cannot be loaded: %s", dlerror());
+  Rccl r;
+  r.lib = lib;
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) return fv_fail(FV_ERR_UNSUPPORTED, "librccl.so lacks the nccl* entry points");
+  g_rccl = r;
+  return FV_OK;
+}
+int rccl_fail(int e, const char* what) {
+  return fv_fail(FV_ERR_HIP, "RCCL error %d (%s) in %s", e, g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?", what);
+}
+}  // namespace
+
+int fv_comm_unique_id(fv_handle* h, fv_rccl_id* id_out) {
+  HandleScope _hs(h);
+  if (!h || !id_out) return fv_fail(FV_ERR_ARG, "fv_comm_unique_id: null argument");
+  FV_TRY(rccl_load());
+  const int e = g_rccl.GetUniqueId(id_out);
+  return e ? rccl_fail(e, "ncclGetUniqueId") : FV_OK;
+}
+
+int fv_comm_init(fv_handle* h, const fv_rccl_id* id, int rank, int world, void** comm_out) {
+  HandleScope _hs(h);
+  if (!h || !id || !comm_out || world < 1 || rank < 0 || rank >= world) return fv_fail(FV_ERR_ARG, "fv_comm_init: bad argument");
+  FV_TRY(rccl_load());
+  FV_HIP_CHECK(hipSetDevice(h->device));
+  const int e = g_rccl.CommInitRank(comm_out, world, *id, rank);
+  return e ? rccl_fail(e, "ncclCommInitRank") : FV_OK;
+}
+
+int fv_comm_destroy(fv_handle* h, void* comm) {
+  HandleScope _hs(h);
+  if (!h || !comm) return fv_fail(FV_ERR_ARG, "fv_comm_destroy: null argument");
+  FV_TRY(rccl_load());
+  const int e = g_rccl.CommDestroy(comm);
+  return e ? rccl_fail(e, "ncclCommDestroy") : FV_OK;
+}
+
+int fv_allreduce_grads(fv_handle* h, void* comm, float* flat_grads, int64_t n, fv_stream s) {
+  HandleScope _hs(h);
+  if (!h || !comm || !flat_grads || n <= 0) return fv_fail(FV_ERR_ARG, "fv_allreduce_grads: bad argument");
+  FV_TRY(rccl_load());
+  const int e = g_rccl.AllReduce(flat_grads, flat_grads, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm, static_cast<hipStream_t>(s));
+  return e ? rccl_fail(e, "ncclAllReduce") : FV_OK;
 }
 
 }  // extern "C"

@@ -234,6 +234,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   v[i] = vi;
 }
 
+// y += x (x != null) or y *= *scale (x == null): gradient accumulation over micro-batches / an upstream loss gradient
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long n4,
+                                                    const float* __restrict__ scale) {
+  const float sc = scale ? *scale : 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 a = reinterpret_cast<float4*>(y)[i];
+    if (x) {
+      const float4 b = reinterpret_cast<const float4*>(x)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    } else {
+      a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
+    }
+    reinterpret_cast<float4*>(y)[i] = a;
+  }
+}
+
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace
@@ -342,6 +358,15 @@ int launch_head_backward(const HeadDims& d, const float* P, const float* grad_ac
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(d.hid, 256)), blk, 0, s, g1, G + ho.o[3], B, d.hid);
   hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(d.ds, 256), b8), blk, 0, s, g1, P + ho.o[2], g2, d.ds, B, d.hid, d.ds);
   hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3(cdiv(d.ds, 256)), blk, 0, s, g2, sv.xh0, G + ho.o[0], G + ho.o[1], B, d.ds);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_axpy(float* y, const float* x, int64_t n, const float* scale_dev, hipStream_t s) {
+  // the flat head buffers keep every tensor 16-byte aligned and their total a multiple of 4 elements (head_offsets)
+  if (n % 4 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15)) return fv_fail(FV_ERR_ARG, "axpy: buffers must be 16-byte aligned, n %% 4 == 0");
+  const unsigned nb = cdiv(n / 4, 256);
+  hipLaunchKernelGGL(axpy_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, y, x, (long)(n / 4), scale_dev);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

@@ -39,7 +39,14 @@ class ModelDesc(C.Structure):
 
 class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
-                ("shape", C.c_int64 * 4)]
+                ("shape", C.c_int64 * 4), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RcclId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+TENSOR_PROVIDER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(TensorDesc))
 
 
 class AdamWHParams(C.Structure):
@@ -64,6 +71,7 @@ _vp, _i, _f, _u64, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64
 SIGNATURES = {
     "fv_create": (_i, [C.POINTER(ModelDesc), _i, C.POINTER(_vp)]),
     "fv_load_weights": (_i, [_vp, C.POINTER(TensorDesc), _i]),
+    "fv_load_weights_cb": (_i, [_vp, TENSOR_PROVIDER, _vp]),
     "fv_destroy": (None, [_vp]),
     "fv_last_error": (C.c_char_p, [_vp]),
     "fv_version": (C.c_char_p, []),
@@ -71,12 +79,19 @@ SIGNATURES = {
     "fv_bind_workspace": (_i, [_vp, _vp, C.c_size_t]),
     "fv_preprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "fv_vision_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "fv_vision_forward_taps": (_i, [_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), _i, _vp]),
     "fv_llm_forward_pooled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fv_head_layout": (_i, [_vp, C.POINTER(_i64 * 13)]),
     "fv_head_saved_bytes": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
     "fv_head_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _u64, _u64, _vp, _vp, _vp]),
     "fv_head_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "fv_head_backward": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
+    "fv_grad_accumulate": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "fv_grad_scale": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "fv_comm_unique_id": (_i, [_vp, C.POINTER(RcclId)]),
+    "fv_comm_init": (_i, [_vp, C.POINTER(RcclId), _i, _i, C.POINTER(_vp)]),
+    "fv_comm_destroy": (_i, [_vp, _vp]),
+    "fv_allreduce_grads": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "fv_profile": (_i, [_vp, _i]),
     "fv_profile_read": (_i, [_vp, C.POINTER(ProfileEntry), C.POINTER(GemmProfile), _i, C.POINTER(_i)]),
     "fv_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(AdamWHParams), _i64, _vp, _vp]),
@@ -127,7 +142,7 @@ def load():
     return lib
 
 
-def check(rc: int, what: str = "") -> None:
+def check(rc: int, what: str = "", handle=None) -> None:
     if rc != 0:
-        msg = load().fv_last_error(None)
+        msg = load().fv_last_error(handle)
         raise FastVLAHipError(f"{what or 'libfastvla_hip'} failed (status {rc}): {msg.decode() if msg else '?'}")

@@ -102,6 +102,48 @@ class FastVLAEngine:
             _lib.check(self.lib.fv_load_weights(self.h, descs, len(state)), "fv_load_weights")
         self.loaded = True
 
+    def load_weights_streaming(self, provider) -> None:
+        """Pack the frozen weights pulling ONE tensor at a time: provider(name) -> torch.Tensor (f32 or bf16, on the CPU or on
+        this engine's device) or None when the checkpoint has no such key.  Nothing but the tensor being packed is alive on
+        the host side, and bf16 tensors are copied as they are (fv_load_weights_cb)."""
+        keep = {}
+
+        def cb(_user, name, out):
+            try:
+                t = provider(name.decode())
+            except Exception as exc:  # an exception must not unwind through the C frames
+                keep["exc"] = exc
+                return 1
+            if t is None:
+                return 1
+            t = t.detach()
+            if t.dtype not in (torch.float32, torch.bfloat16):
+                t = t.float()
+            if t.device.type == "cuda" and t.device != self.device:
+                t = t.to(self.device)
+            t = t.contiguous()
+            if t.ndim > 4:
+                keep["exc"] = ValueError(f"{name.decode()}: rank > 4")
+                return 1
+            keep["t"] = t  # alive until the next call
+            d = out.contents
+            d.data = t.data_ptr()
+            d.dtype = _lib.FV_F32 if t.dtype == torch.float32 else _lib.FV_BF16
+            d.ndim = max(t.ndim, 1)
+            for j, n in enumerate(t.shape if t.ndim else (1,)):
+                d.shape[j] = n
+            d.device = int(t.device.type == "cuda")
+            return 0
+
+        fn = _lib.TENSOR_PROVIDER(cb)
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            rc = self.lib.fv_load_weights_cb(self.h, fn, None)
+        if "exc" in keep:
+            raise keep["exc"]
+        _lib.check(rc, "fv_load_weights_cb", self.h)
+        self.loaded = True
+
     # ---------------------------------------------------------------- workspace
     def workspace_bytes(self, B: int, T: int, splice: bool) -> int:
         n = C.c_size_t()
@@ -143,6 +185,22 @@ class FastVLAEngine:
         _lib.check(self.lib.fv_vision_forward(self.h, pix.data_ptr(), B, tok.data_ptr(), _ptr(tout), _stream()),
                    "fv_vision_forward")
         return (tok, tout) if return_tower_out else tok
+
+    def vision_forward_taps(self, pix: torch.Tensor):
+        """-> (tokens f32, tower_out bf16, [stem, stage0, ...] NHWC bf16): per-stage activation maps for the parity tests."""
+        B = pix.shape[0]
+        t, l = self.model.tower, self.model.llm
+        self.ensure_workspace(B, 1, False)
+        tok = torch.empty(B, t.num_tokens, l.hidden, dtype=torch.float32, device=self.device)
+        tout = torch.empty(B, t.num_tokens, t.out_dim, dtype=torch.bfloat16, device=self.device)
+        side = t.image_size // 4
+        taps = [torch.empty(B, side, side, t.dims[0], dtype=torch.bfloat16, device=self.device)]
+        for i, c in enumerate(t.dims):
+            taps.append(torch.empty(B, side >> i, side >> i, c, dtype=torch.bfloat16, device=self.device))
+        arr = (C.c_void_p * len(taps))(*[x.data_ptr() for x in taps])
+        _lib.check(self.lib.fv_vision_forward_taps(self.h, pix.data_ptr(), B, tok.data_ptr(), tout.data_ptr(), arr, len(taps),
+                                                   _stream()), "fv_vision_forward_taps", self.h)
+        return tok, tout, taps
 
     def llm_pooled(self, ids: torch.Tensor, lens: torch.Tensor, img_tokens: Optional[torch.Tensor] = None,
                    pool_mode: int = 0) -> torch.Tensor:
@@ -245,6 +303,38 @@ class FastVLAEngine:
         _lib.check(self.lib.fv_head_backward(self.h, flat_params.data_ptr(), grad_actions.data_ptr(), B, float(dropout_p),
                                              saved.data_ptr(), flat_grads.data_ptr(), _stream()), "fv_head_backward")
         return flat_grads
+
+    def grad_accumulate(self, acc: torch.Tensor, grads: torch.Tensor) -> None:
+        """acc += grads (flat head buffers) on the current stream."""
+        _lib.check(self.lib.fv_grad_accumulate(self.h, acc.data_ptr(), grads.data_ptr(), acc.numel(), _stream()),
+                   "fv_grad_accumulate", self.h)
+
+    def grad_scale(self, grads: torch.Tensor, scale_dev: torch.Tensor) -> None:
+        """grads *= scale_dev[0] (a device scalar) on the current stream."""
+        _lib.check(self.lib.fv_grad_scale(self.h, grads.data_ptr(), grads.numel(), scale_dev.data_ptr(), _stream()),
+                   "fv_grad_scale", self.h)
+
+    # ---------------------------------------------------------------- RCCL without torch in between (fv_comm_*)
+    def comm_unique_id(self) -> bytes:
+        rid = _lib.RcclId()
+        _lib.check(self.lib.fv_comm_unique_id(self.h, C.byref(rid)), "fv_comm_unique_id", self.h)
+        return C.string_at(C.addressof(rid), 128)
+
+    def comm_init(self, uid: bytes, rank: int, world: int) -> int:
+        rid = _lib.RcclId()
+        C.memmove(C.addressof(rid), uid, 128)
+        comm = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fv_comm_init(self.h, C.byref(rid), rank, world, C.byref(comm)), "fv_comm_init", self.h)
+        return comm.value
+
+    def comm_destroy(self, comm: int) -> None:
+        _lib.check(self.lib.fv_comm_destroy(self.h, comm), "fv_comm_destroy", self.h)
+
+    def allreduce_grads(self, comm: int, flat_grads: torch.Tensor) -> None:
+        """one in-place sum all-reduce of the flat head gradient on the CURRENT torch stream (ncclAllReduce over xGMI)."""
+        _lib.check(self.lib.fv_allreduce_grads(self.h, comm, flat_grads.data_ptr(), flat_grads.numel(), _stream()),
+                   "fv_allreduce_grads", self.h)
 
     # ---------------------------------------------------------------- profiling (bench.py)
     def profile(self, enable: bool) -> None:

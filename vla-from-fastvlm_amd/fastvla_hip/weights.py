@@ -144,3 +144,55 @@ def init_backbone(model: ModelConfig, seed: int = 1234) -> Dict[str, torch.Tenso
     p = init_tower(model.tower, model.llm.hidden, gen)
     p.update(init_llm(model.llm, gen))
     return p
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Streaming form: one tensor at a time, generated where it is needed (FastVLAEngine.load_weights_streaming).
+# A 7B decoder is 7.6 G parameters -- 30 GB as an fp32 dict on the host; here each tensor is drawn from its OWN generator
+# (seeded by the run seed and the tensor's name) on the target device, in bf16 where the library stores bf16, so the
+# biggest live object is one weight matrix and any single tensor can be regenerated for the oracle by name.
+def _name_seed(seed: int, name: str) -> int:
+    import zlib
+    return (seed * 1_000_003 + zlib.crc32(name.encode())) & 0x7FFFFFFFFFFFFFFF
+
+
+def llm_tensor(cfg, name: str, seed: int = 1234, device="cpu", std: float = 0.02):
+    """One decoder tensor by checkpoint key (same distributions as init_llm); None for keys the decoder does not have."""
+    if not name.startswith(LLM):
+        return None
+    key = name[len(LLM):]
+    h, d = cfg.hidden, cfg.head_dim
+    shapes = {"embed_tokens.weight": (cfg.vocab, h), "norm.weight": (h,)}
+    if key.startswith("layers."):
+        _, idx, rest = key.split(".", 2)
+        if not idx.isdigit() or int(idx) >= cfg.layers:
+            return None
+        shapes = {"input_layernorm.weight": (h,), "post_attention_layernorm.weight": (h,),
+                  "self_attn.q_proj.weight": (cfg.heads * d, h), "self_attn.k_proj.weight": (cfg.kv_heads * d, h),
+                  "self_attn.v_proj.weight": (cfg.kv_heads * d, h), "self_attn.q_proj.bias": (cfg.heads * d,),
+                  "self_attn.k_proj.bias": (cfg.kv_heads * d,), "self_attn.v_proj.bias": (cfg.kv_heads * d,),
+                  "self_attn.o_proj.weight": (h, cfg.heads * d), "mlp.gate_proj.weight": (cfg.inter, h),
+                  "mlp.up_proj.weight": (cfg.inter, h), "mlp.down_proj.weight": (h, cfg.inter)}
+        key = rest
+    if key not in shapes:
+        return None
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(_name_seed(seed, name))
+    shape = shapes[key]
+    if key.endswith("norm.weight") or key.endswith("layernorm.weight"):
+        return 1.0 + torch.randn(shape, generator=g, device=dev) * 0.05
+    t = torch.randn(shape, generator=g, device=dev) * std
+    return t.to(torch.bfloat16) if len(shape) == 2 else t
+
+
+def stream_backbone(model: ModelConfig, seed: int = 1234, device="cpu"):
+    """provider(name) -> tensor for FastVLAEngine.load_weights_streaming: the tower + projector (125 M parameters) from
+    init_tower on the host, every decoder tensor drawn on `device` when asked for."""
+    tower = init_tower(model.tower, model.llm.hidden, torch.Generator().manual_seed(seed))
+
+    def provider(name: str):
+        if name in tower:
+            return tower[name]
+        return llm_tensor(model.llm, name, seed, device)
+
+    return provider
