@@ -87,6 +87,53 @@ def _mhsa(x, p, pre, cfg: TowerCfg):
     return o.transpose(1, 2).reshape(b, c, h, w)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16-faithful mode.  The product keeps tower activations in bf16 (fp32 accumulation inside every kernel) and rounds the
+# depthwise weights of its matrix-core depthwise kernels to bf16; the reference under its default
+# TrainingConfig.mixed_precision="bf16" (training/trainer.py:31) rounds at least as often.  Against the fp32 graph above
+# that is 2-3 % rel-L2 after 44 blocks at 1024^2 -- too loose to notice a wrong tap in one of 49 taps.  `emulate_bf16=True`
+# restates the SAME graph with a round-to-bf16 at exactly the points where the product's kernels round
+# (csrc/engine.hip tower_pass; one `_r` per tensor that reaches HBM or an MFMA operand), so the comparison isolates the
+# kernels' arithmetic from the precision policy.  Everything else (fp32 accumulation, exact-erf GELU, softmax) stays as is.
+def _r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _dw_mfma(map_w: int, c: int) -> bool:
+    """stride-1 depthwise layers the product runs on MFMA with bf16 Toeplitz tables (csrc/tower_kernels.hip
+    dwconv_mfma_supported): their weights are rounded to bf16; smaller maps use the fp32-weight VALU kernel."""
+    return map_w >= 32 and c % 32 == 0
+
+
+def _convffn_bf16(x, p, pre, cfg: TowerCfg):
+    """dw7x7 with the BatchNorm folded into weights/bias the way fv_load_weights folds it (csrc/engine.hip load_ffn), the
+    folded weights rounded to bf16 where the MFMA depthwise kernel serves the layer; t, the GELU'd hidden and nothing else
+    rounded (the second product's fp32 accumulator goes straight into the layer-scale + residual epilogue)."""
+    c, w = x.shape[1], x.shape[-1]
+    sc = p[pre + "conv.bn.weight"] / torch.sqrt(p[pre + "conv.bn.running_var"] + cfg.bn_eps)
+    wf = p[pre + "conv.conv.weight"] * sc.view(-1, 1, 1, 1)
+    bf = p[pre + "conv.bn.bias"] - p[pre + "conv.bn.running_mean"] * sc
+    t = _r(F.conv2d(x, _r(wf) if _dw_mfma(w, c) else wf, bf, padding=3, groups=c))
+    h = _r(gelu(_conv(t, p, pre + "fc1")))
+    return _conv(h, p, pre + "fc2")
+
+
+def _mhsa_bf16(x, p, pre, cfg: TowerCfg):
+    """attention32_kernel's rounding points: q/k/v bf16 (the qkv GEMM's output), scores and softmax in fp32, the
+    exponentiated P rounded to bf16 as the second product's operand with the row sum taken over the ROUNDED P, output bf16."""
+    b, c, h, w = x.shape
+    n = h * w
+    nh = c // cfg.head_dim
+    t = x.flatten(2).transpose(1, 2)
+    qkv = _r(F.linear(t, p[pre + "qkv.weight"])).reshape(b, n, 3, nh, cfg.head_dim).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    s = (q @ k.transpose(-2, -1)) * cfg.head_dim ** -0.5
+    pr = _r(torch.exp(s - s.amax(dim=-1, keepdim=True)))
+    o = _r((pr @ v) / pr.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(b, n, c)
+    o = F.linear(o, p[pre + "proj.weight"], p[pre + "proj.bias"])
+    return o.transpose(1, 2).reshape(b, c, h, w)
+
+
 def network_index_map(cfg: TowerCfg):
     """mci.py FastViT.__init__ ordering: [RepCPE?] stage [PatchEmbed] ...  -> list of (kind, stage)."""
     out = []
@@ -101,47 +148,62 @@ def network_index_map(cfg: TowerCfg):
 
 
 def tower_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: TowerCfg = TowerCfg(), prefix: str = VT,
-                  taps: dict | None = None) -> torch.Tensor:
-    """x: (B,3,S,S) fp32, S % 64 == 0  ->  image embeddings (B, (S/64)^2, out_dim)."""
+                  taps: dict | None = None, emulate_bf16: bool = False) -> torch.Tensor:
+    """x: (B,3,S,S) fp32, S % 64 == 0  ->  image embeddings (B, (S/64)^2, out_dim).
+    emulate_bf16: the same graph with the product's bf16 rounding points (see the block comment above)."""
     q = {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
+    R = _r if emulate_bf16 else (lambda t: t)
     c0 = cfg.dims[0]
-    x = gelu(_conv(x, q, "patch_embed.0.reparam_conv", stride=2, padding=1))
+    w0 = q["patch_embed.0.reparam_conv.weight"]
+    if emulate_bf16 and c0 % 16 == 0 and c0 <= 128:   # the implicit-GEMM stem packs its weights as bf16 MFMA operands
+        w0 = _r(w0)
+    x = R(gelu(F.conv2d(x, w0, q["patch_embed.0.reparam_conv.bias"], stride=2, padding=1)))
     if taps is not None:
         taps["stem0"] = x
-    x = gelu(_conv(x, q, "patch_embed.1.reparam_conv", stride=2, padding=1, groups=c0))
-    x = gelu(_conv(x, q, "patch_embed.2.reparam_conv"))
+    x = R(gelu(_conv(x, q, "patch_embed.1.reparam_conv", stride=2, padding=1, groups=c0)))
+    x = R(gelu(_conv(x, q, "patch_embed.2.reparam_conv")))
     if taps is not None:
         taps["stem"] = x
     for idx, (kind, i) in enumerate(network_index_map(cfg)):
         c = cfg.dims[i]
+        mw = x.shape[-1]
         if kind == "cpe":
-            x = _conv(x, q, f"network.{idx}.reparam_conv", padding=3, groups=c)
+            wc = q[f"network.{idx}.reparam_conv.weight"]
+            x = R(F.conv2d(x, _r(wc) if emulate_bf16 and _dw_mfma(mw, c) else wc, q[f"network.{idx}.reparam_conv.bias"], padding=3, groups=c))
         elif kind == "down":
-            x = gelu(_conv(x, q, f"network.{idx}.proj.0.lkb_reparam", stride=2, padding=3, groups=c))
-            x = gelu(_conv(x, q, f"network.{idx}.proj.1.reparam_conv"))
+            wl = q[f"network.{idx}.proj.0.lkb_reparam.weight"]
+            if emulate_bf16 and c % 32 == 0 and mw % 2 == 0 and mw >= 16:   # dwconv_s2_mfma_supported
+                wl = _r(wl)
+            x = R(gelu(F.conv2d(x, wl, q[f"network.{idx}.proj.0.lkb_reparam.bias"], stride=2, padding=3, groups=c)))
+            x = R(gelu(_conv(x, q, f"network.{idx}.proj.1.reparam_conv")))
         else:
             for j in range(cfg.layers[i]):
                 pre = f"network.{idx}.{j}."
+                ffn = _convffn_bf16 if emulate_bf16 else _convffn
                 if i in cfg.attn_stages:
-                    y = _layernorm_channel(x, q[pre + "norm.weight"], q[pre + "norm.bias"], cfg.ln_eps)
-                    x = x + q[pre + "layer_scale_1"].view(1, -1, 1, 1) * _mhsa(y, q, pre + "token_mixer.", cfg)
-                    x = x + q[pre + "layer_scale_2"].view(1, -1, 1, 1) * _convffn(x, q, pre + "convffn.", cfg)
+                    y = R(_layernorm_channel(x, q[pre + "norm.weight"], q[pre + "norm.bias"], cfg.ln_eps))
+                    att = (_mhsa_bf16 if emulate_bf16 else _mhsa)(y, q, pre + "token_mixer.", cfg)
+                    x = R(x + q[pre + "layer_scale_1"].view(1, -1, 1, 1) * att)
+                    x = R(x + q[pre + "layer_scale_2"].view(1, -1, 1, 1) * ffn(x, q, pre + "convffn.", cfg))
                 else:
-                    x = _conv(x, q, pre + "token_mixer.reparam_conv", padding=1, groups=c)
-                    x = x + q[pre + "layer_scale"].view(1, -1, 1, 1) * _convffn(x, q, pre + "convffn.", cfg)
+                    wm = q[pre + "token_mixer.reparam_conv.weight"]
+                    x = R(F.conv2d(x, _r(wm) if emulate_bf16 and _dw_mfma(mw, c) else wm, q[pre + "token_mixer.reparam_conv.bias"], padding=1, groups=c))
+                    x = R(x + q[pre + "layer_scale"].view(1, -1, 1, 1) * ffn(x, q, pre + "convffn.", cfg))
             if taps is not None:
                 taps[f"stage{i}"] = x
     c = cfg.dims[-1]
-    x = _conv(x, q, "conv_exp.reparam_conv", padding=1, groups=c)
+    x = R(_conv(x, q, "conv_exp.reparam_conv", padding=1, groups=c))
     s = x.mean(dim=(2, 3), keepdim=True)
     s = F.relu(_conv(s, q, "conv_exp.se.reduce"))
     s = torch.sigmoid(_conv(s, q, "conv_exp.se.expand"))
-    x = gelu(x * s)
+    x = R(gelu(x * s))
     return x.flatten(2).transpose(1, 2).contiguous()
 
 
-def projector_forward(p: Dict[str, torch.Tensor], tokens: torch.Tensor, prefix: str = PROJ) -> torch.Tensor:
+def projector_forward(p: Dict[str, torch.Tensor], tokens: torch.Tensor, prefix: str = PROJ, emulate_bf16: bool = False) -> torch.Tensor:
     h = gelu(F.linear(tokens, p[prefix + "0.weight"], p[prefix + "0.bias"]))
+    if emulate_bf16:  # the hidden is the second GEMM's bf16 operand; the output stays fp32 (FV_EPI_F32)
+        h = _r(h)
     return F.linear(h, p[prefix + "2.weight"], p[prefix + "2.bias"])
 
 

@@ -54,14 +54,17 @@ def last_timestep(x: torch.Tensor, base_ndim: int) -> torch.Tensor:
 def backbone_features(params: Dict[str, torch.Tensor], images: torch.Tensor, input_ids: torch.Tensor,
                       attention_mask: torch.Tensor, *, image_size: int, llm_cfg: qwen2.Qwen2Cfg,
                       tower_cfg: fastvit_hd.TowerCfg = fastvit_hd.TowerCfg(), splice: bool = False,
-                      pad_value: float = 0.0, run_tower: bool = True, pool: str = "last_token"):
+                      pad_value: float = 0.0, run_tower: bool = True, pool: str = "last_token",
+                      emulate_bf16_tower: bool = False):
     """-> (pooled (B,H), image_tokens or None).  With splice=False the tower/projector output is computed and then
     dropped, exactly what the literal reference does."""
     img_tok = None
     if run_tower or splice:
         pix = preprocess.letterbox(images, image_size, pad_value)
-        emb = fastvit_hd.tower_forward(params, pix, tower_cfg)
-        img_tok = fastvit_hd.projector_forward(params, emb)
+        if emulate_bf16_tower:  # the product's precision policy for the tower (oracle/fastvit_hd.py, bf16-faithful mode)
+            pix = fastvit_hd._r(pix)
+        emb = fastvit_hd.tower_forward(params, pix, tower_cfg, emulate_bf16=emulate_bf16_tower)
+        img_tok = fastvit_hd.projector_forward(params, emb, emulate_bf16=emulate_bf16_tower)
     pooled = qwen2.llm_pooled(params, input_ids, attention_mask, llm_cfg, img_tok, splice=splice, pool=pool)
     return pooled, img_tok
 

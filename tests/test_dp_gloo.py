@@ -89,3 +89,58 @@ def test_single_process_is_a_noop():
     from vla_fastvlm.training.dp import allreduce_flat_grads, world_size
     g = torch.ones(5)
     assert world_size() == 1 and allreduce_flat_grads(g) == 1.0 and torch.equal(g, torch.ones(5))
+
+
+# ------------------------------------------------------------------------------------------------ round 2 additions
+def _worker_replicas(rank, world, port, out):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for p_ in (str(root), str(root / "vla-from-fastvlm_amd")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    from vla_fastvlm.training.dp import GradExchange, broadcast_flat, shard_batches
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    # ranks are seeded DIFFERENTLY (the caller builds the model before any seed is set): the broadcast makes them equal
+    torch.manual_seed(100 + rank)
+    p, feats, states, tgt = _setup()
+    flat = _flat({k: torch.randn_like(v) for k, v in p.items()})
+    before = flat.clone()
+    broadcast_flat(flat, src=0)
+    # 5 batches on 2 ranks: both ranks must run exactly 2 steps (the ragged 5th batch is dropped), never 3 vs 2
+    mine = list(shard_batches(range(5), rank, world))
+    assert mine == [rank, 2 + rank], mine
+    ex = GradExchange(None)  # CPU: synchronous collective behind the same start()/finish() protocol
+    keys = head.HEAD_KEYS
+    sizes = [p[k].numel() for k in keys]
+    for step, b in enumerate(mine, 1):
+        cur = {k: v.view_as(p[k]) for k, v in zip(keys, flat.split(sizes))}
+        sl = slice(4 * (b % 2), 4 * (b % 2) + 4)
+        pred, cache = head.head_forward(cur, feats[sl], states[sl], keep_cache=True)
+        _, grads = head.head_mse_backward(cur, cache, pred, tgt[sl])
+        g = _flat(grads)
+        scale = ex.start(g)
+        ex.finish()
+        flat = flat - 0.1 * scale * g  # any deterministic update of the reduced gradient
+    out[rank] = (before, flat.clone())
+    dist.destroy_process_group()
+
+
+def test_replicas_start_equal_and_stay_equal():
+    """only the gradient is exchanged, so rank 0's parameters must be broadcast first; and every rank must run
+    the same number of steps or the all-reduces stop pairing up."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_replicas, args=(2, port, out), nprocs=2, join=True)
+    assert not torch.equal(out[0][0], out[1][0])   # the ranks really started from different parameters
+    assert torch.equal(out[0][1], out[1][1])       # ... and are bit-identical after N steps
+
+
+def test_shard_batches_single_rank_and_generators():
+    from vla_fastvlm.training.dp import shard_batches
+    assert list(shard_batches(iter(range(4)), 0, 1)) == [0, 1, 2, 3]
+    gen = (i for i in range(7))                    # no __len__: the lock-step protocol needs none
+    assert list(shard_batches(gen, 2, 3)) == [2, 5]

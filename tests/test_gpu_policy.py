@@ -159,3 +159,120 @@ def test_prompt_feature_cache_matches_uncached():
     bb.cache_prompt_features = False
     bb.skip_unused_tower = False
     assert torch.equal(bb.forward_ids(images, ids2, mask), mixed)
+
+
+# ------------------------------------------------------------------------------------------------ round 2: step body
+def _dev(batch):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def _fresh(seed=31, dropout=0.0):
+    torch.manual_seed(seed)
+    return FastVLAPolicy(FastVLAConfig(vlm_model_name="synthetic:tiny:77", hidden_dim=48, fusion_dim=64, dropout=dropout)).to(DEV)
+
+
+def _half(batch, lo, hi):
+    return {k: (v[lo:hi] if torch.is_tensor(v) else v[lo:hi]) for k, v in batch.items()}
+
+
+def test_loss_scaled_backward_matches_scaled_gradients(pol):
+    """the upstream dL/dloss (e.g. a loss weight, or accelerate's 1/accumulation) reaches the head gradients: fv_grad_scale"""
+    batch = _dev(_batch())
+    pol.train()
+    pol.zero_grad()
+    pol.compute_loss(batch)["loss"].backward()
+    g1 = [p.grad.detach().clone() for p in pol.model.head_parameters()]
+    pol.zero_grad()
+    (0.25 * pol.compute_loss(batch)["loss"]).backward()
+    torch.cuda.synchronize()
+    for a, p in zip(g1, pol.model.head_parameters()):
+        assert torch.allclose(p.grad, 0.25 * a, rtol=1e-6, atol=1e-9)
+    pol.zero_grad()
+    with torch.no_grad():  # evaluation path: no graph, same number
+        out = pol.compute_loss(batch)
+    assert not out["loss"].requires_grad and torch.isfinite(out["loss"])
+
+
+def test_gradient_accumulation_equals_full_batch():
+    """reference training/trainer.py:96,171: k micro-batches accumulated (mean of the micro-batch gradients) then ONE
+    clip + AdamW step == the step on the concatenated batch (equal micro-batch sizes, MSE is a mean)."""
+    batch = _batch(B=4 if False else 3)
+    batch = {"images": torch.cat([batch["images"], batch["images"][:1]]), "states": torch.cat([batch["states"], batch["states"][:1]]),
+             "actions": torch.cat([batch["actions"], -batch["actions"][:1]]), "tasks": batch["tasks"] + ["again"]}
+    kw = dict(lr=3e-4, weight_decay=0.01, max_grad_norm=1.0)
+    a, b = _fresh(), _fresh()
+    a.train(), b.train()
+    full = a.fused_train_step(_dev(batch), **kw)
+    o1 = b.fused_train_step(_dev(_half(batch, 0, 2)), grad_accum_steps=2, **kw)
+    before = b.model._flat.clone()
+    assert not o1["synced"] and torch.equal(before, b.model.materialize())  # no update on the first micro-batch
+    o2 = b.fused_train_step(_dev(_half(batch, 2, 4)), grad_accum_steps=2, **kw)
+    torch.cuda.synchronize()
+    assert full["synced"] and o2["synced"]
+    assert abs(float(full["grad_norm"]) - float(o2["grad_norm"])) <= 2e-5 * float(full["grad_norm"])
+    assert float((a.model._flat - b.model._flat).abs().max()) <= 2e-6
+    assert abs(0.5 * (float(o1["loss"]) + float(o2["loss"])) - float(full["loss"])) <= 1e-5 * abs(float(full["loss"]))
+    # a ragged tail: force_sync applies the update with accelerate's fixed 1/k scale
+    o3 = b.fused_train_step(_dev(_half(batch, 0, 2)), grad_accum_steps=2, force_sync=True, **kw)
+    assert o3["synced"] and b._opt_state["step"] == 2 and b._opt_state["micro"] == 0
+
+
+def test_pipelined_steps_equal_serial_steps():
+    """the look-ahead loop (batch k+1's frozen forward enqueued before the optimiser waits on batch k's exchange) changes the
+    order of independent work only: parameters after 3 steps are bit-identical to the serial loop."""
+    batches = [_dev(_half(_batch(), i, i + 2)) for i in (0, 1)] + [_dev(_batch())]
+    kw = dict(lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    a, b = _fresh(41, 0.1), _fresh(41, 0.1)
+    a.train(), b.train()
+    for bt in batches:
+        a.fused_train_step(bt, **kw)
+    prepared = None
+    for i, bt in enumerate(batches):
+        nxt = batches[i + 1] if i + 1 < len(batches) else None
+        out = b.fused_train_step(bt if prepared is None else None, prepared=prepared, next_batch=nxt, **kw)
+        prepared = out["next"]
+    torch.cuda.synchronize()
+    assert prepared is None and torch.equal(a.model._flat, b.model._flat)
+
+
+def test_trainer_resume_restores_optimizer_state(tmp_path):
+    """save -> load -> one step == uninterrupted training (AdamW moments, bias-correction step and the LR index
+    come back; reference trainer.py:257-262 restores them through accelerator.load_state)."""
+    from vla_fastvlm.training import Trainer, TrainingConfig
+    data = [_half(_batch(), 0, 2), _half(_batch(), 1, 3), _batch(), _half(_batch(), 0, 2)]
+    cfg = dict(num_epochs=1, learning_rate=1e-3, warmup_ratio=0.5, logging_steps=1000, eval_steps=1000, seed=1)
+    a = _fresh(51)
+    Trainer(a, data, None, TrainingConfig(output_dir=str(tmp_path / "a"), save_steps=1000, max_steps=4, **cfg)).fit()
+    b = _fresh(51)
+    tb = Trainer(b, data[:3], None, TrainingConfig(output_dir=str(tmp_path / "b"), save_steps=3, max_steps=4, **cfg))
+    tb.num_training_steps = 4
+    tb.fit()
+    ck = tmp_path / "b" / "checkpoints" / "step-3"
+    assert (ck / "optimizer.pt").is_file() and (ck / "policy_state_dict.pt").is_file()
+    c = _fresh(99)  # different init: everything must come from the checkpoint
+    tc = Trainer(c, data[3:], None, TrainingConfig(output_dir=str(tmp_path / "c"), save_steps=1000, max_steps=4, resume_from=str(ck), **cfg))
+    tc.fit()
+    torch.cuda.synchronize()
+    assert tc.update_step == 4 and c._opt_state["step"] == 4
+    assert float((a.model._flat - c.model._flat).abs().max()) <= 1e-7
+
+
+def test_last_error_is_per_handle_and_comm_world1():
+    from fastvla_hip import FastVLAEngine, _lib
+    m = arch.preset("tiny")
+    e1 = FastVLAEngine(m, hidden_dim=32, fusion_dim=32, max_batch=2, max_text_tokens=8)
+    e2 = FastVLAEngine(m, hidden_dim=32, fusion_dim=32, max_batch=2, max_text_tokens=8)
+    lib = e1.lib
+    assert lib.fv_workspace_bytes(e1.h, -1, 4, 0, None) != 0          # error on handle 1
+    assert lib.fv_bind_workspace(e2.h, 12345, 64) != 0                # a different error on handle 2
+    m1, m2 = lib.fv_last_error(e1.h).decode(), lib.fv_last_error(e2.h).decode()
+    assert "fv_workspace_bytes" in m1 and "aligned" in m2 and m1 != m2
+    # RCCL entry points: a one-rank communicator on this GPU, all-reduce is the identity
+    uid = e1.comm_unique_id()
+    comm = e1.comm_init(uid, 0, 1)
+    g = torch.arange(16, dtype=torch.float32, device=DEV)
+    e1.allreduce_grads(comm, g)
+    torch.cuda.synchronize()
+    assert torch.equal(g.cpu(), torch.arange(16, dtype=torch.float32))
+    e1.comm_destroy(comm)
+    e1.close(), e2.close()

@@ -155,7 +155,7 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(v, again.state_dict()[k])
 
 
-def test_hf_checkpoint_directory_is_resolved(tmp_path):
+def test_hf_checkpoint_directory_is_resolved(tmp_path, monkeypatch):
     """A local llava_qwen2 directory (config.json + safetensors with canonical inference-form keys) -> architecture and
     tensors for fv_load_weights; lm_head is dropped."""
     from safetensors.torch import save_file
@@ -178,5 +178,28 @@ def test_hf_checkpoint_directory_is_resolved(tmp_path):
     loaded = load_hf_checkpoint_dir(d)
     assert "lm_head.weight" not in loaded and set(loaded) == set(state) - {"lm_head.weight"}
     assert torch.equal(loaded["model.norm.weight"], state["model.norm.weight"])
-    bb = FastVLMBackbone(FastVLMBackboneConfig(model_id=str(d)))
+    monkeypatch.setenv("FASTVLA_SYNTHETIC_TOKENIZER", "1")  # this directory ships no tokenizer files (next test: that raises)
+    with pytest.warns(UserWarning):
+        bb = FastVLMBackbone(FastVLMBackboneConfig(model_id=str(d)))
     assert bb.output_dim == m.llm.hidden and bb.expected_size == 1024 and bb._weights_source[0] == "hf_dir"
+
+
+def test_real_checkpoint_without_tokenizer_raises(tmp_path, monkeypatch):
+    """a real checkpoint whose tokenizer files are missing must raise (reference fastvlm_adapter.py:366-367),
+    not run on hashed ids; only synthetic weights (or an explicit opt-in) get the SyntheticTokenizer."""
+    import json
+    from vla_fastvlm.model.fastvlm_adapter import FastVLMBackbone, FastVLMBackboneConfig
+    d = tmp_path / "llava-fastvithd_0.5b_stage3"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(dict(model_type="llava_qwen2", hidden_size=896, num_hidden_layers=24, num_attention_heads=14,
+                                                   num_key_value_heads=2, intermediate_size=4864, vocab_size=151936,
+                                                   mm_vision_tower="mobileclip_l_1024")))
+    (d / "model.safetensors").write_bytes(b"")
+    monkeypatch.delenv("FASTVLA_SYNTHETIC_TOKENIZER", raising=False)
+    with pytest.raises(RuntimeError, match="Tokenizer is missing"):
+        FastVLMBackbone(FastVLMBackboneConfig(model_id=str(d)))
+    monkeypatch.setenv("FASTVLA_SYNTHETIC_TOKENIZER", "1")
+    with pytest.warns(UserWarning, match="SyntheticTokenizer"):
+        bb = FastVLMBackbone(FastVLMBackboneConfig(model_id=str(d)))
+    assert isinstance(bb.tokenizer, SyntheticTokenizer)
+    assert isinstance(FastVLMBackbone(FastVLMBackboneConfig(model_id="synthetic:tiny")).tokenizer, SyntheticTokenizer)

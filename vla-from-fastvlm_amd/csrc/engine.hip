@@ -570,7 +570,7 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   int rc = dev_alloc(h, cs.size() * 4, &p);
   if (rc == FV_OK && hipMemcpy(p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fv_fail(FV_ERR_HIP, "rope table upload failed");
   h->rope = static_cast<float2*>(p);
-  if (rc == FV_OK) { rc = dev_alloc(h, 64, &p); h->norm_scratch = static_cast<float*>(p); }
+  if (rc == FV_OK) { rc = dev_alloc(h, fv::adamw_scratch_bytes(), &p); h->norm_scratch = static_cast<float*>(p); }
   if (rc != FV_OK) { fv_destroy(h); return rc; }
   *out = h;
   return FV_OK;

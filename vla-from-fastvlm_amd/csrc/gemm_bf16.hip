@@ -518,6 +518,9 @@ __global__ __launch_bounds__(256, C == 96 ? 3 : 1) void pwconv_kernel(Params p) 
 int gemm_glds_tile(const GemmArgs& a) {
   static const bool off = getenv("FASTVLA_NO_GEMM256") != nullptr;
   if (off || a.K % 64 || a.K < 128) return 0;
+  // gemm256_kernel keeps per-lane source byte offsets in 32 bits ((row * lda) * 2 for A, (row * K) * 2 for W): operands of
+  // 4 GiB or more go to the register-staged kernel, which addresses with size_t
+  if ((size_t)a.M * a.lda * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return 0;
   const bool f32 = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
   if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT && !f32) return 0;
   if (a.epi == FV_EPI_SWIGLU_SPLIT && a.bias) return 0;
@@ -563,7 +566,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   }
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
   static const bool no_splitk = getenv("FASTVLA_NO_SPLITK") != nullptr;
-  if (!no_splitk && a.splitk_ws && f32out && !getenv("FASTVLA_NO_GEMM256") && a.M % 256 == 0 && a.K % 64 == 0 && a.N % 4 == 0) {
+  if (!no_splitk && a.splitk_ws && f32out && !getenv("FASTVLA_NO_GEMM256") && a.M % 256 == 0 && a.K % 64 == 0 && a.N % 4 == 0 &&
+      (size_t)a.M * a.lda * 2 < ((size_t)1 << 32) && (size_t)a.N * a.K * 2 < ((size_t)1 << 32)) {
     const int tn = (a.N + 255) / 256, tiles = (a.M / 256) * tn, nkt = (a.ksplit ? 2 : 1) * (a.K / 64);
     int splits = tiles < cus ? cus / tiles : 1;
     if (splits > 8) splits = 8;

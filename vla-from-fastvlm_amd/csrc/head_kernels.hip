@@ -203,14 +203,27 @@ __global__ __launch_bounds__(256) void ln_bwd_cols_kernel(const float* __restric
 }
 
 // ---- AdamW + clip ----
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+// Global gradient norm in a FIXED summation order (per-block partials, then one block folds them): float atomics would make
+// the norm -- and through the clip coefficient every parameter -- depend on arrival order, so two data-parallel replicas
+// (or two runs) would drift apart by an ulp per step.
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
   __shared__ float red[4];
   float s = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(float* __restrict__ partial, int nb) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[1 + i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -284,6 +297,8 @@ Saved carve(const HeadDims& d, int B, float* base) {
   return s;
 }
 }  // namespace
+
+size_t adamw_scratch_bytes() { return (size_t)(SUMSQ_BLOCKS + 4) * sizeof(float); }
 
 size_t head_saved_bytes(const HeadDims& d, int B) { return carve(d, B, nullptr).total * sizeof(float); }
 
@@ -375,9 +390,10 @@ int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, c
                       int64_t step, float* norm_scratch, float* grad_norm_out, hipStream_t s) {
   if (!p || !g || !m || !v || !norm_scratch) return fv_fail(FV_ERR_ARG, "adamw: null pointer");
   if (n <= 0 || step < 1) return fv_fail(FV_ERR_ARG, "adamw: n and step must be positive");
-  FV_HIP_CHECK(hipMemsetAsync(norm_scratch, 0, 16, s));
   const unsigned nb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, g, (long)n, norm_scratch);
+  const unsigned nsb = nb < (unsigned)SUMSQ_BLOCKS ? nb : (unsigned)SUMSQ_BLOCKS;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nsb), dim3(256), 0, s, g, (long)n, norm_scratch);
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, s, norm_scratch, (int)nsb);
   const float bc1 = (float)(1.0 - pow((double)hp.beta1, (double)step));
   const float bc2 = (float)sqrt(1.0 - pow((double)hp.beta2, (double)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, s, p, g, m, v, (long)n, hp, bc1, bc2, norm_scratch, grad_norm_out);

@@ -96,6 +96,7 @@ int launch_head_backward(const HeadDims& d, const float* P, const float* grad_ac
                          const float* targets, int B, float drop_p, const float* saved, float* loss, float* G,
                          float* scratch, hipStream_t s);
 size_t head_bwd_scratch_bytes(const HeadDims& d, int B);
+size_t adamw_scratch_bytes();  // norm_scratch of launch_adamw_clip: [0] = sum of squares, [1..] per-block partials
 int launch_axpy(float* y, const float* x, int64_t n, const float* scale_dev, hipStream_t s);  // y += x, or y *= *scale_dev when x is null
 int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const fv_adamw_hparams& hp,
                       int64_t step, float* norm_scratch, float* grad_norm_out, hipStream_t s);

@@ -40,6 +40,32 @@ class _HeadFunction(torch.autograd.Function):
         return (None, None, None, None) + tuple(views[k] for k in HEAD_KEYS)
 
 
+class _HeadLossFunction(torch.autograd.Function):
+    """(loss, actions) = (mse(head(pooled, states), targets), head(...)) with the head forward, the MSE and the head
+    backward all inside libfastvla_hip.so (fv_head_forward + fv_head_mse_backward): what the reference spells as
+    `F.mse_loss(pred, target)` + autograd (fastvla/modeling_fastvla.py:56, lerobot_fastvla/modeling_fastvla.py:132).
+    backward() only scales the flat gradient by the incoming dL/dloss (fv_grad_scale) and hands out views of it."""
+
+    @staticmethod
+    def forward(ctx, owner, pooled, states, targets, training, *params):
+        eng, flat = owner._engine(), owner._flat
+        p = float(owner.config.dropout) if training else 0.0
+        owner._drop_calls += 1
+        actions, saved = eng.head_forward(flat, pooled, states, training=bool(training and p > 0.0), dropout_p=p,
+                                          seed=owner._drop_seed, offset=owner._drop_calls)
+        loss, grads = eng.head_backward(flat, actions, targets, saved, dropout_p=p)
+        ctx.owner, ctx.grads = owner, grads
+        ctx.mark_non_differentiable(actions)
+        return loss[0], actions
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_actions):
+        eng = ctx.owner._engine()
+        eng.grad_scale(ctx.grads, grad_loss.reshape(1).to(ctx.grads.device, torch.float32).contiguous())
+        views = eng.head_views(ctx.grads)
+        return (None, None, None, None, None) + tuple(views[k] for k in HEAD_KEYS)
+
+
 class FastVLMWithExpert(nn.Module):
     def __init__(self, config: FastVLAConfig) -> None:
         super().__init__()
@@ -102,7 +128,25 @@ class FastVLMWithExpert(nn.Module):
             raise ValueError(f"states must be (B,{self.config.state_dim}), got {tuple(states.shape)}")
         return _HeadFunction.apply(self, pooled, states, self.training, *self.head_parameters())
 
+    def head_loss(self, pooled: torch.Tensor, states: torch.Tensor, targets: torch.Tensor):
+        """-> (loss 0-dim, actions): MSE of the head's prediction against `targets`, differentiable w.r.t. the 12 head
+        tensors, with no torch operator between the pooled feature and the loss."""
+        self.materialize(pooled.device)
+        states = states.to(pooled.device, torch.float32)
+        targets = targets.to(pooled.device, torch.float32).contiguous()
+        if states.ndim != 2 or states.shape[1] != self.config.state_dim:
+            raise ValueError(f"states must be (B,{self.config.state_dim}), got {tuple(states.shape)}")
+        if targets.shape != (pooled.shape[0], self.config.action_dim):
+            raise ValueError(f"targets must be (B,{self.config.action_dim}), got {tuple(targets.shape)}")
+        return _HeadLossFunction.apply(self, pooled, states, targets, self.training, *self.head_parameters())
+
     def forward(self, images: torch.Tensor, states: torch.Tensor, tasks: List[str], device: torch.device | None = None) -> torch.Tensor:
         if device is None:
             device = images.device
         return self.head(self.features(images, tasks, device=device), states)
+
+    def forward_loss(self, images, states, tasks: List[str], targets: torch.Tensor, device: torch.device | None = None):
+        """-> (loss, actions) for `compute_loss` / the LeRobot `forward(batch)`."""
+        if device is None:
+            device = images.device
+        return self.head_loss(self.features(images, tasks, device=device), states, targets)

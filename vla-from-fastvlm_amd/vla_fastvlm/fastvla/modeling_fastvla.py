@@ -8,7 +8,6 @@ from typing import Dict, List, Optional
 
 import torch
 from torch import nn
-from torch.nn import functional as F
 
 from .configuration_fastvla import FastVLAConfig
 from .fastvlm_with_expert import FastVLMWithExpert
@@ -36,8 +35,17 @@ class FastVLAPolicy(nn.Module):
         return self.model(images, states, tasks, device=device)
 
     def compute_loss(self, batch: Dict[str, torch.Tensor | List[str]]) -> Dict[str, torch.Tensor]:
-        pred = self.forward(batch["images"], batch["states"], batch["tasks"])
-        mse = F.mse_loss(pred, batch["actions"].to(pred.device, pred.dtype))
+        """reference fastvla/modeling_fastvla.py:52-57: {"loss": mse (differentiable w.r.t. the head), "mse": detached}.
+        Head forward, MSE and the head gradients come from one pass through the library (no torch operator in between)."""
+        images, states, tasks = batch["images"], batch["states"], batch["tasks"]
+        device = images.device
+        images = self.processor.prepare_images(images, device)
+        states = self.processor.prepare_states(states, device)
+        tasks = self.processor.prepare_tasks(tasks, batch_size=images.shape[0])
+        targets = batch["actions"]
+        if targets.ndim == 3:
+            targets = targets[:, 0]
+        mse, _pred = self.model.forward_loss(images, states, tasks, targets, device=device)
         return {"loss": mse, "mse": mse.detach()}
 
     @torch.inference_mode()
@@ -51,13 +59,10 @@ class FastVLAPolicy(nn.Module):
         return
 
     # ------------------------------------------------------------------ native train step
-    def fused_train_step(self, batch: Dict[str, torch.Tensor | List[str]], *, lr: float, betas=(0.9, 0.95), eps: float = 1e-8,
-                         weight_decay: float = 1e-4, max_grad_norm: Optional[float] = 1.0,
-                         process_group=None) -> Dict[str, torch.Tensor]:
-        """One optimiser step with the ordering of reference training/trainer.py:171-182 (loss -> backward -> clip ->
-        AdamW), entirely on the HIP path.  Under torch.distributed the flat head gradient is summed across ranks with
-        ONE all-reduce on a side stream and the 1/world scale is folded into the optimiser kernel."""
-        from ..training.dp import allreduce_flat_grads
+    def prepare_batch(self, batch: Dict[str, torch.Tensor | List[str]]) -> Dict[str, torch.Tensor]:
+        """Everything of a train step that does NOT depend on the trainable parameters: image prep, tokenisation and the
+        frozen backbone forward (reference model/fastvlm_adapter.py:501: no_grad, frozen) -> pooled features.  Enqueued on
+        the current stream; a pipelined loop calls it for batch k+1 while batch k's gradient all-reduce is in flight."""
         m = self.model
         dev = m.backbone.engine().device
         images = self.processor.prepare_images(batch["images"], dev)
@@ -66,20 +71,85 @@ class FastVLAPolicy(nn.Module):
         targets = batch["actions"].to(dev, torch.float32)
         if targets.ndim == 3:
             targets = targets[:, 0]
-        eng, flat = m._engine(), m.materialize(dev)
         with torch.no_grad():
             pooled = m.features(images, tasks, device=dev)
-        if self._opt_state is None or self._opt_state["m"].data_ptr() == 0 or self._opt_state["flat"] is not flat:
-            self._opt_state = dict(m=torch.zeros_like(flat), v=torch.zeros_like(flat), g=torch.zeros_like(flat), step=0,
-                                   flat=flat, comm=torch.cuda.Stream(device=dev), norm=torch.zeros(1, device=dev))
+        return {"pooled": pooled, "states": states, "targets": targets.contiguous()}
+
+    def _optimizer_state(self, flat: torch.Tensor) -> Dict:
         st = self._opt_state
-        st["step"] += 1
+        if st is None or st.get("flat") is not flat:
+            from ..training.dp import GradExchange
+            dev = flat.device
+            keep = st or {}
+            st = dict(m=torch.zeros_like(flat), v=torch.zeros_like(flat), g=torch.zeros_like(flat), acc=None, step=0, micro=0,
+                      flat=flat, exchange=GradExchange(dev), norm=torch.zeros(1, device=dev), loss=torch.zeros(1, device=dev))
+            if "resume" in keep:  # load_optimizer_state() ran before the flat buffer existed
+                r = keep["resume"]
+                st["m"].copy_(r["m"].to(dev))
+                st["v"].copy_(r["v"].to(dev))
+                st["step"] = int(r["step"])
+            self._opt_state = st
+        return st
+
+    def load_optimizer_state(self, m: torch.Tensor, v: torch.Tensor, step: int) -> None:
+        """Restore AdamW moments and the bias-correction step (Trainer._load_checkpoint; reference trainer.py:257-262
+        restores them through accelerator.load_state)."""
+        flat = self.model._flat
+        if flat is None:
+            self._opt_state = {"resume": {"m": m, "v": v, "step": int(step)}}
+            return
+        st = self._optimizer_state(flat)
+        st["m"].copy_(m.to(flat.device))
+        st["v"].copy_(v.to(flat.device))
+        st["step"] = int(step)
+
+    def fused_train_step(self, batch: Optional[Dict] = None, *, lr: float, betas=(0.9, 0.95), eps: float = 1e-8,
+                         weight_decay: float = 1e-4, max_grad_norm: Optional[float] = 1.0, process_group=None,
+                         prepared: Optional[Dict] = None, next_batch: Optional[Dict] = None,
+                         grad_accum_steps: int = 1, force_sync: bool = False) -> Dict[str, torch.Tensor]:
+        """One pass of the step body of reference training/trainer.py:171-182 (loss -> backward -> [accumulate] -> clip ->
+        AdamW), entirely on the HIP path.
+
+        * grad_accum_steps = k: the flat gradient is summed over k calls (fv_grad_accumulate); the exchange, the clip and
+          the optimiser run on every k-th call -- or when `force_sync` says the loader is exhausted -- with the 1/k of
+          accelerate's `accumulate` folded into the optimiser's grad_scale (trainer.py:96,171).
+        * under torch.distributed the accumulated gradient is summed across ranks with ONE all-reduce on a side stream
+          (1/world folded into grad_scale as well).  When `next_batch` is given, ITS frozen backbone forward is enqueued
+          between the start of the all-reduce and the optimiser kernel, so the collective runs underneath it; the
+          prepared batch comes back under "next" and is passed as `prepared=` to the following call.
+        """
+        m = self.model
+        prep = prepared if prepared is not None else self.prepare_batch(batch)
+        dev = prep["pooled"].device
+        eng, flat = m._engine(), m.materialize(dev)
+        st = self._optimizer_state(flat)
+        k = max(1, int(grad_accum_steps))
+        st["micro"] += 1
+        sync = force_sync or st["micro"] % k == 0
         p = float(self.config.dropout) if self.training else 0.0
         m._drop_calls += 1
-        actions, saved = eng.head_forward(flat, pooled, states, training=p > 0.0, dropout_p=p, seed=m._drop_seed,
-                                          offset=m._drop_calls)
-        loss, grads = eng.head_backward(flat, actions, targets, saved, dropout_p=p, flat_grads=st["g"])
-        scale = allreduce_flat_grads(grads, st["comm"], process_group)
-        eng.adamw_step(flat, grads, st["m"], st["v"], st["step"], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                       max_grad_norm=max_grad_norm or 0.0, grad_scale=scale, grad_norm_out=st["norm"])
-        return {"loss": loss[0], "mse": loss[0].detach(), "grad_norm": st["norm"][0], "actions": actions}
+        actions, saved = eng.head_forward(flat, prep["pooled"], prep["states"], training=p > 0.0, dropout_p=p,
+                                          seed=m._drop_seed, offset=m._drop_calls)
+        if k > 1 and st["acc"] is None:
+            st["acc"] = torch.zeros_like(flat)
+        first = st["micro"] == 1  # first micro-batch of an accumulation window: the backward writes the window's buffer
+        target_buf = st["g"] if k == 1 else (st["acc"] if first else st["g"])
+        loss, grads = eng.head_backward(flat, actions, prep["targets"], saved, dropout_p=p, flat_grads=target_buf)
+        if k > 1 and not first:
+            eng.grad_accumulate(st["acc"], grads)
+        total = st["g"] if k == 1 else st["acc"]
+        out = {"loss": loss[0], "mse": loss[0].detach(), "actions": actions, "synced": sync, "next": None}
+        scale = 1.0
+        if sync:
+            st["exchange"].group = process_group
+            scale = st["exchange"].start(total) / k       # all-reduce launched on the side stream
+        if next_batch is not None:
+            out["next"] = self.prepare_batch(next_batch)  # frozen forward of batch k+1, underneath the collective
+        if sync:
+            st["exchange"].finish(dev)
+            st["step"] += 1
+            st["micro"] = 0
+            eng.adamw_step(flat, total, st["m"], st["v"], st["step"], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                           max_grad_norm=max_grad_norm or 0.0, grad_scale=scale, grad_norm_out=st["norm"])
+        out["grad_norm"] = st["norm"][0]
+        return out

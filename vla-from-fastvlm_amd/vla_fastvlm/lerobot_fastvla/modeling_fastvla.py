@@ -8,7 +8,6 @@ from typing import Any
 
 import torch
 from torch import Tensor
-from torch.nn import functional as F
 
 from ..fastvla.configuration_fastvla import FastVLAConfig as CoreFastVLAConfig
 from ..fastvla.fastvlm_with_expert import FastVLMWithExpert
@@ -96,10 +95,11 @@ class FastVLAPolicy(PreTrainedPolicy):
         return self._action_queue.popleft()
 
     def forward(self, batch: dict[str, Tensor]) -> tuple[Tensor, dict]:
-        pred = self._predict_actions(batch)
+        images, states, tasks = self._prepare_inputs(batch)
         gt = batch[ACTION]
         if gt.ndim == 3:
             gt = gt[:, 0]
-        loss = F.mse_loss(pred, gt.to(pred.device, pred.dtype))
+        # head forward + MSE (+ the head gradients autograd will ask for) in one pass through the library
+        loss, _pred = self.model.forward_loss(images, states, tasks, gt, device=images.device)
         val = loss.item()
         return loss, {"loss": val, "mse": val}

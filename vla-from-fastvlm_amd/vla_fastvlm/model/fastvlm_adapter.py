@@ -198,15 +198,25 @@ class FastVLMBackbone(nn.Module):
         raise OSError(f"unknown FastVLM model id '{model_id}' (known: {sorted(set(_KNOWN_MODELS))}, or 'synthetic:<preset>')")
 
     def _load_tokenizer(self):
-        if self._weights_source[0] != "synthetic":
-            try:
-                from transformers import AutoTokenizer
-                tok = AutoTokenizer.from_pretrained(self.config.model_id, trust_remote_code=False, local_files_only=True)
-                tok.padding_side = self.config.tokenizer_padding_side
-                return tok
-            except Exception:
-                pass
-        return SyntheticTokenizer(self.arch.llm.vocab, padding_side=self.config.tokenizer_padding_side)
+        """Real checkpoints need their real tokenizer: a missing one raises RuntimeError like the reference
+        (model/fastvlm_adapter.py:366-367) instead of silently hashing bytes to ids.  The byte-hash SyntheticTokenizer is
+        for seeded synthetic weights only (or, with a warning, under FASTVLA_SYNTHETIC_TOKENIZER=1)."""
+        if self._weights_source[0] == "synthetic":
+            return SyntheticTokenizer(self.arch.llm.vocab, padding_side=self.config.tokenizer_padding_side)
+        src = self._weights_source[1] if self._weights_source[0] == "hf_dir" else self.config.model_id
+        try:
+            from transformers import AutoTokenizer
+            tok = AutoTokenizer.from_pretrained(src, trust_remote_code=False, local_files_only=True)
+            tok.padding_side = self.config.tokenizer_padding_side
+            return tok
+        except Exception as exc:
+            if os.environ.get("FASTVLA_SYNTHETIC_TOKENIZER", "0") == "1":
+                import warnings
+                warnings.warn(f"tokenizer of '{src}' could not be loaded ({exc}); FASTVLA_SYNTHETIC_TOKENIZER=1: using the "
+                              "byte-hash SyntheticTokenizer -- input ids are NOT the checkpoint's vocabulary")
+                return SyntheticTokenizer(self.arch.llm.vocab, padding_side=self.config.tokenizer_padding_side)
+            raise RuntimeError(f"Tokenizer is missing for checkpoint '{src}': {exc}.  Put the tokenizer files next to the "
+                               "weights, or set FASTVLA_SYNTHETIC_TOKENIZER=1 to run with hashed ids (smoke tests only).") from exc
 
     def _resolve_expected_image_size(self) -> int:
         if self.config.force_image_size is not None:

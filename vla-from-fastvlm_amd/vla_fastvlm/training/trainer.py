@@ -4,9 +4,14 @@ Keeps the reference's `TrainingConfig` fields and `Trainer(model, train_dl, eval
 (src/vla_fastvlm/training/trainer.py:20-51,145-166) but not its machinery: there is no `accelerate`; one process per
 GPU under torch.distributed (RCCL), batches sharded round-robin by rank, and the step body of trainer.py:171-182
 (loss -> backward -> clip_grad_norm_ -> AdamW.step -> LambdaLR.step) is ONE call into libfastvla_hip.so
-(`FastVLAPolicy.fused_train_step`): head forward, MSE, head backward, all-reduce of the flat 12 MB gradient on a side
-stream, fused clip + AdamW.  The frozen backbone never sees a gradient (reference fastvlm_adapter.py:501 wraps it in
-no_grad unconditionally), so this IS the whole trainable path.
+(`FastVLAPolicy.fused_train_step`): head forward, MSE, head backward, [gradient accumulation,] all-reduce of the flat
+12 MB gradient on a side stream, fused clip + AdamW.  The frozen backbone never sees a gradient (reference
+fastvlm_adapter.py:501 wraps it in no_grad unconditionally), so this IS the whole trainable path -- and because it is
+frozen, batch k+1's backbone forward is enqueued before the optimiser waits on batch k's all-reduce (the loop looks one
+batch ahead), which is how the collective overlaps with compute here.
+
+What accelerate/DDP did implicitly for the reference and is explicit here: rank 0's head parameters (and, on resume, the
+AdamW moments) are broadcast at start-up; every rank runs the same number of steps (dp.shard_batches).
 """
 from __future__ import annotations
 
@@ -20,7 +25,7 @@ from typing import Dict, Iterable, Optional
 import torch
 
 from ..device import move_batch_to_device
-from .dp import shard_batches
+from .dp import broadcast_flat, shard_batches
 
 logger = logging.getLogger(__name__)
 
@@ -60,8 +65,8 @@ class Trainer:
                  config: TrainingConfig | None = None) -> None:
         import torch.distributed as dist
         self.config = config or TrainingConfig()
-        if self.config.gradient_accumulation_steps != 1:
-            raise NotImplementedError("the fused HIP train step applies every batch; gradient_accumulation_steps must be 1")
+        if self.config.gradient_accumulation_steps < 1:
+            raise ValueError("gradient_accumulation_steps must be >= 1")
         torch.manual_seed(self.config.seed)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
@@ -75,9 +80,11 @@ class Trainer:
         self.train_dataloader = train_dataloader
         self.eval_dataloader = eval_dataloader
         self.num_training_steps = self._compute_total_training_steps()
-        self.global_step = 0
+        self.global_step = 0     # batches seen (reference trainer.py:182 counts micro-batches)
+        self.update_step = 0     # optimiser updates (the LambdaLR index: accelerate steps the scheduler on sync steps)
         self.epoch = 0
         self.last_lr = 0.0
+        self._resume_opt = None
 
     @property
     def is_main_process(self) -> bool:
@@ -90,8 +97,8 @@ class Trainer:
         if self.config.max_steps:
             return self.config.max_steps
         if hasattr(self.train_dataloader, "__len__") and len(self.train_dataloader) > 0:
-            per_epoch = max(len(self.train_dataloader) // self.world, 1)
-            return per_epoch * self.config.num_epochs
+            per_epoch = max(len(self.train_dataloader) // self.world // self.config.gradient_accumulation_steps, 1)
+            return per_epoch * self.config.num_epochs  # optimiser updates, as reference trainer.py:223-231
         raise ValueError("Unable to infer total training steps from dataloader; please set max_steps.")
 
     def fit(self) -> None:
@@ -102,21 +109,53 @@ class Trainer:
             (out / "training_config.json").write_text(json.dumps(asdict(self.config), indent=2))
         if self.config.resume_from:
             self._load_checkpoint(self.config.resume_from)
+        self._sync_replicas()
         for epoch in range(self.config.num_epochs):
             self.epoch = epoch
             self._train_one_epoch()
-            if self.global_step >= self.num_training_steps:
+            if self.update_step >= self.num_training_steps:
                 break
+
+    def _sync_replicas(self) -> None:
+        """Put the head in its flat device buffer, restore the optimiser state of a resumed run, and make every rank start
+        from rank 0's parameters / moments (the caller builds the model before any seed is set, so replicas may differ)."""
+        core = getattr(self.model, "model", None)
+        if core is None or not hasattr(core, "materialize"):
+            return
+        flat = core.materialize(self.device)
+        if self._resume_opt is not None and hasattr(self.model, "load_optimizer_state"):
+            self.model.load_optimizer_state(self._resume_opt["m"], self._resume_opt["v"], int(self._resume_opt["step"]))
+            self._resume_opt = None
+        if self.world > 1:
+            broadcast_flat(flat)
+            st = getattr(self.model, "_opt_state", None)
+            if st and "m" in st:
+                broadcast_flat(st["m"])
+                broadcast_flat(st["v"])
 
     def _train_one_epoch(self) -> None:
         cfg = self.config
+        k = cfg.gradient_accumulation_steps
         self.model.train()
-        for batch in self._shard(self.train_dataloader):
-            batch = move_batch_to_device(batch, self.device)
-            self.last_lr = cfg.learning_rate * linear_warmup_decay(self.global_step, self.num_training_steps, cfg.warmup_ratio)
-            out = self.model.fused_train_step(batch, lr=self.last_lr, betas=cfg.betas, eps=cfg.eps,
-                                              weight_decay=cfg.weight_decay, max_grad_norm=cfg.max_grad_norm)
+        it = iter(self._shard(self.train_dataloader))
+        nxt = next(it, None)
+        prepared, micro = None, 0
+        while nxt is not None:
+            batch = move_batch_to_device(nxt, self.device) if prepared is None else None
+            nxt = next(it, None)  # one batch of look-ahead: "is this the last one" and the overlap partner of the all-reduce
+            micro += 1
+            will_sync = micro % k == 0 or nxt is None
+            stop_after = will_sync and ((cfg.max_steps and self.update_step + 1 >= cfg.max_steps) or self.update_step + 1 >= self.num_training_steps)
+            self.last_lr = cfg.learning_rate * linear_warmup_decay(self.update_step, self.num_training_steps, cfg.warmup_ratio)
+            out = self.model.fused_train_step(batch, prepared=prepared, lr=self.last_lr, betas=cfg.betas, eps=cfg.eps,
+                                              weight_decay=cfg.weight_decay, max_grad_norm=cfg.max_grad_norm,
+                                              grad_accum_steps=k, force_sync=nxt is None,  # accelerate syncs at the end of the loader
+                                              next_batch=move_batch_to_device(nxt, self.device) if nxt is not None and not stop_after else None)
+            prepared = out["next"]
             self.global_step += 1
+            if out["synced"]:
+                self.update_step += 1
+                micro = 0
             if self.is_main_process and self.global_step % cfg.logging_steps == 0:
                 self._log({"train/loss": float(out["loss"]), "train/mse": float(out["mse"]), "train/lr": self.last_lr,
                            "train/epoch": self.epoch, "train/grad_norm": float(out["grad_norm"])})
@@ -126,7 +165,7 @@ class Trainer:
                     self._log(metrics)
             if self.global_step % cfg.save_steps == 0:
                 self._save_checkpoint(f"step-{self.global_step}")
-            if (cfg.max_steps and self.global_step >= cfg.max_steps) or self.global_step >= self.num_training_steps:
+            if stop_after:
                 break
 
     def _log(self, metrics: Dict[str, float]) -> None:
@@ -160,7 +199,8 @@ class Trainer:
         torch.save({k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}, d / "policy_state_dict.pt")
         st = getattr(self.model, "_opt_state", None)
         if st is not None:
-            torch.save({"m": st["m"].cpu(), "v": st["v"].cpu(), "step": st["step"], "global_step": self.global_step}, d / "optimizer.pt")
+            torch.save({"m": st["m"].cpu(), "v": st["v"].cpu(), "step": st["step"], "global_step": self.global_step,
+                        "update_step": self.update_step}, d / "optimizer.pt")
 
     def _load_checkpoint(self, path: str) -> None:
         p = Path(path)
@@ -170,5 +210,6 @@ class Trainer:
         own = self.model.state_dict()
         self.model.load_state_dict({k: v for k, v in state.items() if k in own}, strict=False)
         if (p / "optimizer.pt").is_file():
-            self._resume_opt = torch.load(p / "optimizer.pt", map_location="cpu")
+            self._resume_opt = torch.load(p / "optimizer.pt", map_location="cpu")  # applied by _sync_replicas()
             self.global_step = int(self._resume_opt.get("global_step", 0))
+            self.update_step = int(self._resume_opt.get("update_step", self._resume_opt.get("step", 0)))
