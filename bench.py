@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=6)   # ~12 s of host work on 16 threads
+    ap.add_argument("--no-c1", action="store_true", help="skip the C1 (bs=4, 32-token, train step) CPU protocol of BASELINE.md section 3")
+    ap.add_argument("--c1-steps", type=int, default=10, help="C1 protocol: steps requested (first excluded)")
+    ap.add_argument("--c1-budget", type=float, default=60.0, help="C1 protocol: stop starting new CPU steps after this many seconds")
+    ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to "
                                                       "rehearse the multi-process path on a one-GPU box)")
@@ -86,8 +90,15 @@ def main():
                         max_batch=max(B, args.train_batch), max_text_tokens=T, tower_microbatch=args.microbatch,
                         llm_precision=args.llm_precision)
     t0 = time.time()
-    w = weights.init_backbone(model, seed=1234)  # identical on every rank (frozen replica)
-    eng.load_weights(w)
+    big = 3 * model.llm.hidden * model.llm.inter * model.llm.layers > 2e9   # 7B: 7.6 G parameters = 30 GB as an fp32 host dict
+    if big:
+        # streamed: every decoder tensor is drawn on the device in bf16 when the packer asks for it (fv_load_weights_cb);
+        # identical on every rank (seeded by name).  No host copy exists, so the CPU-oracle legs are skipped for this model.
+        w = None
+        eng.load_weights_streaming(weights.stream_backbone(model, seed=args.seed, device=dev))
+    else:
+        w = weights.init_backbone(model, seed=args.seed)  # identical on every rank (frozen replica)
+        eng.load_weights(w)
     t_load = time.time() - t0
 
     # trainable head: torch.nn default-style init, identical on every rank
@@ -195,41 +206,78 @@ def main():
                     "n": r["launches"] // ps,
                     "tflops": round(_fl(r) / max(r["ms"], 1e-9) / 1e9, 1)} for r in top]
 
-    # ---- data-parallel training step (C3): forward + MSE + head backward + all-reduce + clip + AdamW
+    # ---- data-parallel training step (C3): forward + MSE + head backward + all-reduce + clip + AdamW.
+    # Pipelined as vla_fastvlm.training.Trainer runs it: the frozen backbone forward of batch k+1 is enqueued between the
+    # START of batch k's gradient all-reduce (side stream, RCCL over xGMI) and the optimiser kernel that needs its result,
+    # so the collective runs underneath ~30 ms of tower kernels.  One timed step = one backbone forward + one head step.
     train = None
     if not args.no_train:
+        from vla_fastvlm.training.dp import GradExchange
         Bt = args.train_batch
         m_buf, v_buf = torch.zeros_like(flat), torch.zeros_like(flat)
         grads = torch.zeros_like(flat)
         saved = eng.head_saved(Bt)
-        comm = torch.cuda.Stream(device=dev)
-        state = {"step": 0, "ar_ms": 0.0}
+        ex = GradExchange(dev)
+        state = {"step": 0, "pooled": None, "timed": False, "ar": []}
 
-        def step_train():
+        def frozen_forward():
+            return eng.backbone(images[:Bt], ids[:Bt], lens[:Bt], splice=args.splice)
+
+        def head_step(pooled):
             state["step"] += 1
-            pooled = eng.backbone(images[:Bt], ids[:Bt], lens[:Bt], splice=args.splice)
-            act, _ = eng.head_forward(flat, pooled, states[:Bt], training=True, dropout_p=0.1, seed=1234 + rank,
+            act, _ = eng.head_forward(flat, pooled, states[:Bt], training=True, dropout_p=0.1, seed=args.seed + rank,
                                       offset=state["step"], saved=saved)
             eng.head_backward(flat, act, targets[:Bt], saved, dropout_p=0.1, flat_grads=grads)
-            if world > 1:  # one flat 12 MB bucket on a side stream (RCCL over xGMI), then 1/world inside the optimiser
-                comm.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(comm):
-                    dist.all_reduce(grads)
-                torch.cuda.current_stream().wait_stream(comm)
-            eng.adamw_step(flat, grads, m_buf, v_buf, state["step"], lr=1e-4, weight_decay=1e-4, max_grad_norm=1.0,
-                           grad_scale=1.0 / world)
+
+        def optimiser(scale):
+            eng.adamw_step(flat, grads, m_buf, v_buf, state["step"], lr=1e-4, weight_decay=1e-4, max_grad_norm=1.0, grad_scale=scale)
+
+        def step_train():           # pipelined: exchange(k) || frozen forward(k+1)
+            head_step(state["pooled"])
+            scale = ex.start(grads, timed=state["timed"])
+            state["pooled"] = frozen_forward()
+            ex.finish(dev)
+            if state["timed"] and world > 1:
+                state["ar"].append(ex.last_ms())
+            optimiser(scale)
+
+        def step_train_serial():    # the unpipelined order, for the overlap figure
+            head_step(frozen_forward())
+            scale = ex.start(grads)
+            ex.finish(dev)
+            optimiser(scale)
 
         flat_backup = flat.clone()
-        elt = timed(step_train, max(2, args.steps // 2), max(1, args.warmup // 2))
         nst = max(2, args.steps // 2)
+        state["pooled"] = frozen_forward()
+        elt = timed(step_train, nst, max(1, args.warmup // 2))
+        ar_ms = overlap = ser_ms = None
+        if world > 1:
+            els = timed(step_train_serial, nst, 1)
+            ser_ms = 1e3 * els / nst
+            state["timed"] = True
+            state["pooled"] = frozen_forward()
+            for _ in range(3):
+                step_train()
+            torch.cuda.synchronize()
+            state["timed"] = False
+            ar_ms = sum(state["ar"]) / max(1, len(state["ar"]))
+            tt = torch.tensor([ar_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ar_ms = float(tt)
+            # share of the collective's duration that no longer extends the step: (serial - pipelined) / all-reduce time
+            overlap = max(0.0, min(1.0, (ser_ms - 1e3 * elt / nst) / ar_ms)) if ar_ms > 0 else None
         flat.copy_(flat_backup)
         train = {"value": round(world * nst / elt, 3), "unit": "train steps/s (whole job)", "ms_per_step": round(1e3 * elt / nst, 3),
-                 "global_batch": Bt * world, "parallelism": f"dp{world}", "collective": f"{args.backend} all_reduce(flat head grads)" if world > 1 else None,
-                 "grad_bytes": int(flat.numel() * 4)}
+                 "global_batch": Bt * world, "parallelism": f"dp{world}",
+                 "collective": f"{args.backend} all_reduce(flat head grads), started before the next batch's frozen forward" if world > 1 else None,
+                 "grad_bytes": int(flat.numel() * 4), "allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
+                 "ms_per_step_serial_exchange": None if ser_ms is None else round(ser_ms, 3),
+                 "overlap_frac": None if overlap is None else round(overlap, 3)}
 
     # ---- CPU baseline (rank 0, N=1 only): the fp32 oracle on a bounded sample of the same workload
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and w is not None:
         from oracle import fastvit_hd, head as ohead, policy, qwen2
         n = args.cpu_sample
         lc = qwen2.Qwen2Cfg(hidden=model.llm.hidden, layers=model.llm.layers, heads=model.llm.heads, kv_heads=model.llm.kv_heads,
@@ -254,6 +302,77 @@ def main():
                          f"(letterbox+tower+projector+decoder+pool+head) of the fp32 torch oracle",
                "parity_actions_rel_l2": err}
 
+    # ---- C1 protocol: FastVLM-0.5B, bs=4, 336^2 + 32-token prompt, train steps
+    # (forward + MSE + head backward + clip + AdamW) of the CPU port, first step excluded, mean +- std; "algorithmic" = the work
+    # the result needs, "as_shipped" adds what the reference also computes and drops (full-vocabulary lm_head logits for every
+    # token, 25 retained hidden-state tensors, a KV cache).  The GPU path's own C1 step is timed beside it.
+    c1 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_c1 and w is not None:
+        from oracle import fastvit_hd, head as ohead, policy, qwen2
+        import statistics
+        Bc, Tc = 4, 32
+        lc = qwen2.Qwen2Cfg(hidden=model.llm.hidden, layers=model.llm.layers, heads=model.llm.heads, kv_heads=model.llm.kv_heads,
+                            head_dim=model.llm.head_dim, inter=model.llm.inter, vocab=model.llm.vocab)
+        tc = fastvit_hd.TowerCfg(layers=model.tower.layers, dims=model.tower.dims)
+        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(share, int(os.environ.get("FASTVLA_CPU_THREADS", "16")))))
+        hp = {k: v.detach().cpu().clone() for k, v in eng.head_views(flat).items()}
+        mo = {k: torch.zeros_like(v) for k, v in hp.items()}
+        vo = {k: torch.zeros_like(v) for k, v in hp.items()}
+        ci, cids = images[:Bc].cpu(), ids[:Bc, :Tc].cpu().long()
+        cmask = torch.ones(Bc, Tc, dtype=torch.long)
+        cst, ctg = states[:Bc].cpu(), targets[:Bc].cpu()
+        emb_w = w["model.embed_tokens.weight"]
+        alg, shipped, t_start, first_pred = [], [], time.perf_counter(), None
+        for i in range(args.c1_steps):
+            if i > 1 and time.perf_counter() - t_start > args.c1_budget:
+                break
+            t = time.perf_counter()
+            with torch.no_grad():
+                r = policy.train_step(w, hp, mo, vo, i + 1, ci, cst, ctg, cids, cmask, lr=1e-4, weight_decay=1e-4, max_grad_norm=1.0,
+                                      image_size=model.tower.image_size, llm_cfg=lc, tower_cfg=tc, splice=args.splice)
+            t_alg = time.perf_counter() - t
+            if first_pred is None:
+                first_pred = r["pred"]
+            hp, mo, vo = r["params"], r["m"], r["v"]
+            t = time.perf_counter()
+            with torch.no_grad():  # reference-only work (fastvlm_adapter.py:519-536): logits for all tokens, retained states, KV cache
+                hid = torch.randn(Bc, Tc, model.llm.hidden)
+                logits = torch.nn.functional.linear(hid, emb_w)
+                kept = [hid.clone() for _ in range(model.llm.layers + 1)]
+                kv = torch.zeros(model.llm.layers, 2, Bc, model.llm.kv_heads, Tc, model.llm.head_dim)
+                del logits, kept, kv
+            t_extra = time.perf_counter() - t
+            if i > 0:
+                alg.append(t_alg)
+                shipped.append(t_alg + t_extra)
+        # the same C1 step on the GPU path (first step excluded, 10 timed)
+        fl = flat.clone()
+        mb_, vb_, gb_ = torch.zeros_like(fl), torch.zeros_like(fl), torch.zeros_like(fl)
+        sv = eng.head_saved(Bc)
+        i32 = ids[:Bc, :Tc].contiguous()
+        l32 = torch.full((Bc,), Tc, dtype=torch.int32, device=dev)
+        c1s = {"n": 0}
+
+        def c1_step():
+            c1s["n"] += 1
+            pooled = eng.backbone(images[:Bc], i32, l32, splice=args.splice)
+            act, _ = eng.head_forward(fl, pooled, states[:Bc], saved=sv)
+            eng.head_backward(fl, act, targets[:Bc], sv, flat_grads=gb_)
+            eng.adamw_step(fl, gb_, mb_, vb_, c1s["n"], lr=1e-4, weight_decay=1e-4, max_grad_norm=1.0)
+            return act
+
+        g_first = c1_step().cpu()
+        g_el = timed(c1_step, 10, 0)
+        def ms(v):
+            return {"mean_ms": round(1e3 * statistics.mean(v), 1), "std_ms": round(1e3 * (statistics.pstdev(v) if len(v) > 1 else 0.0), 1), "steps": len(v)}
+        c1 = {"config": "C1: FastVLM-0.5B bs=4, 336x336 + 32-token prompt, train step (fwd + MSE + head bwd + clip + AdamW), first step excluded",
+              "cpu_algorithmic": ms(alg), "cpu_as_shipped": ms(shipped), "cpu_kind": "port (fp32 torch oracle)",
+              "cpu_threads": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "steps_requested": args.c1_steps,
+              "budget_s": args.c1_budget, "gpu_ms_per_step": round(1e3 * g_el / 10, 3),
+              "gpu_vs_cpu_algorithmic": round(statistics.mean(alg) / (g_el / 10), 1),
+              "parity_actions_rel_l2_step1": float((g_first - first_pred).norm() / first_pred.norm())}
+
     if rank == 0:
         out = {
             "metric": "policy steps/sec (img+prompt->action) FastVLM-0.5B bs=64" if args.model == "fastvlm-0.5b" and B == 64
@@ -270,7 +389,7 @@ def main():
                        "stream_overlap": bool(eng.overlap_streams and not args.splice),
                        "llm_precision": "split-bf16 (hi+lo) operands, fp32 attention" if args.llm_precision else "bf16 operands"},
             "samples_per_s": round(value * B, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "train_dp": train,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
         }
         print(json.dumps(out))

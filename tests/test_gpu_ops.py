@@ -303,6 +303,44 @@ def test_fused_convffn(Cc, M):
     assert torch.equal(rd, out)
 
 
+def _pack_w2q(w2):
+    """fc2 weight (C, 4C) -> [4C/32][C][32], slot 16s+8h+j of each 32-block = hidden 16s + 8(j>>2) + 4h + (j&3) (fastvla_hip.h)."""
+    Cc, Hd = w2.shape
+    idx = torch.tensor([16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for s in range(2) for h in range(2) for j in range(8)])
+    return w2.view(Cc, Hd // 32, 32)[:, :, idx].permute(1, 0, 2).contiguous()
+
+
+# the 32x32x16 variant the engine runs at the real tower widths; the big cases give every persistent block several row tiles
+@pytest.mark.parametrize("Cc,M", [(96, 1000), (192, 300), (384, 130), (384, 128), (96, 150013), (192, 131072 + 77), (384, 70001)])
+def test_fused_convffn32(Cc, M):
+    torch.manual_seed(Cc + M + 1)
+    Hd = 4 * Cc
+    x, res = bf(torch.randn(M, Cc)), bf(torch.randn(M, Cc))
+    w1, w2 = bf(torch.randn(Hd, Cc) / math.sqrt(Cc)), bf(torch.randn(Cc, Hd) / math.sqrt(Hd))
+    b1, b2, ls = torch.randn(Hd) * 0.1, torch.randn(Cc) * 0.1, torch.rand(Cc) * 0.3 + 0.05
+    wide = torch.float64 if M < 5000 else torch.float32
+    hid = bf(F.gelu(x.to(wide) @ w1.to(wide).t() + b1.to(wide)).float())  # the kernel rounds the hidden to bf16 too
+    ref = (res.to(wide) + ls.to(wide) * (hid.to(wide) @ w2.to(wide).t() + b2.to(wide))).float()
+    xd, rd, w1d, w2d = dev_bf16(x), dev_bf16(res), dev_bf16(w1), dev_bf16(_pack_w2q(w2))
+    b1d, b2d, lsd = dev_f32(b1), dev_f32(b2), dev_f32(ls)
+    out = torch.full((M, Cc), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_convffn32(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
+                               rd.data_ptr(), out.data_ptr(), M, Cc, stream()), "fv_op_convffn32")
+    torch.cuda.synchronize()
+    check_close(out.float().cpu(), ref, what=f"fused convffn32 C={Cc}")
+    # the two kernels compute the same thing: against each other the difference is accumulation order only
+    out16 = torch.empty_like(out)
+    call(lib().fv_op_convffn(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), dev_bf16(_pack_w2(w2)).data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
+                             rd.data_ptr(), out16.data_ptr(), M, Cc, stream()), "fv_op_convffn")
+    torch.cuda.synchronize()
+    check_close(out.float().cpu(), out16.float().cpu(), rel=2e-3, amax=2e-2, what=f"convffn32 vs convffn16 C={Cc}")
+    # in place on the residual buffer (how the engine calls it)
+    call(lib().fv_op_convffn32(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
+                               rd.data_ptr(), rd.data_ptr(), M, Cc, stream()), "fv_op_convffn32 in place")
+    torch.cuda.synchronize()
+    assert torch.equal(rd, out)
+
+
 def _toeplitz(w, k):
     """depthwise weights (C,1,k,k) -> bf16 table [C/16][k][NM][16][4 i][4 kk] = w[ky][4m + kk - i] (fastvla_hip.h)."""
     Cc = w.shape[0]

@@ -100,6 +100,40 @@ __device__ __forceinline__ void gelu2_n(f32x2 (&x)[N]) {
 #pragma unroll
   for (int n = 0; n < N; ++n) x[n] = x[n] * xc[n];
 }
+// The same form with a degree-6 polynomial in x^2 (7 coefficients, R = 3.9375): max |error| 1.8e-4 over all x -- below the bf16
+// rounding of the value it produces for |gelu| > 0.1 (bf16 half-ulp = 2^-9 relative) -- for two packed fmas less per pair.
+// For consumers that round the result to bf16 as an MFMA operand and are short of VALU issue slots (convffn32_kernel).
+template <int N>
+__device__ __forceinline__ void gelu2_n7(f32x2 (&x)[N]) {
+  const float R = 3.9375f;
+  f32x2 xc[N], x2[N], p[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    xc[n].x = __builtin_amdgcn_fmed3f(x[n].x, -R, R);
+    xc[n].y = __builtin_amdgcn_fmed3f(x[n].y, -R, R);
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) x2[n] = xc[n] * xc[n];
+#pragma unroll
+  for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(x2[n], (f32x2){2.60001215e-08f, 2.60001215e-08f}, (f32x2){-1.76554451e-06f, -1.76554451e-06f});
+#define FV_HORNER7(c)                                                                       \
+  _Pragma("unroll") for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(p[n], x2[n], (f32x2){c, c});
+  FV_HORNER7(5.13497647e-05f) FV_HORNER7(-0.000848164123f) FV_HORNER7(0.00894825811f) FV_HORNER7(-0.0650006125f) FV_HORNER7(0.398250524f)
+#undef FV_HORNER7
+  static_assert(N == 1 || N == 2 || N == 4, "gelu2_n7 chains");
+  if constexpr (N == 1) {
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %0, %1, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0" : "+v"(xc[0]) : "v"(p[0]));
+  } else if constexpr (N == 2) {
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %0, %2, 0.5 op_sel_hi:[1,1,0] clamp\n\tv_pk_fma_f32 %1, %1, %3, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0"
+        : "+v"(xc[0]), "+v"(xc[1]) : "v"(p[0]), "v"(p[1]));
+  } else {
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %0, %4, 0.5 op_sel_hi:[1,1,0] clamp\n\tv_pk_fma_f32 %1, %1, %5, 0.5 op_sel_hi:[1,1,0] clamp\n\t"
+        "v_pk_fma_f32 %2, %2, %6, 0.5 op_sel_hi:[1,1,0] clamp\n\tv_pk_fma_f32 %3, %3, %7, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0"
+        : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) x[n] = x[n] * xc[n];
+}
 __device__ __forceinline__ f32x2 gelu2_f(f32x2 x) {
   f32x2 v[1] = {x};
   gelu2_n<1>(v);

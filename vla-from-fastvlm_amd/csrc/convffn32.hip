@@ -1,0 +1,458 @@
+// convffn32.hip -- the fused ConvFFN pointwise half (see convffn_fused.hip for the formulation) on the 32x32x16 MFMA:
+//     out = res + ls * ( fc2( GELU( fc1(x) + b1 ) ) + b2 )          C in {96, 192, 384}, hidden = 4C
+// ([UNVENDORED] mci.py ConvFFN.forward + RepMixerBlock layer-scale residual; call site of the whole VLM:
+// reference src/vla_fastvlm/model/fastvlm_adapter.py:533).
+//
+// Why a second kernel.  convffn_kernel is bound by what ONE wave per SIMD has to issue beside its MFMAs:
+// per 32-hidden chunk 96 x v_mfma_f32_16x16x32_bf16 hold the SIMD's vector issue for 8 of their 16 cycles each -- 768 of the
+// chunk's 1536 MFMA cycles -- and the fragment reads, the weight staging and the GELU queue up behind them.  The same
+// products on v_mfma_f32_32x32x16_bf16 are 48 instructions of 32 cycles that hold issue for 8: 384 cycles held, 1152 free,
+// with the SAME operand traffic (a 1 KB fragment still feeds 16 K MACs), the same registers (C/2 output accumulators,
+// C/4 x-fragment registers per 32 rows) and half the MFMA instructions to interleave with.
+//
+//   per wave: MT tiles of 32 pixels; per block: 4 waves sharing the weight stream (one persistent block per CU)
+//   chunk of 32 hidden units:
+//     H^T[32 hid x 32 px] = W1[chunk] . x^T      A = W1 rows (lane r = hidden row, half h = k 8h..8h+7 of the 16-deep step)
+//                                                B = x fragments in registers
+//     bias + GELU in registers.  D layout: column = pixel (lane & 31), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): registers
+//     8s .. 8s+7 converted pairwise ARE the B fragment of k-step s of the second product once W2's hidden columns are
+//     permuted to 16 s + 8 (j >> 2) + 4 h + (j & 3) at pack time (cdna_hip_programming.md section 3, "An accumulator tile as the
+//     next MFMA's operand")
+//     out^T[32 ch x 32 px] += W2[:, chunk] . H^T  two k-steps per output tile, accumulators live across all chunks
+#include "kernels.h"
+
+namespace fv {
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct Ffn32Params {
+  const bf16_t* x; const bf16_t* w1; const float* b1; const bf16_t* w2q; const float* b2; const float* ls;
+  const bf16_t* res; bf16_t* out; int M, nchunks;
+};
+
+// output accumulators pinned to the accumulator half of the register file, hidden-tile accumulators to the architectural
+// half (the GELU reads them); see convffn_fused.hip for why these MFMAs are asm statements
+__device__ __forceinline__ void mfma32_out(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <bool BA>  // BA: the x fragment lives in the accumulator half too
+__device__ __forceinline__ void mfma32_hid(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (BA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32_hid_init(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+}
+// XDL write -> VALU read of the hidden accumulators (8-pass MFMA: 12+ wait states), paid once per chunk behind the first
+// product's last MFMA; and VALU write -> MFMA B operand ahead of the second product
+template <int N>
+__device__ __forceinline__ void settle_hid(f32x16 (&h)[N]) {
+  static_assert(N == 1 || N == 2 || N == 4, "row tiles per wave");
+  if constexpr (N == 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(h[0]));
+  else if constexpr (N == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(h[0]), "+v"(h[1]));
+  else asm volatile("s_nop 7\n\ts_nop 7" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+}
+template <int N>
+__device__ __forceinline__ void settle_ops(bf16x8 (&v)[N][2]) {
+  if constexpr (N == 1) asm volatile("s_nop 3" : "+v"(v[0][0]), "+v"(v[0][1]));
+  else if constexpr (N == 2) asm volatile("s_nop 3" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]));
+  else asm volatile("s_nop 3" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[3][0]), "+v"(v[3][1]));
+}
+
+#define F32_ST_GET(J)                                                                                              \
+  ((J) == 0 ? st0 : (J) == 1 ? st1 : (J) == 2 ? st2 : (J) == 3 ? st3 : (J) == 4 ? st4 : (J) == 5 ? st5 : (J) == 6 ? st6 \
+   : (J) == 7 ? st7 : (J) == 8 ? st8 : (J) == 9 ? st9 : (J) == 10 ? st10 : st11)
+#define F32_ST_SET(J, V)                                                                                           \
+  {                                                                                                                \
+    const uint4 v_ = (V);                                                                                          \
+    if ((J) == 0) st0 = v_; else if ((J) == 1) st1 = v_; else if ((J) == 2) st2 = v_; else if ((J) == 3) st3 = v_;  \
+    else if ((J) == 4) st4 = v_; else if ((J) == 5) st5 = v_; else if ((J) == 6) st6 = v_; else if ((J) == 7) st7 = v_; \
+    else if ((J) == 8) st8 = v_; else if ((J) == 9) st9 = v_; else if ((J) == 10) st10 = v_; else st11 = v_;        \
+  }
+
+constexpr int ring_depth32(int nr, int want) { return nr % want == 0 ? want : ring_depth32(nr, want - 1); }
+
+// LDS plan shared by the kernel and its launcher
+template <int C, int MT>
+struct Ffn32Lds {
+  static constexpr int W1_STRIDE = C * 2 + 16;   // == 16 * odd (mod 256): the 32 rows of a 32x32x16 A fragment read conflict-free
+  static constexpr int W2_STRIDE = 64 + 16;
+  static constexpr int W1_BYTES = 32 * W1_STRIDE, W2_BYTES = C * W2_STRIDE, BUF = W1_BYTES + W2_BYTES;
+  static constexpr int CQ = 96;                  // channels per epilogue pass
+  static constexpr int ORB = CQ * 4 + 16;        // fp32 row of a pass + 16 B (conflict-free 16-B column writes)
+  static constexpr int EPI_WAVE = 32 * ORB;      // one pass of one wave
+  static constexpr int TABLES = 2 * C * 4 + 4 * C * 4;                      // b2, ls, b1 (fp32)
+  static constexpr bool EPI_OWN = 2 * BUF + TABLES + 4 * EPI_WAVE <= 160 * 1024;   // else the pass borrows a quarter weight slot
+  static constexpr int TOTAL = 2 * BUF + TABLES + (EPI_OWN ? 4 * EPI_WAVE : 0);
+  static_assert(EPI_OWN || (EPI_WAVE <= BUF / 4 && (BUF / 4) % 16 == 0), "epilogue pass must fit in a quarter of a weight slot");
+  static_assert(TOTAL <= 160 * 1024, "LDS");
+};
+
+template <int C, int MT>
+__global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
+  using L = Ffn32Lds<C, MT>;
+  constexpr int KS = C / 16;            // k-steps of the first product
+  constexpr int NT = C / 32;            // output-channel tiles of the second product (two k-steps each)
+  constexpr int W1_STRIDE = L::W1_STRIDE, W2_STRIDE = L::W2_STRIDE, W1_BYTES = L::W1_BYTES, BUF = L::BUF;
+  constexpr int W1_CH = 32 * C / 8, W2_CH = C * 4;            // 16-byte pieces per weight chunk
+  constexpr int NLD = (W1_CH + W2_CH) / 256;                  // staging loads per thread per chunk
+  static_assert((W1_CH + W2_CH) % 256 == 0 && NLD <= 12 && 2 * NLD == KS, "staging schedule: one store or one load per first-product step");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF] weight slots, b2[C], ls[C], b1[4C], (epilogue)
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nch = p.nchunks;                                   // C / 8: even, >= 4
+  const uint32_t tid16 = (uint32_t)tid * 16u;
+  const int ntiles = (p.M + 128 * MT - 1) / (128 * MT);
+
+  // ---- x fragments: lane holds x[pixel m = fr][16 ks + 8 fh .. +8] for its MT pixel tiles (rows past M clamp to M - 1)
+  bf16x8 xf[MT][KS];
+#define F32_LOAD_X(TILE)                                                                                     \
+  {                                                                                                          \
+    int lx_ = lane;                                                                                          \
+    asm volatile("" : "+v"(lx_)); /* keeps this address math out of the chunk loop's live registers */       \
+    const long mb_ = (long)(TILE) * (128 * MT) + wid * (32 * MT);                                            \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                      \
+      const long m_ = min(mb_ + mt * 32 + (lx_ & 31), (long)p.M - 1);                                        \
+      const bf16_t* xp_ = p.x + m_ * C + (lx_ >> 5) * 8;                                                     \
+      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                      \
+        xf[mt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp_ + ks * 16));             \
+    }                                                                                                        \
+  }
+  F32_LOAD_X(blockIdx.x)
+  f32x16 oacc[NT][MT];
+
+  uint4 st0, st1, st2, st3, st4, st5, st6, st7, st8, st9, st10, st11;
+  st0 = st1 = st2 = st3 = st4 = st5 = st6 = st7 = st8 = st9 = st10 = st11 = make_uint4(0, 0, 0, 0);
+#define F32_PIECE_OFF(c) ((c) < W1_CH ? ((c) / (C / 8)) * W1_STRIDE + ((c) % (C / 8)) * 16 : W1_BYTES + (((c) - W1_CH) >> 2) * W2_STRIDE + (((c) - W1_CH) & 3) * 16)
+#define F32_STAGE_LOAD(HC)                                                                                   \
+  {                                                                                                          \
+    const bf16_t* g1 = p.w1 + (size_t)(HC) * 32 * C;  /* [32][C] */                                          \
+    const bf16_t* g2 = p.w2q + (size_t)(HC) * C * 32; /* [C][32], hidden permuted */                         \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
+      const int c = tid + 256 * i;                                                                           \
+      const bf16_t* src = c < W1_CH ? g1 + (size_t)c * 8 : g2 + (size_t)(c - W1_CH) * 8;                     \
+      F32_ST_SET(i, *reinterpret_cast<const uint4*>(src))                                                    \
+    }                                                                                                        \
+  }
+#define F32_STAGE_STORE(BUFI)                                                                                \
+  {                                                                                                          \
+    char* base = smem + (BUFI) * BUF;                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
+      const int c = tid + 256 * i;                                                                           \
+      *reinterpret_cast<uint4*>(base + F32_PIECE_OFF(c)) = F32_ST_GET(i);                                    \
+    }                                                                                                        \
+  }
+  F32_STAGE_LOAD(0)
+  F32_STAGE_STORE(0)
+  F32_STAGE_LOAD(1)                       // rides in registers through chunk 0, stored to LDS during it
+  // second-product bias, layer scale and first-product bias, staged once per block
+  float* sb2 = reinterpret_cast<float*>(smem + 2 * BUF);
+  float* sls = sb2 + C;
+  float* sb1 = sls + C;
+  for (int i = tid; i < C / 4; i += 256) {   // sb2 holds ls * b2: out = res + (ls * acc + ls * b2), one fma per channel
+    const float4 b = reinterpret_cast<const float4*>(p.b2)[i], l = reinterpret_cast<const float4*>(p.ls)[i];
+    reinterpret_cast<float4*>(sb2)[i] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, b.w * l.w);
+    reinterpret_cast<float4*>(sls)[i] = l;
+  }
+  for (int i = tid; i < C; i += 256) reinterpret_cast<float4*>(sb1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  __syncthreads();
+
+  // Fragment stream of one chunk: reads 0..KS-1 are W1 fragments (k-step i), reads KS..NR-1 are W2 fragments (output tile
+  // (i - KS) >> 1, k-step (i - KS) & 1).  The reads run PD steps ahead of the MFMAs that consume them, across the chunk
+  // boundary too (the chunk's one barrier sits PD steps before its end): see convffn_fused.hip.
+#ifndef FFN32_PD
+#define FFN32_PD 6
+#endif
+  constexpr bool XA = true;                // upper half of the x fragments in AGPRs (MFMA reads A / B from either half)
+  constexpr int NR = KS + 2 * NT, PD = ring_depth32(NR, FFN32_PD < NR / 2 ? FFN32_PD : NR / 2);
+  static_assert(2 * NLD <= NR - PD && NR % PD == 0, "ring");
+#define F32_FRAG(I, W1S, W2S)                                                                                      \
+  ((I) < KS ? *reinterpret_cast<const uint4*>((W1S) + fr * W1_STRIDE + (I) * 32 + fh * 16)                          \
+            : *reinterpret_cast<const uint4*>((W2S) + ((((I) - KS) >> 1) * 32 + fr) * W2_STRIDE + (((I) - KS) & 1) * 32 + fh * 16))
+  uint4 ring[PD];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) ring[i] = F32_FRAG(i, smem, smem + W1_BYTES);
+
+  // epilogue geometry: one pass turns 32 rows x CQ channels of fp32 through the wave's staging area
+  constexpr int CQ = L::CQ, ORB = L::ORB, NPASS = C / CQ;      // passes per row tile
+  constexpr int RP = 32 * (CQ / 8) / 64;                       // 8-channel items per lane per pass
+  static_assert(C % CQ == 0 && CQ % 32 == 0 && (32 * (CQ / 8)) % 64 == 0, "epilogue pass");
+#ifndef FFN32_RD
+#define FFN32_RD (NPASS * MT)
+#endif
+  // residual rows: ALL passes of the tile are requested at the top of the epilogue (rr reuses the registers the x fragments
+  // just vacated): a pass is far shorter than an HBM read, so fetching one pass ahead exposed one memory latency per pass
+  constexpr int RD = FFN32_RD;
+  uint4 rr[RD][RP];
+#define F32_LOAD_RES(Q, MB)                                                                                  \
+  {                                                                                                          \
+    int lr_ = lane;                                                                                          \
+    asm volatile("" : "+v"(lr_));                                                                            \
+    _Pragma("unroll") for (int it = 0; it < RP; ++it) {                                                      \
+      const int item_ = it * 64 + lr_, row_ = item_ / (CQ / 8), c8_ = item_ % (CQ / 8);                      \
+      const long m_ = min((MB) + ((Q) / NPASS) * 32 + row_, (long)p.M - 1);                                  \
+      rr[(Q) % RD][it] = *reinterpret_cast<const uint4*>(p.res + m_ * C + ((Q) % NPASS) * CQ + c8_ * 8);      \
+    }                                                                                                        \
+  }
+
+#ifdef FFN32_ABL_GELU   /* tools/ffn32_ablate.sh only: identity activation, to price the GELU */
+#define F32_GELU(G)
+#else
+#ifdef FFN32_GELU9
+#define F32_GELU(G) gelu2_n<4>(G);
+#else
+#define F32_GELU(G) gelu2_n7<4>(G);   /* the hidden is rounded to bf16 right behind it: 1.8e-4 is under that rounding */
+#endif
+#endif
+#ifdef FFN32_ABL_STAGE  /* ... no weight staging (global loads, LDS stores): wrong results, same MFMAs */
+#define F32_ABL_STAGE 1
+#else
+#define F32_ABL_STAGE 0
+#endif
+#ifdef FFN32_ABL_NOSTORE  /* ... staging loads but no LDS stores */
+#define F32_ABL_NOSTORE 1
+#else
+#define F32_ABL_NOSTORE 0
+#endif
+#if defined(FFN32_ST_B64)      /* staging store as two 8-byte LDS stores */
+#define F32_LDS_STORE(P, V) { const uint4 v__ = (V); *reinterpret_cast<uint2*>(P) = make_uint2(v__.x, v__.y); *reinterpret_cast<uint2*>((P) + 8) = make_uint2(v__.z, v__.w); }
+#elif defined(FFN32_ST_B32)    /* ... as four 4-byte LDS stores */
+#define F32_LDS_STORE(P, V) { const uint4 v__ = (V); volatile uint32_t* q__ = reinterpret_cast<volatile uint32_t*>(P); q__[0] = v__.x; q__[1] = v__.y; q__[2] = v__.z; q__[3] = v__.w; }
+#else
+#define F32_LDS_STORE(P, V) *reinterpret_cast<uint4*>(P) = (V);
+#endif
+#ifdef FFN32_ABL_STORERS  /* ... only the waves whose bit is set in the mask store (0x3: waves 0,1; 0x5: waves 0,2; 0x1: wave 0) */
+#define F32_ABL_STORER ((FFN32_ABL_STORERS >> wid) & 1)
+#else
+#define F32_ABL_STORER 1
+#endif
+#ifdef FFN32_ABL_NOLOAD   /* ... LDS stores but no staging loads */
+#define F32_ABL_NOLOAD 1
+#else
+#define F32_ABL_NOLOAD 0
+#endif
+#ifdef FFN32_ABL_L1       /* ... every staging load reads the same 4 KB (an L1 hit): the instruction stream without the L2 traffic */
+#define F32_ABL_L1 1
+#else
+#define F32_ABL_L1 0
+#endif
+#ifdef FFN32_ABL_FRAG   /* ... no fragment reads past the first ring fill */
+#define F32_ABL_FRAG 1
+#else
+#define F32_ABL_FRAG 0
+#endif
+#define F32_CHUNK                                                                                                   \
+  {                                                                                                                 \
+    const int cur = hc & 1;                                                                                         \
+    /* weight staging two chunks deep: during chunk hc the registers loaded during chunk hc-1 (chunk hc+1's weights) */ \
+    /* go to the idle slot and are refilled with chunk hc+2's; the chunk index wraps into the next tile            */ \
+    const int hn = hc + 2 - (hc + 2 >= nch ? nch : 0);                                                              \
+    const bf16_t* g1n = p.w1 + (size_t)hn * 32 * C;                                                                 \
+    const bf16_t* g2n = p.w2q + (size_t)hn * C * 32;                                                                \
+    char* nbase = smem + (cur ^ 1) * BUF;                                                                           \
+    const char* w1s = smem + cur * BUF;                                                                             \
+    const char* w2s = w1s + W1_BYTES;                                                                               \
+    f32x16 hacc[MT];                                                                                                \
+    bf16x8 hf[MT][2];                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                                \
+      if (i == NR - PD) __syncthreads();                                                                            \
+      const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i % PD]);                                                    \
+      if (!F32_ABL_FRAG) ring[i % PD] = i + PD < NR ? F32_FRAG(i + PD, w1s, w2s) : F32_FRAG(i + PD - NR, nbase, nbase + W1_BYTES); \
+      if (i < KS) { /* H^T += W1[chunk rows, k-step i] . x^T */                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                         \
+          if (i == 0) mfma32_hid_init(hacc[mt], a, xf[mt][0]);                                                      \
+          else if (XA && i >= KS / 2) mfma32_hid<XA>(hacc[mt], a, xf[mt][i >= KS / 2 ? i : KS - 1]);                \
+          else mfma32_hid<false>(hacc[mt], a, xf[mt][i]);                                                           \
+        }                                                                                                           \
+        if (!F32_ABL_STAGE) { /* staging: even steps store register j to the idle slot, odd steps reload it for the chunk after */ \
+          const int j = i >> 1;                                                                                     \
+          const int c = tid + 256 * j;                                                                              \
+          if ((i & 1) == 0) {                                                                                       \
+            if (!F32_ABL_NOSTORE && F32_ABL_STORER) { F32_LDS_STORE(nbase + F32_PIECE_OFF(c), F32_ST_GET(j)) }      \
+          } else if (!F32_ABL_NOLOAD) {                                                                             \
+            if constexpr (W1_CH % 256 == 0) {                                                                       \
+              const char* sb_ = F32_ABL_L1 ? reinterpret_cast<const char*>(p.w1)                                    \
+                                : j * 256 < W1_CH ? reinterpret_cast<const char*>(g1n) + j * 4096                   \
+                                                : reinterpret_cast<const char*>(g2n) + (j * 256 - W1_CH) * 16;      \
+              F32_ST_SET(j, *reinterpret_cast<const uint4*>(sb_ + tid16))                                           \
+            } else {                                                                                                \
+              const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)(c - W1_CH) * 8;                  \
+              F32_ST_SET(j, *reinterpret_cast<const uint4*>(src))                                                   \
+            }                                                                                                       \
+          }                                                                                                         \
+        }                                                                                                           \
+        if (i == KS - 1) { /* bias + GELU in registers -> the two B fragments of the second product */              \
+          const float4 bq0 = *reinterpret_cast<const float4*>(sb1 + hc * 32 + 4 * fh);                              \
+          const float4 bq1 = *reinterpret_cast<const float4*>(sb1 + hc * 32 + 8 + 4 * fh);                          \
+          const float4 bq2 = *reinterpret_cast<const float4*>(sb1 + hc * 32 + 16 + 4 * fh);                         \
+          const float4 bq3 = *reinterpret_cast<const float4*>(sb1 + hc * 32 + 24 + 4 * fh);                         \
+          settle_hid<MT>(hacc);                                                                                     \
+          _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                         \
+              const float4 ba = s ? bq2 : bq0, bb = s ? bq3 : bq1;                                                  \
+              f32x2 g[4] = {{hacc[mt][8 * s + 0] + ba.x, hacc[mt][8 * s + 1] + ba.y},                               \
+                            {hacc[mt][8 * s + 2] + ba.z, hacc[mt][8 * s + 3] + ba.w},                               \
+                            {hacc[mt][8 * s + 4] + bb.x, hacc[mt][8 * s + 5] + bb.y},                               \
+                            {hacc[mt][8 * s + 6] + bb.z, hacc[mt][8 * s + 7] + bb.w}};                              \
+              F32_GELU(g)                                                                                           \
+              uint4 u;                                                                                              \
+              u.x = pack_bf2(g[0].x, g[0].y); u.y = pack_bf2(g[1].x, g[1].y);                                       \
+              u.z = pack_bf2(g[2].x, g[2].y); u.w = pack_bf2(g[3].x, g[3].y);                                       \
+              hf[mt][s] = __builtin_bit_cast(bf16x8, u);                                                            \
+              __builtin_amdgcn_sched_barrier(0); /* one group of four chains at a time */                           \
+            }                                                                                                       \
+          }                                                                                                         \
+          settle_ops<MT>(hf);                                                                                       \
+        }                                                                                                           \
+      } else { /* out^T[tile] += W2[tile rows, chunk k-step] . H^T */                                               \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) mfma32_out(oacc[(i - KS) >> 1][mt], a, hf[mt][(i - KS) & 1]); \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+    const long mb = (long)tile * (128 * MT) + wid * (32 * MT);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[nt][mt][e] = 0.f;
+    for (int hc = 0; hc < nch; ++hc) F32_CHUNK
+    __builtin_amdgcn_sched_barrier(0);  // keep the epilogue's loads out of the chunk
+#ifdef FFN32_ABL_EPI   /* tools/ffn32_variants.sh only: no epilogue (wrong results); the accumulators stay live through one store */
+    {
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) sum += f32x4{oacc[nt][mt][0], oacc[nt][mt][5], oacc[nt][mt][10], oacc[nt][mt][15]};
+      if (sum[0] == 1234.5f) *reinterpret_cast<f32x4*>(p.out) = sum;
+#ifndef FFN32_ABL_XLOAD
+      F32_LOAD_X(tile + (int)gridDim.x)
+#endif
+      __syncthreads();
+      continue;
+    }
+#endif
+#pragma unroll
+    for (int q0 = 0; q0 < (RD == NPASS * MT ? RD : RD - 1) && q0 < NPASS * MT; ++q0) F32_LOAD_RES(q0, mb)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");  // last XDL writes of the output accumulators -> VALU reads below
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue: each wave turns 32 rows x CQ channels at a time through LDS as raw fp32 (accumulator registers 4q..4q+3 of
+    // tile t are channels 32 t + 8 q + 4 fh + 0..3 of pixel fr: one 16-byte write each); on the way out a lane owns 8
+    // consecutive channels of a row: bias, layer scale, residual add and the one bf16 rounding happen there, every global
+    // access is 16 B of a fully used line.
+    char* so = L::EPI_OWN ? smem + 2 * BUF + L::TABLES + wid * L::EPI_WAVE : smem + ((nch - 1) & 1) * BUF + wid * (BUF / 4);
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int fre = le & 31, fhe = le >> 5;
+#pragma unroll
+    for (int q = 0; q < NPASS * MT; ++q) {
+      const int mt = q / NPASS, pass = q % NPASS;
+      if (q == NPASS * MT - 1) F32_LOAD_X(tile + (int)gridDim.x)   // the next tile's x fragments fly during the last pass only
+#pragma unroll
+      for (int tl = 0; tl < CQ / 32; ++tl)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x16& o = oacc[pass * (CQ / 32) + tl][mt];
+          *reinterpret_cast<f32x4*>(so + fre * ORB + (tl * 32 + qd * 8 + fhe * 4) * 4) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
+        }
+      asm volatile("" ::: "memory");  // wave-local hand-over: LDS serves a wave's accesses in order
+#pragma unroll
+      for (int it = 0; it < RP; ++it) {
+        const int item = it * 64 + le, row = item / (CQ / 8), c8 = item % (CQ / 8);
+        const int cb = pass * CQ + c8 * 8;
+        const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
+        const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
+        const float4 b0 = *reinterpret_cast<const float4*>(sb2 + cb), b1 = *reinterpret_cast<const float4*>(sb2 + cb + 4);
+        const float4 l0 = *reinterpret_cast<const float4*>(sls + cb), l1 = *reinterpret_cast<const float4*>(sls + cb + 4);
+        const uint4 r4 = rr[q % RD][it];
+        uint4 o;
+        o.x = pack_bf2(bf_lo(r4.x) + fmaf(l0.x, y0.x, b0.x), bf_hi(r4.x) + fmaf(l0.y, y0.y, b0.y));
+        o.y = pack_bf2(bf_lo(r4.y) + fmaf(l0.z, y0.z, b0.z), bf_hi(r4.y) + fmaf(l0.w, y0.w, b0.w));
+        o.z = pack_bf2(bf_lo(r4.z) + fmaf(l1.x, y1.x, b1.x), bf_hi(r4.z) + fmaf(l1.y, y1.y, b1.y));
+        o.w = pack_bf2(bf_lo(r4.w) + fmaf(l1.z, y1.z, b1.z), bf_hi(r4.w) + fmaf(l1.w, y1.w, b1.w));
+        const long m = mb + mt * 32 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + cb) = o;
+        if (it & 1) __builtin_amdgcn_sched_barrier(0);   // two items' operands in flight at a time
+      }
+      if (RD < NPASS * MT && q + RD - 1 < NPASS * MT) F32_LOAD_RES(q + RD - 1, mb)
+      asm volatile("" ::: "memory");                      // the next pass's writes stay behind these reads
+    }
+    __syncthreads();  // a borrowed slot is the next tile's staging target again
+  }
+#undef F32_CHUNK
+#undef F32_GELU
+#undef F32_LOAD_RES
+#undef F32_LOAD_X
+#undef F32_FRAG
+#undef F32_STAGE_LOAD
+#undef F32_STAGE_STORE
+#undef F32_PIECE_OFF
+}
+
+int num_cus32() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 256;
+    n = prop.multiProcessorCount;
+  }
+  return n;
+}
+
+template <int C, int MT>
+int launch_one32(const Ffn32Params& p, hipStream_t s) {
+  constexpr int LDS = Ffn32Lds<C, MT>::TOTAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn32_kernel<C, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const long tiles = ((long)p.M + 128 * MT - 1) / (128 * MT);
+  const long blocks = tiles < num_cus32() ? tiles : num_cus32();   // one persistent block per CU, tiles dealt round-robin
+  hipLaunchKernelGGL((convffn32_kernel<C, MT>), dim3((unsigned)blocks), dim3(256), LDS, s, p);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+}  // namespace
+
+bool convffn32_supported(int C, int ratio) { return ratio == 4 && (C == 96 || C == 192 || C == 384); }
+
+// w2 [C][hidden] row-major -> [hidden/32][C][32] with slot 16 s + 8 h + j of each 32-block holding hidden
+// 16 s + 8 (j >> 2) + 4 h + (j & 3): element j of lane half h in k-step s of the second product (see the file header)
+void convffn32_pack_w2(const float* w2, float* out, int C, int hidden) {
+  for (int hc = 0; hc < hidden / 32; ++hc)
+    for (int n = 0; n < C; ++n)
+      for (int s = 0; s < 2; ++s)
+        for (int h = 0; h < 2; ++h)
+          for (int j = 0; j < 8; ++j)
+            out[((size_t)hc * C + n) * 32 + 16 * s + 8 * h + j] = w2[(size_t)n * hidden + hc * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+}
+
+int launch_convffn32(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2q, const float* b2, const float* ls,
+                     const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s) {
+  if (!x || !w1 || !b1 || !w2q || !b2 || !ls || !res || !out) return fv_fail(FV_ERR_ARG, "convffn32: null pointer");
+  if (M <= 0 || hidden != 4 * C || !convffn32_supported(C, 4)) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: unsupported C=%d hidden=%d", C, hidden);
+  if (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2q | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ls | (uintptr_t)res | (uintptr_t)out) & 15)
+    return fv_fail(FV_ERR_ARG, "convffn32: misaligned pointer");
+  if (x == out) return fv_fail(FV_ERR_ARG, "convffn32: x must not alias out");
+  Ffn32Params p{x, w1, b1, w2q, b2, ls, res, out, M, hidden / 32};
+  switch (C) {
+#ifndef FFN32_MT96
+#define FFN32_MT96 4
+#endif
+    case 96: return launch_one32<96, FFN32_MT96>(p, s);
+    case 192: return launch_one32<192, 2>(p, s);
+    case 384: return launch_one32<384, 1>(p, s);
+  }
+  return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: unsupported C=%d", C);
+}
+
+}  // namespace fv

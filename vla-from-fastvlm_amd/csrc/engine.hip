@@ -60,7 +60,7 @@ inline float host_bf2f(bf16_t b) {
   return f;
 }
 
-struct FFN { float *dw_w = nullptr, *dw_b = nullptr; bf16_t* fc1_w = nullptr; float* fc1_b = nullptr; bf16_t* fc2_w = nullptr; float *fc2_b = nullptr, *ls = nullptr; bf16_t* w2p = nullptr; bf16_t* dw_t = nullptr; };
+struct FFN { float *dw_w = nullptr, *dw_b = nullptr; bf16_t* fc1_w = nullptr; float* fc1_b = nullptr; bf16_t* fc2_w = nullptr; float *fc2_b = nullptr, *ls = nullptr; bf16_t* w2p = nullptr; bf16_t* w2q = nullptr; bf16_t* dw_t = nullptr; };
 struct Block {
   float *mix_w = nullptr, *mix_b = nullptr; bf16_t* mix_t = nullptr;  // RepMixer (+ Toeplitz table for the MFMA path)
   float *ln_w = nullptr, *ln_b = nullptr; bf16_t *qkv_w = nullptr, *proj_w = nullptr; float *proj_b = nullptr, *ls1 = nullptr;  // attention
@@ -127,6 +127,7 @@ struct fv_handle {
   void* rccl = nullptr;       // dlopen handle of librccl (fv_comm_* / fv_allreduce_grads), resolved on first use
   bool no_fused_ffn = false;  // FASTVLA_NO_FUSED_FFN=1: A/B switch back to the two-GEMM ConvFFN
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
+  bool no_ffn32 = false;      // FASTVLA_NO_FFN32=1: A/B switch back to the 16x16x32 fused ConvFFN
 };
 
 namespace {
@@ -304,6 +305,10 @@ int load_ffn(Loader& L, const std::string& pre, int C, int hidden, float bn_eps,
       w2p.resize(w2.size());
       fv::convffn_pack_w2(w2.data(), w2p.data(), C, hidden);
       f.w2p = L.up_bf16(w2p);
+      if (fv::convffn32_supported(C, 4)) {  // second layout: the 32x32x16 kernel's k-permutation
+        fv::convffn32_pack_w2(w2.data(), w2p.data(), C, hidden);
+        f.w2q = L.up_bf16(w2p);
+      }
     }
   }
   f.fc2_b = L.vec(pre + "fc2.bias", C);
@@ -415,6 +420,12 @@ int dw_s1(fv_handle* h, const bf16_t* x, const float* w, const bf16_t* ttab, con
   return fv::launch_dwconv(x, w, bias, y, mb, H, H, C, k, 1, 1, 0, s);
 }
 
+// fused ConvFFN pointwise half: the 32x32x16 kernel where it exists (C = 96 / 192 / 384), else the 16x16x32 one
+int fused_ffn(fv_handle* h, const FFN& f, const bf16_t* t, const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s) {
+  if (f.w2q && !h->no_ffn32) return fv::launch_convffn32(t, f.fc1_w, f.fc1_b, f.w2q, f.fc2_b, f.ls, res, out, M, C, hidden, s);
+  return fv::launch_convffn(t, f.fc1_w, f.fc1_b, f.w2p, f.fc2_b, f.ls, res, out, M, C, hidden, s);
+}
+
 int run_ffn(fv_handle* h, const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t* hid, bf16_t* res_out, int mb, int H, int W, int C,
             int ratio, hipStream_t s) {
   // dw_out = dw7x7(x_dw_in) (+BN folded); hid = gelu(fc1(dw_out)); res_out += ls * fc2(hid)
@@ -422,7 +433,7 @@ int run_ffn(fv_handle* h, const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t*
   FV_P(FV_FAM_DWCONV, dw_flops(mb, H, W, C, 7), 4.0 * M * C, dw_s1(h, x_dw_in, f.dw_w, f.dw_t, f.dw_b, dw_out, mb, H, C, 7, s));
   if (f.w2p && !h->no_fused_ffn) {
     prof_begin(h, FV_FAM_GEMM, 4.0 * M * C * (double)(C * ratio), 6.0 * M * C, s, M, C, C * ratio, 6);
-    const int rc = fv::launch_convffn(dw_out, f.fc1_w, f.fc1_b, f.w2p, f.fc2_b, f.ls, res_out, res_out, M, C, C * ratio, s);
+    const int rc = fused_ffn(h, f, dw_out, res_out, res_out, M, C, C * ratio, s);
     prof_end(h, s);
     return rc;
   }
@@ -485,7 +496,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
           FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 3) + dw_flops(mb, H, H, C, 7), 6.0 * M * C,
                fv::launch_dwconv_pair(cur, b.mix_t, b.mix_b, b.ffn.dw_t, b.ffn.dw_b, oth, hid, mb, H, H, C, s));
           prof_begin(h, FV_FAM_GEMM, 4.0 * M * C * (double)(C * d.tower_mlp_ratio), 6.0 * M * C, s, M, C, C * d.tower_mlp_ratio, 6);
-          const int rc = fv::launch_convffn(hid, b.ffn.fc1_w, b.ffn.fc1_b, b.ffn.w2p, b.ffn.fc2_b, b.ffn.ls, oth, oth, M, C, C * d.tower_mlp_ratio, s);
+          const int rc = fused_ffn(h, b.ffn, hid, oth, oth, M, C, C * d.tower_mlp_ratio, s);
           prof_end(h, s);
           if (rc != FV_OK) return rc;
         } else {
@@ -561,6 +572,7 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   h->hd = fv::HeadDims{d.llm_hidden, d.state_dim, d.action_dim, d.hidden_dim, d.fusion_dim};
   if (const char* e = getenv("FASTVLA_NO_FUSED_FFN")) h->no_fused_ffn = e[0] == '1';
   if (const char* e = getenv("FASTVLA_NO_MFMA_DW")) h->no_mfma_dw = e[0] == '1';
+  if (const char* e = getenv("FASTVLA_NO_FFN32")) h->no_ffn32 = e[0] == '1';
   // RoPE table for every position the path can see (text + spliced image tokens)
   const int P = (d.image_size >> (d.tower_stages + 1)) * (d.image_size >> (d.tower_stages + 1));
   h->rope_rows = d.max_text_tokens + P + 8;
