@@ -54,3 +54,35 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.delenv("FASTVLA_HIP_LIB")
     monkeypatch.setattr(_lib, "_LIB", None)
     _lib.load()
+
+
+def test_convffn32_chunk_loop_has_no_register_file_copies(tmp_path):
+    """Build-time guard for csrc/convffn32.hip.  Its MFMAs are inline asm, so hipcc pads no hazard around them: if the register
+    allocator ever decides to keep an MFMA operand in the other half of the register file and copy it over per use
+    (v_accvgpr_write / _read in the chunk loop), the MFMA behind the copy reads a stale operand now and then -- results that
+    differ from run to run in the last bit (seen once, with the x fragments loaded through a buffer descriptor at C = 192).
+    The chunk loop (the innermost loop holding the 48 MFMAs) must contain no such copy and no scratch access."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc")
+    if hipcc is None:
+        pytest.skip("hipcc not on PATH")
+    src = Path(__file__).resolve().parent.parent / "vla-from-fastvlm_amd" / "csrc" / "convffn32.hip"
+    out = tmp_path / "convffn32.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-pragma-unroll-threshold=4000000", "-S",
+                    "--cuda-device-only", str(src), "-o", str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN2fv[^\n]*convffn32_kernel[^\n:]*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 3
+    for name, body in kernels:
+        lines = body.split("\n")
+        starts = [i for i, l in enumerate(lines) if "Inner Loop Header: Depth=2" in l]
+        assert starts, name
+        s0 = starts[0]
+        end = next(i for i in range(s0 + 100, len(lines)) if re.search(r"s_cbranch_scc[01] \.LBB", lines[i]))
+        loop = lines[s0:end]
+        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == 48, name
+        assert not [l for l in loop if "v_accvgpr" in l], name
+        assert not [l for l in loop if "scratch_" in l], name
+    assert ".vgpr_spill_count: 0" in text or "vgpr_spill_count" not in text

@@ -303,11 +303,25 @@ def test_fused_convffn(Cc, M):
     assert torch.equal(rd, out)
 
 
-def _pack_w2q(w2):
-    """fc2 weight (C, 4C) -> [4C/32][C][32], slot 16s+8h+j of each 32-block = hidden 16s + 8(j>>2) + 4h + (j&3) (fastvla_hip.h)."""
+def _pack_wq(w1, w2):
+    """fc1 (4C,C) + fc2 (C,4C) -> the convffn32 weight stream [4C/32][64 C] (fastvla_hip.h, fv_op_convffn32)."""
     Cc, Hd = w2.shape
-    idx = torch.tensor([16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for s in range(2) for h in range(2) for j in range(8)])
-    return w2.view(Cc, Hd // 32, 32)[:, :, idx].permute(1, 0, 2).contiguous()
+    nch = Hd // 32
+    sh, mask = {384: (0, 15), 192: (1, 7), 96: (2, 3)}[Cc]
+    r = torch.arange(32)
+    c = torch.arange(Cc // 8)
+    phys1 = c[None, :] ^ ((r[:, None] >> sh) & mask)                      # (32, C/8): physical chunk of logical chunk c in row r
+    t1 = torch.empty(nch, 32, Cc // 8, 8)
+    t1[:, r[:, None], phys1] = w1.view(nch, 32, Cc // 8, 8)
+    n = torch.arange(Cc)
+    hid = torch.tensor([[16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for j in range(8)] for s in range(2) for h in range(2)])  # (4 chunks, 8)
+    phys2 = torch.arange(4)[None, :] ^ ((n[:, None] >> 2) & 3)              # (C, 4)
+    w2c = w2.view(Cc, nch, 32)[:, :, hid]                                   # (C, nch, 4, 8): logical chunks
+    t2 = torch.empty(nch, Cc, 4, 8)
+    t2[:, n[:, None], phys2] = w2c.permute(1, 0, 2, 3)
+    T = torch.cat([t1.reshape(nch, -1), t2.reshape(nch, -1)], dim=1)        # (nch, 64 C) slot images
+    G = T.view(nch, -1, 4, 64, 2).permute(0, 1, 3, 2, 4)                    # [kb][d][l][b] -> [kb][l][d][b]
+    return G.reshape(nch, 64 * Cc).contiguous()
 
 
 # the 32x32x16 variant the engine runs at the real tower widths; the big cases give every persistent block several row tiles
@@ -321,13 +335,19 @@ def test_fused_convffn32(Cc, M):
     wide = torch.float64 if M < 5000 else torch.float32
     hid = bf(F.gelu(x.to(wide) @ w1.to(wide).t() + b1.to(wide)).float())  # the kernel rounds the hidden to bf16 too
     ref = (res.to(wide) + ls.to(wide) * (hid.to(wide) @ w2.to(wide).t() + b2.to(wide))).float()
-    xd, rd, w1d, w2d = dev_bf16(x), dev_bf16(res), dev_bf16(w1), dev_bf16(_pack_w2q(w2))
+    xd, rd, w1d, wqd = dev_bf16(x), dev_bf16(res), dev_bf16(w1), dev_bf16(_pack_wq(w1, w2))
     b1d, b2d, lsd = dev_f32(b1), dev_f32(b2), dev_f32(ls)
     out = torch.full((M, Cc), float("nan"), dtype=torch.bfloat16, device=DEV)
-    call(lib().fv_op_convffn32(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
+    call(lib().fv_op_convffn32(xd.data_ptr(), wqd.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
                                rd.data_ptr(), out.data_ptr(), M, Cc, stream()), "fv_op_convffn32")
     torch.cuda.synchronize()
     check_close(out.float().cpu(), ref, what=f"fused convffn32 C={Cc}")
+    # run to run bit-identical (a stale MFMA operand behind an unpadded hazard shows as last-bit flicker, not as a wrong tile)
+    out2 = torch.full((M, Cc), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(lib().fv_op_convffn32(xd.data_ptr(), wqd.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
+                               rd.data_ptr(), out2.data_ptr(), M, Cc, stream()), "fv_op_convffn32 again")
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
     # the two kernels compute the same thing: against each other the difference is accumulation order only
     out16 = torch.empty_like(out)
     call(lib().fv_op_convffn(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), dev_bf16(_pack_w2(w2)).data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
@@ -335,7 +355,7 @@ def test_fused_convffn32(Cc, M):
     torch.cuda.synchronize()
     check_close(out.float().cpu(), out16.float().cpu(), rel=2e-3, amax=2e-2, what=f"convffn32 vs convffn16 C={Cc}")
     # in place on the residual buffer (how the engine calls it)
-    call(lib().fv_op_convffn32(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
+    call(lib().fv_op_convffn32(xd.data_ptr(), wqd.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(),
                                rd.data_ptr(), rd.data_ptr(), M, Cc, stream()), "fv_op_convffn32 in place")
     torch.cuda.synchronize()
     assert torch.equal(rd, out)

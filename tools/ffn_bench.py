@@ -11,7 +11,7 @@ sys.path.insert(0, str(ROOT / "vla-from-fastvlm_amd"))
 sys.path.insert(0, str(ROOT / "tests"))
 sys.path.insert(0, str(ROOT))
 import fastvla_hip  # noqa: E402
-from test_gpu_ops import _pack_w2, _pack_w2q  # noqa: E402
+from test_gpu_ops import _pack_w2, _pack_wq  # noqa: E402
 
 lib = fastvla_hip.load()
 dev = "cuda:0"
@@ -24,10 +24,10 @@ for C, M in ((384, 64 * 64 * 64), (192, 64 * 128 * 128), (96, 64 * 256 * 256)):
     w1 = (torch.randn(Hd, C) / math.sqrt(C)).bfloat16()
     w2 = (torch.randn(C, Hd) / math.sqrt(Hd)).bfloat16()
     b1, b2, ls = torch.randn(Hd, device=dev) * 0.1, torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) * 0.3
-    w1d, w2p, w2q = w1.to(dev), _pack_w2(w2.float()).bfloat16().to(dev), _pack_w2q(w2.float()).bfloat16().to(dev)
+    w1d, w2p, wq = w1.to(dev), _pack_w2(w2.float()).bfloat16().to(dev), _pack_wq(w1.float(), w2.float()).bfloat16().to(dev)
     out = torch.empty_like(x)
     fns = {"16x16x32": lambda: lib.fv_op_convffn(x.data_ptr(), w1d.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), ls.data_ptr(), res.data_ptr(), out.data_ptr(), M, C, st),
-           "32x32x16": lambda: lib.fv_op_convffn32(x.data_ptr(), w1d.data_ptr(), b1.data_ptr(), w2q.data_ptr(), b2.data_ptr(), ls.data_ptr(), res.data_ptr(), out.data_ptr(), M, C, st)}
+           "32x32x16": lambda: lib.fv_op_convffn32(x.data_ptr(), wq.data_ptr(), b1.data_ptr(), b2.data_ptr(), ls.data_ptr(), res.data_ptr(), out.data_ptr(), M, C, st)}
     times = {k: [] for k in fns}
     for r in range(rounds + 1):
         for k, f in fns.items():

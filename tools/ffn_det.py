@@ -1,0 +1,39 @@
+import sys, math, torch
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/vla-from-fastvlm_amd'); sys.path.insert(0,'/root/repo/tests')
+import fastvla_hip
+from test_gpu_ops import _pack_wq
+lib=fastvla_hip.load(); dev="cuda:0"; st=torch.cuda.current_stream().cuda_stream
+for C,M in ((192,131149),(384,70001),(96,150013),(192,131072)):
+    torch.manual_seed(1)
+    Hd=4*C
+    x=torch.randn(M,C).bfloat16().to(dev); res=torch.randn(M,C).bfloat16().to(dev)
+    w1=(torch.randn(Hd,C)/math.sqrt(C)).bfloat16().float(); w2=(torch.randn(C,Hd)/math.sqrt(Hd)).bfloat16().float()
+    wq=_pack_wq(w1,w2).bfloat16().to(dev)
+    b1=(torch.randn(Hd)*0.1).to(dev); b2=(torch.randn(C)*0.1).to(dev); ls=(torch.rand(C)*0.3).to(dev)
+    outs=[]
+    for r in range(3):
+        o=torch.empty_like(x)
+        assert lib.fv_op_convffn32(x.data_ptr(),wq.data_ptr(),b1.data_ptr(),b2.data_ptr(),ls.data_ptr(),res.data_ptr(),o.data_ptr(),M,C,st)==0
+        torch.cuda.synchronize(); outs.append(o)
+    rd=res.clone()
+    assert lib.fv_op_convffn32(x.data_ptr(),wq.data_ptr(),b1.data_ptr(),b2.data_ptr(),ls.data_ptr(),rd.data_ptr(),rd.data_ptr(),M,C,st)==0
+    torch.cuda.synchronize()
+    d01=(outs[0]!=outs[1]).nonzero(); d02=(outs[0]!=outs[2]).nonzero(); dip=(outs[0]!=rd).nonzero()
+    print(C,M,"run0!=run1:",len(d01),"run0!=run2:",len(d02),"inplace!=run0:",len(dip), "rows:", sorted(set(dip[:,0].tolist()))[:10] if len(dip) else "")
+C,M=192,131072
+torch.manual_seed(1)
+Hd=4*C
+x=torch.randn(M,C).bfloat16().to(dev); res=torch.randn(M,C).bfloat16().to(dev)
+w1=(torch.randn(Hd,C)/math.sqrt(C)).bfloat16().float(); w2=(torch.randn(C,Hd)/math.sqrt(Hd)).bfloat16().float()
+wq=_pack_wq(w1,w2).bfloat16().to(dev)
+b1=(torch.randn(Hd)*0.1).to(dev); b2=(torch.randn(C)*0.1).to(dev); ls=(torch.rand(C)*0.3).to(dev)
+hid=torch.nn.functional.gelu(x.float()@w1.to(dev).t()+b1).bfloat16().float()
+ref=(res.float()+ls*(hid@w2.to(dev).t()+b2))
+for r in range(2):
+    o=torch.empty_like(x)
+    lib.fv_op_convffn32(x.data_ptr(),wq.data_ptr(),b1.data_ptr(),b2.data_ptr(),ls.data_ptr(),res.data_ptr(),o.data_ptr(),M,C,st); torch.cuda.synchronize()
+    err=(o.float()-ref).abs()
+    bad=(err>0.05).nonzero()
+    rows=sorted(set(bad[:,0].tolist()))
+    print("run",r,"bad elems",len(bad),"bad rows",len(rows), "first rows",rows[:8],"tiles",sorted(set(x//256 for x in rows))[:12], "row%256",sorted(set(x%256 for x in rows))[:40])
+    if len(bad): print("cols of first bad row", bad[bad[:,0]==rows[0]][:,1].tolist()[:40], "max err", float(err.max()))

@@ -19,7 +19,16 @@
 //     permuted to 16 s + 8 (j >> 2) + 4 h + (j & 3) at pack time (cdna_hip_programming.md section 3, "An accumulator tile as the
 //     next MFMA's operand")
 //     out^T[32 ch x 32 px] += W2[:, chunk] . H^T  two k-steps per output tile, accumulators live across all chunks
+#include <vector>
+
 #include "kernels.h"
+
+#ifndef FFN32_BUF   /* bit 0: x, bit 1: residual, bit 2: output through buffer descriptors */
+#define FFN32_BUF 6
+#endif
+#define F32_BUFX ((FFN32_BUF & 1) != 0)
+#define F32_BUFR ((FFN32_BUF & 2) != 0)
+#define F32_BUFO ((FFN32_BUF & 4) != 0)
 
 namespace fv {
 namespace {
@@ -27,7 +36,7 @@ namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct Ffn32Params {
-  const bf16_t* x; const bf16_t* w1; const float* b1; const bf16_t* w2q; const float* b2; const float* ls;
+  const bf16_t* x; const bf16_t* wq; const float* b1; const float* b2; const float* ls;
   const bf16_t* res; bf16_t* out; int M, nchunks;
 };
 
@@ -73,20 +82,26 @@ __device__ __forceinline__ void settle_ops(bf16x8 (&v)[N][2]) {
 
 constexpr int ring_depth32(int nr, int want) { return nr % want == 0 ? want : ring_depth32(nr, want - 1); }
 
-// LDS plan shared by the kernel and its launcher
+// LDS plan shared by the kernel, its launcher and the weight packer.
+// A weight slot holds one chunk's W1 image (32 hidden rows x C, 2C bytes per row) followed by its W2 image (C output-channel
+// rows x 32 hidden, 64 bytes per row), both UNPADDED: staging writes them in whole 256-byte runs (ds_write_addtid_b32: a
+// wave-instruction stores 64 lanes x 4 bytes at M0 + offset + 4 * lane, no address register, 2 cycles -- stage_micro.hip:
+// buffer load + 4 of these cost 12 clk of a wave's issue time per 1 KB piece beside 32x32x16 MFMAs, a global load + ds_write_b128
+// 47), so row padding is not available and the bank spread comes from an XOR swizzle of the 16-byte chunk index instead:
+//   W1 chunk c of row r lives at chunk c ^ ((r >> SWS1) & SWM1); W2 chunk c (= 2 s + h) of row n at chunk c ^ ((n >> 2) & 3).
+// Both make the 16 lanes of every ds_read_b128 lane group (distinct rows mod 16, same logical chunk) hit 16 different 16-byte
+// slots of the 256-byte bank row.
 template <int C, int MT>
 struct Ffn32Lds {
-  static constexpr int W1_STRIDE = C * 2 + 16;   // == 16 * odd (mod 256): the 32 rows of a 32x32x16 A fragment read conflict-free
-  static constexpr int W2_STRIDE = 64 + 16;
-  static constexpr int W1_BYTES = 32 * W1_STRIDE, W2_BYTES = C * W2_STRIDE, BUF = W1_BYTES + W2_BYTES;
+  static constexpr int ROW1 = C * 2, ROW2 = 64;
+  static constexpr int SWS1 = C == 384 ? 0 : C == 192 ? 1 : 2, SWM1 = C == 384 ? 15 : C == 192 ? 7 : 3;
+  static constexpr int W1_BYTES = 32 * ROW1, W2_BYTES = C * ROW2, BUF = W1_BYTES + W2_BYTES;   // 128 C bytes, a multiple of 1 KB
   static constexpr int CQ = 96;                  // channels per epilogue pass
   static constexpr int ORB = CQ * 4 + 16;        // fp32 row of a pass + 16 B (conflict-free 16-B column writes)
   static constexpr int EPI_WAVE = 32 * ORB;      // one pass of one wave
-  static constexpr int TABLES = 2 * C * 4 + 4 * C * 4;                      // b2, ls, b1 (fp32)
-  static constexpr bool EPI_OWN = 2 * BUF + TABLES + 4 * EPI_WAVE <= 160 * 1024;   // else the pass borrows a quarter weight slot
-  static constexpr int TOTAL = 2 * BUF + TABLES + (EPI_OWN ? 4 * EPI_WAVE : 0);
-  static_assert(EPI_OWN || (EPI_WAVE <= BUF / 4 && (BUF / 4) % 16 == 0), "epilogue pass must fit in a quarter of a weight slot");
-  static_assert(TOTAL <= 160 * 1024, "LDS");
+  static constexpr int TABLES = 2 * C * 4 + 4 * C * 4;                      // ls * b2, ls, b1 (fp32)
+  static constexpr int TOTAL = 2 * BUF + TABLES + 4 * EPI_WAVE;
+  static_assert(BUF % 1024 == 0 && TOTAL <= 160 * 1024, "LDS");
 };
 
 template <int C, int MT>
@@ -94,17 +109,27 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
   using L = Ffn32Lds<C, MT>;
   constexpr int KS = C / 16;            // k-steps of the first product
   constexpr int NT = C / 32;            // output-channel tiles of the second product (two k-steps each)
-  constexpr int W1_STRIDE = L::W1_STRIDE, W2_STRIDE = L::W2_STRIDE, W1_BYTES = L::W1_BYTES, BUF = L::BUF;
-  constexpr int W1_CH = 32 * C / 8, W2_CH = C * 4;            // 16-byte pieces per weight chunk
-  constexpr int NLD = (W1_CH + W2_CH) / 256;                  // staging loads per thread per chunk
-  static_assert((W1_CH + W2_CH) % 256 == 0 && NLD <= 12 && 2 * NLD == KS, "staging schedule: one store or one load per first-product step");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF] weight slots, b2[C], ls[C], b1[4C], (epilogue)
+  constexpr int ROW1 = L::ROW1, W1_BYTES = L::W1_BYTES, BUF = L::BUF;
+  constexpr int NLD = BUF / 1024 / 4;                         // 1 KB staging pieces per wave per chunk
+  static_assert(BUF % 4096 == 0 && NLD <= 12 && 2 * NLD == KS, "staging schedule: one store or one load per first-product step");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF] weight slots, ls*b2[C], ls[C], b1[4C], epilogue staging
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int nch = p.nchunks;                                   // C / 8: even, >= 4
-  const uint32_t tid16 = (uint32_t)tid * 16u;
   const int ntiles = (p.M + 128 * MT - 1) / (128 * MT);
+  // the packed weight stream through a buffer descriptor: a buffer load costs a wave ~6 clk of issue beside the MFMAs where a
+  // global load costs ~23 (tools/stage_micro.hip); lane offset in a VGPR (piece of wave wid, 16 B per lane), chunk and piece in
+  // the scalar offset
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.wq), 0, nch * BUF, 0x00020000);
+  const uint32_t wvoff = (uint32_t)tid * 16u;
+  // activations through descriptors too (32-bit byte offsets: M * C * 2 < 4 GiB, checked by the launcher)
+  const uint32_t act_bytes = (uint32_t)p.M * (uint32_t)(C * 2);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, act_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, act_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, act_bytes, 0x00020000);
+  // LDS address of this wave's first 1 KB piece in slot 0 (wave-uniform: M0 of the add-tid stores)
+  const uint32_t wm0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)smem + (uint32_t)wid * 1024u);
 
   // ---- x fragments: lane holds x[pixel m = fr][16 ks + 8 fh .. +8] for its MT pixel tiles (rows past M clamp to M - 1)
   bf16x8 xf[MT][KS];
@@ -115,9 +140,10 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
     const long mb_ = (long)(TILE) * (128 * MT) + wid * (32 * MT);                                            \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                      \
       const long m_ = min(mb_ + mt * 32 + (lx_ & 31), (long)p.M - 1);                                        \
-      const bf16_t* xp_ = p.x + m_ * C + (lx_ >> 5) * 8;                                                     \
+      const uint32_t xo_ = (uint32_t)m_ * (uint32_t)(C * 2) + (uint32_t)(lx_ >> 5) * 16u;                    \
       _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                      \
-        xf[mt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp_ + ks * 16));             \
+        xf[mt][ks] = F32_BUFX ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo_ + ks * 32, 0, 0)) \
+                              : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.x) + xo_ + ks * 32)); \
     }                                                                                                        \
   }
   F32_LOAD_X(blockIdx.x)
@@ -125,28 +151,23 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
 
   uint4 st0, st1, st2, st3, st4, st5, st6, st7, st8, st9, st10, st11;
   st0 = st1 = st2 = st3 = st4 = st5 = st6 = st7 = st8 = st9 = st10 = st11 = make_uint4(0, 0, 0, 0);
-#define F32_PIECE_OFF(c) ((c) < W1_CH ? ((c) / (C / 8)) * W1_STRIDE + ((c) % (C / 8)) * 16 : W1_BYTES + (((c) - W1_CH) >> 2) * W2_STRIDE + (((c) - W1_CH) & 3) * 16)
-#define F32_STAGE_LOAD(HC)                                                                                   \
+  // piece j of this wave: bytes [(4 j + wid) KB, +1 KB) of the chunk; each lane's 16 bytes leave as four dword stores that land
+  // 256 bytes apart ([dword][lane] inside the KB) -- the packer (convffn32_pack) lays the global image out so that this IS the
+  // swizzled LDS image
+#define F32_PIECE_LOAD(J, HC) F32_ST_SET(J, __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (HC) * BUF + (J) * 4096, 0)))
+#define F32_PIECE_STORE(J, SLOT)                                                                             \
   {                                                                                                          \
-    const bf16_t* g1 = p.w1 + (size_t)(HC) * 32 * C;  /* [32][C] */                                          \
-    const bf16_t* g2 = p.w2q + (size_t)(HC) * C * 32; /* [C][32], hidden permuted */                         \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
-      const int c = tid + 256 * i;                                                                           \
-      const bf16_t* src = c < W1_CH ? g1 + (size_t)c * 8 : g2 + (size_t)(c - W1_CH) * 8;                     \
-      F32_ST_SET(i, *reinterpret_cast<const uint4*>(src))                                                    \
-    }                                                                                                        \
+    const uint4 v_ = F32_ST_GET(J);                                                                          \
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"   \
+                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"                     \
+                 :: "v"(v_.x), "v"(v_.y), "v"(v_.z), "v"(v_.w), "s"(wm0 + (uint32_t)((SLOT) * BUF + (J) * 4096)) : "memory"); \
   }
-#define F32_STAGE_STORE(BUFI)                                                                                \
-  {                                                                                                          \
-    char* base = smem + (BUFI) * BUF;                                                                        \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
-      const int c = tid + 256 * i;                                                                           \
-      *reinterpret_cast<uint4*>(base + F32_PIECE_OFF(c)) = F32_ST_GET(i);                                    \
-    }                                                                                                        \
-  }
-  F32_STAGE_LOAD(0)
-  F32_STAGE_STORE(0)
-  F32_STAGE_LOAD(1)                       // rides in registers through chunk 0, stored to LDS during it
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) F32_PIECE_LOAD(j, 0)
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) F32_PIECE_STORE(j, 0)
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) F32_PIECE_LOAD(j, 1)   // rides in registers through chunk 0, stored to LDS during it
   // second-product bias, layer scale and first-product bias, staged once per block
   float* sb2 = reinterpret_cast<float*>(smem + 2 * BUF);
   float* sls = sb2 + C;
@@ -157,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
     reinterpret_cast<float4*>(sls)[i] = l;
   }
   for (int i = tid; i < C; i += 256) reinterpret_cast<float4*>(sb1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-tid stores are invisible to hipcc's counters
   __syncthreads();
 
   // Fragment stream of one chunk: reads 0..KS-1 are W1 fragments (k-step i), reads KS..NR-1 are W2 fragments (output tile
@@ -168,12 +190,24 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
   constexpr bool XA = true;                // upper half of the x fragments in AGPRs (MFMA reads A / B from either half)
   constexpr int NR = KS + 2 * NT, PD = ring_depth32(NR, FFN32_PD < NR / 2 ? FFN32_PD : NR / 2);
   static_assert(2 * NLD <= NR - PD && NR % PD == 0, "ring");
-#define F32_FRAG(I, W1S, W2S)                                                                                      \
-  ((I) < KS ? *reinterpret_cast<const uint4*>((W1S) + fr * W1_STRIDE + (I) * 32 + fh * 16)                          \
-            : *reinterpret_cast<const uint4*>((W2S) + ((((I) - KS) >> 1) * 32 + fr) * W2_STRIDE + (((I) - KS) & 1) * 32 + fh * 16))
+  // swizzled fragment addresses: W1 step i reads logical chunk 2 i + fh of row fr, i.e. physical chunk (2 i + fh) ^ s1 -- the XOR
+  // touches the low bits only, so the lane part repeats every NA1 steps and the rest is an immediate offset; W2 step (t, s)
+  // reads logical chunk 2 s + fh of row 32 t + fr
+  constexpr int GB1 = L::SWM1 + 1, NA1 = GB1 / 2;
+  uint32_t fa1[NA1], fa2[2];
+  {
+    const uint32_t s1 = (uint32_t)(fr >> L::SWS1) & L::SWM1, s2 = (uint32_t)(fr >> 2) & 3u;
+#pragma unroll
+    for (int m = 0; m < NA1; ++m) fa1[m] = (uint32_t)fr * ROW1 + 16u * ((((uint32_t)(2 * m + fh)) & L::SWM1) ^ s1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) fa2[q] = (uint32_t)W1_BYTES + (uint32_t)fr * 64u + 16u * ((uint32_t)(2 * q + fh) ^ s2);
+  }
+#define F32_FRAG(I, SLOTP)                                                                                          \
+  ((I) < KS ? *reinterpret_cast<const uint4*>((SLOTP) + fa1[(I) % NA1] + ((I) / NA1) * (GB1 * 16))                  \
+            : *reinterpret_cast<const uint4*>((SLOTP) + fa2[((I) - KS) & 1] + (((I) - KS) >> 1) * 2048))
   uint4 ring[PD];
 #pragma unroll
-  for (int i = 0; i < PD; ++i) ring[i] = F32_FRAG(i, smem, smem + W1_BYTES);
+  for (int i = 0; i < PD; ++i) ring[i] = F32_FRAG(i, smem);
 
   // epilogue geometry: one pass turns 32 rows x CQ channels of fp32 through the wave's staging area
   constexpr int CQ = L::CQ, ORB = L::ORB, NPASS = C / CQ;      // passes per row tile
@@ -193,7 +227,9 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
     _Pragma("unroll") for (int it = 0; it < RP; ++it) {                                                      \
       const int item_ = it * 64 + lr_, row_ = item_ / (CQ / 8), c8_ = item_ % (CQ / 8);                      \
       const long m_ = min((MB) + ((Q) / NPASS) * 32 + row_, (long)p.M - 1);                                  \
-      rr[(Q) % RD][it] = *reinterpret_cast<const uint4*>(p.res + m_ * C + ((Q) % NPASS) * CQ + c8_ * 8);      \
+      const uint32_t ro_ = (uint32_t)m_ * (uint32_t)(C * 2) + (uint32_t)(((Q) % NPASS) * CQ + c8_ * 8) * 2u;  \
+      rr[(Q) % RD][it] = F32_BUFR ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ro_, 0, 0)) \
+                                  : *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.res) + ro_); \
     }                                                                                                        \
   }
 
@@ -211,33 +247,6 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
 #else
 #define F32_ABL_STAGE 0
 #endif
-#ifdef FFN32_ABL_NOSTORE  /* ... staging loads but no LDS stores */
-#define F32_ABL_NOSTORE 1
-#else
-#define F32_ABL_NOSTORE 0
-#endif
-#if defined(FFN32_ST_B64)      /* staging store as two 8-byte LDS stores */
-#define F32_LDS_STORE(P, V) { const uint4 v__ = (V); *reinterpret_cast<uint2*>(P) = make_uint2(v__.x, v__.y); *reinterpret_cast<uint2*>((P) + 8) = make_uint2(v__.z, v__.w); }
-#elif defined(FFN32_ST_B32)    /* ... as four 4-byte LDS stores */
-#define F32_LDS_STORE(P, V) { const uint4 v__ = (V); volatile uint32_t* q__ = reinterpret_cast<volatile uint32_t*>(P); q__[0] = v__.x; q__[1] = v__.y; q__[2] = v__.z; q__[3] = v__.w; }
-#else
-#define F32_LDS_STORE(P, V) *reinterpret_cast<uint4*>(P) = (V);
-#endif
-#ifdef FFN32_ABL_STORERS  /* ... only the waves whose bit is set in the mask store (0x3: waves 0,1; 0x5: waves 0,2; 0x1: wave 0) */
-#define F32_ABL_STORER ((FFN32_ABL_STORERS >> wid) & 1)
-#else
-#define F32_ABL_STORER 1
-#endif
-#ifdef FFN32_ABL_NOLOAD   /* ... LDS stores but no staging loads */
-#define F32_ABL_NOLOAD 1
-#else
-#define F32_ABL_NOLOAD 0
-#endif
-#ifdef FFN32_ABL_L1       /* ... every staging load reads the same 4 KB (an L1 hit): the instruction stream without the L2 traffic */
-#define F32_ABL_L1 1
-#else
-#define F32_ABL_L1 0
-#endif
 #ifdef FFN32_ABL_FRAG   /* ... no fragment reads past the first ring fill */
 #define F32_ABL_FRAG 1
 #else
@@ -249,39 +258,24 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
     /* weight staging two chunks deep: during chunk hc the registers loaded during chunk hc-1 (chunk hc+1's weights) */ \
     /* go to the idle slot and are refilled with chunk hc+2's; the chunk index wraps into the next tile            */ \
     const int hn = hc + 2 - (hc + 2 >= nch ? nch : 0);                                                              \
-    const bf16_t* g1n = p.w1 + (size_t)hn * 32 * C;                                                                 \
-    const bf16_t* g2n = p.w2q + (size_t)hn * C * 32;                                                                \
-    char* nbase = smem + (cur ^ 1) * BUF;                                                                           \
-    const char* w1s = smem + cur * BUF;                                                                             \
-    const char* w2s = w1s + W1_BYTES;                                                                               \
+    const char* cbase = smem + cur * BUF;                                                                           \
+    const char* nbase = smem + (cur ^ 1) * BUF;                                                                     \
     f32x16 hacc[MT];                                                                                                \
     bf16x8 hf[MT][2];                                                                                               \
     _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                                \
-      if (i == NR - PD) __syncthreads();                                                                            \
+      if (i == NR - PD) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }                     \
       const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i % PD]);                                                    \
-      if (!F32_ABL_FRAG) ring[i % PD] = i + PD < NR ? F32_FRAG(i + PD, w1s, w2s) : F32_FRAG(i + PD - NR, nbase, nbase + W1_BYTES); \
+      if (!F32_ABL_FRAG) ring[i % PD] = i + PD < NR ? F32_FRAG(i + PD, cbase) : F32_FRAG(i + PD - NR, nbase);       \
       if (i < KS) { /* H^T += W1[chunk rows, k-step i] . x^T */                                                     \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                         \
           if (i == 0) mfma32_hid_init(hacc[mt], a, xf[mt][0]);                                                      \
           else if (XA && i >= KS / 2) mfma32_hid<XA>(hacc[mt], a, xf[mt][i >= KS / 2 ? i : KS - 1]);                \
           else mfma32_hid<false>(hacc[mt], a, xf[mt][i]);                                                           \
         }                                                                                                           \
-        if (!F32_ABL_STAGE) { /* staging: even steps store register j to the idle slot, odd steps reload it for the chunk after */ \
+        if (!F32_ABL_STAGE) { /* staging: even steps store piece j to the idle slot, odd steps reload its register for the chunk after */ \
           const int j = i >> 1;                                                                                     \
-          const int c = tid + 256 * j;                                                                              \
-          if ((i & 1) == 0) {                                                                                       \
-            if (!F32_ABL_NOSTORE && F32_ABL_STORER) { F32_LDS_STORE(nbase + F32_PIECE_OFF(c), F32_ST_GET(j)) }      \
-          } else if (!F32_ABL_NOLOAD) {                                                                             \
-            if constexpr (W1_CH % 256 == 0) {                                                                       \
-              const char* sb_ = F32_ABL_L1 ? reinterpret_cast<const char*>(p.w1)                                    \
-                                : j * 256 < W1_CH ? reinterpret_cast<const char*>(g1n) + j * 4096                   \
-                                                : reinterpret_cast<const char*>(g2n) + (j * 256 - W1_CH) * 16;      \
-              F32_ST_SET(j, *reinterpret_cast<const uint4*>(sb_ + tid16))                                           \
-            } else {                                                                                                \
-              const bf16_t* src = c < W1_CH ? g1n + (size_t)c * 8 : g2n + (size_t)(c - W1_CH) * 8;                  \
-              F32_ST_SET(j, *reinterpret_cast<const uint4*>(src))                                                   \
-            }                                                                                                       \
-          }                                                                                                         \
+          if ((i & 1) == 0) F32_PIECE_STORE(j, cur ^ 1)                                                             \
+          else F32_PIECE_LOAD(j, hn)                                                                                \
         }                                                                                                           \
         if (i == KS - 1) { /* bias + GELU in registers -> the two B fragments of the second product */              \
           const float4 bq0 = *reinterpret_cast<const float4*>(sb1 + hc * 32 + 4 * fh);                              \
@@ -312,6 +306,13 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
     }                                                                                                               \
   }
 
+#ifdef FFN32_STAGGER   /* experiment: de-phase the blocks so that their epilogues (the launch's whole HBM traffic) do not coincide */
+  {
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long wait_ = (unsigned long long)(((blockIdx.x >> 3) % FFN32_STAGGER_K) * (FFN32_STAGGER));
+    while (__builtin_amdgcn_s_memtime() - t0_ < wait_) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   for (int tile = blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
     const long mb = (long)tile * (128 * MT) + wid * (32 * MT);
 #pragma unroll
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
     // tile t are channels 32 t + 8 q + 4 fh + 0..3 of pixel fr: one 16-byte write each); on the way out a lane owns 8
     // consecutive channels of a row: bias, layer scale, residual add and the one bf16 rounding happen there, every global
     // access is 16 B of a fully used line.
-    char* so = L::EPI_OWN ? smem + 2 * BUF + L::TABLES + wid * L::EPI_WAVE : smem + ((nch - 1) & 1) * BUF + wid * (BUF / 4);
+    char* so = smem + 2 * BUF + L::TABLES + wid * L::EPI_WAVE;
     int le = lane;
     asm volatile("" : "+v"(le));
     const int fre = le & 31, fhe = le >> 5;
@@ -377,22 +378,23 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
         o.z = pack_bf2(bf_lo(r4.z) + fmaf(l1.x, y1.x, b1.x), bf_hi(r4.z) + fmaf(l1.y, y1.y, b1.y));
         o.w = pack_bf2(bf_lo(r4.w) + fmaf(l1.z, y1.z, b1.z), bf_hi(r4.w) + fmaf(l1.w, y1.w, b1.w));
         const long m = mb + mt * 32 + row;
-        if (m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + cb) = o;
+        // rows past M fall outside the descriptor's range: the hardware drops those stores
+        if (F32_BUFO) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, o), orsrc,
+                                               m < p.M ? (uint32_t)m * (uint32_t)(C * 2) + (uint32_t)cb * 2u : 0xffffff00u, 0, 0);
+        else if (m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + cb) = o;
         if (it & 1) __builtin_amdgcn_sched_barrier(0);   // two items' operands in flight at a time
       }
       if (RD < NPASS * MT && q + RD - 1 < NPASS * MT) F32_LOAD_RES(q + RD - 1, mb)
       asm volatile("" ::: "memory");                      // the next pass's writes stay behind these reads
     }
-    __syncthreads();  // a borrowed slot is the next tile's staging target again
   }
 #undef F32_CHUNK
 #undef F32_GELU
 #undef F32_LOAD_RES
 #undef F32_LOAD_X
 #undef F32_FRAG
-#undef F32_STAGE_LOAD
-#undef F32_STAGE_STORE
-#undef F32_PIECE_OFF
+#undef F32_PIECE_LOAD
+#undef F32_PIECE_STORE
 }
 
 int num_cus32() {
@@ -425,25 +427,44 @@ int launch_one32(const Ffn32Params& p, hipStream_t s) {
 
 bool convffn32_supported(int C, int ratio) { return ratio == 4 && (C == 96 || C == 192 || C == 384); }
 
-// w2 [C][hidden] row-major -> [hidden/32][C][32] with slot 16 s + 8 h + j of each 32-block holding hidden
-// 16 s + 8 (j >> 2) + 4 h + (j & 3): element j of lane half h in k-step s of the second product (see the file header)
-void convffn32_pack_w2(const float* w2, float* out, int C, int hidden) {
-  for (int hc = 0; hc < hidden / 32; ++hc)
+// fc1 weight w1 [4C][C] and fc2 weight w2 [C][4C] (row-major fp32, values already bf16-representable or to be rounded by the
+// caller) -> ONE stream out[4C/32][64 C]: per 32-hidden chunk the byte image the kernel's weight slot holds, in the order its
+// staging reads it.  Slot image T (elements of 2 bytes): W1 part = 32 rows x C with 8-element chunk c of row r at chunk
+// c ^ ((r >> SWS1) & SWM1); W2 part = C rows x 32 with the element j of lane half h in k-step s (hidden 16 s + 8 (j >> 2) + 4 h +
+// (j & 3): the order in which a converted 32x32 accumulator tile is the next product's B operand) in chunk (2 s + h) ^ ((n >> 2) & 3).
+// Staging moves each KB as lane l's 16 bytes -> four dwords stored 256 bytes apart, so the global image G of a KB is
+// G[8 l + 2 d + b] = T[128 d + 2 l + b] (l < 64 lanes, d < 4 dwords, b < 2 elements).
+void convffn32_pack(const float* w1, const float* w2, float* out, int C) {
+  const int hidden = 4 * C, nch = hidden / 32, be = 64 * C;   // elements per chunk
+  const int sh1 = C == 384 ? 0 : C == 192 ? 1 : 2, mask1 = C == 384 ? 15 : C == 192 ? 7 : 3;
+  std::vector<float> T((size_t)be);
+  for (int hc = 0; hc < nch; ++hc) {
+    for (int r = 0; r < 32; ++r)
+      for (int c = 0; c < C / 8; ++c)
+        for (int e = 0; e < 8; ++e) T[(size_t)r * C + (size_t)(c ^ ((r >> sh1) & mask1)) * 8 + e] = w1[(size_t)(hc * 32 + r) * C + c * 8 + e];
     for (int n = 0; n < C; ++n)
       for (int s = 0; s < 2; ++s)
         for (int h = 0; h < 2; ++h)
           for (int j = 0; j < 8; ++j)
-            out[((size_t)hc * C + n) * 32 + 16 * s + 8 * h + j] = w2[(size_t)n * hidden + hc * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+            T[(size_t)32 * C + (size_t)n * 32 + (size_t)((2 * s + h) ^ ((n >> 2) & 3)) * 8 + j] =
+                w2[(size_t)n * hidden + hc * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+    float* G = out + (size_t)hc * be;
+    for (int kb = 0; kb < be / 512; ++kb)
+      for (int l = 0; l < 64; ++l)
+        for (int d = 0; d < 4; ++d)
+          for (int b = 0; b < 2; ++b) G[kb * 512 + 8 * l + 2 * d + b] = T[(size_t)kb * 512 + 128 * d + 2 * l + b];
+  }
 }
 
-int launch_convffn32(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2q, const float* b2, const float* ls,
+int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const float* b2, const float* ls,
                      const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s) {
-  if (!x || !w1 || !b1 || !w2q || !b2 || !ls || !res || !out) return fv_fail(FV_ERR_ARG, "convffn32: null pointer");
+  if (!x || !wq || !b1 || !b2 || !ls || !res || !out) return fv_fail(FV_ERR_ARG, "convffn32: null pointer");
   if (M <= 0 || hidden != 4 * C || !convffn32_supported(C, 4)) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: unsupported C=%d hidden=%d", C, hidden);
-  if (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2q | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ls | (uintptr_t)res | (uintptr_t)out) & 15)
+  if (((uintptr_t)x | (uintptr_t)wq | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ls | (uintptr_t)res | (uintptr_t)out) & 15)
     return fv_fail(FV_ERR_ARG, "convffn32: misaligned pointer");
   if (x == out) return fv_fail(FV_ERR_ARG, "convffn32: x must not alias out");
-  Ffn32Params p{x, w1, b1, w2q, b2, ls, res, out, M, hidden / 32};
+  if ((size_t)M * C * 2 >= ((size_t)1 << 32) - 65536) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: M * C * 2 must stay below 4 GiB (32-bit buffer offsets)");
+  Ffn32Params p{x, wq, b1, b2, ls, res, out, M, hidden / 32};
   switch (C) {
 #ifndef FFN32_MT96
 #define FFN32_MT96 4

@@ -305,9 +305,11 @@ int load_ffn(Loader& L, const std::string& pre, int C, int hidden, float bn_eps,
       w2p.resize(w2.size());
       fv::convffn_pack_w2(w2.data(), w2p.data(), C, hidden);
       f.w2p = L.up_bf16(w2p);
-      if (fv::convffn32_supported(C, 4)) {  // second layout: the 32x32x16 kernel's k-permutation
-        fv::convffn32_pack_w2(w2.data(), w2p.data(), C, hidden);
-        f.w2q = L.up_bf16(w2p);
+      std::vector<float> w1;
+      if (fv::convffn32_supported(C, 4) && L.expect(pre + "fc1.weight", w1, (size_t)hidden * C)) {  // the 32x32x16 kernel's stream
+        std::vector<float> wq((size_t)2 * hidden * C);
+        fv::convffn32_pack(w1.data(), w2.data(), wq.data(), C);
+        f.w2q = L.up_bf16(wq);
       }
     }
   }
@@ -422,7 +424,7 @@ int dw_s1(fv_handle* h, const bf16_t* x, const float* w, const bf16_t* ttab, con
 
 // fused ConvFFN pointwise half: the 32x32x16 kernel where it exists (C = 96 / 192 / 384), else the 16x16x32 one
 int fused_ffn(fv_handle* h, const FFN& f, const bf16_t* t, const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s) {
-  if (f.w2q && !h->no_ffn32) return fv::launch_convffn32(t, f.fc1_w, f.fc1_b, f.w2q, f.fc2_b, f.ls, res, out, M, C, hidden, s);
+  if (f.w2q && !h->no_ffn32) return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s);
   return fv::launch_convffn(t, f.fc1_w, f.fc1_b, f.w2p, f.fc2_b, f.ls, res, out, M, C, hidden, s);
 }
 

@@ -31,10 +31,11 @@ void convffn_pack_w2(const float* w2, float* out, int C, int hidden);
 int launch_convffn(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2p, const float* b2, const float* ls,
                    const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s);
 
-// the same fused ConvFFN on v_mfma_f32_32x32x16_bf16 (convffn32.hip): C in {96, 192, 384}; w2q = convffn32_pack_w2 layout
+// the same fused ConvFFN on v_mfma_f32_32x32x16_bf16 (convffn32.hip): C in {96, 192, 384}; wq = convffn32_pack stream (fc1 and
+// fc2 weights, [4C/32 chunks][64 C elements])
 bool convffn32_supported(int C, int ratio);
-void convffn32_pack_w2(const float* w2, float* out, int C, int hidden);
-int launch_convffn32(const bf16_t* x, const bf16_t* w1, const float* b1, const bf16_t* w2q, const float* b2, const float* ls,
+void convffn32_pack(const float* w1, const float* w2, float* out, int C);
+int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const float* b2, const float* ls,
                      const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s);
 
 int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox,

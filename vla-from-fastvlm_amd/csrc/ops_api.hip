@@ -98,10 +98,10 @@ int fv_op_convffn(const void* x, const void* w1, const float* b1, const void* w2
                             static_cast<const bf16_t*>(res), static_cast<bf16_t*>(out), M, C, 4 * C, static_cast<hipStream_t>(s));
 }
 
-int fv_op_convffn32(const void* x, const void* w1, const float* b1, const void* w2q, const float* b2, const float* ls,
-                    const void* res, void* out, int M, int C, fv_stream s) {
-  return fv::launch_convffn32(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w1), b1, static_cast<const bf16_t*>(w2q), b2, ls,
-                              static_cast<const bf16_t*>(res), static_cast<bf16_t*>(out), M, C, 4 * C, static_cast<hipStream_t>(s));
+int fv_op_convffn32(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
+                    int M, int C, fv_stream s) {
+  return fv::launch_convffn32(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(wq), b1, b2, ls, static_cast<const bf16_t*>(res),
+                              static_cast<bf16_t*>(out), M, C, 4 * C, static_cast<hipStream_t>(s));
 }
 
 }  // extern "C"
