@@ -171,7 +171,9 @@ def main():
     # the MFMA family is two kernels: the fused ConvFFN (epi 6: 4*M*C*4C flop) and the plain GEMM (2*M*N*|K|)
     def _fl(r):
         return (4.0 if r["epi"] == 6 else 2.0) * r["m"] * r["n"] * abs(r["k"]) * r["launches"]
-    groups = {"convffn_kernel (fused fc1+GELU+fc2, bf16 MFMA 16x16x32)": [r for r in shapes if r["epi"] == 6],
+    ffn_name = ("convffn_kernel (fused fc1+GELU+fc2, bf16 MFMA 16x16x32)" if os.environ.get("FASTVLA_NO_FFN32", "0") == "1"
+                else "convffn32_kernel (fused fc1+GELU+fc2, bf16 MFMA 32x32x16)")
+    groups = {ffn_name: [r for r in shapes if r["epi"] == 6],
               "gemm_kernel (bf16 MFMA 16x16x32, fp32 acc)": [r for r in shapes if r["epi"] != 6]}
     gstat = {k: dict(ms=sum(r["ms"] for r in v), flops=sum(_fl(r) for r in v), n=sum(r["launches"] for r in v))
              for k, v in groups.items() if v}

@@ -248,16 +248,20 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       ow[j] = j < SW ? (uint32_t)(((size_t)min(bn + row, p.N - 1) * p.K + chunk * 8) * 2) : 0u;   // rows past N (padded last tile) repeat the last
     }
   };
+  // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): per-lane 32-bit byte offset in a VGPR, the K-tile's offset
+  // in an SGPR.  Beside MFMAs a wave pays ~31 clk of issue for such a piece where the global_load_lds form (64-bit per-lane
+  // address) pays ~52 (tools/stage_micro.hip); launch_gemm keeps operands of 4 GiB or more away from this kernel.
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, 0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, 0xffffffffu, 0x00020000);
   auto stage = [&](const uint32_t (&oa)[4], const uint32_t (&ow)[4], int kt, int buf) {
     const int kw = kt >= nk1 ? kt - nk1 : kt;
-    const char* ab = reinterpret_cast<const char*>(p.A) + ((size_t)kw * BK + (kt >= nk1 ? p.K : 0)) * 2;
-    const char* wb = reinterpret_cast<const char*>(p.W) + (size_t)kw * BK * 2;
+    const int aoff = (kw * BK + (kt >= nk1 ? p.K : 0)) * 2, woff = kw * BK * 2;
     char* la = g2_smem + buf * BUFB + wslot;
     char* lw = la + AB;
 #pragma unroll
-    for (int j = 0; j < SA; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(ab + oa[j]), (lds_ptr_t)(la + j * (NTH * 16)), 16, 0, 0);
+    for (int j = 0; j < SA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(la + j * (NTH * 16)), 16, oa[j], aoff, 0, 0);
 #pragma unroll
-    for (int j = 0; j < SW; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(wb + ow[j]), (lds_ptr_t)(lw + j * (NTH * 16)), 16, 0, 0);
+    for (int j = 0; j < SW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(lw + j * (NTH * 16)), 16, ow[j], woff, 0, 0);
   };
   // lane's fragment offsets: row fr of a 16-row tile, swizzled chunk per k-step
   const uint32_t fo0 = (uint32_t)(fr * 128 + (((0 * 4 + fq) ^ (fr & 7)) << 4));
