@@ -139,6 +139,13 @@ int fv_head_saved_bytes(fv_handle* h, int B, size_t* out_bytes);
 int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled, const float* states, int B,
                     int training, float dropout_p, uint64_t seed, uint64_t offset, float* actions, void* saved,
                     fv_stream s);
+/* Dataset statistics folded into the head: replaces the STATE / ACTION parts of LeRobot's
+ * NormalizerProcessorStep / UnnormalizerProcessorStep around the policy (lerobot_fastvla/processor_fastvla.py:34-48, MEAN_STD per
+ * lerobot_fastvla/configuration_fastvla.py:21-27): fv_head_forward then computes LayerNorm((states - state_mean) / (state_std + eps))
+ * ... and, when training == 0, returns actions * action_std + action_mean.  HOST vectors of state_dim / action_dim floats; all four
+ * NULL switches the folding off.  Training keeps its loss in normalised action space (targets arrive normalised). */
+int fv_head_set_io_norm(fv_handle* h, const float* state_mean, const float* state_std, const float* action_mean,
+                        const float* action_std, float eps);
 /* replaces F.mse_loss + autograd backward of the head (fastvla/modeling_fastvla.py:56,
  * lerobot_fastvla/modeling_fastvla.py:132; trainer.py:175): writes loss (1 f32, device) and ALL 12 grads into
  * flat_grads (overwritten, not accumulated). */

@@ -276,3 +276,40 @@ def test_last_error_is_per_handle_and_comm_world1():
     assert torch.equal(g.cpu(), torch.arange(16, dtype=torch.float32))
     e1.comm_destroy(comm)
     e1.close(), e2.close()
+
+
+def test_folded_dataset_normalisation_matches_the_processor_arithmetic():
+    """STATE (x - mean) / (std + 1e-8) ahead of the policy and ACTION a * std + mean behind it -- what LeRobot's
+    Normalizer / Unnormalizer steps do (reference lerobot_fastvla/processor_fastvla.py:34-48) -- folded into the head kernels:
+    raw states in, un-normalised actions out, bit-for-bit the unfolded policy fed normalised states, up to the fp32 rounding of
+    the affine maps; training keeps its loss in normalised space."""
+    from vla_fastvlm.lerobot_fastvla import FastVLAConfig as LRConfig, FastVLAPolicy as LRPolicy
+    from vla_fastvlm.lerobot_fastvla._lerobot_compat import HAVE_LEROBOT, FeatureType, PolicyFeature
+    if HAVE_LEROBOT:
+        pytest.skip("stand-in semantics are only exercised without lerobot")
+    feats = {"observation.images.top": PolicyFeature(FeatureType.VISUAL, (3, 64, 64)), "observation.state": PolicyFeature(FeatureType.STATE, (6,))}
+    cfg = LRConfig(vlm_model_name="synthetic:tiny:77", hidden_dim=32, fusion_dim=48, input_features=feats,
+                   output_features={"action": PolicyFeature(FeatureType.ACTION, (5,))}, dropout=0.0)
+    torch.manual_seed(3)
+    pol = LRPolicy(cfg).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    stats = {"observation.state": {"mean": torch.randn(6, generator=g), "std": torch.rand(6, generator=g) + 0.5},
+             "action": {"mean": torch.randn(5, generator=g), "std": torch.rand(5, generator=g) + 0.5}}
+    raw = torch.randn(3, 6, generator=g) * 2 + 1
+    batch = {"observation.images.top": torch.rand(3, 3, 64, 64, generator=g).to(DEV), "task": ["a", "b", "c"]}
+    norm_state = (raw - stats["observation.state"]["mean"]) / (stats["observation.state"]["std"] + 1e-8)
+    pol.reset()
+    a_norm = pol.select_action({**batch, "observation.state": norm_state.to(DEV)}).cpu()
+    ref = a_norm * stats["action"]["std"] + stats["action"]["mean"]
+    pol.fold_dataset_stats(stats)
+    pol.reset()
+    a_fold = pol.select_action({**batch, "observation.state": raw.to(DEV)}).cpu()
+    assert float((a_fold - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # training: loss against NORMALISED targets, states raw -- equals the unfolded loss on normalised states
+    tgt = torch.randn(3, 1, 5, generator=g)
+    pol.train()
+    loss_fold, _ = pol.forward({**batch, "observation.state": raw.to(DEV), "action": tgt.to(DEV)})
+    pol.fold_dataset_stats(None)
+    loss_ref, _ = pol.forward({**batch, "observation.state": norm_state.to(DEV), "action": tgt.to(DEV)})
+    torch.cuda.synchronize()
+    assert abs(float(loss_fold) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))

@@ -125,6 +125,8 @@ struct fv_handle {
   void* const* taps = nullptr;  // fv_vision_forward_taps: per-stage copies of the activation map (parity tests)
   int n_taps = 0;
   void* rccl = nullptr;       // dlopen handle of librccl (fv_comm_* / fv_allreduce_grads), resolved on first use
+  fv::HeadIoNorm io{nullptr, nullptr, nullptr, nullptr};   // fv_head_set_io_norm: dataset statistics folded into the head
+  bool has_io = false;
   bool no_fused_ffn = false;  // FASTVLA_NO_FUSED_FFN=1: A/B switch back to the two-GEMM ConvFFN
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
   bool no_ffn32 = false;      // FASTVLA_NO_FFN32=1: A/B switch back to the 16x16x32 fused ConvFFN
@@ -904,9 +906,29 @@ int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled,
   hipStream_t st = static_cast<hipStream_t>(s);
   prof_begin(h, FV_FAM_HEAD, 2.0 * B * fv::head_offsets(h->hd).o[12], 4.0 * fv::head_offsets(h->hd).o[12], st);
   const int rc = fv::launch_head_forward(h->hd, flat_params, pooled, states, B, training, dropout_p, seed, offset, actions,
-                                         static_cast<float*>(saved), st);
+                                         static_cast<float*>(saved), st, h->has_io ? &h->io : nullptr);
   prof_end(h, st);
   return rc;
+}
+
+int fv_head_set_io_norm(fv_handle* h, const float* state_mean, const float* state_std, const float* action_mean,
+                        const float* action_std, float eps) {
+  HandleScope _hs(h);
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  if (!state_mean && !state_std && !action_mean && !action_std) { h->has_io = false; return FV_OK; }   // all NULL: folding off
+  if (!state_mean || !state_std || !action_mean || !action_std) return fv_fail(FV_ERR_ARG, "fv_head_set_io_norm: give all four vectors or none");
+  FV_HIP_CHECK(hipSetDevice(h->device));
+  const int ds = h->hd.ds, da = h->hd.da;
+  std::vector<float> v((size_t)2 * ds + 2 * da);
+  for (int i = 0; i < ds; ++i) { v[i] = state_mean[i]; v[ds + i] = 1.0f / (state_std[i] + eps); }
+  for (int i = 0; i < da; ++i) { v[2 * ds + i] = action_mean[i]; v[2 * ds + da + i] = action_std[i]; }
+  void* p = nullptr;
+  FV_TRY(dev_alloc(h, v.size() * 4, &p));
+  FV_HIP_CHECK(hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  float* f = static_cast<float*>(p);
+  h->io = fv::HeadIoNorm{f, f + ds, f + 2 * ds, f + 2 * ds + da};
+  h->has_io = true;
+  return FV_OK;
 }
 
 int fv_head_mse_backward(fv_handle* h, const float* flat_params, const float* actions, const float* targets, int B,

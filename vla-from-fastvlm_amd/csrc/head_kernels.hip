@@ -24,21 +24,25 @@ __device__ __forceinline__ uint4 philox(uint4 c, uint2 k) {
 }
 
 // one wave per row: y = LN(x) * w + b, saves xhat and rstd
+// pre_mean / pre_istd (may be null): the dataset normalisation of the input folded in, x <- (x - pre_mean) * pre_istd
+// (LeRobot NormalizerProcessorStep, MEAN_STD; reference lerobot_fastvla/processor_fastvla.py:34-39)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                       const float* __restrict__ b, float* __restrict__ y,
-                                                      float* __restrict__ xhat, float* __restrict__ rstd, int rows, int n) {
+                                                      float* __restrict__ xhat, float* __restrict__ rstd, int rows, int n,
+                                                      const float* __restrict__ pre_mean, const float* __restrict__ pre_istd) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (size_t)row * ldx;
+  auto in = [&](int i) { return pre_mean ? (xr[i] - pre_mean[i]) * pre_istd[i] : xr[i]; };
   float s = 0.f;
-  for (int i = lane; i < n; i += 64) s += xr[i];
+  for (int i = lane; i < n; i += 64) s += in(i);
   const float mean = wave_sum(s) / (float)n;
   float q = 0.f;
-  for (int i = lane; i < n; i += 64) { const float d = xr[i] - mean; q += d * d; }
+  for (int i = lane; i < n; i += 64) { const float d = in(i) - mean; q += d * d; }
   const float rs = rsqrtf(wave_sum(q) / (float)n + LN_EPS);
   for (int i = lane; i < n; i += 64) {
-    const float h = (xr[i] - mean) * rs;
+    const float h = (in(i) - mean) * rs;
     xhat[(size_t)row * n + i] = h;
     y[(size_t)row * n + i] = h * w[i] + b[i];
   }
@@ -50,7 +54,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           float* __restrict__ y, int ldy, float* __restrict__ z, int B,
-                                                          int N, int K, int act) {
+                                                          int N, int K, int act, const float* __restrict__ post_scale,
+                                                          const float* __restrict__ post_shift) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b0 = blockIdx.y * 8;
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
       if (b0 + j >= B) break;
       const float v = acc[j] + bv;
       if (act) { z[(size_t)(b0 + j) * N + n] = v; y[(size_t)(b0 + j) * ldy + n] = silu_f(v); }
-      else y[(size_t)(b0 + j) * ldy + n] = v;
+      else y[(size_t)(b0 + j) * ldy + n] = post_scale ? v * post_scale[n] + post_shift[n] : v;   // action un-normalisation folded in
     }
   }
 }
@@ -309,7 +314,7 @@ size_t head_bwd_scratch_bytes(const HeadDims& d, int B) {
 
 int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, const float* states, int B,
                         int training, float drop_p, uint64_t seed, uint64_t offset, float* actions, float* saved,
-                        hipStream_t s) {
+                        hipStream_t s, const HeadIoNorm* io) {
   if (!P || !pooled || !states || !actions || !saved) return fv_fail(FV_ERR_ARG, "head_forward: null pointer");
   if (B <= 0) return fv_fail(FV_ERR_ARG, "head_forward: B must be positive");
   if (drop_p < 0.f || drop_p >= 1.f) return fv_fail(FV_ERR_ARG, "head_forward: dropout p out of range");
@@ -317,14 +322,20 @@ int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, 
   const Saved sv = carve(d, B, saved);
   const int cw = d.feat + d.hid;
   const dim3 blk(256);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(B, 4)), blk, 0, s, states, d.ds, P + ho.o[0], P + ho.o[1], sv.n0, sv.xh0, sv.rstd0, B, d.ds);
+  const float* sm = io ? io->state_mean : nullptr;
+  const float* si = io ? io->state_istd : nullptr;
+  // the action un-normalisation belongs to inference only: training computes its loss against NORMALISED targets
+  const float* as = io && !training ? io->action_std : nullptr;
+  const float* am = io && !training ? io->action_mean : nullptr;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(B, 4)), blk, 0, s, states, d.ds, P + ho.o[0], P + ho.o[1], sv.n0, sv.xh0, sv.rstd0, B, d.ds, sm, si);
   hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv((long)B * d.feat, 256)), blk, 0, s, pooled, d.feat, sv.cat, cw, B, d.feat);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(d.hid, 4), cdiv(B, 8)), blk, 0, s, sv.n0, d.ds, P + ho.o[2], P + ho.o[3], sv.cat + d.feat, cw, sv.z1, B, d.hid, d.ds, 1);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(d.fus, 4), cdiv(B, 8)), blk, 0, s, sv.cat, cw, P + ho.o[4], P + ho.o[5], sv.z2, d.fus, (float*)nullptr, B, d.fus, cw, 0);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(B, 4)), blk, 0, s, sv.z2, d.fus, P + ho.o[6], P + ho.o[7], sv.n2, sv.xh2, sv.rstd2, B, d.fus);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(d.hid, 4), cdiv(B, 8)), blk, 0, s, sv.n0, d.ds, P + ho.o[2], P + ho.o[3], sv.cat + d.feat, cw, sv.z1, B, d.hid, d.ds, 1, (const float*)nullptr, (const float*)nullptr);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(d.fus, 4), cdiv(B, 8)), blk, 0, s, sv.cat, cw, P + ho.o[4], P + ho.o[5], sv.z2, d.fus, (float*)nullptr, B, d.fus, cw, 0, (const float*)nullptr, (const float*)nullptr);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(B, 4)), blk, 0, s, sv.z2, d.fus, P + ho.o[6], P + ho.o[7], sv.n2, sv.xh2, sv.rstd2, B, d.fus,
+                     (const float*)nullptr, (const float*)nullptr);
   hipLaunchKernelGGL(silu_dropout_kernel, dim3(cdiv((long)B * d.fus, 256)), blk, 0, s, sv.n2, sv.d2, sv.mask, (long)B * d.fus, training, drop_p, seed, offset);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(d.fus, 4), cdiv(B, 8)), blk, 0, s, sv.d2, d.fus, P + ho.o[8], P + ho.o[9], sv.a3, d.fus, sv.z3, B, d.fus, d.fus, 1);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(d.da, 4), cdiv(B, 8)), blk, 0, s, sv.a3, d.fus, P + ho.o[10], P + ho.o[11], actions, d.da, (float*)nullptr, B, d.da, d.fus, 0);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(d.fus, 4), cdiv(B, 8)), blk, 0, s, sv.d2, d.fus, P + ho.o[8], P + ho.o[9], sv.a3, d.fus, sv.z3, B, d.fus, d.fus, 1, (const float*)nullptr, (const float*)nullptr);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(d.da, 4), cdiv(B, 8)), blk, 0, s, sv.a3, d.fus, P + ho.o[10], P + ho.o[11], actions, d.da, (float*)nullptr, B, d.da, d.fus, 0, as, am);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

@@ -95,9 +95,12 @@ struct HeadDims { int feat, ds, da, hid, fus; };
 struct HeadOffsets { int64_t o[13]; };
 HeadOffsets head_offsets(const HeadDims& d);
 size_t head_saved_bytes(const HeadDims& d, int B);
+// dataset normalisation folded into the head (device vectors; LeRobot MEAN_STD): states <- (states - state_mean) * state_istd
+// ahead of the first LayerNorm; actions <- actions * action_std + action_mean behind the last Linear when not training
+struct HeadIoNorm { const float *state_mean, *state_istd, *action_mean, *action_std; };
 int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, const float* states, int B,
                         int training, float drop_p, uint64_t seed, uint64_t offset, float* actions, float* saved,
-                        hipStream_t s);
+                        hipStream_t s, const HeadIoNorm* io = nullptr);
 // grad_actions != null: generic backward from dL/dactions (loss untouched); else fused MSE(actions, targets) + backward
 int launch_head_backward(const HeadDims& d, const float* P, const float* grad_actions, const float* actions,
                          const float* targets, int B, float drop_p, const float* saved, float* loss, float* G,

@@ -84,6 +84,7 @@ SIGNATURES = {
     "fv_head_layout": (_i, [_vp, C.POINTER(_i64 * 13)]),
     "fv_head_saved_bytes": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
     "fv_head_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _u64, _u64, _vp, _vp, _vp]),
+    "fv_head_set_io_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _f]),
     "fv_head_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "fv_head_backward": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "fv_grad_accumulate": (_i, [_vp, _vp, _vp, _i64, _vp]),

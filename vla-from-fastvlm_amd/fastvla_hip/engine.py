@@ -279,6 +279,22 @@ class FastVLAEngine:
                                             saved.data_ptr(), _stream()), "fv_head_forward")
         return actions, saved
 
+    def set_io_norm(self, state_mean=None, state_std=None, action_mean=None, action_std=None, eps: float = 1e-8) -> None:
+        """Fold the dataset's MEAN_STD statistics into the head kernels (fv_head_set_io_norm); all None switches it off."""
+        vecs = [state_mean, state_std, action_mean, action_std]
+        if all(v is None for v in vecs):
+            _lib.check(self.lib.fv_head_set_io_norm(self.h, None, None, None, None, float(eps)), "fv_head_set_io_norm", self.h)
+            return
+        dims = [self.head_dims["ds"], self.head_dims["ds"], self.head_dims["da"], self.head_dims["da"]]
+        keep = []
+        for v, n in zip(vecs, dims):
+            t = torch.as_tensor(v, dtype=torch.float32).detach().cpu().contiguous().reshape(-1)
+            if t.numel() != n:
+                raise ValueError(f"normalisation vector has {t.numel()} elements, expected {n}")
+            keep.append(t)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fv_head_set_io_norm(self.h, *[t.data_ptr() for t in keep], float(eps)), "fv_head_set_io_norm", self.h)
+
     def head_backward(self, flat_params: torch.Tensor, actions: torch.Tensor, targets: torch.Tensor, saved: torch.Tensor,
                       dropout_p: float = 0.0, flat_grads: Optional[torch.Tensor] = None):
         B = actions.shape[0]

@@ -57,6 +57,18 @@ class FastVLAPolicy(PreTrainedPolicy):
     def reset(self):
         self._action_queue: deque[Tensor] = deque([], maxlen=self.config.n_action_steps)
 
+    def fold_dataset_stats(self, dataset_stats) -> None:
+        """Take over the STATE / ACTION MEAN_STD normalisation LeRobot's processors would apply around the policy
+        (reference lerobot_fastvla/processor_fastvla.py:34-48 with the map of configuration_fastvla.py:21-27): raw states go
+        in, un-normalised actions come out of `select_action`, with the arithmetic folded into the head kernels.
+        `forward(batch)` still expects NORMALISED action targets (the loss lives in normalised space).  None switches it off."""
+        if dataset_stats is None:
+            self.model.backbone.set_io_normalization()
+            return
+        act_key = next((k for k, ft in (self.config.output_features or {}).items() if ft.type is FeatureType.ACTION), ACTION)
+        st, ac = dataset_stats[self._state_key], dataset_stats[act_key]
+        self.model.backbone.set_io_normalization(state_mean=st["mean"], state_std=st["std"], action_mean=ac["mean"], action_std=ac["std"])
+
     def _prepare_inputs(self, batch: dict[str, Tensor]) -> tuple[Tensor, Tensor, list[str]]:
         images = batch[self._image_keys[0]]  # only the first camera feeds the backbone
         if images.ndim == 5:

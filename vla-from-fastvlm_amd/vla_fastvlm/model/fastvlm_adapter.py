@@ -166,6 +166,7 @@ class FastVLMBackbone(nn.Module):
         # ... and the tower, whose output the literal reference computes and never consumes
         self.skip_unused_tower = os.environ.get("FASTVLA_SKIP_UNUSED_TOWER", "0") == "1"
         self._engine: Optional[FastVLAEngine] = None
+        self._io_norm: Optional[dict] = None   # dataset statistics folded into the head kernels (set_io_normalization)
         self._head_dims = dict(state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024)
         self._max_batch = int(os.environ.get("FASTVLA_MAX_BATCH", "64"))
         print(f"[FastVLMBackbone] expected (S,S) = ({self.expected_size},{self.expected_size})")
@@ -258,8 +259,20 @@ class FastVLMBackbone(nn.Module):
             else:
                 state = torch.load(arg, map_location="cpu") if arg.endswith(".pt") else _load_safetensors(arg)
             eng.load_weights(state)
+            if self._io_norm is not None:
+                eng.set_io_norm(**self._io_norm)
             self._engine = eng
         return self._engine
+
+    def set_io_normalization(self, state_mean=None, state_std=None, action_mean=None, action_std=None, eps: float = 1e-8) -> None:
+        """Fold the dataset's MEAN_STD statistics of the state input and the action output into the head kernels
+        (replaces LeRobot's Normalizer/Unnormalizer steps for those features, reference
+        lerobot_fastvla/processor_fastvla.py:34-48).  All None switches the folding off."""
+        off = all(v is None for v in (state_mean, state_std, action_mean, action_std))
+        self._io_norm = None if off else dict(state_mean=state_mean, state_std=state_std, action_mean=action_mean,
+                                              action_std=action_std, eps=eps)
+        if self._engine is not None:
+            self._engine.set_io_norm(**(self._io_norm or {}))
 
     # ------------------------------------------------------------------ preprocessing
     def _prepare_images_tensor(self, images, device: torch.device) -> Tensor:
@@ -371,12 +384,17 @@ def arch_from_hf_config(config_json) -> "fv_arch.ModelConfig":
 
 
 def load_hf_checkpoint_dir(path) -> Dict[str, Tensor]:
-    """All tensors of every *.safetensors shard in the directory, keys unchanged; `lm_head.*` is dropped (the path never
-    computes logits).  Missing or mis-shaped tensors are reported by fv_load_weights with the key name."""
+    """All tensors of every *.safetensors shard in the directory; `lm_head.*` is dropped (the path never computes logits) and a
+    vision tower in TRAINING form (multi-branch MobileOne blocks, RepMixer, RepCPE, large-kernel + small-kernel convs with their
+    BatchNorms) is folded to the inference form the library packs (vla_fastvlm/model/reparam.py).  Missing or mis-shaped
+    tensors are reported by fv_load_weights with the key name."""
     from safetensors.torch import load_file
     state: Dict[str, Tensor] = {}
     for shard in sorted(Path(path).glob("*.safetensors")):
         for k, v in load_file(str(shard)).items():
             if not k.startswith("lm_head."):
                 state[k] = v
+    from .reparam import fold_train_form, is_train_form
+    if is_train_form(state):   # a checkpoint saved before re-parameterisation: fold its branches / BatchNorms on the host, once
+        state = fold_train_form(state)
     return state
