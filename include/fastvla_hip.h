@@ -135,7 +135,9 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
 int fv_head_layout(fv_handle* h, int64_t offsets[13]);
 int fv_head_saved_bytes(fv_handle* h, int B, size_t* out_bytes);
 /* replaces FastVLMWithExpert.forward after the backbone (fastvla/fastvlm_with_expert.py:50-54).
- * training != 0 applies Dropout(p) with a Philox mask derived from (seed, offset); saved = activations for backward. */
+ * training: 0 = inference; 1 = training, Dropout(p) applied with a Philox mask derived from (seed, offset); 2 = training without
+ * dropout (p = 0).  Any non-zero value keeps the actions in normalised space when fv_head_set_io_norm folded the dataset
+ * statistics in (the loss is computed against normalised targets).  saved = activations for backward. */
 int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled, const float* states, int B,
                     int training, float dropout_p, uint64_t seed, uint64_t offset, float* actions, void* saved,
                     fv_stream s);

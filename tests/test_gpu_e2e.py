@@ -243,3 +243,38 @@ def test_7b_shaped_decoder_layers():
         r, _ = check_close(got.cpu(), ref, rel=tol, amax=10 * tol, what=f"7B-shaped pooled prec={prec}")
         print(f"[7b-2layer] prec={prec} pooled rel_l2={r:.2e}")
         eng.close()
+
+
+@pytest.mark.parametrize("splice", [False, True])
+def test_policy_step_is_graph_capturable_and_replays_bit_identically(splice):
+    """include/fastvla_hip.h promises: asynchronous on the caller's stream, no allocation, no synchronisation inside the forward
+    calls -- i.e. a step can be captured into a hipGraph.  Capture the whole inference step (two streams in literal mode: the
+    decoder runs beside the tower), replay it on new inputs and compare with the eager path bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    m = arch.preset("tiny")
+    w = weights.init_backbone(m, seed=11)
+    eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=64, fusion_dim=96, max_batch=4, max_text_tokens=16)
+    eng.load_weights(w)
+    g = torch.Generator().manual_seed(12)
+    B, T = 3, 9
+    shapes = head.head_shapes(m.llm.hidden, 14, 14, 64, 96)
+    p = {k: torch.randn(*s, generator=g) * 0.2 + (1.0 if k in ("state_projection.0.weight", "fusion.1.weight") else 0.0) for k, s in shapes.items()}
+    flat = _flat_head(eng, p)
+    img = torch.rand(B, 3, 80, 96, generator=g).to(DEV)
+    ids = torch.randint(0, m.llm.vocab, (B, T), generator=g).to(DEV, torch.int32)
+    lens = torch.tensor([9, 4, 7], dtype=torch.int32, device=DEV)
+    states = torch.randn(B, 14, generator=g).to(DEV)
+    replay, actions = eng.capture_policy_step(img, ids, lens, flat, states, splice=splice)
+    for trial in range(3):
+        img.copy_(torch.rand(B, 3, 80, 96, generator=g))
+        ids.copy_(torch.randint(0, m.llm.vocab, (B, T), generator=g))
+        states.copy_(torch.randn(B, 14, generator=g))
+        replay()
+        torch.cuda.synchronize()
+        got = actions.clone()
+        pooled = eng.backbone(img, ids, lens, splice=splice)
+        ref, _ = eng.head_forward(flat, pooled, states)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all() and torch.equal(got, ref), (trial, float((got - ref).abs().max()))
+    eng.close()

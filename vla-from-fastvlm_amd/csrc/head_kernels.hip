@@ -327,6 +327,7 @@ int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, 
   // the action un-normalisation belongs to inference only: training computes its loss against NORMALISED targets
   const float* as = io && !training ? io->action_std : nullptr;
   const float* am = io && !training ? io->action_mean : nullptr;
+  training &= 1;   // bit 0: dropout active; any non-zero value: actions stay in normalised space
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(B, 4)), blk, 0, s, states, d.ds, P + ho.o[0], P + ho.o[1], sv.n0, sv.xh0, sv.rstd0, B, d.ds, sm, si);
   hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv((long)B * d.feat, 256)), blk, 0, s, pooled, d.feat, sv.cat, cw, B, d.feat);
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(d.hid, 4), cdiv(B, 8)), blk, 0, s, sv.n0, d.ds, P + ho.o[2], P + ho.o[3], sv.cat + d.feat, cw, sv.z1, B, d.hid, d.ds, 1, (const float*)nullptr, (const float*)nullptr);

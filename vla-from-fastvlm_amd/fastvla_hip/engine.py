@@ -241,6 +241,38 @@ class FastVLAEngine:
         pooled.record_stream(cur)
         return pooled
 
+    # ---------------------------------------------------------------- hipGraph capture of the inference step
+    def capture_policy_step(self, images: torch.Tensor, ids: torch.Tensor, lens: torch.Tensor, flat_params: torch.Tensor,
+                            states: torch.Tensor, *, splice: bool = False, pool_mode: int = 0):
+        """Capture letterbox -> tower -> projector -> decoder -> pool -> head as ONE hipGraph (every entry point of the library is
+        asynchronous on the caller's stream, allocates nothing and never synchronises: include/fastvla_hip.h).  The given
+        tensors become the graph's static inputs: copy new data INTO them (same shapes) and call replay().
+        -> (replay, actions): `replay()` launches the graph on the current stream, `actions` (B, A) is its static output.
+        At B = 1 the eager step is launch-bound (~350 launches); the graph replays it in one submission."""
+        B, T = ids.shape
+        ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        lens = lens.to(device=self.device, dtype=torch.int32).contiguous()
+        images, states = images.to(self.device).contiguous(), states.to(self.device, torch.float32).contiguous()
+        self.ensure_workspace(B, T, splice)
+        saved = self.head_saved(B)
+
+        def step():
+            pooled = self.backbone(images, ids, lens, splice=splice, pool_mode=pool_mode)
+            act, _ = self.head_forward(flat_params, pooled, states, saved=saved)
+            return act
+
+        side = torch.cuda.Stream(device=self.device)   # warm-up off the default stream: one-time attribute calls, workspace, side stream
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            actions = step()
+        return graph.replay, actions
+
     # ---------------------------------------------------------------- action expert
     def head_numel(self) -> int:
         return self.head_offsets[12]
@@ -265,8 +297,10 @@ class FastVLAEngine:
         return torch.empty(n.value // 4, dtype=torch.float32, device=self.device)
 
     def head_forward(self, flat_params: torch.Tensor, pooled: torch.Tensor, states: torch.Tensor, *, training: bool = False,
-                     dropout_p: float = 0.0, seed: int = 0, offset: int = 0, saved: Optional[torch.Tensor] = None
-                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+                     dropout_p: float = 0.0, seed: int = 0, offset: int = 0, saved: Optional[torch.Tensor] = None,
+                     normalized_actions: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """normalized_actions: keep the output in normalised action space even without dropout (loss / training paths when
+        set_io_norm folded the dataset statistics in)."""
         B = pooled.shape[0]
         states = states.to(device=self.device, dtype=torch.float32).contiguous()
         pooled = pooled.contiguous()
@@ -274,8 +308,10 @@ class FastVLAEngine:
             raise ValueError(f"states must be (B,{self.head_dims['ds']}), got {tuple(states.shape)}")
         saved = saved if saved is not None else self.head_saved(B)
         actions = torch.empty(B, self.head_dims["da"], dtype=torch.float32, device=self.device)
+        # 1 = dropout active, 2 = training-mode arithmetic without dropout (folded action statistics are NOT applied), 0 = inference
+        mode = 0 if not (training or normalized_actions) else (1 if training and dropout_p > 0.0 else 2)
         _lib.check(self.lib.fv_head_forward(self.h, flat_params.data_ptr(), pooled.data_ptr(), states.data_ptr(), B,
-                                            int(training), float(dropout_p), seed, offset, actions.data_ptr(),
+                                            mode, float(dropout_p), seed, offset, actions.data_ptr(),
                                             saved.data_ptr(), _stream()), "fv_head_forward")
         return actions, saved
 

@@ -28,7 +28,7 @@ class _HeadFunction(torch.autograd.Function):
         p = float(owner.config.dropout) if training else 0.0
         owner._drop_calls += 1
         actions, saved = eng.head_forward(flat, pooled, states, training=bool(training and p > 0.0), dropout_p=p,
-                                          seed=owner._drop_seed, offset=owner._drop_calls)
+                                          seed=owner._drop_seed, offset=owner._drop_calls, normalized_actions=bool(training))
         ctx.owner, ctx.saved, ctx.p = owner, saved, p
         return actions
 
@@ -52,7 +52,7 @@ class _HeadLossFunction(torch.autograd.Function):
         p = float(owner.config.dropout) if training else 0.0
         owner._drop_calls += 1
         actions, saved = eng.head_forward(flat, pooled, states, training=bool(training and p > 0.0), dropout_p=p,
-                                          seed=owner._drop_seed, offset=owner._drop_calls)
+                                          seed=owner._drop_seed, offset=owner._drop_calls, normalized_actions=True)  # a loss: normalised space
         loss, grads = eng.head_backward(flat, actions, targets, saved, dropout_p=p)
         ctx.owner, ctx.grads = owner, grads
         ctx.mark_non_differentiable(actions)

@@ -129,7 +129,7 @@ class FastVLAPolicy(nn.Module):
         p = float(self.config.dropout) if self.training else 0.0
         m._drop_calls += 1
         actions, saved = eng.head_forward(flat, prep["pooled"], prep["states"], training=p > 0.0, dropout_p=p,
-                                          seed=m._drop_seed, offset=m._drop_calls)
+                                          seed=m._drop_seed, offset=m._drop_calls, normalized_actions=True)
         if k > 1 and st["acc"] is None:
             st["acc"] = torch.zeros_like(flat)
         first = st["micro"] == 1  # first micro-batch of an accumulation window: the backward writes the window's buffer
