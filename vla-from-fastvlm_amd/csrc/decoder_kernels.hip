@@ -7,6 +7,7 @@
 #include "kernels.h"
 
 namespace fv {
+#define FV_TRY_RC(expr) do { const int rc_ = (expr); if (rc_ != FV_OK) return rc_; } while (0)
 namespace {
 
 __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __restrict__ ids,
@@ -237,7 +238,10 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out_hi,
                                                                      bf16_t* __restrict__ out_lo, const int32_t* __restrict__ lens,
                                                                      int len_add, int ld, int ldo, int T, int heads, int kv_heads,
-                                                                     float scale) {
+                                                                     float scale, const float2* __restrict__ rope) {
+  // rope != null: qkv holds the UN-rotated projections and the rotate-half RoPE ([site] modeling_qwen2.py:105-135) is applied
+  // here, to the query fragments in registers and to the K rows on their way into LDS (position = index in the sequence;
+  // table [pos][D/2] of (cos, sin)) -- one launch and one read-modify-write pass over q and k less per layer
   constexpr int DT = D / 16;               // 16-row tiles of O^T, and 16-float column groups of a K row
   constexpr int KCH = D == 64 ? 64 : 32;   // keys per LDS chunk
   constexpr int LDR = D + 4;               // padded row (floats)
@@ -261,6 +265,16 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
     const float* qp = qkv + ((size_t)b * T + min(qg, T - 1)) * ld + h * D + 4 * fg;
 #pragma unroll
     for (int c = 0; c < DT; ++c) fq[c] = *reinterpret_cast<const float4*>(qp + 16 * c);
+    if (rope) {   // d = 16 c + 4 fg + e pairs with d + D/2 = 16 (c + DT/2) + 4 fg + e: the same lane
+      const float2* t = rope + (size_t)min(qg, T - 1) * (D / 2) + 4 * fg;
+#pragma unroll
+      for (int c = 0; c < DT / 2; ++c) {
+        const float4 cs0 = *reinterpret_cast<const float4*>(t + 16 * c), cs1 = *reinterpret_cast<const float4*>(t + 16 * c + 2);
+        const float4 a = fq[c], b = fq[c + DT / 2];
+        fq[c] = make_float4(a.x * cs0.x - b.x * cs0.y, a.y * cs0.z - b.y * cs0.w, a.z * cs1.x - b.z * cs1.y, a.w * cs1.z - b.w * cs1.w);
+        fq[c + DT / 2] = make_float4(b.x * cs0.x + a.x * cs0.y, b.y * cs0.z + a.y * cs0.w, b.z * cs1.x + a.z * cs1.y, b.w * cs1.z + a.w * cs1.w);
+      }
+    }
   }
   f32x4 o[DT];
 #pragma unroll
@@ -270,12 +284,29 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
   const int kend = min(len, qb * 64 + 64);   // causal: keys beyond the block's last query are never visible
   for (int k0 = 0; k0 < kend; k0 += KCH) {
     __syncthreads();
-    for (int i = tid; i < KCH * D / 4; i += 256) {
-      const int key = i / (D / 4), c4 = i % (D / 4);
-      const int krow = min(k0 + key, T - 1);
-      const float* base = qkv + ((size_t)b * T + krow) * ld + qd + hk * D + c4 * 4;
-      *reinterpret_cast<float4*>(sK + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base);
-      *reinterpret_cast<float4*>(sV + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base + kd);
+    if (rope) {   // a thread takes the four d of the first half AND their partners d + D/2 of a key row
+      for (int i = tid; i < KCH * D / 8; i += 256) {
+        const int key = i / (D / 8), c4 = i % (D / 8);
+        const int krow = min(k0 + key, T - 1);
+        const float* base = qkv + ((size_t)b * T + krow) * ld + qd + hk * D + c4 * 4;
+        const float4 a = *reinterpret_cast<const float4*>(base), bb = *reinterpret_cast<const float4*>(base + D / 2);
+        const float2* t = rope + (size_t)krow * (D / 2) + c4 * 4;
+        const float4 cs0 = *reinterpret_cast<const float4*>(t), cs1 = *reinterpret_cast<const float4*>(t + 2);
+        *reinterpret_cast<float4*>(sK + key * LDR + c4 * 4) =
+            make_float4(a.x * cs0.x - bb.x * cs0.y, a.y * cs0.z - bb.y * cs0.w, a.z * cs1.x - bb.z * cs1.y, a.w * cs1.z - bb.w * cs1.w);
+        *reinterpret_cast<float4*>(sK + key * LDR + D / 2 + c4 * 4) =
+            make_float4(bb.x * cs0.x + a.x * cs0.y, bb.y * cs0.z + a.y * cs0.w, bb.z * cs1.x + a.z * cs1.y, bb.w * cs1.z + a.w * cs1.w);
+        *reinterpret_cast<float4*>(sV + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base + kd);
+        *reinterpret_cast<float4*>(sV + key * LDR + D / 2 + c4 * 4) = *reinterpret_cast<const float4*>(base + kd + D / 2);
+      }
+    } else {
+      for (int i = tid; i < KCH * D / 4; i += 256) {
+        const int key = i / (D / 4), c4 = i % (D / 4);
+        const int krow = min(k0 + key, T - 1);
+        const float* base = qkv + ((size_t)b * T + krow) * ld + qd + hk * D + c4 * 4;
+        *reinterpret_cast<float4*>(sK + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base);
+        *reinterpret_cast<float4*>(sV + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base + kd);
+      }
     }
     __syncthreads();
 #pragma unroll 1
@@ -395,8 +426,8 @@ int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, in
   return FV_OK;
 }
 
-int launch_attention_f32(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
-                         int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s) {
+int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
+                         int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope) {
   if (!qkv || !out_hi || !out_lo) return fv_fail(FV_ERR_ARG, "attention_f32: null pointer");
   if (ldo < heads * D || ldo % 8) return fv_fail(FV_ERR_ARG, "attention_f32: bad ldo");
   if (B <= 0 || T <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads || ld % 4 || ld < (heads + 2 * kv_heads) * D)
@@ -407,12 +438,14 @@ int launch_attention_f32(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_l
   static const bool no_mfma = getenv("FASTVLA_NO_ATTN_F32_MFMA") != nullptr;
   if (D >= 64 && !no_mfma) {
     const long nb = (long)B * heads * ((T + 63) / 64);
-    if (D == 64) hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale);
-    else hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale);
+    // rope given: q and k are rotated inside the kernel (no separate pass over the packed projections)
+    if (D == 64) hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope);
+    else hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
   }
   if (G * NT > 256) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: too many q heads per kv head (%d)", G);
+  if (rope) FV_TRY_RC(launch_rope_f32(qkv, rope, ld, B * T, T, heads, kv_heads, D, s));   // the VALU kernel reads rotated q / k
   // queries per block: as many as 256 threads hold (any count, not a power of two: G = 7 leaves 44 % of the lanes idle at
   // 16), then levelled over the tiles so the causal key ranges of the tiles are balanced
   int QT = 256 / (G * NT);

@@ -861,13 +861,16 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
     bf16_t* cs = reinterpret_cast<bf16_t*>(ws + wp.act_lo);   // [rows][2*I]
     float* qkvf = reinterpret_cast<float*>(ws + wp.qkvf);
     const int I = d.llm_inter, I2 = 2 * I;
-    for (const DecLayer& L : h->dec.layers) {
-      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
+    for (size_t li = 0; li < h->dec.layers.size(); ++li) {
+      const DecLayer& L = h->dec.layers[li];
+      // layer 0 norms its own input; every later layer's input_layernorm output arrives from the previous layer's down
+      // projection (fused into its split-K reducer)
+      if (li == 0) FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
       fv::GemmArgs q1{xs, 2 * Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkvf, qkvw, FV_EPI_F32, 1};
       FV_TRY(gemm_p(h, q1, s));
-      FV_P(FV_FAM_ELT, 3.0 * rows * (qd + kd), 8.0 * rows * (qd + kd), fv::launch_rope_f32(qkvf, h->rope, qkvw, rows, Tt, d.llm_heads, d.llm_kv_heads, D, s));
-      FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tt * Tt * qd, 4.0 * rows * (qkvw + qd),
-           fv::launch_attention_f32(qkvf, qkvw, as, as + qd, 2 * qd, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, Ni, att_scale, s));
+      // RoPE rides inside the attention kernel (q fragments in registers, K rows on their way into LDS)
+      FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tt * Tt * qd + 3.0 * rows * (qd + kd), 4.0 * rows * (qkvw + qd),
+           fv::launch_attention_f32(qkvf, qkvw, as, as + qd, 2 * qd, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, Ni, att_scale, s, h->rope));
       fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
       FV_TRY(gemm_p(h, o1, s));
       FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
@@ -876,6 +879,9 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
       fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
       d1.splitk_ws = wp.splitk_bytes ? reinterpret_cast<float*>(ws + wp.splitk) : nullptr;
       d1.splitk_bytes = wp.splitk_bytes;
+      if (li + 1 < h->dec.layers.size()) {
+        d1.norm_w = h->dec.layers[li + 1].ln1; d1.norm_y = xs; d1.norm_ylo = xs + Hd; d1.norm_ld = 2 * Hd; d1.norm_eps = d.rms_eps;
+      }
       FV_TRY(gemm_p(h, d1, s));
     }
   }

@@ -434,6 +434,42 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = acc;
 }
 
+// The same reduction with the NEXT layer's RMSNorm fused in ([site] modeling_qwen2.py:247-252): one wave per row sums the partial
+// slabs (+ bias, + fp32 residual), writes the residual stream and, knowing the whole row, its normalised bf16 hi (+ lo) GEMM
+// operand -- the decoder's down projection hands the next layer's input_layernorm output over without another launch.
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ part, int splits, int M, int N, int npad,
+                                                                  const float* __restrict__ bias, const float* res, int ldr, float* out,
+                                                                  int ldo, const float* __restrict__ nw, bf16_t* __restrict__ y,
+                                                                  bf16_t* __restrict__ ylo, int ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float ss = 0.f;
+  for (int n = lane * 4; n < N; n += 256) {
+    float4 acc = res ? *reinterpret_cast<const float4*>(res + (size_t)m * ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + n); acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
+    for (int s = 0; s < splits; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)s * M + m) * npad + n);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = acc;
+    ss += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+  }
+  const float r = rsqrtf(wave_sum(ss) / (float)N + eps);
+  for (int n = lane * 4; n < N; n += 256) {   // the lane re-reads the four values it has just written
+    const float4 a = *reinterpret_cast<const float4*>(out + (size_t)m * ldo + n), w = *reinterpret_cast<const float4*>(nw + n);
+    const float o0 = w.x * (a.x * r), o1 = w.y * (a.y * r), o2 = w.z * (a.z * r), o3 = w.w * (a.w * r);
+    uint2 hv;
+    hv.x = pack_bf2(o0, o1); hv.y = pack_bf2(o2, o3);
+    *reinterpret_cast<uint2*>(y + (size_t)m * ldy + n) = hv;
+    if (ylo) {
+      uint2 lv;
+      lv.x = pack_bf2(o0 - bf_lo(hv.x), o1 - bf_hi(hv.x)); lv.y = pack_bf2(o2 - bf_lo(hv.y), o3 - bf_hi(hv.y));
+      *reinterpret_cast<uint2*>(ylo + (size_t)m * ldy + n) = lv;
+    }
+  }
+}
+
 // ---- pointwise conv with a small square weight (K = N = C in {96, 192}: the stem's third conv and the first PatchEmbed
 // 1x1), 0.9 ms of HBM-bound work per step that the tiled kernels ran at 2.3-3.1 TB/s: with a K loop of two or three tiles a
 // block is mostly prologue and epilogue.  Here the weight sits in LDS for the life of a persistent block, a wave streams
@@ -538,9 +574,25 @@ int gemm_glds_tile(const GemmArgs& a) {
   return 0;
 }
 
+thread_local bool g_norm_fused = false;   // set by launch_gemm_core when the split-K reducer took the RMSNorm with it
+
 }  // namespace
 
+static int launch_gemm_core(const GemmArgs& a, hipStream_t s);
+
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
+  if (a.norm_w) {   // a following RMSNorm of the fp32 output rows: fused into the split-K reducer when that path is taken
+    const bool f32 = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
+    if (!f32 || !a.norm_y || a.ldo != a.N || a.norm_ld < a.N || a.N % 8) return fv_fail(FV_ERR_ARG, "gemm: fused norm needs an fp32 epilogue, ldo == N and N %% 8 == 0");
+  }
+  const int rc = launch_gemm_core(a, s);
+  if (rc != FV_OK) return rc;
+  if (a.norm_w && rc == FV_OK && !g_norm_fused) return launch_rmsnorm(static_cast<const float*>(a.out), a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.M, a.N, a.norm_eps, s);
+  return FV_OK;
+}
+
+static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
+  g_norm_fused = false;
   if (!a.A || !a.W || !a.out) return fv_fail(FV_ERR_ARG, "gemm: null operand");
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fv_fail(FV_ERR_ARG, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.K % 8 || a.lda % 8 || a.N % 8) return fv_fail(FV_ERR_ARG, "gemm: K, lda, N must be multiples of 8 (K=%d lda=%d N=%d)", a.K, a.lda, a.N);
@@ -583,8 +635,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       p.nwg = tiles * splits;
       hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(p.nwg < cus ? p.nwg : cus / 8 * 8), dim3(512), 2 * 512 * 128, s, p);
       const long quads = (long)a.M * (a.N / 4);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, p.npad, a.bias,
-                         a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo);
+      if (a.norm_w) g_norm_fused = true;
+      if (a.norm_w)
+        hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, p.npad, a.bias,
+                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo,
+                           a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps);
+      else
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, p.npad, a.bias,
+                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo);
       FV_HIP_CHECK(hipGetLastError());
       return FV_OK;
     }

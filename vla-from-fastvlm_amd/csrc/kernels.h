@@ -22,6 +22,9 @@ struct GemmArgs {
   int ksplit = 0;               // 1: A holds [hi | lo] (2K columns, lda >= 2K); out = (hi + lo) . W^T in one launch
   float* splitk_ws = nullptr;   // optional scratch for split-K partial sums (fp32 epilogues, few output tiles, long K)
   size_t splitk_bytes = 0;
+  // optional RMSNorm of the fp32 output rows (the decoder's next-layer input_layernorm): y (+ y_lo) = bf16 hi (+ lo) of
+  // w * out * rsqrt(mean(out^2) + eps), row stride norm_ld; fused into the split-K reducer, a separate launch otherwise
+  const float* norm_w = nullptr; bf16_t* norm_y = nullptr; bf16_t* norm_ylo = nullptr; int norm_ld = 0; float norm_eps = 0.f;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -81,8 +84,10 @@ int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* im
 // y_lo != null: also writes the bf16 remainder (x ~= y + y_lo), the split operand of the parity-mode decoder GEMMs
 int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s);
 int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D, hipStream_t s);
-int launch_attention_f32(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
-                         int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s);
+// rope != null: qkv holds un-rotated projections; the rotate-half RoPE is fused into the MFMA kernel (head_dim 64 / 128) or applied
+// in place by a rope_f32 launch ahead of the VALU kernel (head_dim 32)
+int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
+                         int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope = nullptr);
 // table: [>=T][D/2] (cos, sin) pairs built by rope_table_host(); position = row % T
 int launch_rope(bf16_t* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D,
                 hipStream_t s);
