@@ -41,3 +41,15 @@ for C, M in ((384, 64 * 64 * 64), (192, 64 * 128 * 128), (96, 64 * 256 * 256)):
                 times[k].append(e0.elapsed_time(e1) / 4)
     fl = 16.0 * M * C * C
     print(f"C={C} M={M}: " + "  ".join(f"{k}: med {sorted(v)[len(v)//2]*1e3:.0f} us min {min(v)*1e3:.0f} us = {fl/min(v)/1e9:.0f} TF ({fl/min(v)/1e9/2500:.3f})" for k, v in times.items()))
+
+    if hasattr(lib, "fv_dbg_ffn32_stamps"):
+        import ctypes
+        buf = (ctypes.c_ulonglong * (256 * 8))()
+        lib.fv_dbg_ffn32_stamps.argtypes = [ctypes.c_void_p]
+        torch.cuda.synchronize()
+        assert lib.fv_dbg_ffn32_stamps(buf) == 0
+        import statistics
+        rows = [[buf[b * 8 + z] for z in range(5)] for b in range(256)]
+        rows = [r for r in rows if r[4]]
+        med = [statistics.median(r[z] / r[4] for r in rows) for z in range(4)]
+        print(f"   stamps per tile (wave 0, median over blocks, clk): chunk loop {med[0]:.0f}  epilogue head {med[1]:.0f}  passes {med[2]:.0f}  (residual wait {med[3]:.0f})  tiles/block {rows[0][4]}")

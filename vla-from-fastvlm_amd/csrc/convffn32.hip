@@ -23,12 +23,20 @@
 
 #include "kernels.h"
 
-#ifndef FFN32_BUF   /* bit 0: x, bit 1: residual, bit 2: output through buffer descriptors */
-#define FFN32_BUF 6
+#ifndef FFN32_BUF   /* bit 0: the x fragments through a buffer descriptor too (residual and output always are) */
+#define FFN32_BUF 0
 #endif
 #define F32_BUFX ((FFN32_BUF & 1) != 0)
-#define F32_BUFR ((FFN32_BUF & 2) != 0)
-#define F32_BUFO ((FFN32_BUF & 4) != 0)
+
+#ifdef FFN32_STAMPS   /* tools/ffn32_variants.sh diagnostic build only: cycle sums per phase of block 0..255, wave 0 */
+__device__ unsigned long long g_ffn32_stamps[256 * 8];
+extern "C" int fv_dbg_ffn32_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ffn32_stamps), sizeof(g_ffn32_stamps));
+}
+#define F32_STAMP(VAR) unsigned long long VAR; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(VAR) :: "memory");
+#else
+#define F32_STAMP(VAR)
+#endif
 
 namespace fv {
 namespace {
@@ -211,8 +219,30 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
 
   // epilogue geometry: one pass turns 32 rows x CQ channels of fp32 through the wave's staging area
   constexpr int CQ = L::CQ, ORB = L::ORB, NPASS = C / CQ;      // passes per row tile
-  constexpr int RP = 32 * (CQ / 8) / 64;                       // 8-channel items per lane per pass
-  static_assert(C % CQ == 0 && CQ % 32 == 0 && (32 * (CQ / 8)) % 64 == 0, "epilogue pass");
+  // read-out of a pass: a lane keeps ONE 8-channel chunk (ec = lane % 12; lanes 60..63 idle) and walks the rows five at a time
+  // (er = lane / 12): its bias / layer-scale registers are loaded once per pass, the index arithmetic once per tile, and an
+  // instruction still covers five whole 192-byte row segments
+  constexpr int ECH = CQ / 8, ERW = 64 / ECH, RP = (32 + ERW - 1) / ERW;   // 12 chunks, 5 rows per instruction, 7 instructions
+  static_assert(C % CQ == 0 && CQ % 32 == 0 && ECH == 12, "epilogue pass");
+  // epilogue lane constants (tile-independent)
+  int le = lane;
+  asm volatile("" : "+v"(le));
+  const int er = le / ECH, ec8 = (le - er * ECH) * 8;                       // row within a group of ERW, first of the lane's 8 channels
+  // idle lanes / rows: an offset beyond any descriptor (the launcher keeps M * C * 2 < 2 GiB, so adding a row offset to it never
+  // wraps).  The hardware's range check covers the VGPR offset only, NOT the scalar offset: every byte of the row address
+  // therefore goes into the VGPR -- a ragged last tile's rows past M are then dropped by the same check.
+  const uint32_t OOB = 0x80000000u;
+  const uint32_t eoff = er < ERW ? (uint32_t)(er * C + ec8) * 2u : OOB;      // byte offset of the lane's chunk in row er
+  const uint32_t eoff_last = (er < ERW && (RP - 1) * ERW + er < 32) ? eoff : OOB;   // last instruction: rows 30, 31 only
+  char* const so = smem + 2 * BUF + L::TABLES + wid * L::EPI_WAVE;           // the wave's fp32 staging area
+  char* const sow = so + (le & 31) * ORB + (le >> 5) * 16;                   // write side: pixel fr, channel quad 4 fh
+  const char* const sor = so + min(er, ERW - 1) * ORB + ec8 * 4;            // read side: row er, the lane's 8 channels
+  const char* const sor_last = so + min((RP - 1) * ERW + er, 31) * ORB + ec8 * 4;
+#ifndef FFN32_XPASS   /* epilogue pass in which the next tile's x fragments are requested (default: the last) */
+#define F32_XPASS (NPASS * MT - 1)
+#else
+#define F32_XPASS (FFN32_XPASS < NPASS * MT ? FFN32_XPASS : NPASS * MT - 1)
+#endif
 #ifndef FFN32_RD
 #define FFN32_RD (NPASS * MT)
 #endif
@@ -220,19 +250,25 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
   // just vacated): a pass is far shorter than an HBM read, so fetching one pass ahead exposed one memory latency per pass
   constexpr int RD = FFN32_RD;
   uint4 rr[RD][RP];
+  // rows past M (ragged last tile) and the idle lanes / rows carry an offset outside the descriptor: loads return 0, stores vanish
 #define F32_LOAD_RES(Q, MB)                                                                                  \
   {                                                                                                          \
-    int lr_ = lane;                                                                                          \
-    asm volatile("" : "+v"(lr_));                                                                            \
-    _Pragma("unroll") for (int it = 0; it < RP; ++it) {                                                      \
-      const int item_ = it * 64 + lr_, row_ = item_ / (CQ / 8), c8_ = item_ % (CQ / 8);                      \
-      const long m_ = min((MB) + ((Q) / NPASS) * 32 + row_, (long)p.M - 1);                                  \
-      const uint32_t ro_ = (uint32_t)m_ * (uint32_t)(C * 2) + (uint32_t)(((Q) % NPASS) * CQ + c8_ * 8) * 2u;  \
-      rr[(Q) % RD][it] = F32_BUFR ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ro_, 0, 0)) \
-                                  : *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.res) + ro_); \
-    }                                                                                                        \
+    const uint32_t so_ = (uint32_t)((MB) + ((Q) / NPASS) * 32) * (uint32_t)(C * 2) + (uint32_t)(((Q) % NPASS) * CQ * 2); \
+    _Pragma("unroll") for (int it = 0; it < RP; ++it)                                                        \
+      rr[(Q) % RD][it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(                    \
+          rrsrc, F32_ABL_NORES ? OOB : (it == RP - 1 ? eoff_last : eoff) + (so_ + (uint32_t)(it * (ERW * C * 2))), 0, 0)); \
   }
 
+#ifdef FFN32_ABL_NOOUT  /* tools/ffn32_variants.sh only: every output store falls outside the descriptor (dropped) */
+#define F32_ABL_NOOUT 1
+#else
+#define F32_ABL_NOOUT 0
+#endif
+#ifdef FFN32_ABL_NORES  /* ... every residual load falls outside the descriptor (returns 0, no memory traffic) */
+#define F32_ABL_NORES 1
+#else
+#define F32_ABL_NORES 0
+#endif
 #ifdef FFN32_ABL_GELU   /* tools/ffn32_ablate.sh only: identity activation, to price the GELU */
 #define F32_GELU(G)
 #else
@@ -321,8 +357,10 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[nt][mt][e] = 0.f;
+    F32_STAMP(ts0)
     for (int hc = 0; hc < nch; ++hc) F32_CHUNK
     __builtin_amdgcn_sched_barrier(0);  // keep the epilogue's loads out of the chunk
+    F32_STAMP(ts1)
 #ifdef FFN32_ABL_EPI   /* tools/ffn32_variants.sh only: no epilogue (wrong results); the accumulators stay live through one store */
     {
       asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
@@ -347,46 +385,62 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
     // tile t are channels 32 t + 8 q + 4 fh + 0..3 of pixel fr: one 16-byte write each); on the way out a lane owns 8
     // consecutive channels of a row: bias, layer scale, residual add and the one bf16 rounding happen there, every global
     // access is 16 B of a fully used line.
-    char* so = smem + 2 * BUF + L::TABLES + wid * L::EPI_WAVE;
-    int le = lane;
-    asm volatile("" : "+v"(le));
-    const int fre = le & 31, fhe = le >> 5;
+    F32_STAMP(ts2)
+#ifdef FFN32_STAMPS
+    unsigned long long tw_ = 0;
+#endif
 #pragma unroll
     for (int q = 0; q < NPASS * MT; ++q) {
       const int mt = q / NPASS, pass = q % NPASS;
-      if (q == NPASS * MT - 1) F32_LOAD_X(tile + (int)gridDim.x)   // the next tile's x fragments fly during the last pass only
+      if (q == F32_XPASS) F32_LOAD_X(tile + (int)gridDim.x)   // the next tile's x fragments fly from this pass on
 #pragma unroll
       for (int tl = 0; tl < CQ / 32; ++tl)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const f32x16& o = oacc[pass * (CQ / 32) + tl][mt];
-          *reinterpret_cast<f32x4*>(so + fre * ORB + (tl * 32 + qd * 8 + fhe * 4) * 4) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
+          *reinterpret_cast<f32x4*>(sow + (tl * 32 + qd * 8) * 4) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
         }
       asm volatile("" ::: "memory");  // wave-local hand-over: LDS serves a wave's accesses in order
+#ifdef FFN32_STAMPS
+      F32_STAMP(tp1_)
+      if (q == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      F32_STAMP(tp2_)
+      tw_ += tp2_ - tp1_;
+#endif
+      const float4 b0 = *reinterpret_cast<const float4*>(sb2 + pass * CQ + ec8), b1 = *reinterpret_cast<const float4*>(sb2 + pass * CQ + ec8 + 4);
+      const float4 l0 = *reinterpret_cast<const float4*>(sls + pass * CQ + ec8), l1 = *reinterpret_cast<const float4*>(sls + pass * CQ + ec8 + 4);
+      const uint32_t so_ = (uint32_t)(mb + mt * 32) * (uint32_t)(C * 2) + (uint32_t)(pass * CQ * 2);   // wave-uniform part of the row address
 #pragma unroll
       for (int it = 0; it < RP; ++it) {
-        const int item = it * 64 + le, row = item / (CQ / 8), c8 = item % (CQ / 8);
-        const int cb = pass * CQ + c8 * 8;
-        const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
-        const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
-        const float4 b0 = *reinterpret_cast<const float4*>(sb2 + cb), b1 = *reinterpret_cast<const float4*>(sb2 + cb + 4);
-        const float4 l0 = *reinterpret_cast<const float4*>(sls + cb), l1 = *reinterpret_cast<const float4*>(sls + cb + 4);
+        const char* sr = it == RP - 1 ? sor_last : sor + it * (ERW * ORB);
+        const float4 y0 = *reinterpret_cast<const float4*>(sr), y1 = *reinterpret_cast<const float4*>(sr + 16);
         const uint4 r4 = rr[q % RD][it];
         uint4 o;
         o.x = pack_bf2(bf_lo(r4.x) + fmaf(l0.x, y0.x, b0.x), bf_hi(r4.x) + fmaf(l0.y, y0.y, b0.y));
         o.y = pack_bf2(bf_lo(r4.y) + fmaf(l0.z, y0.z, b0.z), bf_hi(r4.y) + fmaf(l0.w, y0.w, b0.w));
         o.z = pack_bf2(bf_lo(r4.z) + fmaf(l1.x, y1.x, b1.x), bf_hi(r4.z) + fmaf(l1.y, y1.y, b1.y));
         o.w = pack_bf2(bf_lo(r4.w) + fmaf(l1.z, y1.z, b1.z), bf_hi(r4.w) + fmaf(l1.w, y1.w, b1.w));
-        const long m = mb + mt * 32 + row;
-        // rows past M fall outside the descriptor's range: the hardware drops those stores
-        if (F32_BUFO) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, o), orsrc,
-                                               m < p.M ? (uint32_t)m * (uint32_t)(C * 2) + (uint32_t)cb * 2u : 0xffffff00u, 0, 0);
-        else if (m < p.M) *reinterpret_cast<uint4*>(p.out + m * C + cb) = o;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, o), orsrc,
+                                               F32_ABL_NOOUT ? OOB : (it == RP - 1 ? eoff_last : eoff) + (so_ + (uint32_t)(it * (ERW * C * 2))), 0, 0);
         if (it & 1) __builtin_amdgcn_sched_barrier(0);   // two items' operands in flight at a time
       }
       if (RD < NPASS * MT && q + RD - 1 < NPASS * MT) F32_LOAD_RES(q + RD - 1, mb)
       asm volatile("" ::: "memory");                      // the next pass's writes stay behind these reads
     }
+#ifdef FFN32_STAMPS
+    {
+      F32_STAMP(ts3)
+      if (tid == 0 && blockIdx.x < 256) {
+        unsigned long long* d = g_ffn32_stamps + blockIdx.x * 8;
+        if (tile == (int)blockIdx.x) { for (int z = 0; z < 8; ++z) d[z] = 0; }
+        d[0] += ts1 - ts0;   // chunk loop
+        d[1] += ts2 - ts1;   // residual requests + settle
+        d[2] += ts3 - ts2;   // passes
+        d[3] += tw_;         // of which: wait for the residual loads at the first pass
+        d[4] += 1;           // tiles
+      }
+    }
+#endif
   }
 #undef F32_CHUNK
 #undef F32_GELU
@@ -463,7 +517,7 @@ int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const f
   if (((uintptr_t)x | (uintptr_t)wq | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ls | (uintptr_t)res | (uintptr_t)out) & 15)
     return fv_fail(FV_ERR_ARG, "convffn32: misaligned pointer");
   if (x == out) return fv_fail(FV_ERR_ARG, "convffn32: x must not alias out");
-  if ((size_t)M * C * 2 >= ((size_t)1 << 32) - 65536) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: M * C * 2 must stay below 4 GiB (32-bit buffer offsets)");
+  if ((size_t)M * C * 2 >= ((size_t)1 << 31)) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: M * C * 2 must stay below 2 GiB (32-bit buffer offsets)");
   Ffn32Params p{x, wq, b1, b2, ls, res, out, M, hidden / 32};
   switch (C) {
 #ifndef FFN32_MT96

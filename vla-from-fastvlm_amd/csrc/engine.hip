@@ -426,7 +426,7 @@ int dw_s1(fv_handle* h, const bf16_t* x, const float* w, const bf16_t* ttab, con
 
 // fused ConvFFN pointwise half: the 32x32x16 kernel where it exists (C = 96 / 192 / 384), else the 16x16x32 one
 int fused_ffn(fv_handle* h, const FFN& f, const bf16_t* t, const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s) {
-  if (f.w2q && !h->no_ffn32) return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s);
+  if (f.w2q && !h->no_ffn32 && (size_t)M * C * 2 < ((size_t)1 << 31)) return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s);
   return fv::launch_convffn(t, f.fc1_w, f.fc1_b, f.w2p, f.fc2_b, f.ls, res, out, M, C, hidden, s);
 }
 
