@@ -495,7 +495,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
     for (const Block& b : tw.stages[i]) {
       if (!d.tower_is_attn[i]) {
         static const bool pair_ok = !getenv("FASTVLA_NO_DW_PAIR");
-        if (pair_ok && !h->no_mfma_dw && !h->no_fused_ffn && b.mix_t && b.ffn.dw_t && b.ffn.w2p && fv::dwconv_pair_supported(H, H, C)) {
+        if (pair_ok && !h->no_mfma_dw && !h->no_fused_ffn && b.mix_t && b.ffn.dw_t && b.ffn.w2p && fv::dwconv_pair_supported(mb, H, H, C)) {
           // token mixer and the ConvFFN's 7x7 in one marching kernel: cur -> oth (x') and hid (t); then oth += ls * ffn(t)
           FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 3) + dw_flops(mb, H, H, C, 7), 6.0 * M * C,
                fv::launch_dwconv_pair(cur, b.mix_t, b.mix_b, b.ffn.dw_t, b.ffn.dw_b, oth, hid, mb, H, H, C, s));

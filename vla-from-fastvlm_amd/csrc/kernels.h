@@ -64,7 +64,7 @@ bool dwconv_s2_mfma_supported(int H, int W, int C, int k, int stride, int mult);
 int launch_dwconv_s2_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, bf16_t* y, int B, int H, int W, int C, int gelu,
                           hipStream_t s);
 // x' = dw3x3(x), t = dw7x7(x') in one marching kernel (RepMixer token mixer + ConvFFN conv); tables as for launch_dwconv_mfma
-bool dwconv_pair_supported(int H, int W, int C);
+bool dwconv_pair_supported(int B, int H, int W, int C);
 int launch_dwconv_pair(const bf16_t* x, const bf16_t* t3, const float* b3, const bf16_t* t7, const float* b7, bf16_t* y1, bf16_t* y2,
                        int B, int H, int W, int C, hipStream_t s);
 int launch_dwconv_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,

@@ -1016,8 +1016,19 @@ __global__ __launch_bounds__(256, DW_MARCH_OCC) void dwconv_march_kernel(const b
 // LDS is what sets the occupancy: the x ring is 12 rows (row (r - 4) mod 12; 10 are live), the x' ring 16, and the t tile
 // borrows the x' rows unit g - 1 vacates once group g's 7x7 is done -- 73.5 KB, two blocks per CU (at one, with three
 // barriers a step and nothing else resident, the fused kernel was slower than the two it replaces).
+#ifndef DP_ABL
+#define DP_ABL 0   // diagnostics (tools/dw_variants.sh; results are wrong): 1 no x loads, 2 no x' stores, 4 no t stores, 8 no MFMAs, 16 no emit at all
+#endif
 constexpr int DP_NQ = 10, DP_RS = DP_NQ * 256 + 64, DP_XR = 12;
 constexpr int DP_LDS = (DP_XR + 16) * DP_RS;
+#ifdef DP_STAMPS
+__device__ unsigned long long g_dp_stamps[512 * 16];   // diagnostics: per block (first 512), clocks per phase summed over the steps (wave 0)
+#define DP_T(I) { const unsigned long long n_ = __builtin_readcyclecounter(); if (tid == 0) st_[I] += n_ - t0_; t0_ = __builtin_readcyclecounter(); }
+#else
+#define DP_T(I)
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ t3,
                                                                const float* __restrict__ b3, const bf16_t* __restrict__ t7,
                                                                const float* __restrict__ b7, bf16_t* __restrict__ y1,
@@ -1055,21 +1066,54 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
 
   // one x unit = 8 rows x NQ quads x 4 channel groups of (4 pixels x 8 channels) tasks; x columns start at tx*32 - 4
   constexpr int NTASK = 8 * NQ * 4, TPT = (NTASK + 255) / 256;
-  uint4 px[TPT][4];
+  u32x4 px[TPT][4];
+  // Global accesses go through buffer descriptors with 32-bit per-lane offsets: a lane's STATIC part (image, its task's row and
+  // column, channel slice) is computed once, a step adds one scalar, and anything outside the map becomes an out-of-range offset the
+  // descriptor drops (loads return 0 = the zero padding).  As 64-bit pointers every access carried a u64 multiply chain and an
+  // exec-mask branch: 20 of them per thread and step.  COLOOB + any step offset stays in [tensor bytes, 2^32) (launcher's guard).
+  constexpr uint32_t COLOOB = 0x7FFFFFF0u, ROWOOB = 0x80000000u;
+  const uint32_t rowbytes = (uint32_t)W * (uint32_t)C * 2u;
+  const uint32_t tbytes = (uint32_t)((size_t)gridDim.x / ((size_t)tiles_x * nslices) * H * rowbytes);
+  // x loads are inline asm: vmcnt counts loads and stores in one in-order queue, and hipcc, unable to count the stores of a step
+  // across the loop's branches, waited vmcnt(0) for the x unit -- i.e. for the write acknowledgements of every store issued after
+  // those loads.  The loads are a full step old when they are needed; DP_WAIT_X leaves the younger stores outstanding.
+  const uint64_t xa_ = (uint64_t)reinterpret_cast<uintptr_t>(x);
+  const i32x4 xrsrc = {(int)__builtin_amdgcn_readfirstlane((uint32_t)xa_), (int)__builtin_amdgcn_readfirstlane((uint32_t)(xa_ >> 32) & 0xffffu),
+                       (int)__builtin_amdgcn_readfirstlane(tbytes), 0x00020000};
+  const __amdgpu_buffer_rsrc_t y1rsrc = __builtin_amdgcn_make_buffer_rsrc(y1, 0, tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(y2, 0, tbytes, 0x00020000);
+  const uint32_t img = (uint32_t)b * (uint32_t)H * rowbytes + (uint32_t)c0 * 2u;
+  uint32_t xo[TPT][4];     // x unit 0: row 4 + task row, columns tx*32 - 4 + quad*4 + j
+  int xrow[TPT];
+#pragma unroll
+  for (int tt = 0; tt < TPT; ++tt) {
+    const int task = tid + 256 * tt;
+    const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;
+    xrow[tt] = row + 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ix = tx * TW - 4 + quad * 4 + j;
+      xo[tt][j] = (!(DP_ABL & 1) && task < NTASK && ix >= 0 && ix < W)
+                      ? img + (uint32_t)(row + 4) * rowbytes + (uint32_t)ix * (uint32_t)C * 2u + (uint32_t)cg * 16u
+                      : COLOOB;
+    }
+  }
 #define DP_LOAD_XUNIT(U)                                                                                         \
   {                                                                                                              \
+    const uint32_t so_ = (uint32_t)(8 * (U)) * rowbytes;   /* modular: U may be negative */                      \
     _Pragma("unroll") for (int tt = 0; tt < TPT; ++tt) {                                                         \
-      const int task = tid + 256 * tt;                                                                           \
-      const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;                                  \
-      const int iy = 8 * (U) + 4 + row, ix0 = tx * TW - 4 + quad * 4;                                            \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                            \
-        const int ix = ix0 + j;                                                                                  \
-        px[tt][j] = (task < NTASK && iy >= 0 && iy < H && ix >= 0 && ix < W)                                     \
-                        ? *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + cg * 8)  \
-                        : make_uint4(0, 0, 0, 0);                                                                \
+      if (tt == 0 || wid < (NTASK - 256 * tt + 63) / 64) {   /* wave-uniform: the last tasks live in wave 0 */    \
+        const bool ok_ = (unsigned)(xrow[tt] + 8 * (U)) < (unsigned)H;                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+          const uint32_t v_ = ok_ ? xo[tt][j] + so_ : ROWOOB;                                                    \
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(px[tt][j]) : "v"(v_), "s"(xrsrc) : "memory"); \
+        }                                                                                                        \
       }                                                                                                          \
     }                                                                                                            \
   }
+#define DP_WAIT_X(N)                                                                                             \
+  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]),      \
+               "+v"(px[1][0]), "+v"(px[1][1]), "+v"(px[1][2]), "+v"(px[1][3]) :: "memory");
 #define DP_WRITE_XUNIT(U)                                                                                        \
   {                                                                                                              \
     _Pragma("unroll") for (int tt = 0; tt < TPT; ++tt) {                                                         \
@@ -1095,18 +1139,49 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
       }                                                                                                          \
     }                                                                                                            \
   }
+  uint32_t y1o[2][4], y2o[4];   // static parts of the x' / t store offsets (step g = 0)
+#pragma unroll
+  for (int et = 0; et < 2; ++et) {
+    const int task = tid + 256 * et;
+    const int cg = task & 3, quad = (task >> 2) % 9, row = (task >> 2) / 9;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lc = 4 * quad - 3 + j, ox = tx * TW + lc;
+      y1o[et][j] = (!(DP_ABL & 2) && task < 8 * 9 * 4 && lc >= 0 && lc < TW && ox < W)
+                       ? img + (uint32_t)(row + 3) * rowbytes + (uint32_t)ox * (uint32_t)C * 2u + (uint32_t)cg * 16u
+                       : COLOOB;
+    }
+  }
+  {
+    const int cg = tid & 3, quad = (tid >> 2) & 7, row = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ox = tx * TW + quad * 4 + j;
+      y2o[j] = (!(DP_ABL & 4) && ox < W) ? img + (uint32_t)row * rowbytes + (uint32_t)ox * (uint32_t)C * 2u + (uint32_t)cg * 16u : COLOOB;
+    }
+  }
   uint32_t sw[4];   // lane's four swizzled channel offsets (one per quad & 3)
 #pragma unroll
   for (int v = 0; v < 4; ++v) sw[v] = (uint32_t)(((gg * 16 + bch) ^ ((v << 1) | gg)) << 3);
 
+  static_assert(TPT == 2, "DP_WAIT_X names both task slots");
   DP_LOAD_XUNIT(-2)
+  DP_WAIT_X(0)
   DP_WRITE_XUNIT(-2)
   DP_LOAD_XUNIT(-1)
+  DP_WAIT_X(0)
   DP_WRITE_XUNIT(-1)
   DP_LOAD_XUNIT(0)
+#define DP_DUMMY_STORES(N) _Pragma("unroll") for (int z_ = 0; z_ < (N); ++z_) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(px[1][0]), "v"(ROWOOB), "s"(xrsrc) : "memory");
+  DP_DUMMY_STORES(8)
 
+#ifdef DP_STAMPS
+  unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_readcyclecounter();
+#endif
   for (int g = -1; g < ng; ++g) {
+    DP_T(11)
     __syncthreads();   // x unit g is in its ring; the previous step's output tile and x' rows have been read
+    DP_T(0)
     // ---- x' unit g = dw3x3 over x units g - 1, g: lane's row r' = 8g + 3 + rg*4 + jr, 10 quads of columns
     {
       f32x4 acc[NQ];
@@ -1123,7 +1198,7 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
-            if (q + m < NQ) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a3[ky][m], xq[q + m], acc[q], 0, 0, 0);
+            if (q + m < NQ && !(DP_ABL & 8)) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a3[ky][m], xq[q + m], acc[q], 0, 0, 0);
       }
       const int r1 = 8 * g + 3 + rg * 4 + jr;
       const bool rowok = r1 >= 0 && r1 < H;
@@ -1142,37 +1217,45 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
         *reinterpret_cast<uint2*>(prow + sw[q & 3] + q * 256) = u;
       }
     }
+    DP_T(1)
     __syncthreads();   // x' unit g is in its ring; every wave is done with x unit g - 1
-    if (g + 1 < ng) DP_WRITE_XUNIT(g + 1)
+    DP_T(2)
+    if (g + 1 < ng) {
+      // x unit g + 1 was requested a step ago; younger than it are the 4 x' and 4 t stores of step g - 1 (the prologue and step -1
+      // issue dropped out-of-range stores in their place so that ONE wait count fits every step)
+      DP_WAIT_X(8)
+      DP_WRITE_XUNIT(g + 1)
+    }
+    DP_T(3)
     if (g + 2 < ng) DP_LOAD_XUNIT(g + 2)
+    DP_T(4)
     // ---- emit x' rows 8g + 3 .. 8g + 10 (columns of this strip only): 8 rows x 9 quads x 4 channel groups, v_perm transpose
+    {
+      const uint32_t so1 = (uint32_t)(8 * g) * rowbytes;
 #pragma unroll
-    for (int et = 0; et < 2; ++et) {
-      const int task = tid + 256 * et;
-      if (task < 8 * 9 * 4) {
-        const int cg = task & 3, quad = (task >> 2) % 9, row = (task >> 2) / 9;
-        const uint32_t src = (uint32_t)((8 * (g & 1) + row) * RS + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
-        uint2 r[8];
+      for (int et = 0; et < 2; ++et) {
+        const int task = tid + 256 * et;
+        if (task < 8 * 9 * 4 && !(DP_ABL & 16)) {
+          const int cg = task & 3, quad = (task >> 2) % 9, row = (task >> 2) / 9;
+          const uint32_t src = (uint32_t)((8 * (g & 1) + row) * RS + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
+          uint2 r[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sP + (src ^ (uint32_t)(e * 8)));
-        const int oy = 8 * g + 3 + row;
-        if (oy >= 0 && oy < H) {
+          for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sP + (src ^ (uint32_t)(e * 8)));
+          const bool ok = (unsigned)(8 * g + 3 + row) < (unsigned)H;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int lc = 4 * quad - 3 + j, ox = tx * TW + lc;     // column inside the strip / in the map
-            if (lc >= 0 && lc < TW && ox < W) {
-              uint4 o;
-              const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+            u32x4 o;
+            const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
 #define FV_PX(A, B) __builtin_amdgcn_perm((j & 2) ? r[B].y : r[B].x, (j & 2) ? r[A].y : r[A].x, sel)
-              o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
+            o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
 #undef FV_PX
-              *reinterpret_cast<uint4*>(y1 + (((size_t)b * H + oy) * W + ox) * C + c0 + cg * 8) = o;
-            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, y1rsrc, ok ? y1o[et][j] + so1 : ROWOOB, 0, 0);
           }
         }
       }
     }
-    if (g < 0) continue;
+    DP_T(5)
+    if (g < 0) { DP_DUMMY_STORES(4) continue; }
     // ---- t rows 8g .. 8g + 7 = dw7x7 over x' units g - 1, g
     {
       f32x4 acc[8];
@@ -1189,9 +1272,11 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
         for (int m = 0; m < 3; ++m)
 #pragma unroll
           for (int q = 0; q < 8; ++q)
-            if (q + m < NQ) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a7[ky][m], xq[q + m], acc[q], 0, 0, 0);
+            if (q + m < NQ && !(DP_ABL & 8)) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a7[ky][m], xq[q + m], acc[q], 0, 0, 0);
       }
+      DP_T(6)
       __syncthreads();   // every wave is done with x' unit g - 1: its ring rows carry the t tile out
+      DP_T(7)
       char* orow = sP + (8 * ((g + 1) & 1) + rg * 4 + jr) * RS;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -1201,7 +1286,9 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
         *reinterpret_cast<uint2*>(orow + sw[q & 3] + q * 256) = u;
       }
     }
+    DP_T(8)
     __syncthreads();
+    DP_T(9)
     {
       const char* sO = sP + 8 * ((g + 1) & 1) * RS;
       const int cg = tid & 3, quad = (tid >> 2) & 7, row = tid >> 5;   // 8 rows x 8 quads x 4 channel groups
@@ -1209,25 +1296,29 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
       uint2 r[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sO + (src ^ (uint32_t)(e * 8)));
-      const int oy = g * 8 + row, ox0 = tx * TW + quad * 4;
-      if (oy < H) {
-        bf16_t* yp = y2 + (((size_t)b * H + oy) * W + ox0) * C + c0 + cg * 8;
+      if (!(DP_ABL & 16)) {
+        const bool ok = g * 8 + row < H;
+        const uint32_t so2 = (uint32_t)(8 * g) * rowbytes;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (ox0 + j < W) {
-            uint4 o;
-            const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+          u32x4 o;
+          const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
 #define FV_PX(A, B) __builtin_amdgcn_perm((j & 2) ? r[B].y : r[B].x, (j & 2) ? r[A].y : r[A].x, sel)
-            o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
+          o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
 #undef FV_PX
-            *reinterpret_cast<uint4*>(yp + (size_t)j * C) = o;
-          }
+          __builtin_amdgcn_raw_buffer_store_b128(o, y2rsrc, ok ? y2o[j] + so2 : ROWOOB, 0, 0);
         }
       }
     }
+    DP_T(10)
   }
+#ifdef DP_STAMPS
+  if (tid == 0 && blockIdx.x < 512) { for (int z = 0; z < 12; ++z) g_dp_stamps[blockIdx.x * 16 + z] = st_[z]; g_dp_stamps[blockIdx.x * 16 + 12] = (unsigned long long)ng + 1; }
+#endif
 #undef DP_LOAD_XUNIT
 #undef DP_WRITE_XUNIT
+#undef DP_WAIT_X
+#undef DP_DUMMY_STORES
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNormChannel
@@ -1540,11 +1631,15 @@ int launch_stem_fused(const bf16_t* pix, const bf16_t* wp, const float* b1, cons
 
 // x (B,H,W,C) -> y1 = dw3x3(x) + b3 and y2 = dw7x7(y1) + b7 in one marching kernel (dwpair_march_kernel); t3 / t7 are the
 // Toeplitz tables of dwconv_toeplitz_pack for k = 3 / 7.  x must not alias y1 or y2.
-bool dwconv_pair_supported(int H, int W, int C) { return H >= 16 && W >= 32 && C % 32 == 0; }
+// (the kernel addresses its tensors through buffer descriptors with 32-bit offsets: B*H*W*C*2 bytes plus two units of rows must
+// stay below its out-of-range markers; larger maps take the two separate kernels)
+bool dwconv_pair_supported(int B, int H, int W, int C) {
+  return H >= 16 && W >= 32 && C % 32 == 0 && ((long)B * H + 16) * W * C * 2 <= 0x7FFFFFF0L;
+}
 int launch_dwconv_pair(const bf16_t* x, const bf16_t* t3, const float* b3, const bf16_t* t7, const float* b7, bf16_t* y1, bf16_t* y2,
                        int B, int H, int W, int C, hipStream_t s) {
   if (!x || !t3 || !b3 || !t7 || !b7 || !y1 || !y2) return fv_fail(FV_ERR_ARG, "dwconv_pair: null pointer");
-  if (B <= 0 || !dwconv_pair_supported(H, W, C)) return fv_fail(FV_ERR_UNSUPPORTED, "dwconv_pair: unsupported shape H=%d W=%d C=%d", H, W, C);
+  if (B <= 0 || !dwconv_pair_supported(B, H, W, C)) return fv_fail(FV_ERR_UNSUPPORTED, "dwconv_pair: unsupported shape H=%d W=%d C=%d", H, W, C);
   if (x == y1 || x == y2 || y1 == y2) return fv_fail(FV_ERR_ARG, "dwconv_pair: buffers must be distinct");
   static bool attr_set = false;
   if (!attr_set) {
@@ -1585,3 +1680,7 @@ int launch_se_gelu(const bf16_t* x, const float* w1, const float* b1, const floa
 }
 
 }  // namespace fv
+
+#ifdef DP_STAMPS
+extern "C" int fv_dbg_dp_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fv::g_dp_stamps), 512 * 16 * 8); }
+#endif
