@@ -483,10 +483,11 @@ def test_stem_fused(S, B):
     check_close(y.float().cpu().permute(0, 3, 1, 2), ref, what=f"fused stem S={S}")
 
 
-@pytest.mark.parametrize("C,H,W", [(32, 16, 32), (96, 40, 64), (64, 19, 37), (192, 24, 96)])
+@pytest.mark.parametrize("C,H,W", [(32, 16, 32), (96, 40, 64), (64, 19, 37), (192, 24, 96), (128, 33, 50), (384, 16, 32), (64, 72, 64)])
 def test_dwconv_pair(C, H, W):
     """x' = dw3x3(x) and t = dw7x7(x') from one marching kernel vs the two convolutions on the host (x' rounded to bf16
-    in between, as both the kernel's LDS ring and the unfused pair's HBM round trip do)."""
+    in between, as both the kernel's LDS ring and the unfused pair's HBM round trip do).  C % 64 == 0 takes the 16-column x
+    64-channel geometry (full cache lines), the rest the 32 x 32 one; ragged H and W exercise both sets of ring slots."""
     torch.manual_seed(C + H + W)
     B = 2
     x = bf(torch.randn(B, C, H, W))
@@ -504,6 +505,37 @@ def test_dwconv_pair(C, H, W):
     torch.cuda.synchronize()
     check_close(y1.float().cpu().permute(0, 3, 1, 2), ref1, what=f"dw pair 3x3 C{C} {H}x{W}")
     check_close(y2.float().cpu().permute(0, 3, 1, 2), ref2, what=f"dw pair 7x7 C{C} {H}x{W}")
+
+
+@pytest.mark.parametrize("C,H", [(192, 128), (384, 64)])
+def test_dwconv_pair_tower_shape_repeats(C, H):
+    """The tower's own shapes, four launches: each must match the host convolutions and the launches must agree bit for bit.  (A
+    write-after-write race between two prologue ring writes of different waves once corrupted x row 0 of about one block in 10^4:
+    only a shape with thousands of blocks, repeated, sees that.)"""
+    torch.manual_seed(C)
+    B = 3
+    x = bf(torch.randn(B, C, H, H))
+    w3, w7 = bf(torch.randn(C, 1, 3, 3) / 3), bf(torch.randn(C, 1, 7, 7) / 7)
+    b3, b7 = torch.randn(C) * 0.1, torch.randn(C) * 0.1
+    ref1 = bf(F.conv2d(x, w3, b3, padding=1, groups=C))
+    ref2 = F.conv2d(ref1, w7, b7, padding=3, groups=C)
+    xd = dev_bf16(x.permute(0, 2, 3, 1))
+    t3, t7 = dev_bf16(_toeplitz(w3, 3)), dev_bf16(_toeplitz(w7, 7))
+    b3d, b7d = dev_f32(b3), dev_f32(b7)
+    first = None
+    for rep in range(4):
+        y1 = torch.full((B, H, H, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        y2 = torch.full((B, H, H, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        call(lib().fv_op_dwconv_pair(xd.data_ptr(), t3.data_ptr(), b3d.data_ptr(), t7.data_ptr(), b7d.data_ptr(), y1.data_ptr(), y2.data_ptr(),
+                                     B, H, H, C, stream()), "fv_op_dwconv_pair")
+        torch.cuda.synchronize()
+        if first is None:
+            first = (y1, y2)
+            check_close(y1.float().cpu().permute(0, 3, 1, 2), ref1, what=f"dw pair 3x3 C{C} {H}x{H}")
+            check_close(y2.float().cpu().permute(0, 3, 1, 2), ref2, what=f"dw pair 7x7 C{C} {H}x{H}")
+            assert float((y2.float().cpu().permute(0, 3, 1, 2) - ref2).abs().max()) < 0.1   # a corrupted row is O(1), rounding is 0.03
+        else:
+            assert torch.equal(y1, first[0]) and torch.equal(y2, first[1]), f"launch {rep} differs from launch 0"
 
 
 @pytest.mark.parametrize("M,C", [(128 * 3, 192), (128 * 800, 96), (128 * 300, 192)])

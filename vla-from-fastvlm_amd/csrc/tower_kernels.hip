@@ -8,6 +8,7 @@
 // All are bounded by HBM streaming or by the fp32 VALU (49 taps/element for the 7x7), never MFMA-shaped; loads and
 // stores are 8 or 16 B per lane with the channel index fastest across lanes.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace fv {
 namespace {
@@ -1016,11 +1017,29 @@ __global__ __launch_bounds__(256, DW_MARCH_OCC) void dwconv_march_kernel(const b
 // LDS is what sets the occupancy: the x ring is 12 rows (row (r - 4) mod 12; 10 are live), the x' ring 16, and the t tile
 // borrows the x' rows unit g - 1 vacates once group g's 7x7 is done -- 73.5 KB, two blocks per CU (at one, with three
 // barriers a step and nothing else resident, the fused kernel was slower than the two it replaces).
+#ifndef DP_DEFAULT_GEO
+#define DP_DEFAULT_GEO 1
+#endif
 #ifndef DP_ABL
 #define DP_ABL 0   // diagnostics (tools/dw_variants.sh; results are wrong): 1 no x loads, 2 no x' stores, 4 no t stores, 8 no MFMAs, 16 no emit at all
 #endif
-constexpr int DP_NQ = 10, DP_RS = DP_NQ * 256 + 64, DP_XR = 12;
-constexpr int DP_LDS = (DP_XR + 16) * DP_RS;
+// Geometry by channels per block.  CHB = 32: a 32-column x 32-channel strip (64-byte runs per pixel: any C % 32 == 0).  CHB = 64:
+// a 16-column x 64-channel strip -- every global access is a full 128-byte line.  tools/slice_micro.hip: a pure stream with this
+// kernel's traffic (one tensor in, two out) tops out at 3.6-4.0 TB/s with 64-byte runs and reaches 4.9-5.1 TB/s with 128-byte ones.
+// A ring row holds CHB / 32 planes of (NQ quads x 256 B): inside a plane everything is the 32-channel layout.  The rings are as
+// short as liveness allows at CHB = 64 (x: 8 new rows + the 2 the next 3x3 still needs; x': 8 new + the 6 the next 7x7 needs;
+// the t tile sits in the slots the NEXT x' unit will take) so that two blocks still share a CU.
+template <int CHB, int TW_>
+struct DpGeo {
+  static constexpr int TW = TW_, NTQ = TW / 4, NQ = NTQ + 2, NEQ = NTQ + 1;
+  static constexpr int NPL = CHB / 32, PLB = NQ * 256, RS = NPL * PLB + 64;
+  static constexpr int XR = (CHB == 32 && TW == 32) ? 12 : 10, PR = (CHB == 32 && TW == 32) ? 16 : 14;
+  static constexpr int LDS = (XR + PR) * RS;
+  static constexpr int NCG = CHB / 8;      // 16-byte channel groups per pixel
+  static constexpr int NGG = CHB / 16;     // 16-channel MFMA groups = waves across channels
+  static constexpr int NRG = NGG / 2;      // 4-row groups one wave computes per 8-row unit
+  static constexpr int OCC = LDS <= 40 * 1024 ? 3 : 2;   // blocks per CU the kernel is compiled for (registers: 512 / (4 * OCC / 4))
+};
 #ifdef DP_STAMPS
 __device__ unsigned long long g_dp_stamps[512 * 16];   // diagnostics: per block (first 512), clocks per phase summed over the steps (wave 0)
 #define DP_T(I) { const unsigned long long n_ = __builtin_readcyclecounter(); if (tid == 0) st_[I] += n_ - t0_; t0_ = __builtin_readcyclecounter(); }
@@ -1029,30 +1048,36 @@ __device__ unsigned long long g_dp_stamps[512 * 16];   // diagnostics: per block
 #endif
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
-__global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ t3,
+template <int N> __device__ __forceinline__ int dp_wrap(int v) { return v >= N ? v - N : v; }   // v in [0, 2N)
+template <int CHB, int TW_>
+__global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ t3,
                                                                const float* __restrict__ b3, const bf16_t* __restrict__ t7,
                                                                const float* __restrict__ b7, bf16_t* __restrict__ y1,
                                                                bf16_t* __restrict__ y2, int H, int W, int C, int tiles_x,
                                                                int nslices) {
-  constexpr int TW = 32, NQ = DP_NQ, RS = DP_RS, RSO = DP_RS, XR = DP_XR;
+  using G = DpGeo<CHB, TW_>;
+  constexpr int TW = G::TW, NQ = G::NQ, NTQ = G::NTQ, NEQ = G::NEQ, RS = G::RS, XR = G::XR, PR = G::PR, PLB = G::PLB;
+  constexpr int NCG = G::NCG, NGG = G::NGG, NRG = G::NRG;
   extern __shared__ __attribute__((aligned(16))) char dp_smem[];
-  char* sX = dp_smem;                 // x ring (XR rows)
-  char* sP = dp_smem + XR * RS;       // x' ring (16 rows); the t output tile borrows its vacated half
+  char* sX = dp_smem;                 // x ring: row R (absolute, R = -12 ...) at slot (R + 120) % XR
+  char* sP = dp_smem + XR * RS;       // x' ring: row R' at slot (R' + 112) % PR; the t tile borrows the slots of the next unit
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int slice = bid % nslices; bid /= nslices;
   const int tx = bid % tiles_x;
   const long b = bid / tiles_x;
-  const int c0 = slice * 32;
-  const int gg = wid & 1, rg = wid >> 1;          // wave = (16-channel group, 4 rows)
-  const int bch = lane >> 2, jr = lane & 3;       // lane = (channel within the group, row within the 4)
+  const int c0 = slice * CHB;
+  const int gg = wid % NGG, rg0 = (wid / NGG) * NRG;   // wave = (16-channel group, first of its NRG 4-row groups)
+  const int bch = lane >> 2, jr = lane & 3;            // lane = (channel within the group, row within the 4)
   const int ng = (H + 7) / 8;
+  const uint32_t pl = (uint32_t)(gg >> 1) * PLB;       // the wave's plane inside a ring row
 
   s16x4 a3[3][2], a7[7][3];
   {
-    const char* s3 = reinterpret_cast<const char*>(t3) + (size_t)slice * (2 * 3 * 2 * 512) + (size_t)gg * 3 * 2 * 512 + lane * 8;
-    const char* s7 = reinterpret_cast<const char*>(t7) + (size_t)slice * (2 * 7 * 3 * 512) + (size_t)gg * 7 * 3 * 512 + lane * 8;
+    const size_t grp = (size_t)(c0 / 16 + gg);
+    const char* s3 = reinterpret_cast<const char*>(t3) + grp * (3 * 2 * 512) + lane * 8;
+    const char* s7 = reinterpret_cast<const char*>(t7) + grp * (7 * 3 * 512) + lane * 8;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1064,8 +1089,8 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
   }
   const float bv3 = b3[c0 + gg * 16 + bch], bv7 = b7[c0 + gg * 16 + bch];
 
-  // one x unit = 8 rows x NQ quads x 4 channel groups of (4 pixels x 8 channels) tasks; x columns start at tx*32 - 4
-  constexpr int NTASK = 8 * NQ * 4, TPT = (NTASK + 255) / 256;
+  // one x unit = 8 rows x NQ quads x NCG channel groups of (4 pixels x 8 channels) tasks; x columns start at tx*TW - 4
+  constexpr int NTASK = 8 * NQ * NCG, TPT = (NTASK + 255) / 256;
   u32x4 px[TPT][4];
   // Global accesses go through buffer descriptors with 32-bit per-lane offsets: a lane's STATIC part (image, its task's row and
   // column, channel slice) is computed once, a step adds one scalar, and anything outside the map becomes an out-of-range offset the
@@ -1083,13 +1108,15 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
   const __amdgpu_buffer_rsrc_t y1rsrc = __builtin_amdgcn_make_buffer_rsrc(y1, 0, tbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(y2, 0, tbytes, 0x00020000);
   const uint32_t img = (uint32_t)b * (uint32_t)H * rowbytes + (uint32_t)c0 * 2u;
-  uint32_t xo[TPT][4];     // x unit 0: row 4 + task row, columns tx*32 - 4 + quad*4 + j
+  uint32_t xo[TPT][4];     // x unit 0: row 4 + task row, columns tx*TW - 4 + quad*4 + j
+  uint32_t xdst[TPT];      // LDS position inside a ring row
   int xrow[TPT];
 #pragma unroll
   for (int tt = 0; tt < TPT; ++tt) {
     const int task = tid + 256 * tt;
-    const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;
+    const int cg = task % NCG, quad = (task / NCG) % NQ, row = (task / NCG) / NQ;
     xrow[tt] = row + 4;
+    xdst[tt] = (uint32_t)((cg >> 2) * PLB + quad * 256 + (cg & 3) * 64) | (uint32_t)((((quad & 3) << 1) | ((cg & 3) >> 1)) << 3);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ix = tx * TW - 4 + quad * 4 + j;
@@ -1102,7 +1129,7 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
   {                                                                                                              \
     const uint32_t so_ = (uint32_t)(8 * (U)) * rowbytes;   /* modular: U may be negative */                      \
     _Pragma("unroll") for (int tt = 0; tt < TPT; ++tt) {                                                         \
-      if (tt == 0 || wid < (NTASK - 256 * tt + 63) / 64) {   /* wave-uniform: the last tasks live in wave 0 */    \
+      if (tt == 0 || wid < (NTASK - 256 * tt + 63) / 64) {   /* wave-uniform: the last tasks live in the first waves */ \
         const bool ok_ = (unsigned)(xrow[tt] + 8 * (U)) < (unsigned)H;                                           \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
           const uint32_t v_ = ok_ ? xo[tt][j] + so_ : ROWOOB;                                                    \
@@ -1112,21 +1139,22 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
     }                                                                                                            \
   }
 #define DP_WAIT_X(N)                                                                                             \
-  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]),      \
-               "+v"(px[1][0]), "+v"(px[1][1]), "+v"(px[1][2]), "+v"(px[1][3]) :: "memory");
+  if constexpr (TPT == 2)                                                                                        \
+    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]),    \
+                 "+v"(px[TPT - 1][0]), "+v"(px[TPT - 1][1]), "+v"(px[TPT - 1][2]), "+v"(px[TPT - 1][3]) :: "memory"); \
+  else                                                                                                           \
+    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]) :: "memory");
 #define DP_WRITE_XUNIT(U)                                                                                        \
   {                                                                                                              \
     _Pragma("unroll") for (int tt = 0; tt < TPT; ++tt) {                                                         \
       const int task = tid + 256 * tt;                                                                           \
       if (task < NTASK) {                                                                                        \
-        const int cg = task & 3, quad = (task >> 2) % NQ, row = (task >> 2) / NQ;                                \
         const uint32_t d[4][4] = {{px[tt][0].x, px[tt][0].y, px[tt][0].z, px[tt][0].w},                          \
                                   {px[tt][1].x, px[tt][1].y, px[tt][1].z, px[tt][1].w},                          \
                                   {px[tt][2].x, px[tt][2].y, px[tt][2].z, px[tt][2].w},                          \
                                   {px[tt][3].x, px[tt][3].y, px[tt][3].z, px[tt][3].w}};                         \
-        const int xr_ = (((U) + 3) % 3 * 8 + row) % XR; /* (8 U + row) mod 12 for U >= -3 */                     \
-        const uint32_t dst = (uint32_t)(xr_ * RS + quad * 256 + cg * 64) |                                       \
-                             (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);                                   \
+        const int xr_ = (8 * (U) + xrow[tt] + 120) % XR;                                                         \
+        const uint32_t dst = (uint32_t)(xr_ * RS) + xdst[tt];   /* RS is a multiple of 64: the low bits stay xdst's */ \
         _Pragma("unroll") for (int dd = 0; dd < 4; ++dd) {                                                       \
           uint2 ev, od;                                                                                          \
           ev.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x05040100u);                                         \
@@ -1139,40 +1167,48 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
       }                                                                                                          \
     }                                                                                                            \
   }
-  uint32_t y1o[2][4], y2o[4];   // static parts of the x' / t store offsets (step g = 0)
+  constexpr int NET = 8 * NEQ * NCG;   // x' emit tasks: 8 rows x the NEQ quads that hold strip columns x NCG channel groups
+  constexpr int NEP = (NET + 255) / 256, NTT = 8 * NTQ * NCG;   // x' emit task slots per thread; t emit tasks (<= 256)
+  static_assert(NEP <= 2 && NTT <= 256, "emit task maps");
+  uint32_t y1o[NEP][4], y2o[4];   // static parts of the x' / t store offsets (step g = 0)
+  uint32_t e1src[NEP], e2src;     // their LDS positions inside a ring row
+  int e1row[NEP], e2row;
 #pragma unroll
-  for (int et = 0; et < 2; ++et) {
+  for (int et = 0; et < NEP; ++et) {
     const int task = tid + 256 * et;
-    const int cg = task & 3, quad = (task >> 2) % 9, row = (task >> 2) / 9;
+    const int cg = task % NCG, quad = (task / NCG) % NEQ, row = (task / NCG) / NEQ;
+    e1row[et] = row;
+    e1src[et] = (uint32_t)((cg >> 2) * PLB + quad * 256 + (cg & 3) * 64) | (uint32_t)((((quad & 3) << 1) | ((cg & 3) >> 1)) << 3);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int lc = 4 * quad - 3 + j, ox = tx * TW + lc;
-      y1o[et][j] = (!(DP_ABL & 2) && task < 8 * 9 * 4 && lc >= 0 && lc < TW && ox < W)
+      y1o[et][j] = (!(DP_ABL & 2) && task < NET && lc >= 0 && lc < TW && ox < W)
                        ? img + (uint32_t)(row + 3) * rowbytes + (uint32_t)ox * (uint32_t)C * 2u + (uint32_t)cg * 16u
                        : COLOOB;
     }
   }
   {
-    const int cg = tid & 3, quad = (tid >> 2) & 7, row = tid >> 5;
+    const int cg = tid % NCG, quad = (tid / NCG) % NTQ, row = tid / (NCG * NTQ);
+    e2row = row;
+    e2src = (uint32_t)((cg >> 2) * PLB + quad * 256 + (cg & 3) * 64) | (uint32_t)((((quad & 3) << 1) | ((cg & 3) >> 1)) << 3);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ox = tx * TW + quad * 4 + j;
-      y2o[j] = (!(DP_ABL & 4) && ox < W) ? img + (uint32_t)row * rowbytes + (uint32_t)ox * (uint32_t)C * 2u + (uint32_t)cg * 16u : COLOOB;
+      y2o[j] = (!(DP_ABL & 4) && tid < NTT && ox < W) ? img + (uint32_t)row * rowbytes + (uint32_t)ox * (uint32_t)C * 2u + (uint32_t)cg * 16u : COLOOB;
     }
   }
-  uint32_t sw[4];   // lane's four swizzled channel offsets (one per quad & 3)
+  uint32_t sw[4];   // lane's four swizzled channel offsets (one per quad & 3), plane included
 #pragma unroll
-  for (int v = 0; v < 4; ++v) sw[v] = (uint32_t)(((gg * 16 + bch) ^ ((v << 1) | gg)) << 3);
+  for (int v = 0; v < 4; ++v) sw[v] = pl + (uint32_t)((((gg & 1) * 16 + bch) ^ ((v << 1) | (gg & 1))) << 3);
 
-  static_assert(TPT == 2, "DP_WAIT_X names both task slots");
-  DP_LOAD_XUNIT(-2)
-  DP_WAIT_X(0)
-  DP_WRITE_XUNIT(-2)
+  static_assert(TPT <= 2, "DP_WAIT_X names the first and the last task slot");
+  // x unit -2 (rows -12 .. -5) is never written: step -1 reads its last two rows, but only into x' rows < 0, which are stored as
+  // zero whatever the 3x3 saw.  (Writing it raced with unit -1: their ring slots overlap and no barrier separates the two writes.)
   DP_LOAD_XUNIT(-1)
   DP_WAIT_X(0)
   DP_WRITE_XUNIT(-1)
   DP_LOAD_XUNIT(0)
-#define DP_DUMMY_STORES(N) _Pragma("unroll") for (int z_ = 0; z_ < (N); ++z_) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(px[1][0]), "v"(ROWOOB), "s"(xrsrc) : "memory");
+#define DP_DUMMY_STORES(N) _Pragma("unroll") for (int z_ = 0; z_ < (N); ++z_) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(px[0][0]), "v"(ROWOOB), "s"(xrsrc) : "memory");
   DP_DUMMY_STORES(8)
 
 #ifdef DP_STAMPS
@@ -1182,15 +1218,18 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
     DP_T(11)
     __syncthreads();   // x unit g is in its ring; the previous step's output tile and x' rows have been read
     DP_T(0)
-    // ---- x' unit g = dw3x3 over x units g - 1, g: lane's row r' = 8g + 3 + rg*4 + jr, 10 quads of columns
-    {
+    // ---- x' unit g = dw3x3 over x units g - 1, g: lane's row r' = 8g + 3 + rg*4 + jr, NQ quads of columns
+#pragma unroll
+    for (int rgi = 0; rgi < NRG; ++rgi) {
+      const int rg = rg0 + rgi;
       f32x4 acc[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int rb = (8 * ((g + 3) % 3) + rg * 4 + jr + 10) % XR;   // x ring row of ky = 0: (r' - 1 - 4) mod 12, kept >= 0
+      for (int q = 0; q < NQ; ++q) acc[q] = f32x4{bv3, bv3, bv3, bv3};   // the bias rides in as the accumulators' start
+      const int r1 = 8 * g + 3 + rg * 4 + jr;
+      const int rb = (r1 - 1 + 120) % XR;   // x ring slot of ky = 0
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
-        const uint32_t ro = (uint32_t)((rb + ky) % XR) * RS;
+        const uint32_t ro = (uint32_t)dp_wrap<XR>(rb + ky) * RS;
         s16x4 xq[NQ];
 #pragma unroll
         for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sX + ro + sw[t & 3] + t * 256));
@@ -1200,16 +1239,15 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
           for (int q = 0; q < NQ; ++q)
             if (q + m < NQ && !(DP_ABL & 8)) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a3[ky][m], xq[q + m], acc[q], 0, 0, 0);
       }
-      const int r1 = 8 * g + 3 + rg * 4 + jr;
       const bool rowok = r1 >= 0 && r1 < H;
-      char* prow = sP + (uint32_t)((8 * (g & 1)) + rg * 4 + jr) * RS;
+      char* prow = sP + (uint32_t)((r1 + 112) % PR) * RS;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int col = tx * TW + 4 * q - 3 + i;
-          v[i] = (rowok && col >= 0 && col < W) ? acc[q][i] + bv3 : 0.0f;
+          v[i] = (rowok && col >= 0 && col < W) ? acc[q][i] : 0.0f;
         }
         uint2 u;
         u.x = pack_bf2(v[0], v[1]);
@@ -1229,19 +1267,19 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
     DP_T(3)
     if (g + 2 < ng) DP_LOAD_XUNIT(g + 2)
     DP_T(4)
-    // ---- emit x' rows 8g + 3 .. 8g + 10 (columns of this strip only): 8 rows x 9 quads x 4 channel groups, v_perm transpose
+    // ---- emit x' rows 8g + 3 .. 8g + 10 (columns of this strip only), v_perm transpose back to channel-contiguous pixels
     {
       const uint32_t so1 = (uint32_t)(8 * g) * rowbytes;
 #pragma unroll
-      for (int et = 0; et < 2; ++et) {
-        const int task = tid + 256 * et;
-        if (task < 8 * 9 * 4 && !(DP_ABL & 16)) {
-          const int cg = task & 3, quad = (task >> 2) % 9, row = (task >> 2) / 9;
-          const uint32_t src = (uint32_t)((8 * (g & 1) + row) * RS + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
+      for (int et = 0; et < NEP; ++et) {
+        // every wave that owns a task of this slot issues all four stores (the vmcnt of DP_WAIT_X counts them); lanes past the
+        // last task read a ring row that exists and store to an out-of-range offset
+        if ((et == 0 || wid < (NET - 256 + 63) / 64) && !(DP_ABL & 16)) {
+          const uint32_t src = (uint32_t)((8 * g + 3 + e1row[et] + 112) % PR) * RS + e1src[et];
           uint2 r[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sP + (src ^ (uint32_t)(e * 8)));
-          const bool ok = (unsigned)(8 * g + 3 + row) < (unsigned)H;
+          const bool ok = (unsigned)(8 * g + 3 + e1row[et]) < (unsigned)H;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             u32x4 o;
@@ -1258,46 +1296,50 @@ __global__ __launch_bounds__(256, 2) void dwpair_march_kernel(const bf16_t* __re
     if (g < 0) { DP_DUMMY_STORES(4) continue; }
     // ---- t rows 8g .. 8g + 7 = dw7x7 over x' units g - 1, g
     {
-      f32x4 acc[8];
+      f32x4 acc[NRG][NTQ];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int rb = 8 * g + rg * 4 + jr - 6;     // x' ring row of ky = 0: (o - 3 - 3) & 15
+      for (int rgi = 0; rgi < NRG; ++rgi) {
 #pragma unroll
-      for (int ky = 0; ky < 7; ++ky) {
-        const uint32_t ro = (uint32_t)((rb + ky) & 15) * RS;
-        s16x4 xq[NQ];
+        for (int q = 0; q < NTQ; ++q) acc[rgi][q] = f32x4{bv7, bv7, bv7, bv7};
+        const int rb = (8 * g + (rg0 + rgi) * 4 + jr - 3 + 112) % PR;     // x' ring slot of ky = 0 (row o - 3)
 #pragma unroll
-        for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sP + ro + sw[t & 3] + t * 256));
+        for (int ky = 0; ky < 7; ++ky) {
+          const uint32_t ro = (uint32_t)dp_wrap<PR>(rb + ky) * RS;
+          s16x4 xq[NQ];
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+          for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sP + ro + sw[t & 3] + t * 256));
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (q + m < NQ && !(DP_ABL & 8)) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a7[ky][m], xq[q + m], acc[q], 0, 0, 0);
+          for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int q = 0; q < NTQ; ++q)
+              if (!(DP_ABL & 8)) acc[rgi][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a7[ky][m], xq[q + m], acc[rgi][q], 0, 0, 0);
+        }
       }
       DP_T(6)
-      __syncthreads();   // every wave is done with x' unit g - 1: its ring rows carry the t tile out
+      __syncthreads();   // every wave is done with x' unit g - 1: the slots the next unit will take carry the t tile out
       DP_T(7)
-      char* orow = sP + (8 * ((g + 1) & 1) + rg * 4 + jr) * RS;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        uint2 u;
-        u.x = pack_bf2(acc[q][0] + bv7, acc[q][1] + bv7);
-        u.y = pack_bf2(acc[q][2] + bv7, acc[q][3] + bv7);
-        *reinterpret_cast<uint2*>(orow + sw[q & 3] + q * 256) = u;
+      for (int rgi = 0; rgi < NRG; ++rgi) {
+        char* orow = sP + (uint32_t)((8 * g + 11 + (rg0 + rgi) * 4 + jr + 112) % PR) * RS;
+#pragma unroll
+        for (int q = 0; q < NTQ; ++q) {
+          uint2 u;
+          u.x = pack_bf2(acc[rgi][q][0], acc[rgi][q][1]);
+          u.y = pack_bf2(acc[rgi][q][2], acc[rgi][q][3]);
+          *reinterpret_cast<uint2*>(orow + sw[q & 3] + q * 256) = u;
+        }
       }
     }
     DP_T(8)
     __syncthreads();
     DP_T(9)
     {
-      const char* sO = sP + 8 * ((g + 1) & 1) * RS;
-      const int cg = tid & 3, quad = (tid >> 2) & 7, row = tid >> 5;   // 8 rows x 8 quads x 4 channel groups
-      const uint32_t src = (uint32_t)(row * RSO + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3);
+      const uint32_t src = (uint32_t)((8 * g + 11 + e2row + 112) % PR) * RS + e2src;
       uint2 r[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sO + (src ^ (uint32_t)(e * 8)));
+      for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sP + (src ^ (uint32_t)(e * 8)));
       if (!(DP_ABL & 16)) {
-        const bool ok = g * 8 + row < H;
+        const bool ok = g * 8 + e2row < H;
         const uint32_t so2 = (uint32_t)(8 * g) * rowbytes;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1643,13 +1685,25 @@ int launch_dwconv_pair(const bf16_t* x, const bf16_t* t3, const float* b3, const
   if (x == y1 || x == y2 || y1 == y2) return fv_fail(FV_ERR_ARG, "dwconv_pair: buffers must be distinct");
   static bool attr_set = false;
   if (!attr_set) {
-    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpair_march_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpair_march_kernel<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, DpGeo<32, 32>::LDS));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpair_march_kernel<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, DpGeo<64, 16>::LDS));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpair_march_kernel<32, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, DpGeo<32, 16>::LDS));
     attr_set = true;
   }
-  const int tiles_x = (W + 31) / 32, nsl = C / 32;
+  // geometry: 0 = 32 columns x 32 channels (two blocks per CU), 1 = 16 x 64 (full cache lines), 2 = 16 x 32 (three blocks per CU)
+  static const int force = getenv("FASTVLA_DWPAIR_GEO") ? atoi(getenv("FASTVLA_DWPAIR_GEO")) : -1;
+  int geo = force >= 0 ? force : DP_DEFAULT_GEO;
+  if (geo == 1 && C % 64) geo = 0;
+  const int chb = geo == 1 ? 64 : 32, tw = geo == 0 ? 32 : 16;
+  const int tiles_x = (W + tw - 1) / tw, nsl = C / chb;
   const long nstrips = (long)B * tiles_x * nsl;
   if (nstrips > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv_pair: grid too large");
-  hipLaunchKernelGGL(dwpair_march_kernel, dim3((unsigned)nstrips), dim3(256), DP_LDS, s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl);
+  if (geo == 1)
+    hipLaunchKernelGGL((dwpair_march_kernel<64, 16>), dim3((unsigned)nstrips), dim3(256), (DpGeo<64, 16>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl);
+  else if (geo == 2)
+    hipLaunchKernelGGL((dwpair_march_kernel<32, 16>), dim3((unsigned)nstrips), dim3(256), (DpGeo<32, 16>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl);
+  else
+    hipLaunchKernelGGL((dwpair_march_kernel<32, 32>), dim3((unsigned)nstrips), dim3(256), (DpGeo<32, 32>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
