@@ -215,6 +215,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
 //   * the next K-tile's 64 KB is in flight during all 64 MFMAs of the current one; one barrier per K-tile.
 // Operands are swapped (A = weight rows, B = activation rows) so a lane's four accumulators are four consecutive output
 // columns: the epilogue turns 16 rows x 64 columns through LDS with 16-byte writes and leaves as full 128-byte lines.
+#ifndef G2_DEAL
+#define G2_DEAL 0   // 1: deal the LDS-DMA pieces between the MFMA steps (same K-tile time: the issue cost moves, it does not hide; tools/gemm_stamps.py)
+#endif
+#ifdef G2_STAMPS
+__device__ unsigned long long g_g2_stamps[256 * 8];   // diagnostics (tools/gemm_stamps.py): per block, clocks of wave 0 summed over K-tiles
+#define G2_T(I) { const unsigned long long n_ = __builtin_readcyclecounter(); st_[I] += n_ - t0_; t0_ = n_; }
+#else
+#define G2_T(I)
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
@@ -278,6 +287,9 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   stage(offa, offw, k_lo(tile), 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef G2_STAMPS
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_readcyclecounter();
+#endif
   for (; tile < p.nwg; tile += (int)gridDim.x) {
     const int next = tile + (int)gridDim.x;
     if (next < p.nwg) tile_offsets(next, offa_n, offw_n, bm_n, bn_n);
@@ -289,8 +301,21 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kt = kt0; kt < kt1; ++kt) {
       const int cur = (pb + kt - kt0) & 1;
-      if (kt + 1 < kt1) stage(offa, offw, kt + 1, cur ^ 1);
-      else if (next < p.nwg) stage(offa_n, offw_n, kn0, cur ^ 1);
+      G2_T(4)
+      // the next K-tile's SA + SW LDS-DMA pieces are dealt one per MFMA step below (G2_DEAL): issued in a burst here, before any
+      // MFMA of this K-tile, they cost every wave ~470 clk with the matrix pipe idle (tools/gemm_stamps.py)
+      const bool st_same = kt + 1 < kt1, st_any = st_same || next < p.nwg;
+#if G2_DEAL
+      const int st_kt = st_same ? kt + 1 : kn0;
+      const int st_kw = st_kt >= nk1 ? st_kt - nk1 : st_kt;
+      const int st_aoff = (st_kw * BK + (st_kt >= nk1 ? p.K : 0)) * 2, st_woff = st_kw * BK * 2;
+      char* st_la = g2_smem + (cur ^ 1) * BUFB + wslot;
+      char* st_lw = st_la + AB;
+#else
+      if (st_same) stage(offa, offw, kt + 1, cur ^ 1);
+      else if (st_any) stage(offa_n, offw_n, kn0, cur ^ 1);
+#endif
+      G2_T(0)
       const char* la = g2_smem + cur * BUFB + (wr * (16 * MI)) * 128;
       const char* lw = g2_smem + cur * BUFB + AB + (wc * 64) * 128;
       // Fragment reads run two steps (8 MFMAs, ~130 clk) ahead of their use: left to itself hipcc reads each pair of
@@ -307,6 +332,12 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 #pragma unroll
         for (int t = 0; t < 2 * MI; ++t) {
           if (t + 2 < 2 * MI) far[(t + 2) % 3] = G2_RD_A(t + 2);
+#if G2_DEAL
+          if (t < SA + SW && st_any) {
+            if (t < SA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(st_la + (t % 4) * (NTH * 16)), 16, st_same ? offa[t % 4] : offa_n[t % 4], st_aoff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(st_lw + ((t - SA) % 4) * (NTH * 16)), 16, st_same ? offw[(t - SA) % 4] : offw_n[(t - SA) % 4], st_woff, 0, 0);
+          }
+#endif
           if (t == MI - 3) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) fwB[j] = G2_RD_W(1, j);
@@ -319,8 +350,14 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 #undef G2_RD_A
 #undef G2_RD_W
       }
+      G2_T(1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next K-tile has landed ...
+      G2_T(2)
       __syncthreads();                                    // ... for everybody, and nobody still reads this one
+      G2_T(3)
+#ifdef G2_STAMPS
+      st_[6] += 1;
+#endif
     }
 
     // ---- epilogue: per 16-row tile, 64 columns of fp32 through the wave's 4.25 KB of the buffer the last K-tile just
@@ -410,11 +447,15 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       asm volatile("" ::: "memory");   // the next tile's writes stay behind these reads
     }
     __syncthreads();   // the scratch buffer becomes a staging target again in the next tile's first iteration
+    G2_T(5)
     pb = (pb + kt1 - kt0) & 1;
     bm = bm_n; bn = bn_n;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { offa[j] = offa_n[j]; offw[j] = offw_n[j]; }
   }
+#ifdef G2_STAMPS
+  if (tid == 0 && blockIdx.x < 256) for (int z = 0; z < 8; ++z) g_g2_stamps[blockIdx.x * 8 + z] = st_[z];
+#endif
 }
 
 // out[m][n] = (res ? res[m][n] : 0) + (bias ? bias[n] : 0) + sum over splits of part[s][m][n], 4 columns per thread
@@ -690,3 +731,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace fv
+
+#ifdef G2_STAMPS
+extern "C" int fv_dbg_g2_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fv::g_g2_stamps), 256 * 8 * 8); }
+#endif
