@@ -255,7 +255,7 @@ def main():
         elt = timed(step_train, nst, max(1, args.warmup // 2))
         ar_ms = overlap = ser_ms = None
         if world > 1:
-            els = timed(step_train_serial, nst, 1)
+            els = timed(step_train_serial, nst, 2)
             ser_ms = 1e3 * els / nst
             state["timed"] = True
             state["pooled"] = frozen_forward()
