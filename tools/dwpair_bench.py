@@ -1,5 +1,6 @@
 """tools/dwpair_bench.py -- times fv_op_dwconv_pair (RepMixer 3x3 + ConvFFN 7x7 march) at the tower's three real shapes on random
 data, interleaved rounds; prints us per launch and the algorithmic HBM rate (3 tensor passes).  python tools/dwpair_bench.py [rounds]"""
+import os
 import sys
 from pathlib import Path
 
@@ -46,6 +47,12 @@ for C, H in ((384, 64), (192, 128), (96, 256)):
         rows = [r for r in rows if r[12]]
         names = ["bar1", "3x3+x'->lds", "bar2", "wait+x->lds", "x loads", "x' emit", "7x7", "bar3", "t->lds", "bar4", "t emit", "loop"]
         med = [statistics.median(r[z] / r[12] for r in rows) for z in range(12)]
-        print(f"C={C} clk per step (thread 0, median of {len(rows)} blocks): " + "  ".join(f"{n} {m:.0f}" for n, m in zip(names, med)) + f"  | sum {sum(med):.0f}")
+        chb = 64 if C % 64 == 0 and os.environ.get("FASTVLA_DWPAIR_GEO", "1") == "1" else 32
+        tw = 16 if chb == 64 or os.environ.get("FASTVLA_DWPAIR_GEO") == "2" else 32
+        nblk = B * ((H + tw - 1) // tw) * (C // chb)
+        occ = 3 if (chb, tw) == (32, 16) else 2
+        per_block_s = min(ts) * 1e-3 / max(1.0, nblk / (256.0 * occ))          # a block's lifetime if the rounds were equal
+        ghz = sum(med) * rows[0][12] / per_block_s / 1e9
+        print(f"C={C} clk per step (thread 0, median of {len(rows)} blocks): " + "  ".join(f"{n} {m:.0f}" for n, m in zip(names, med)) + f"  | sum {sum(med):.0f}  ~{ghz:.2f} GHz")
     del x, y1, y2
 print("  ".join(out))

@@ -1218,41 +1218,58 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
     DP_T(11)
     __syncthreads();   // x unit g is in its ring; the previous step's output tile and x' rows have been read
     DP_T(0)
-    // ---- x' unit g = dw3x3 over x units g - 1, g: lane's row r' = 8g + 3 + rg*4 + jr, NQ quads of columns
+    // ---- x' unit g = dw3x3 over x units g - 1, g: lane's row r' = 8g + 3 + rg*4 + jr, NQ quads of columns.
+    // The operand rows (one per (row group, ky): NQ ds_read_b64) are requested TWO rows ahead of the MFMAs that take them and the
+    // order is pinned: left to itself hipcc reads a row 3-10 MFMAs before its use and the MFMAs then run at LDS latency (19-25 clk
+    // each in the stamps, for an instruction that issues every 8-11).
+    {
+      constexpr int NR3 = NRG * 3;
+      s16x4 xr[3][NQ];
+      f32x4 acc[NRG][NQ];
+      int rb3[NRG];
 #pragma unroll
-    for (int rgi = 0; rgi < NRG; ++rgi) {
-      const int rg = rg0 + rgi;
-      f32x4 acc[NQ];
+      for (int rgi = 0; rgi < NRG; ++rgi) {
+        rb3[rgi] = (8 * g + 2 + (rg0 + rgi) * 4 + jr + 120) % XR;   // x ring slot of ky = 0 (row r' - 1)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = f32x4{bv3, bv3, bv3, bv3};   // the bias rides in as the accumulators' start
-      const int r1 = 8 * g + 3 + rg * 4 + jr;
-      const int rb = (r1 - 1 + 120) % XR;   // x ring slot of ky = 0
+        for (int q = 0; q < NQ; ++q) acc[rgi][q] = f32x4{bv3, bv3, bv3, bv3};   // the bias rides in as the accumulators' start
+      }
+#define DP_RD3(R, DST)                                                                                              \
+      {                                                                                                             \
+        const uint32_t ro_ = (uint32_t)dp_wrap<XR>(rb3[(R) / 3] + (R) % 3) * RS;                                    \
+        _Pragma("unroll") for (int t = 0; t < NQ; ++t)                                                              \
+          DST[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sX + ro_ + sw[t & 3] + t * 256));      \
+      }
+      DP_RD3(0, xr[0])
+      if (NR3 > 1) DP_RD3(1, xr[1])
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const uint32_t ro = (uint32_t)dp_wrap<XR>(rb + ky) * RS;
-        s16x4 xq[NQ];
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sX + ro + sw[t & 3] + t * 256));
+      for (int r = 0; r < NR3; ++r) {
+        if (r + 2 < NR3) DP_RD3(r + 2, xr[(r + 2) % 3])
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
-            if (q + m < NQ && !(DP_ABL & 8)) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a3[ky][m], xq[q + m], acc[q], 0, 0, 0);
+            if (q + m < NQ && !(DP_ABL & 8)) acc[r / 3][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a3[r % 3][m], xr[r % 3][q + m], acc[r / 3][q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      const bool rowok = r1 >= 0 && r1 < H;
-      char* prow = sP + (uint32_t)((r1 + 112) % PR) * RS;
+#undef DP_RD3
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        float v[4];
+      for (int rgi = 0; rgi < NRG; ++rgi) {
+        const int r1 = 8 * g + 3 + (rg0 + rgi) * 4 + jr;
+        const bool rowok = r1 >= 0 && r1 < H;
+        char* prow = sP + (uint32_t)((r1 + 112) % PR) * RS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int col = tx * TW + 4 * q - 3 + i;
-          v[i] = (rowok && col >= 0 && col < W) ? acc[q][i] : 0.0f;
+        for (int q = 0; q < NQ; ++q) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int col = tx * TW + 4 * q - 3 + i;
+            v[i] = (rowok && col >= 0 && col < W) ? acc[rgi][q][i] : 0.0f;
+          }
+          uint2 u;
+          u.x = pack_bf2(v[0], v[1]);
+          u.y = pack_bf2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(prow + sw[q & 3] + q * 256) = u;
         }
-        uint2 u;
-        u.x = pack_bf2(v[0], v[1]);
-        u.y = pack_bf2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(prow + sw[q & 3] + q * 256) = u;
       }
     }
     DP_T(1)
@@ -1297,24 +1314,34 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
     // ---- t rows 8g .. 8g + 7 = dw7x7 over x' units g - 1, g
     {
       f32x4 acc[NRG][NTQ];
+      constexpr int NR7 = NRG * 7;
+      s16x4 xr[3][NQ];
+      int rb7[NRG];
 #pragma unroll
       for (int rgi = 0; rgi < NRG; ++rgi) {
 #pragma unroll
         for (int q = 0; q < NTQ; ++q) acc[rgi][q] = f32x4{bv7, bv7, bv7, bv7};
-        const int rb = (8 * g + (rg0 + rgi) * 4 + jr - 3 + 112) % PR;     // x' ring slot of ky = 0 (row o - 3)
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-          const uint32_t ro = (uint32_t)dp_wrap<PR>(rb + ky) * RS;
-          s16x4 xq[NQ];
-#pragma unroll
-          for (int t = 0; t < NQ; ++t) xq[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sP + ro + sw[t & 3] + t * 256));
-#pragma unroll
-          for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int q = 0; q < NTQ; ++q)
-              if (!(DP_ABL & 8)) acc[rgi][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a7[ky][m], xq[q + m], acc[rgi][q], 0, 0, 0);
-        }
+        rb7[rgi] = (8 * g + (rg0 + rgi) * 4 + jr - 3 + 112) % PR;     // x' ring slot of ky = 0 (row o - 3)
       }
+#define DP_RD7(R, DST)                                                                                              \
+      {                                                                                                             \
+        const uint32_t ro_ = (uint32_t)dp_wrap<PR>(rb7[(R) / 7] + (R) % 7) * RS;                                    \
+        _Pragma("unroll") for (int t = 0; t < NQ; ++t)                                                              \
+          DST[t] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(sP + ro_ + sw[t & 3] + t * 256));      \
+      }
+      DP_RD7(0, xr[0])
+      DP_RD7(1, xr[1])
+#pragma unroll
+      for (int r = 0; r < NR7; ++r) {   // same two-rows-ahead operand schedule as the 3x3
+        if (r + 2 < NR7) DP_RD7(r + 2, xr[(r + 2) % 3])
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int q = 0; q < NTQ; ++q)
+            if (!(DP_ABL & 8)) acc[r / 7][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a7[r % 7][m], xr[r % 3][q + m], acc[r / 7][q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef DP_RD7
       DP_T(6)
       __syncthreads();   // every wave is done with x' unit g - 1: the slots the next unit will take carry the t tile out
       DP_T(7)
