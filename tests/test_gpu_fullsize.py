@@ -224,6 +224,41 @@ def test_7b_decoder_full_width_four_layers():
     eng.close()
 
 
+def test_1p5b_decoder_full_width_four_layers():
+    """FastVLM-1.5B decoder geometry at full width (Qwen2-1.5B: 1536 hidden, 12 q / 2 kv heads of 128, inter 8960), 4 of its 28
+    layers, vs the fp32 oracle -- the reference's third model size (`--model-id apple/FastVLM-1.5B`); GQA ratio 6 and a
+    hidden size that is not a multiple of 256 take other tile paths than 0.5B and 7B."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    full = arch.preset("fastvlm-1.5b").llm
+    llm = arch.LLMConfig(hidden=full.hidden, layers=4, heads=full.heads, kv_heads=full.kv_heads, head_dim=full.head_dim, inter=full.inter, vocab=8192)
+    m = arch.ModelConfig("1.5b-4layer", llm, arch.preset("tiny").tower)
+    prov = weights.stream_backbone(m, seed=6, device=DEV)
+    asked = []
+
+    def provider(name):
+        asked.append(name)
+        return prov(name)
+
+    eng = FastVLAEngine(m, hidden_dim=64, fusion_dim=64, max_batch=4, max_text_tokens=64, llm_precision=1)
+    eng.load_weights_streaming(provider)
+    lc = qwen2.Qwen2Cfg(hidden=llm.hidden, layers=4, heads=llm.heads, kv_heads=llm.kv_heads, head_dim=llm.head_dim, inter=llm.inter, vocab=8192)
+    w = {n: prov(n).float().cpu() for n in asked if n.startswith("model.") and not n.startswith("model.vision_tower") and not n.startswith("model.mm_projector")}
+    torch.manual_seed(7)
+    B, T = 4, 64
+    ids = torch.randint(0, 8192, (B, T))
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, 40:] = 0
+    mask[3, 1:] = 0
+    with torch.no_grad():
+        ref = qwen2.llm_pooled(w, ids, mask, lc)
+    got = eng.llm_pooled(ids, mask.sum(1))
+    torch.cuda.synchronize()
+    r, _ = check_close(got.cpu(), ref, rel=3e-4, amax=3e-3, what="1.5B-width 4-layer pooled (split-bf16)")
+    print(f"[1.5b-4layer] pooled rel_l2={r:.2e}")
+    eng.close()
+
+
 def test_7b_whole_preset_properties():
     """BASELINE.json configs[3] (C4) shape: the whole fastvlm-7b preset (28 layers, 152064-row embedding, 1024^2 tower),
     B=16, 64-token prompts.  No CPU oracle finishes this in test time, so the checks are the size-independent ones:

@@ -64,6 +64,9 @@ class ModelConfig:
 
 PRESETS = {
     "fastvlm-0.5b": ModelConfig("fastvlm-0.5b"),
+    # apple/FastVLM-1.5B: the Qwen2-1.5B decoder behind the same FastViT-HD tower (projector 3072 -> 1536)
+    "fastvlm-1.5b": ModelConfig("fastvlm-1.5b", LLMConfig(hidden=1536, layers=28, heads=12, kv_heads=2, head_dim=128,
+                                                        inter=8960, vocab=151936)),
     "fastvlm-7b": ModelConfig("fastvlm-7b", LLMConfig(hidden=3584, layers=28, heads=28, kv_heads=4, head_dim=128,
                                                     inter=18944, vocab=152064)),
     # reduced shapes for parity tests the CPU oracle finishes in seconds (same graph, same kernels)

@@ -31,6 +31,7 @@ Tensor = torch.Tensor
 # Hub ids of the checkpoints the reference documents (README.md:27-40, scripts/download_fastvlm.sh:14-22) -> preset
 _KNOWN_MODELS = {
     "apple/fastvlm-0.5b": "fastvlm-0.5b", "llava-fastvithd_0.5b_stage3": "fastvlm-0.5b", "llava-fastvithd_0.5b_stage2": "fastvlm-0.5b",
+    "apple/fastvlm-1.5b": "fastvlm-1.5b", "llava-fastvithd_1.5b_stage3": "fastvlm-1.5b", "llava-fastvithd_1.5b_stage2": "fastvlm-1.5b",
     "apple/fastvlm-7b": "fastvlm-7b", "llava-fastvithd_7b_stage3": "fastvlm-7b", "llava-fastvithd_7b_stage2": "fastvlm-7b",
 }
 
