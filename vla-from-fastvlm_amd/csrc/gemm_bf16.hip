@@ -230,8 +230,14 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 // MI = 16-row tiles per wave along M (the block has 2 waves along M), WN = waves along N (64 columns each):
 // <8, 4> = 256 x 256 with 8 waves (one block per CU), <4, 2> = 128 x 128 with 4 waves (two per CU) for problems with too few
 // 256-tiles to fill the chip (the decoder's N = 896 / 1152 projections at M = 4096).
-template <int MI, int WN>
+// ASYM (<8, 4, true>): only the wr == 0 waves -- one per SIMD -- issue the LDS-DMA, their own 1 KB pieces and those of the wave four
+// above them (same lanes, 32 rows further: a scalar offset for A; W rows are clamped per row, hence offw2).  The wr == 1 waves go
+// straight to their fragment reads and MFMAs and run ahead.  Measured (tools/gemm_shapes.py, A/B in one session): +6 % on the decoder's
+// M = 4096 gate/up and split-K down projections, +-2 % on the tower's shapes, -15 % at 8192^3 (the staging waves' 16 pieces become the
+// critical path of a long K loop with many tiles per CU) -- launch_gemm uses it for M <= 8192 only.
+template <int MI, int WN, bool ASYM = false>
 __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Params p) {   // <8,4> 256x256, <4,2> 128x128
+  static_assert(!ASYM || WN == 4, "asymmetric staging pairs wave w with wave w + 4");
   constexpr int BMT = 32 * MI, BNT = 64 * WN, NTH = 128 * WN, BUFB = (BMT + BNT) * 128, AB = BMT * 128;
   constexpr int SA = BMT * 8 / NTH, SW = BNT * 8 / NTH;   // 16-byte staging slots per thread: activations / weights
   static_assert(SA * NTH == BMT * 8 && SW * NTH == BNT * 8 && SA <= 4 && SW <= 4, "whole slots per thread");
@@ -244,9 +250,11 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 
   // staging: slot s = j * 512 + tid is 16 B of row s >> 3 at LDS position s & 7, filled from k-chunk (s & 7) ^ (row & 7)
   uint32_t offa[4], offw[4], offa_n[4], offw_n[4];
+  uint32_t offw2[4] = {0u, 0u, 0u, 0u}, offw2_n[4] = {0u, 0u, 0u, 0u};   // ASYM: the partner wave's W rows
+  const int a32 = 32 * p.lda * 2;
   // a unit = (output tile, K split): split-K (p.splits > 1) gives problems with few output tiles and a long K loop -- the
   // decoder's down projection at M = 4096 -- one unit per CU; each unit leaves raw fp32 partial sums for splitk_reduce_kernel
-  auto tile_offsets = [&](int unit, uint32_t (&oa)[4], uint32_t (&ow)[4], int& bm, int& bn) {
+  auto tile_offsets = [&](int unit, uint32_t (&oa)[4], uint32_t (&ow)[4], uint32_t (&ow2)[4], int& bm, int& bn) {
     const int logical = xcd_remap(unit, p.nwg) / p.splits;
     bm = (logical / p.tiles_n) * BMT;
     bn = (logical % p.tiles_n) * BNT;
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       const int sl = j * NTH + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
       oa[j] = j < SA ? (uint32_t)(((size_t)(bm + row) * p.lda + chunk * 8) * 2) : 0u;
       ow[j] = j < SW ? (uint32_t)(((size_t)min(bn + row, p.N - 1) * p.K + chunk * 8) * 2) : 0u;   // rows past N (padded last tile) repeat the last
+      if (ASYM) ow2[j] = j < SW ? (uint32_t)(((size_t)min(bn + row + 32, p.N - 1) * p.K + chunk * 8) * 2) : 0u;
     }
   };
   // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): per-lane 32-bit byte offset in a VGPR, the K-tile's offset
@@ -262,15 +271,30 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   // address) pays ~52 (tools/stage_micro.hip); launch_gemm keeps operands of 4 GiB or more away from this kernel.
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, 0xffffffffu, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, 0xffffffffu, 0x00020000);
-  auto stage = [&](const uint32_t (&oa)[4], const uint32_t (&ow)[4], int kt, int buf) {
+  auto stage = [&](const uint32_t (&oa)[4], const uint32_t (&ow)[4], const uint32_t (&ow2)[4], int kt, int buf) {
     const int kw = kt >= nk1 ? kt - nk1 : kt;
     const int aoff = (kw * BK + (kt >= nk1 ? p.K : 0)) * 2, woff = kw * BK * 2;
     char* la = g2_smem + buf * BUFB + wslot;
     char* lw = la + AB;
+    if constexpr (ASYM) {
+      if (wr == 0) {   // wave-uniform
 #pragma unroll
-    for (int j = 0; j < SA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(la + j * (NTH * 16)), 16, oa[j], aoff, 0, 0);
+        for (int j = 0; j < SA; ++j) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(la + j * (NTH * 16)), 16, oa[j], aoff, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(la + j * (NTH * 16) + 4096), 16, oa[j], aoff + a32, 0, 0);
+        }
 #pragma unroll
-    for (int j = 0; j < SW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(lw + j * (NTH * 16)), 16, ow[j], woff, 0, 0);
+        for (int j = 0; j < SW; ++j) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(lw + j * (NTH * 16)), 16, ow[j], woff, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(lw + j * (NTH * 16) + 4096), 16, ow2[j], woff, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(la + j * (NTH * 16)), 16, oa[j], aoff, 0, 0);
+#pragma unroll
+      for (int j = 0; j < SW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(lw + j * (NTH * 16)), 16, ow[j], woff, 0, 0);
+    }
   };
   // lane's fragment offsets: row fr of a 16-row tile, swizzled chunk per k-step
   const uint32_t fo0 = (uint32_t)(fr * 128 + (((0 * 4 + fq) ^ (fr & 7)) << 4));
@@ -281,10 +305,10 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   // drain under the next tile's MFMAs.  pb = LDS buffer holding the current tile's K-tile 0.
   int tile = blockIdx.x, pb = 0, bm, bn, bm_n = 0, bn_n = 0;
   if (tile >= p.nwg) return;
-  tile_offsets(tile, offa, offw, bm, bn);
+  tile_offsets(tile, offa, offw, offw2, bm, bn);
   auto k_lo = [&](int unit) { return (xcd_remap(unit, p.nwg) % p.splits) * nk / p.splits; };
   auto k_hi = [&](int unit) { return (xcd_remap(unit, p.nwg) % p.splits + 1) * nk / p.splits; };
-  stage(offa, offw, k_lo(tile), 0);
+  stage(offa, offw, offw2, k_lo(tile), 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #ifdef G2_STAMPS
@@ -292,7 +316,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 #endif
   for (; tile < p.nwg; tile += (int)gridDim.x) {
     const int next = tile + (int)gridDim.x;
-    if (next < p.nwg) tile_offsets(next, offa_n, offw_n, bm_n, bn_n);
+    if (next < p.nwg) tile_offsets(next, offa_n, offw_n, offw2_n, bm_n, bn_n);
     const int kt0 = k_lo(tile), kt1 = k_hi(tile), kn0 = next < p.nwg ? k_lo(next) : 0;
     f32x4 acc[4][MI];   // [n tile][m tile]
 #pragma unroll
@@ -312,8 +336,8 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       char* st_la = g2_smem + (cur ^ 1) * BUFB + wslot;
       char* st_lw = st_la + AB;
 #else
-      if (st_same) stage(offa, offw, kt + 1, cur ^ 1);
-      else if (st_any) stage(offa_n, offw_n, kn0, cur ^ 1);
+      if (st_same) stage(offa, offw, offw2, kt + 1, cur ^ 1);
+      else if (st_any) stage(offa_n, offw_n, offw2_n, kn0, cur ^ 1);
 #endif
       G2_T(0)
       const char* la = g2_smem + cur * BUFB + (wr * (16 * MI)) * 128;
@@ -451,7 +475,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
     pb = (pb + kt1 - kt0) & 1;
     bm = bm_n; bn = bn_n;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { offa[j] = offa_n[j]; offw[j] = offw_n[j]; }
+    for (int j = 0; j < 4; ++j) { offa[j] = offa_n[j]; offw[j] = offw_n[j]; offw2[j] = offw2_n[j]; }
   }
 #ifdef G2_STAMPS
   if (tid == 0 && blockIdx.x < 256) for (int z = 0; z < 8; ++z) g_g2_stamps[blockIdx.x * 8 + z] = st_[z];
@@ -660,7 +684,10 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
   }
+  static const bool no_asym = getenv("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
+  const bool asym = !no_asym && a.M <= 8192;
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
   static const bool no_splitk = getenv("FASTVLA_NO_SPLITK") != nullptr;
   if (!no_splitk && a.splitk_ws && f32out && !getenv("FASTVLA_NO_GEMM256") && a.M % 256 == 0 && a.K % 64 == 0 && a.N % 4 == 0 &&
@@ -674,7 +701,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
       p.tiles_n = tn;
       p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
       p.nwg = tiles * splits;
-      hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(p.nwg < cus ? p.nwg : cus / 8 * 8), dim3(512), 2 * 512 * 128, s, p);
+      if (asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), dim3(p.nwg < cus ? p.nwg : cus / 8 * 8), dim3(512), 2 * 512 * 128, s, p);
+      else hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(p.nwg < cus ? p.nwg : cus / 8 * 8), dim3(512), 2 * 512 * 128, s, p);
       const long quads = (long)a.M * (a.N / 4);
       if (a.norm_w) g_norm_fused = true;
       if (a.norm_w)
@@ -711,7 +739,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     p.nwg = (a.M / gt) * p.tiles_n;
     const int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
     const int grid = p.nwg < slots ? p.nwg : slots;
-    if (gt == 256) hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
+    if (gt == 256 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
+    else if (gt == 256) hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<4, 2>), dim3(grid), dim3(256), 2 * 256 * 128, s, p);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
