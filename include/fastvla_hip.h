@@ -121,6 +121,16 @@ int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, vo
  * device buffers; NULL entries are skipped; n_taps <= tower_stages + 1.  The mirror of the oracle's `taps=` argument. */
 int fv_vision_forward_taps(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, void* const* taps,
                            int n_taps, fv_stream s);
+/* Tower UNITS in execution order: unit 0 = the three stem convolutions, then per stage [RepCPE] block ... block [PatchEmbed]
+ * (mci.py `network` ModuleList order; 51 units for fastvithd).  fv_vision_unit_info describes unit u's OUTPUT map
+ * (kind 0 stem / 1 RepCPE / 2 block / 3 PatchEmbed; side x side x channels, bf16 NHWC) and fails with FV_ERR_ARG past the last
+ * unit.  fv_vision_forward_unit_taps is fv_vision_forward that also copies every unit's output to taps[u] (NULL entries
+ * skipped): unit u's input is taps[u-1], so a parity test can feed the ORACLE unit the ENGINE's own input and compare one unit
+ * at a time (teacher forcing: no error amplification through the 44 blocks).  Same call site as fv_vision_forward
+ * (model/fastvlm_adapter.py:533). */
+int fv_vision_unit_info(fv_handle* h, int unit, int32_t* kind, int32_t* stage, int32_t* side, int32_t* channels);
+int fv_vision_forward_unit_taps(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, void* const* taps,
+                                int n_taps, fv_stream s);
 /* replaces embed_tokens + L x Qwen2DecoderLayer + final RMSNorm + FastVLMBackbone._pool_hidden
  * (fastvlm_adapter.py:533,551-559,337-359): ids (B,T) int32 right-padded, lens (B) int32,
  * img_tokens NULL (literal reference: text-only sequence) or (B,Ni,H) f32 spliced in front of the text.
@@ -145,7 +155,10 @@ int fv_head_forward(fv_handle* h, const float* flat_params, const float* pooled,
  * NormalizerProcessorStep / UnnormalizerProcessorStep around the policy (lerobot_fastvla/processor_fastvla.py:34-48, MEAN_STD per
  * lerobot_fastvla/configuration_fastvla.py:21-27): fv_head_forward then computes LayerNorm((states - state_mean) / (state_std + eps))
  * ... and, when training == 0, returns actions * action_std + action_mean.  HOST vectors of state_dim / action_dim floats; all four
- * NULL switches the folding off.  Training keeps its loss in normalised action space (targets arrive normalised). */
+ * NULL switches the folding off.  Training keeps its loss in normalised action space (targets arrive normalised).
+ * A configuration call: it synchronises the device before overwriting the handle's ONE statistics vector.  A hipGraph captured
+ * over fv_head_forward keeps the on/off state of its capture: re-capture after switching the folding on or off (new VALUES
+ * written while it stays on are picked up by replays, the vector's address does not change). */
 int fv_head_set_io_norm(fv_handle* h, const float* state_mean, const float* state_std, const float* action_mean,
                         const float* action_std, float eps);
 /* replaces F.mse_loss + autograd backward of the head (fastvla/modeling_fastvla.py:56,

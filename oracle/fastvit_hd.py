@@ -147,50 +147,61 @@ def network_index_map(cfg: TowerCfg):
     return out
 
 
-def tower_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: TowerCfg = TowerCfg(), prefix: str = VT,
-                  taps: dict | None = None, emulate_bf16: bool = False) -> torch.Tensor:
-    """x: (B,3,S,S) fp32, S % 64 == 0  ->  image embeddings (B, (S/64)^2, out_dim).
-    emulate_bf16: the same graph with the product's bf16 rounding points (see the block comment above)."""
-    q = {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
-    R = _r if emulate_bf16 else (lambda t: t)
-    c0 = cfg.dims[0]
-    w0 = q["patch_embed.0.reparam_conv.weight"]
-    if emulate_bf16 and c0 % 16 == 0 and c0 <= 128:   # the implicit-GEMM stem packs its weights as bf16 MFMA operands
-        w0 = _r(w0)
-    x = R(gelu(F.conv2d(x, w0, q["patch_embed.0.reparam_conv.bias"], stride=2, padding=1)))
-    if taps is not None:
-        taps["stem0"] = x
-    x = R(gelu(_conv(x, q, "patch_embed.1.reparam_conv", stride=2, padding=1, groups=c0)))
-    x = R(gelu(_conv(x, q, "patch_embed.2.reparam_conv")))
-    if taps is not None:
-        taps["stem"] = x
+def tower_units(cfg: TowerCfg):
+    """The tower as a list of sequential UNITS, in execution order (the product's fv_vision_unit_info enumerates the same list):
+    ("stem", 0, None, None), then per stage [("cpe", i, idx, None)], ("block", i, idx, j) ..., [("down", i, idx, None)] with idx the
+    position in mci.py's `network` ModuleList.  conv_exp + SE and the projector follow the last unit."""
+    out = [("stem", 0, None, None)]
     for idx, (kind, i) in enumerate(network_index_map(cfg)):
-        c = cfg.dims[i]
-        mw = x.shape[-1]
-        if kind == "cpe":
-            wc = q[f"network.{idx}.reparam_conv.weight"]
-            x = R(F.conv2d(x, _r(wc) if emulate_bf16 and _dw_mfma(mw, c) else wc, q[f"network.{idx}.reparam_conv.bias"], padding=3, groups=c))
-        elif kind == "down":
-            wl = q[f"network.{idx}.proj.0.lkb_reparam.weight"]
-            if emulate_bf16 and c % 32 == 0 and mw % 2 == 0 and mw >= 16:   # dwconv_s2_mfma_supported
-                wl = _r(wl)
-            x = R(gelu(F.conv2d(x, wl, q[f"network.{idx}.proj.0.lkb_reparam.bias"], stride=2, padding=3, groups=c)))
-            x = R(gelu(_conv(x, q, f"network.{idx}.proj.1.reparam_conv")))
+        if kind == "stage":
+            out.extend(("block", i, idx, j) for j in range(cfg.layers[i]))
         else:
-            for j in range(cfg.layers[i]):
-                pre = f"network.{idx}.{j}."
-                ffn = _convffn_bf16 if emulate_bf16 else _convffn
-                if i in cfg.attn_stages:
-                    y = R(_layernorm_channel(x, q[pre + "norm.weight"], q[pre + "norm.bias"], cfg.ln_eps))
-                    att = (_mhsa_bf16 if emulate_bf16 else _mhsa)(y, q, pre + "token_mixer.", cfg)
-                    x = R(x + q[pre + "layer_scale_1"].view(1, -1, 1, 1) * att)
-                    x = R(x + q[pre + "layer_scale_2"].view(1, -1, 1, 1) * ffn(x, q, pre + "convffn.", cfg))
-                else:
-                    wm = q[pre + "token_mixer.reparam_conv.weight"]
-                    x = R(F.conv2d(x, _r(wm) if emulate_bf16 and _dw_mfma(mw, c) else wm, q[pre + "token_mixer.reparam_conv.bias"], padding=1, groups=c))
-                    x = R(x + q[pre + "layer_scale"].view(1, -1, 1, 1) * ffn(x, q, pre + "convffn.", cfg))
-            if taps is not None:
-                taps[f"stage{i}"] = x
+            out.append((kind, i, idx, None))
+    return out
+
+
+def unit_forward(q: Dict[str, torch.Tensor], x: torch.Tensor, unit, cfg: TowerCfg = TowerCfg(), emulate_bf16: bool = False,
+                 taps: dict | None = None) -> torch.Tensor:
+    """One tower unit on NCHW fp32 input (q = checkpoint dict with the tower prefix stripped).  A per-unit parity test feeds it
+    the product's own input of that unit (teacher forcing) -- same arithmetic as tower_forward, which is the fold over units."""
+    kind, i, idx, j = unit
+    R = _r if emulate_bf16 else (lambda t: t)
+    if kind == "stem":
+        c0 = cfg.dims[0]
+        w0 = q["patch_embed.0.reparam_conv.weight"]
+        if emulate_bf16 and c0 % 16 == 0 and c0 <= 128:   # the implicit-GEMM stem packs its weights as bf16 MFMA operands
+            w0 = _r(w0)
+        x = R(gelu(F.conv2d(x, w0, q["patch_embed.0.reparam_conv.bias"], stride=2, padding=1)))
+        if taps is not None:
+            taps["stem0"] = x
+        x = R(gelu(_conv(x, q, "patch_embed.1.reparam_conv", stride=2, padding=1, groups=c0)))
+        return R(gelu(_conv(x, q, "patch_embed.2.reparam_conv")))
+    c = cfg.dims[i]
+    mw = x.shape[-1]
+    if kind == "cpe":
+        wc = q[f"network.{idx}.reparam_conv.weight"]
+        return R(F.conv2d(x, _r(wc) if emulate_bf16 and _dw_mfma(mw, c) else wc, q[f"network.{idx}.reparam_conv.bias"], padding=3, groups=c))
+    if kind == "down":
+        wl = q[f"network.{idx}.proj.0.lkb_reparam.weight"]
+        if emulate_bf16 and c % 32 == 0 and mw % 2 == 0 and mw >= 16:   # dwconv_s2_mfma_supported
+            wl = _r(wl)
+        x = R(gelu(F.conv2d(x, wl, q[f"network.{idx}.proj.0.lkb_reparam.bias"], stride=2, padding=3, groups=c)))
+        return R(gelu(_conv(x, q, f"network.{idx}.proj.1.reparam_conv")))
+    pre = f"network.{idx}.{j}."
+    ffn = _convffn_bf16 if emulate_bf16 else _convffn
+    if i in cfg.attn_stages:
+        y = R(_layernorm_channel(x, q[pre + "norm.weight"], q[pre + "norm.bias"], cfg.ln_eps))
+        att = (_mhsa_bf16 if emulate_bf16 else _mhsa)(y, q, pre + "token_mixer.", cfg)
+        x = R(x + q[pre + "layer_scale_1"].view(1, -1, 1, 1) * att)
+        return R(x + q[pre + "layer_scale_2"].view(1, -1, 1, 1) * ffn(x, q, pre + "convffn.", cfg))
+    wm = q[pre + "token_mixer.reparam_conv.weight"]
+    x = R(F.conv2d(x, _r(wm) if emulate_bf16 and _dw_mfma(mw, c) else wm, q[pre + "token_mixer.reparam_conv.bias"], padding=1, groups=c))
+    return R(x + q[pre + "layer_scale"].view(1, -1, 1, 1) * ffn(x, q, pre + "convffn.", cfg))
+
+
+def tower_head_forward(q: Dict[str, torch.Tensor], x: torch.Tensor, cfg: TowerCfg = TowerCfg(), emulate_bf16: bool = False) -> torch.Tensor:
+    """conv_exp (dw3x3, channel multiplier 2) + SE + GELU on the last stage's map -> (B, tokens, out_dim)."""
+    R = _r if emulate_bf16 else (lambda t: t)
     c = cfg.dims[-1]
     x = R(_conv(x, q, "conv_exp.reparam_conv", padding=1, groups=c))
     s = x.mean(dim=(2, 3), keepdim=True)
@@ -198,6 +209,26 @@ def tower_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: TowerCfg = T
     s = torch.sigmoid(_conv(s, q, "conv_exp.se.expand"))
     x = R(gelu(x * s))
     return x.flatten(2).transpose(1, 2).contiguous()
+
+
+def strip_prefix(p: Dict[str, torch.Tensor], prefix: str = VT) -> Dict[str, torch.Tensor]:
+    return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
+
+
+def tower_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: TowerCfg = TowerCfg(), prefix: str = VT,
+                  taps: dict | None = None, emulate_bf16: bool = False) -> torch.Tensor:
+    """x: (B,3,S,S) fp32, S % 64 == 0  ->  image embeddings (B, (S/64)^2, out_dim).
+    emulate_bf16: the same graph with the product's bf16 rounding points (see the block comment above)."""
+    q = strip_prefix(p, prefix)
+    units = tower_units(cfg)
+    for n, unit in enumerate(units):
+        x = unit_forward(q, x, unit, cfg, emulate_bf16, taps)
+        if taps is not None:
+            if unit[0] == "stem":
+                taps["stem"] = x
+            elif unit[0] == "block" and (n + 1 == len(units) or units[n + 1][0] != "block" or units[n + 1][1] != unit[1]):
+                taps[f"stage{unit[1]}"] = x
+    return tower_head_forward(q, x, cfg, emulate_bf16)
 
 
 def projector_forward(p: Dict[str, torch.Tensor], tokens: torch.Tensor, prefix: str = PROJ, emulate_bf16: bool = False) -> torch.Tensor:

@@ -278,3 +278,44 @@ def test_policy_step_is_graph_capturable_and_replays_bit_identically(splice):
         torch.cuda.synchronize()
         assert torch.isfinite(got).all() and torch.equal(got, ref), (trial, float((got - ref).abs().max()))
     eng.close()
+
+
+def test_streaming_load_equals_bulk_load_bit_for_bit():
+    """fv_load_weights_cb (one tensor at a time; bf16 or f32 sources, on the host or on the device; pitched
+    hipMemcpy2D gate/up interleave, q|k|v row concatenation) must pack EXACTLY what fv_load_weights packs from the fp32 host
+    dict: same seeded checkpoint through three routes, bit-identical image tokens and pooled features."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    m = arch.preset("small")
+    w = weights.init_backbone(m, seed=17)
+    torch.manual_seed(18)
+    img = torch.rand(3, 3, 90, 120)
+    ids = torch.randint(0, m.llm.vocab, (3, 10))
+    lens = torch.tensor([10, 4, 7])
+
+    def run(load):
+        eng = FastVLAEngine(m, hidden_dim=64, fusion_dim=96, max_batch=4, max_text_tokens=16)
+        load(eng)
+        pix = eng.preprocess(img.to(DEV))
+        tok = eng.vision_forward(pix)
+        pooled = eng.llm_pooled(ids, lens, tok)
+        torch.cuda.synchronize()
+        out = (tok.clone(), pooled.clone())
+        eng.close()
+        return out
+
+    def as_stored(name, device):   # what a real bf16 checkpoint holds: matrices in bf16 (exact here: init_backbone rounds them)
+        t = w.get(name)
+        if t is None:
+            return None
+        if t.ndim >= 2 and torch.equal(t.to(torch.bfloat16).float(), t):
+            t = t.to(torch.bfloat16)
+        return t.to(device)
+
+    ref = run(lambda e: e.load_weights(w))
+    routes = {"f32 host provider": lambda e: e.load_weights_streaming(lambda n: w.get(n)),
+              "bf16 host provider": lambda e: e.load_weights_streaming(lambda n: as_stored(n, "cpu")),
+              "bf16 device provider": lambda e: e.load_weights_streaming(lambda n: as_stored(n, DEV))}
+    for name, load in routes.items():
+        tok, pooled = run(load)
+        assert torch.equal(tok, ref[0]) and torch.equal(pooled, ref[1]), name

@@ -52,11 +52,11 @@ def test_compute_loss_and_autograd_backward(pol):
     pooled, states = _oracle_actions(pol, batch, head_p)
     pred, cache = head.head_forward(head_p, pooled, states, keep_cache=True)
     loss, grads = head.head_mse_backward(head_p, cache, pred, batch["actions"])
-    assert abs(float(out["loss"].detach()) - float(loss)) <= 5e-3 * float(loss)
+    assert abs(float(out["loss"].detach()) - float(loss)) <= 1e-3 * float(loss)   # north_star's bar
     assert set(out) == {"loss", "mse"} and not out["mse"].requires_grad
     for k, p in zip(HEAD_KEYS, pol.model.head_parameters()):
         assert p.grad is not None and p.grad.shape == p.shape
-        assert rel_l2(p.grad.cpu(), grads[k]) < 2e-2, k
+        assert rel_l2(p.grad.cpu(), grads[k]) <= 1e-3, k   # the same path measures ~1e-5 at full size (test_gpu_fullsize.py)
     fg = pol.model.flat_grads()  # autograd may keep the returned views (one flat buffer) or clone them
     print("grads stay views of one flat buffer:", fg is not None)
     # a stock torch optimizer keeps working on the same Parameters
@@ -305,6 +305,13 @@ def test_folded_dataset_normalisation_matches_the_processor_arithmetic():
     pol.reset()
     a_fold = pol.select_action({**batch, "observation.state": raw.to(DEV)}).cpu()
     assert float((a_fold - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # ... and against the ORACLE head (oracle/head.py, pinned by the reference's goldens) fed the normalised states, with LeRobot's
+    # un-normalisation applied in torch: the folded kernels are not only self-consistent, they compute the processors' arithmetic
+    head_p = {k: v.detach().cpu().clone() for k, v in zip(HEAD_KEYS, pol.model.head_parameters())}
+    with torch.no_grad():
+        pooled = pol.model.features(batch["observation.images.top"], ["a\n", "b\n", "c\n"]).cpu()
+    ref_oracle = head.head_forward(head_p, pooled, norm_state) * stats["action"]["std"] + stats["action"]["mean"]
+    assert float((a_fold - ref_oracle).abs().max()) <= 1e-4 * float(ref_oracle.abs().max())
     # training: loss against NORMALISED targets, states raw -- equals the unfolded loss on normalised states
     tgt = torch.randn(3, 1, 5, generator=g)
     pol.train()
@@ -313,3 +320,19 @@ def test_folded_dataset_normalisation_matches_the_processor_arithmetic():
     loss_ref, _ = pol.forward({**batch, "observation.state": norm_state.to(DEV), "action": tgt.to(DEV)})
     torch.cuda.synchronize()
     assert abs(float(loss_fold) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    loss_oracle = head.mse(head.head_forward(head_p, pooled, norm_state), tgt[:, 0])
+    assert abs(float(loss_fold) - float(loss_oracle)) <= 1e-4 * abs(float(loss_oracle))
+    # a gradient asked of the actions in EVAL mode sees normalised actions (the backward differentiates the head, not
+    # the folded `* std + mean` behind it) and the statistics survive a state_dict round trip
+    pol.fold_dataset_stats(stats)
+    pol.eval()
+    a_eval = pol._predict_actions({**batch, "observation.state": raw.to(DEV)})
+    assert a_eval.requires_grad
+    assert float((a_eval.detach().cpu() - head.head_forward(head_p, pooled, norm_state)).abs().max()) <= 1e-4
+    sd = pol.state_dict()
+    assert "model.backbone.io_norm.action_std" in sd
+    pol.fold_dataset_stats(None)
+    pol.load_state_dict(sd)
+    pol.reset()
+    a_again = pol.select_action({**batch, "observation.state": raw.to(DEV)}).cpu()
+    assert torch.equal(a_again, a_fold)

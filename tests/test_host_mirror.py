@@ -203,3 +203,88 @@ def test_real_checkpoint_without_tokenizer_raises(tmp_path, monkeypatch):
         bb = FastVLMBackbone(FastVLMBackboneConfig(model_id=str(d)))
     assert isinstance(bb.tokenizer, SyntheticTokenizer)
     assert isinstance(FastVLMBackbone(FastVLMBackboneConfig(model_id="synthetic:tiny")).tokenizer, SyntheticTokenizer)
+
+
+def test_hf_checkpoint_provider_streams_one_tensor_at_a_time(tmp_path):
+    """The streaming form of the HF-directory loader (fv_load_weights_cb's provider): every key of every shard by name, bf16 kept
+    as bf16, `lm_head.*` never read, unknown keys -> None (the packer reports them as missing)."""
+    from safetensors.torch import save_file
+    from fastvla_hip import arch, weights
+    from vla_fastvlm.model.fastvlm_adapter import hf_checkpoint_provider
+    m = arch.preset("tiny")
+    state = weights.init_backbone(m, seed=2)
+    state["model.layers.0.mlp.down_proj.weight"] = state["model.layers.0.mlp.down_proj.weight"].to(torch.bfloat16)
+    state["lm_head.weight"] = torch.zeros(4, 4)
+    keys = sorted(state)
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    save_file({k: state[k].contiguous() for k in keys[::2]}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({k: state[k].contiguous() for k in keys[1::2]}, str(d / "model-00002-of-00002.safetensors"))
+    prov = hf_checkpoint_provider(d)
+    for k in keys:
+        if k == "lm_head.weight":
+            assert prov(k) is None
+        else:
+            t = prov(k)
+            assert t.dtype == state[k].dtype and torch.equal(t, state[k]), k
+    assert prov("model.layers.99.mlp.up_proj.weight") is None
+
+
+def test_folded_statistics_travel_with_the_state_dict():
+    """STATE / ACTION statistics folded into the head are state of the policy -- state_dict() carries them while the
+    folding is on (and only then: an unfolded policy keeps exactly the reference's keys), load_state_dict() re-applies them."""
+    cfg = FastVLAConfig(vlm_model_name="synthetic:tiny", hidden_dim=16, fusion_dim=16, state_dim=6, action_dim=5)
+    pol = FastVLAPolicy(cfg)
+    plain = set(pol.state_dict())
+    assert not any("io_norm" in k for k in plain)
+    stats = dict(state_mean=torch.arange(6.0), state_std=torch.ones(6) * 2, action_mean=-torch.arange(5.0), action_std=torch.ones(5) * 3)
+    pol.model.backbone.set_io_normalization(**stats)
+    sd = pol.state_dict()
+    extra = set(sd) - plain
+    assert extra == {f"model.backbone.io_norm.{k}" for k in ("state_mean", "state_std", "action_mean", "action_std", "eps")}
+    again = FastVLAPolicy(cfg)
+    assert again.model.backbone._io_norm is None
+    again.load_state_dict(sd)   # strict: the io_norm.* keys are consumed, not "unexpected"
+    got = again.model.backbone._io_norm
+    assert got is not None and abs(got["eps"] - 1e-8) < 1e-12
+    for k, v in stats.items():
+        assert torch.equal(got[k], v)
+    # an unfolded checkpoint leaves a folded policy's statistics alone and loads strictly
+    again.load_state_dict({k: v for k, v in sd.items() if "io_norm" not in k})
+    del sd["model.backbone.io_norm.eps"]
+    with pytest.raises(RuntimeError, match="incomplete folded normalisation"):
+        FastVLAPolicy(cfg).load_state_dict(sd)
+
+
+def test_trainer_schedule_counts_micro_batches_like_the_reference(tmp_path):
+    """with gradient accumulation the reference's LambdaLR (not wrapped by accelerate) advances once per MICRO-batch and
+    max_steps counts micro-batches (training/trainer.py:180-182,203): LR index = global_step, only the update waits for the k-th."""
+    from vla_fastvlm.training import Trainer, TrainingConfig
+    from vla_fastvlm.training.trainer import linear_warmup_decay
+
+    class Fake(torch.nn.Module):
+        config = FastVLAConfig(vlm_model_name="synthetic:tiny")
+
+        def __init__(self):
+            super().__init__()
+            self.calls, self.micro = [], 0
+
+        def fused_train_step(self, batch, *, prepared=None, lr, grad_accum_steps=1, force_sync=False, next_batch=None, **kw):
+            self.micro += 1
+            synced = self.micro % grad_accum_steps == 0 or force_sync
+            if synced:
+                self.micro = 0
+            self.calls.append((lr, synced))
+            return {"loss": 0.0, "mse": 0.0, "grad_norm": 1.0 if synced else float("nan"), "synced": synced, "next": None}
+
+    data = [{"i": i} for i in range(6)]
+    fake = Fake()
+    tr = Trainer(fake, data, None, TrainingConfig(output_dir=str(tmp_path), num_epochs=3, gradient_accumulation_steps=2, learning_rate=1.0,
+                                                   warmup_ratio=0.25, max_steps=8, logging_steps=1, save_steps=10 ** 6, eval_steps=10 ** 6))
+    tr._sync_replicas = lambda: None
+    tr.fit()
+    assert tr.global_step == 8 and tr.update_step == 4 and len(fake.calls) == 8
+    assert [lr for lr, _ in fake.calls] == [linear_warmup_decay(g, 8, 0.25) for g in range(8)]
+    assert [s for _, s in fake.calls] == [False, True] * 4
+    logged = [json.loads(l) for l in (tmp_path / "logs" / "metrics.jsonl").read_text().splitlines()]
+    assert all(("train/grad_norm" in r) == (i % 2 == 1) for i, r in enumerate(logged))

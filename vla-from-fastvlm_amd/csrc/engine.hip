@@ -124,9 +124,12 @@ struct fv_handle {
                               // buffer is only the staging area
   void* const* taps = nullptr;  // fv_vision_forward_taps: per-stage copies of the activation map (parity tests)
   int n_taps = 0;
+  void* const* utaps = nullptr; // fv_vision_forward_unit_taps: one copy per tower unit (stem, RepCPE, block, PatchEmbed)
+  int n_utaps = 0;
   void* rccl = nullptr;       // dlopen handle of librccl (fv_comm_* / fv_allreduce_grads), resolved on first use
   fv::HeadIoNorm io{nullptr, nullptr, nullptr, nullptr};   // fv_head_set_io_norm: dataset statistics folded into the head
   bool has_io = false;
+  float* io_buf = nullptr;    // ONE device vector of 2 ds + 2 da floats per handle, overwritten by every fv_head_set_io_norm
   bool no_fused_ffn = false;  // FASTVLA_NO_FUSED_FFN=1: A/B switch back to the two-GEMM ConvFFN
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
   bool no_ffn32 = false;      // FASTVLA_NO_FFN32=1: A/B switch back to the 16x16x32 fused ConvFFN
@@ -456,6 +459,28 @@ int tap_copy(fv_handle* h, int t, const bf16_t* src, int b0, int mb, size_t per_
   return FV_OK;
 }
 
+// the same per tower UNIT (fv_vision_unit_info order): unit u's output for images [b0, b0 + mb)
+int unit_tap(fv_handle* h, int u, const bf16_t* src, int b0, int mb, size_t per_image, hipStream_t s) {
+  if (!h->utaps || u >= h->n_utaps || !h->utaps[u]) return FV_OK;
+  bf16_t* dst = static_cast<bf16_t*>(h->utaps[u]) + (size_t)b0 * per_image;
+  FV_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)mb * per_image * 2, hipMemcpyDeviceToDevice, s));
+  return FV_OK;
+}
+
+// tower units in execution order: 0 = stem (three convolutions), then per stage [RepCPE] block ... block [PatchEmbed]
+struct UnitInfo { int kind, stage, side, channels; };   // kind: 0 stem, 1 RepCPE, 2 block, 3 PatchEmbed (side / channels of its OUTPUT)
+std::vector<UnitInfo> tower_units(const fv_model_desc& d) {
+  std::vector<UnitInfo> u;
+  int H = d.image_size / 4;
+  u.push_back({0, 0, H, d.tower_dims[0]});
+  for (int i = 0; i < d.tower_stages; ++i) {
+    if (d.tower_is_attn[i]) u.push_back({1, i, H, d.tower_dims[i]});
+    for (int j = 0; j < d.tower_layers[i]; ++j) u.push_back({2, i, H, d.tower_dims[i]});
+    if (i + 1 < d.tower_stages) { H /= 2; u.push_back({3, i, H, d.tower_dims[i + 1]}); }
+  }
+  return u;
+}
+
 int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_out, float* img_tokens, const WsPlan& wp,
                hipStream_t s) {
   const fv_model_desc& d = h->d;
@@ -485,12 +510,15 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
     FV_TRY(gemm_p(h, g, s));
   }
   FV_TRY(tap_copy(h, 0, cur, b0, mb, (size_t)H * H * C0, s));
+  int unit = 0;
+  FV_TRY(unit_tap(h, unit++, cur, b0, mb, (size_t)H * H * C0, s));
   for (int i = 0; i < d.tower_stages; ++i) {
     const int C = d.tower_dims[i];
     const int M = mb * H * H;
     if (d.tower_is_attn[i]) {
       FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 7), 4.0 * M * C, dw_s1(h, cur, tw.cpes[i].w, tw.cpes[i].t, tw.cpes[i].b, oth, mb, H, C, 7, s));
       std::swap(cur, oth);
+      FV_TRY(unit_tap(h, unit++, cur, b0, mb, (size_t)H * H * C, s));
     }
     for (const Block& b : tw.stages[i]) {
       if (!d.tower_is_attn[i]) {
@@ -520,6 +548,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
         FV_TRY(gemm_p(h, gp, s));
         FV_TRY(run_ffn(h, b.ffn, cur, oth, hid, cur, mb, H, H, C, d.tower_mlp_ratio, s));
       }
+      FV_TRY(unit_tap(h, unit++, cur, b0, mb, (size_t)H * H * C, s));
     }
     FV_TRY(tap_copy(h, 1 + i, cur, b0, mb, (size_t)H * H * C, s));
     if (i + 1 < d.tower_stages) {
@@ -531,6 +560,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
       H /= 2;
       fv::GemmArgs g{oth, C2, tw.downs[i].pw_w, mb * H * H, C2, C2, tw.downs[i].pw_b, nullptr, nullptr, 0, cur, C2, FV_EPI_BIAS_GELU};
       FV_TRY(gemm_p(h, g, s));
+      FV_TRY(unit_tap(h, unit++, cur, b0, mb, (size_t)H * H * C2, s));
     }
   }
   const int CL = d.tower_dims[d.tower_stages - 1], CO = d.tower_out_dim, P = H * H;
@@ -810,6 +840,31 @@ int fv_vision_forward_taps(fv_handle* h, const void* pix, int B, void* img_token
   return rc;
 }
 
+int fv_vision_unit_info(fv_handle* h, int unit, int32_t* kind, int32_t* stage, int32_t* side, int32_t* channels) {
+  HandleScope _hs(h);
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  const std::vector<UnitInfo> u = tower_units(h->d);
+  if (unit < 0 || unit >= (int)u.size()) return fv_fail(FV_ERR_ARG, "fv_vision_unit_info: unit %d out of range [0, %d)", unit, (int)u.size());
+  if (kind) *kind = u[unit].kind;
+  if (stage) *stage = u[unit].stage;
+  if (side) *side = u[unit].side;
+  if (channels) *channels = u[unit].channels;
+  return FV_OK;
+}
+
+int fv_vision_forward_unit_taps(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, void* const* taps,
+                                int n_taps, fv_stream s) {
+  HandleScope _hs(h);
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  if (n_taps < 0 || (n_taps && !taps) || n_taps > (int)tower_units(h->d).size()) return fv_fail(FV_ERR_ARG, "fv_vision_forward_unit_taps: bad taps");
+  h->utaps = taps;
+  h->n_utaps = n_taps;
+  const int rc = fv_vision_forward(h, pix, B, img_tokens, tower_out, s);
+  h->utaps = nullptr;
+  h->n_utaps = 0;
+  return rc;
+}
+
 int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens, const void* img_tokens, int Ni, int B,
                           int T, int pool_mode, void* pooled, fv_stream st) {
   HandleScope _hs(h);
@@ -928,10 +983,15 @@ int fv_head_set_io_norm(fv_handle* h, const float* state_mean, const float* stat
   std::vector<float> v((size_t)2 * ds + 2 * da);
   for (int i = 0; i < ds; ++i) { v[i] = state_mean[i]; v[ds + i] = 1.0f / (state_std[i] + eps); }
   for (int i = 0; i < da; ++i) { v[2 * ds + i] = action_mean[i]; v[2 * ds + da + i] = action_std[i]; }
-  void* p = nullptr;
-  FV_TRY(dev_alloc(h, v.size() * 4, &p));
-  FV_HIP_CHECK(hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
-  float* f = static_cast<float*>(p);
+  if (!h->io_buf) {   // allocated once: toggling the folding on / off / on does not grow the handle
+    void* p = nullptr;
+    FV_TRY(dev_alloc(h, v.size() * 4, &p));
+    h->io_buf = static_cast<float*>(p);
+  }
+  // a head kernel still in flight on any stream may be reading the previous statistics: a configuration call, so it simply waits
+  FV_HIP_CHECK(hipDeviceSynchronize());
+  FV_HIP_CHECK(hipMemcpy(h->io_buf, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  float* f = h->io_buf;
   h->io = fv::HeadIoNorm{f, f + ds, f + 2 * ds, f + 2 * ds + da};
   h->has_io = true;
   return FV_OK;

@@ -689,8 +689,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   static const bool no_asym = getenv("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
   const bool asym = !no_asym && a.M <= 8192;
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
-  static const bool no_splitk = getenv("FASTVLA_NO_SPLITK") != nullptr;
-  if (!no_splitk && a.splitk_ws && f32out && !getenv("FASTVLA_NO_GEMM256") && a.M % 256 == 0 && a.K % 64 == 0 && a.N % 4 == 0 &&
+  static const bool no_splitk = getenv("FASTVLA_NO_SPLITK") != nullptr, no_g256 = getenv("FASTVLA_NO_GEMM256") != nullptr;
+  if (!no_splitk && a.splitk_ws && f32out && !no_g256 && a.M % 256 == 0 && a.K % 64 == 0 && a.N % 4 == 0 &&
       (size_t)a.M * a.lda * 2 < ((size_t)1 << 32) && (size_t)a.N * a.K * 2 < ((size_t)1 << 32)) {
     const int tn = (a.N + 255) / 256, tiles = (a.M / 256) * tn, nkt = (a.ksplit ? 2 : 1) * (a.K / 64);
     int splits = tiles < cus ? cus / tiles : 1;

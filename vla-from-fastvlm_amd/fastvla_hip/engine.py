@@ -125,6 +125,10 @@ class FastVLAEngine:
             if t.ndim > 4:
                 keep["exc"] = ValueError(f"{name.decode()}: rank > 4")
                 return 1
+            if t.device.type == "cuda":
+                # the library copies with blocking calls on the null stream: whatever produced t on torch's current stream
+                # (a generator, a dtype cast, a .to(device)) must have finished before the pointer is handed over
+                torch.cuda.current_stream(t.device).synchronize()
             keep["t"] = t  # alive until the next call
             d = out.contents
             d.data = t.data_ptr()
@@ -200,6 +204,31 @@ class FastVLAEngine:
         arr = (C.c_void_p * len(taps))(*[x.data_ptr() for x in taps])
         _lib.check(self.lib.fv_vision_forward_taps(self.h, pix.data_ptr(), B, tok.data_ptr(), tout.data_ptr(), arr, len(taps),
                                                    _stream()), "fv_vision_forward_taps", self.h)
+        return tok, tout, taps
+
+    UNIT_KINDS = ("stem", "cpe", "block", "down")
+
+    def tower_units(self):
+        """-> [(kind, stage, side, channels)] of every tower unit in execution order (fv_vision_unit_info)."""
+        out, u = [], 0
+        k, st, sd, ch = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        while self.lib.fv_vision_unit_info(self.h, u, C.byref(k), C.byref(st), C.byref(sd), C.byref(ch)) == 0:
+            out.append((self.UNIT_KINDS[k.value], st.value, sd.value, ch.value))
+            u += 1
+        return out
+
+    def vision_forward_unit_taps(self, pix: torch.Tensor):
+        """-> (tokens f32, tower_out bf16, [output of unit 0, 1, ...] NHWC bf16): unit u's input is taps[u - 1], so the parity
+        test feeds each oracle unit the ENGINE's own input (teacher forcing)."""
+        B = pix.shape[0]
+        t, l = self.model.tower, self.model.llm
+        self.ensure_workspace(B, 1, False)
+        tok = torch.empty(B, t.num_tokens, l.hidden, dtype=torch.float32, device=self.device)
+        tout = torch.empty(B, t.num_tokens, t.out_dim, dtype=torch.bfloat16, device=self.device)
+        taps = [torch.empty(B, sd, sd, ch, dtype=torch.bfloat16, device=self.device) for _, _, sd, ch in self.tower_units()]
+        arr = (C.c_void_p * len(taps))(*[x.data_ptr() for x in taps])
+        _lib.check(self.lib.fv_vision_forward_unit_taps(self.h, pix.data_ptr(), B, tok.data_ptr(), tout.data_ptr(), arr, len(taps),
+                                                        _stream()), "fv_vision_forward_unit_taps", self.h)
         return tok, tout, taps
 
     def llm_pooled(self, ids: torch.Tensor, lens: torch.Tensor, img_tokens: Optional[torch.Tensor] = None,

@@ -23,12 +23,15 @@ class _HeadFunction(torch.autograd.Function):
     gradient buffer for the 12 parameters (the frozen backbone and the states get no gradient)."""
 
     @staticmethod
-    def forward(ctx, owner, pooled, states, training, *params):
+    def forward(ctx, owner, pooled, states, training, differentiable, *params):
         eng, flat = owner._engine(), owner._flat
         p = float(owner.config.dropout) if training else 0.0
         owner._drop_calls += 1
+        # `differentiable` (a gradient may be asked of these actions, in train OR eval mode): keep them in normalised space --
+        # fv_head_backward differentiates the head, not the folded `* action_std + action_mean` behind it
         actions, saved = eng.head_forward(flat, pooled, states, training=bool(training and p > 0.0), dropout_p=p,
-                                          seed=owner._drop_seed, offset=owner._drop_calls, normalized_actions=bool(training))
+                                          seed=owner._drop_seed, offset=owner._drop_calls,
+                                          normalized_actions=bool(training or differentiable))
         ctx.owner, ctx.saved, ctx.p = owner, saved, p
         return actions
 
@@ -37,7 +40,7 @@ class _HeadFunction(torch.autograd.Function):
         owner = ctx.owner
         grads = owner._engine().head_backward_from_grad(owner._flat, grad_actions, ctx.saved, ctx.p)
         views = owner._engine().head_views(grads)
-        return (None, None, None, None) + tuple(views[k] for k in HEAD_KEYS)
+        return (None, None, None, None, None) + tuple(views[k] for k in HEAD_KEYS)
 
 
 class _HeadLossFunction(torch.autograd.Function):
@@ -126,7 +129,9 @@ class FastVLMWithExpert(nn.Module):
         states = states.to(pooled.device, torch.float32)
         if states.ndim != 2 or states.shape[1] != self.config.state_dim:
             raise ValueError(f"states must be (B,{self.config.state_dim}), got {tuple(states.shape)}")
-        return _HeadFunction.apply(self, pooled, states, self.training, *self.head_parameters())
+        params = self.head_parameters()
+        differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _HeadFunction.apply(self, pooled, states, self.training, differentiable, *params)
 
     def head_loss(self, pooled: torch.Tensor, states: torch.Tensor, targets: torch.Tensor):
         """-> (loss 0-dim, actions): MSE of the head's prediction against `targets`, differentiable w.r.t. the 12 head

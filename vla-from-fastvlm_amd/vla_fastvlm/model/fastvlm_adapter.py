@@ -253,13 +253,17 @@ class FastVLMBackbone(nn.Module):
             eng = FastVLAEngine(model, device=dev, max_batch=self._max_batch, max_text_tokens=self.config.tokenizer_max_length,
                                 tower_microbatch=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")), **self._head_dims)
             kind, arg = self._weights_source
-            if kind == "synthetic":
-                state = fv_weights.init_backbone(self.arch, seed=arg)
+            llm = self.arch.llm
+            big = 3 * llm.hidden * llm.inter * llm.layers > 2e9   # 7B: 7.6 G parameters = 30 GB as an fp32 host dict
+            if kind == "synthetic" and big:
+                # every decoder tensor is drawn on the device in bf16 when the packer asks for it (fv_load_weights_cb)
+                eng.load_weights_streaming(fv_weights.stream_backbone(self.arch, seed=arg, device=dev))
+            elif kind == "synthetic":
+                eng.load_weights(fv_weights.init_backbone(self.arch, seed=arg))
             elif kind == "hf_dir":
-                state = load_hf_checkpoint_dir(arg)
+                eng.load_weights_streaming(hf_checkpoint_provider(arg))   # one tensor alive at a time, bf16 stays bf16
             else:
-                state = torch.load(arg, map_location="cpu") if arg.endswith(".pt") else _load_safetensors(arg)
-            eng.load_weights(state)
+                eng.load_weights(torch.load(arg, map_location="cpu") if arg.endswith(".pt") else _load_safetensors(arg))
             if self._io_norm is not None:
                 eng.set_io_norm(**self._io_norm)
             self._engine = eng
@@ -274,6 +278,24 @@ class FastVLMBackbone(nn.Module):
                                               action_std=action_std, eps=eps)
         if self._engine is not None:
             self._engine.set_io_norm(**(self._io_norm or {}))
+
+    # The folded statistics are STATE of the policy: they travel with state_dict() (only while the folding is on, so a policy
+    # that never folds keeps exactly the reference's keys) and come back through load_state_dict(), which re-applies them.
+    _IO_KEYS = ("state_mean", "state_std", "action_mean", "action_std", "eps")
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self._io_norm is not None:
+            for k in self._IO_KEYS:
+                destination[prefix + "io_norm." + k] = torch.as_tensor(self._io_norm[k], dtype=torch.float32).detach().cpu().clone().reshape(-1)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        found = {k: state_dict.pop(prefix + "io_norm." + k) for k in self._IO_KEYS if prefix + "io_norm." + k in state_dict}
+        if found and len(found) != len(self._IO_KEYS):
+            error_msgs.append(f"incomplete folded normalisation statistics under '{prefix}io_norm.': have {sorted(found)}")
+        elif found:
+            self.set_io_normalization(**{k: found[k].float().cpu() for k in self._IO_KEYS[:4]}, eps=float(found["eps"].reshape(-1)[0]))
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     # ------------------------------------------------------------------ preprocessing
     def _prepare_images_tensor(self, images, device: torch.device) -> Tensor:
@@ -382,6 +404,44 @@ def arch_from_hf_config(config_json) -> "fv_arch.ModelConfig":
     size = infer_size_from_tower_name(tower_name) or 1024
     tower = fv_arch.TowerConfig(image_size=int(size), name=tower_name)
     return fv_arch.ModelConfig(Path(config_json).parent.name or "hf-checkpoint", llm, tower)
+
+
+def hf_checkpoint_provider(path):
+    """provider(name) -> tensor for FastVLAEngine.load_weights_streaming over the *.safetensors shards of a llava_qwen2
+    checkpoint directory (reference scripts/download_fastvlm.sh:14-22, utils/checkpoint.py:29-42): the decoder's tensors are read
+    from their shard one at a time when the packer asks for them (a 7B checkpoint never exists as one host dict and bf16 stays
+    bf16); the vision tower + projector (0.25 GB) are read up front because a TRAINING-form tower has to be folded as a whole
+    (vla_fastvlm/model/reparam.py).  `lm_head.*` is never read: the path computes no logits."""
+    from safetensors import safe_open
+    where: Dict[str, str] = {}
+    for shard in sorted(Path(path).glob("*.safetensors")):
+        with safe_open(str(shard), framework="pt", device="cpu") as f:
+            for k in f.keys():
+                if not k.startswith("lm_head."):
+                    where[k] = str(shard)
+    tower_keys = [k for k in where if k.startswith("model.vision_tower.") or k.startswith("model.mm_projector.")]
+    tower: Dict[str, Tensor] = {}
+    for shard in sorted({where[k] for k in tower_keys}):
+        with safe_open(shard, framework="pt", device="cpu") as f:
+            for k in tower_keys:
+                if where[k] == shard:
+                    tower[k] = f.get_tensor(k)
+    from .reparam import fold_train_form, is_train_form
+    if is_train_form(tower):
+        tower = fold_train_form(tower)
+    handles: Dict[str, Any] = {}
+
+    def provider(name: str):
+        if name in tower:
+            return tower[name]
+        shard = where.get(name)
+        if shard is None:
+            return None
+        if shard not in handles:
+            handles[shard] = safe_open(shard, framework="pt", device="cpu").__enter__()
+        return handles[shard].get_tensor(name)
+
+    return provider
 
 
 def load_hf_checkpoint_dir(path) -> Dict[str, Tensor]:

@@ -32,6 +32,10 @@ logger = logging.getLogger(__name__)
 
 @dataclass
 class TrainingConfig:
+    """Fields and defaults of reference training/trainer.py:20-39.  With `gradient_accumulation_steps` = k > 1 the step
+    counters keep the reference's meaning: its LambdaLR is NOT passed through accelerator.prepare, so the schedule advances
+    once per MICRO-batch (LR index = global_step, trainer.py:180,182), and `max_steps` / `num_training_steps` are compared
+    with global_step too (trainer.py:160,203); only the optimiser update itself waits for the k-th micro-batch."""
     output_dir: str = "outputs/train"
     num_epochs: int = 10
     max_steps: int | None = None
@@ -80,8 +84,8 @@ class Trainer:
         self.train_dataloader = train_dataloader
         self.eval_dataloader = eval_dataloader
         self.num_training_steps = self._compute_total_training_steps()
-        self.global_step = 0     # batches seen (reference trainer.py:182 counts micro-batches)
-        self.update_step = 0     # optimiser updates (the LambdaLR index: accelerate steps the scheduler on sync steps)
+        self.global_step = 0     # micro-batches seen: the reference's only counter (trainer.py:182) -- LR index, max_steps, logging
+        self.update_step = 0     # optimiser updates actually applied (Adam's bias-correction index)
         self.epoch = 0
         self.last_lr = 0.0
         self._resume_opt = None
@@ -113,7 +117,7 @@ class Trainer:
         for epoch in range(self.config.num_epochs):
             self.epoch = epoch
             self._train_one_epoch()
-            if self.update_step >= self.num_training_steps:
+            if self.global_step >= self.num_training_steps:   # reference trainer.py:160
                 break
 
     def _sync_replicas(self) -> None:
@@ -139,14 +143,13 @@ class Trainer:
         self.model.train()
         it = iter(self._shard(self.train_dataloader))
         nxt = next(it, None)
-        prepared, micro = None, 0
+        prepared = None
         while nxt is not None:
             batch = move_batch_to_device(nxt, self.device) if prepared is None else None
             nxt = next(it, None)  # one batch of look-ahead: "is this the last one" and the overlap partner of the all-reduce
-            micro += 1
-            will_sync = micro % k == 0 or nxt is None
-            stop_after = will_sync and ((cfg.max_steps and self.update_step + 1 >= cfg.max_steps) or self.update_step + 1 >= self.num_training_steps)
-            self.last_lr = cfg.learning_rate * linear_warmup_decay(self.update_step, self.num_training_steps, cfg.warmup_ratio)
+            stop_after = bool(cfg.max_steps and self.global_step + 1 >= cfg.max_steps)   # reference trainer.py:203: micro-batches
+            # the reference's LambdaLR steps every micro-batch (it is not wrapped by accelerate): index = global_step
+            self.last_lr = cfg.learning_rate * linear_warmup_decay(self.global_step, self.num_training_steps, cfg.warmup_ratio)
             out = self.model.fused_train_step(batch, prepared=prepared, lr=self.last_lr, betas=cfg.betas, eps=cfg.eps,
                                               weight_decay=cfg.weight_decay, max_grad_norm=cfg.max_grad_norm,
                                               grad_accum_steps=k, force_sync=nxt is None,  # accelerate syncs at the end of the loader
@@ -155,10 +158,12 @@ class Trainer:
             self.global_step += 1
             if out["synced"]:
                 self.update_step += 1
-                micro = 0
+                self._last_grad_norm = float(out["grad_norm"])   # a norm exists only for micro-batches that closed an update
             if self.is_main_process and self.global_step % cfg.logging_steps == 0:
-                self._log({"train/loss": float(out["loss"]), "train/mse": float(out["mse"]), "train/lr": self.last_lr,
-                           "train/epoch": self.epoch, "train/grad_norm": float(out["grad_norm"])})
+                rec = {"train/loss": float(out["loss"]), "train/mse": float(out["mse"]), "train/lr": self.last_lr, "train/epoch": self.epoch}
+                if out["synced"]:
+                    rec["train/grad_norm"] = self._last_grad_norm
+                self._log(rec)
             if self.global_step % cfg.eval_steps == 0 and self.eval_dataloader is not None:
                 metrics = self.evaluate()
                 if self.is_main_process:
