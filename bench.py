@@ -4,6 +4,8 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: bench.py starts its own N ranks, one process per GPU, before it
+                                           touches the GPU itself, and relays rank 0's JSON line)
 
 One "step" = one batch through img + prompt + state -> action (BASELINE.json configs[1]: FastVLM-0.5B select_action,
 bs=64 per GPU, 336x336 synthetic RGB + 64-token prompt, bf16 MFMA with fp32 accumulation): letterbox to 1024^2 ->
@@ -13,8 +15,11 @@ data-parallel TRAINING step (B=32/GPU, RCCL all-reduce of the flat head gradient
 "train_dp" in the same JSON line.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time, against the 2.5 PFLOP/s dense peak
+  roofline      dominant kernel (the fused ConvFFN, convffn32_kernel): algorithmic FLOPs / HIP-event time per launch, against
+                the 2.5 PFLOP/s dense bf16 peak
   cpu_baseline  the fp32 CPU oracle (oracle/, "port") timed on this box's host cores on a bounded sample
+  surface       the same step through the reference's plugin surface (lerobot_fastvla.FastVLAPolicy.select_action / forward,
+                task strings through the tokenizer), beside the engine-level number
 """
 from __future__ import annotations
 
@@ -53,6 +58,7 @@ def parse():
                          "0 = plain bf16 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-surface", action="store_true", help="skip the plugin-surface leg (FastVLAPolicy.select_action / forward)")
     ap.add_argument("--cpu-sample", type=int, default=6)   # ~12 s of host work on 16 threads
     ap.add_argument("--no-c1", action="store_true", help="skip the C1 (bs=4, 32-token, train step) CPU protocol of BASELINE.md section 3")
     ap.add_argument("--c1-steps", type=int, default=10, help="C1 protocol: steps requested (first excluded)")
@@ -64,8 +70,37 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher (the form the reference gets from `accelerate launch`,
+    training/trainer.py:68-78): start N fresh rank processes -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment -- wait for them, relay rank 0's JSON line.  Runs BEFORE this process makes any HIP call or torch.cuda query and
+    never exec()s: the parent stays a plain host process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,6 +117,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}", file=sys.stderr)
 
     from fastvla_hip import FastVLAEngine, arch, weights
     model = arch.preset(args.model)
@@ -100,6 +137,21 @@ def main():
         w = weights.init_backbone(model, seed=args.seed)  # identical on every rank (frozen replica)
         eng.load_weights(w)
     t_load = time.time() - t0
+
+    # what the communication layer itself reports (N > 1): torch.distributed's world and, on the RCCL backend, a communicator made
+    # through the library's own C ABI (fv_comm_*) with one all-reduce through fv_allreduce_grads as a live check
+    dist_info = None
+    if world > 1:
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": torch.cuda.get_device_name(dev)}
+        if args.backend == "nccl" and ndev >= world:
+            box = [eng.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = eng.comm_init(box[0], rank, world)
+            probe = torch.ones(1024, dtype=torch.float32, device=dev)
+            eng.allreduce_grads(comm, probe)
+            torch.cuda.synchronize()
+            dist_info["fv_comm"] = {"ranks": world, "allreduce_of_ones": float(probe[0]), "ok": bool((probe == world).all())}
+            eng.comm_destroy(comm)
 
     # trainable head: torch.nn default-style init, identical on every rank
     g = torch.Generator().manual_seed(4321)
@@ -181,16 +233,18 @@ def main():
     dg = gstat[dom]
     dom_tflops = dg["flops"] / (dg["ms"] * 1e-3) / 1e12
     traffic = None
+    traffic_src = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"  # HBM bytes per launch from rocprofv3 --pmc passes (collected offline)
     if pmc.is_file():
         try:
             traffic = json.loads(pmc.read_text()).get(dom.split(" ")[0])
+            traffic_src = "profiles/pmc_traffic.json: rocprofv3 --pmc passes of an EARLIER run of this command (tools/pmc_traffic.py), not a quantity of this run"
         except Exception:
             traffic = None
     roofline = {
         "bound": "mfma", "kernel": dom,
         "achieved": round(dom_tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "launches_per_step": dg["n"] // ps, "kernel_ms_per_step": round(dg["ms"] / ps, 3),
         "kernel_flops_per_launch": dg["flops"] / dg["n"], "kernel_avg_launch_ms": round(dg["ms"] / dg["n"], 4),
         "all_mfma_kernels": {"achieved": round(gemm_tflops, 2), "frac": round(gemm_tflops / MFMA_PEAK_TFLOPS, 4),
@@ -277,6 +331,58 @@ def main():
                  "ms_per_step_serial_exchange": None if ser_ms is None else round(ser_ms, 3),
                  "overlap_frac": None if overlap is None else round(overlap, 3)}
 
+    # ---- the same step through the reference's plugin surface (reference lerobot_fastvla/modeling_fastvla.py:109-133):
+    # FastVLAPolicy.select_action(batch) / .forward(batch) with a LeRobot batch dict and B task strings through the tokenizer;
+    # Python glue, tokenisation, the action deque and forward()'s `.item()` are inside these numbers.  The policy drives the SAME
+    # engine (frozen weights are not loaded twice); its head parameters are its own nn.Parameters.
+    surface = None
+    if not args.no_surface and not args.splice and world == 1:
+        from vla_fastvlm.lerobot_fastvla import FastVLAConfig as LRConfig, FastVLAPolicy as LRPolicy
+        from vla_fastvlm.lerobot_fastvla._lerobot_compat import FeatureType, PolicyFeature
+        feats = {"observation.images.top": PolicyFeature(FeatureType.VISUAL, (3, args.image, args.image)),
+                 "observation.state": PolicyFeature(FeatureType.STATE, (14,))}
+        torch.manual_seed(4321)
+        pol = LRPolicy(LRConfig(vlm_model_name=f"synthetic:{args.model}:{args.seed}", input_features=feats, tokenizer_max_length=T,
+                                output_features={"action": PolicyFeature(FeatureType.ACTION, (14,))}))
+        pol.model.backbone._engine = eng          # share the loaded engine (same head dims: 14 / 14 / 1024 / 1024)
+        pol.to(dev)
+        pol.model.materialize(dev)
+        # T-token prompts: the synthetic tokenizer maps one byte to one id, so T - 1 characters + the trailing newline
+        tasks = [(f"pick up object {i:03d} and place it in the bin on the left side of the table, then return home " * 2)[: T - 1] for i in range(B)]
+        lbatch = {"observation.images.top": images[:B], "observation.state": states[:B], "action": targets[:B, None], "task": tasks}
+
+        def surf_select():
+            pol.reset()
+            return pol.select_action(lbatch)
+
+        def surf_forward():
+            return pol.forward(lbatch)[0]
+
+        def host_ms(fn, n=3):   # time spent INSIDE the call (enqueue + Python), GPU left to run behind it
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            h = (time.perf_counter() - t) / n
+            torch.cuda.synchronize()
+            return 1e3 * h
+
+        ns = max(3, args.steps // 2)
+        sel = timed(surf_select, ns, 2)
+        sel_host = host_ms(surf_select)
+        pol.train()
+        fwd = timed(surf_forward, ns, 2)
+        pol.eval()
+        eng_ms = ms_per_step
+        surface = {"select_action_ms_per_step": round(1e3 * sel / ns, 3), "select_action_host_ms_per_call": round(sel_host, 3),
+                   "select_action_vs_engine_level": round((1e3 * sel / ns) / eng_ms, 4),
+                   "forward_ms_per_step": round(1e3 * fwd / ns, 3), "steps": ns,
+                   "forward_note": "forward(batch) -> (loss, {'loss','mse'}): head forward + MSE + head gradients in train mode, and the "
+                                   "reference API's loss.item() host sync every step",
+                   "batch": B, "prompt_tokens": T, "tokenizer": type(pol.model.backbone.tokenizer).__name__,
+                   "api": "vla_fastvlm.lerobot_fastvla.FastVLAPolicy.select_action(batch) / .forward(batch)"}
+        del pol
+
     # ---- CPU baseline (rank 0, N=1 only): the fp32 oracle on a bounded sample of the same workload
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and w is not None:
@@ -325,6 +431,13 @@ def main():
         cmask = torch.ones(Bc, Tc, dtype=torch.long)
         cst, ctg = states[:Bc].cpu(), targets[:Bc].cpu()
         emb_w = w["model.embed_tokens.weight"]
+        # inputs of the reference-only work, computed ONCE outside the timed steps (the backbone is frozen, they do not change):
+        # the letterboxed batch and the decoder's real final hidden states with its 25 retained states
+        from oracle import preprocess as opre
+        with torch.no_grad():
+            pix_c1 = opre.letterbox(ci, model.tower.image_size)
+            kept_c1 = {}
+            hid_c1 = qwen2.decoder_forward(w, torch.nn.functional.embedding(cids, emb_w), cmask.sum(1), lc, taps=kept_c1)
         alg, shipped, t_start, first_pred = [], [], time.perf_counter(), None
         for i in range(args.c1_steps):
             if i > 1 and time.perf_counter() - t_start > args.c1_budget:
@@ -338,12 +451,16 @@ def main():
                 first_pred = r["pred"]
             hp, mo, vo = r["params"], r["m"], r["v"]
             t = time.perf_counter()
-            with torch.no_grad():  # reference-only work (fastvlm_adapter.py:519-536): logits for all tokens, retained states, KV cache
-                hid = torch.randn(Bc, Tc, model.llm.hidden)
-                logits = torch.nn.functional.linear(hid, emb_w)
-                kept = [hid.clone() for _ in range(model.llm.layers + 1)]
-                kv = torch.zeros(model.llm.layers, 2, Bc, model.llm.kv_heads, Tc, model.llm.head_dim)
-                del logits, kept, kv
+            with torch.no_grad():
+                # what the reference computes on top, restated: (1) FastVLAProcessor.prepare_images letterboxes to 1024^2 and
+                # FastVLMBackbone.forward letterboxes its result AGAIN (fastvla/processor_fastvla.py:35 -> fastvlm_adapter.py:513,
+                # 479-488): a second, identity-size bilinear pass over B x 3 x 1024^2; (2) lm_head logits over the full vocabulary
+                # for every token of the REAL final hidden states (tied embedding; fastvlm_adapter.py:533 calls the CausalLM);
+                # (3) output_hidden_states=True / use_cache=True keep 25 states and the K/V of every layer alive -- references to
+                # tensors the forward made anyway: memory, no arithmetic (kept_c1 stands for them)
+                again = opre.letterbox(pix_c1, model.tower.image_size)
+                logits = torch.nn.functional.linear(hid_c1, emb_w)
+                del again, logits
             t_extra = time.perf_counter() - t
             if i > 0:
                 alg.append(t_alg)
@@ -370,6 +487,8 @@ def main():
             return {"mean_ms": round(1e3 * statistics.mean(v), 1), "std_ms": round(1e3 * (statistics.pstdev(v) if len(v) > 1 else 0.0), 1), "steps": len(v)}
         c1 = {"config": "C1: FastVLM-0.5B bs=4, 336x336 + 32-token prompt, train step (fwd + MSE + head bwd + clip + AdamW), first step excluded",
               "cpu_algorithmic": ms(alg), "cpu_as_shipped": ms(shipped), "cpu_kind": "port (fp32 torch oracle)",
+              "cpu_as_shipped_adds": "second identity-size letterbox of the 1024^2 batch + full-vocabulary lm_head logits on the real "
+                                     "final hidden states (retained states / KV cache cost memory only)",
               "cpu_threads": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "steps_requested": args.c1_steps,
               "budget_s": args.c1_budget, "gpu_ms_per_step": round(1e3 * g_el / 10, 3),
               "gpu_vs_cpu_algorithmic": round(statistics.mean(alg) / (g_el / 10), 1),
@@ -391,7 +510,7 @@ def main():
                        "stream_overlap": bool(eng.overlap_streams and not args.splice),
                        "llm_precision": "split-bf16 (hi+lo) operands, fp32 attention" if args.llm_precision else "bf16 operands"},
             "samples_per_s": round(value * B, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
         }
         print(json.dumps(out))

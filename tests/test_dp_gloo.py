@@ -144,3 +144,20 @@ def test_shard_batches_single_rank_and_generators():
     assert list(shard_batches(iter(range(4)), 0, 1)) == [0, 1, 2, 3]
     gen = (i for i in range(7))                    # no __len__: the lock-step protocol needs none
     assert list(shard_batches(gen, 2, 3)) == [2, 5]
+
+
+def test_bench_launcher_starts_its_own_ranks_and_reports_failures():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns two rank processes (RANK / WORLD_SIZE / MASTER_* set)
+    before touching any GPU and exits non-zero when a rank fails -- here both do, for the right reason: this container has no HIP
+    device and the product path has no CPU fallback."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--model", "tiny"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("covered by the -m gpu launcher test on a GPU box")
+    assert r.returncode != 0
+    assert "rank(s) failed: [(0, 1), (1, 1)]" in r.stderr and r.stderr.count("needs a HIP device") == 2

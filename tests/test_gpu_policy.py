@@ -336,3 +336,26 @@ def test_folded_dataset_normalisation_matches_the_processor_arithmetic():
     pol.reset()
     a_again = pol.select_action({**batch, "observation.state": raw.to(DEV)}).cpu()
     assert torch.equal(a_again, a_fold)
+
+
+def test_bench_gpus2_spawns_two_ranks_and_fills_train_dp():
+    """`python bench.py --gpus 2` (no torchrun) must run TWO ranks: the parent spawns them before any GPU call,
+    rank 0's JSON line comes back with n_gpus = 2 and a filled train_dp (gloo here: two ranks share this box's one GPU, so RCCL
+    cannot form a communicator; the exchange / overlap fields are exercised all the same)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "tiny", "--batch", "4",
+                        "--train-batch", "4", "--tokens", "16", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8
+    assert line["dist"]["world_size"] == 2 and line["dist"]["backend"] == "gloo"
+    td = line["train_dp"]
+    assert td["parallelism"] == "dp2" and td["global_batch"] == 8 and td["value"] > 0
+    assert td["allreduce_ms"] is not None and td["ms_per_step_serial_exchange"] is not None and td["overlap_frac"] is not None

@@ -317,9 +317,21 @@ class FastVLMBackbone(nn.Module):
             self.tokenizer.padding_side = self.config.tokenizer_padding_side
         except Exception:
             pass
-        tok = self.tokenizer(list(tasks), padding="max_length" if self.config.pad_to_max_length else "longest",
-                             truncation=True, max_length=self.config.tokenizer_max_length, return_tensors="pt")
-        return {k: v.to(device) for k, v in tok.items()}
+        # A policy is asked the same task strings step after step (one env, one instruction): the tokenised batch is kept on the
+        # device in a small LRU keyed by the strings themselves, so a repeated prompt costs neither the host tokenizer nor the
+        # H2D copy of its ids (tokenisation is a pure function of the strings and these settings).
+        tasks = list(tasks)
+        key = (tuple(tasks), bool(self.config.pad_to_max_length), int(self.config.tokenizer_max_length), str(device))
+        lru = self.__dict__.setdefault("_text_lru", {})
+        hit = lru.pop(key, None)
+        if hit is None:
+            tok = self.tokenizer(tasks, padding="max_length" if self.config.pad_to_max_length else "longest",
+                                 truncation=True, max_length=self.config.tokenizer_max_length, return_tensors="pt")
+            hit = {k: v.to(device) for k, v in tok.items()}
+        lru[key] = hit                      # most recent last
+        while len(lru) > 32:
+            lru.pop(next(iter(lru)))
+        return dict(hit)
 
     @staticmethod
     def _pool_hidden(hidden: Tensor, attention_mask: Optional[Tensor], mode: str) -> Tensor:
