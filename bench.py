@@ -342,8 +342,10 @@ def main():
         feats = {"observation.images.top": PolicyFeature(FeatureType.VISUAL, (3, args.image, args.image)),
                  "observation.state": PolicyFeature(FeatureType.STATE, (14,))}
         torch.manual_seed(4321)
-        pol = LRPolicy(LRConfig(vlm_model_name=f"synthetic:{args.model}:{args.seed}", input_features=feats, tokenizer_max_length=T,
-                                output_features={"action": PolicyFeature(FeatureType.ACTION, (14,))}))
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):   # the backbone announces its image size on stdout like the reference; stdout is the JSON line's
+            pol = LRPolicy(LRConfig(vlm_model_name=f"synthetic:{args.model}:{args.seed}", input_features=feats, tokenizer_max_length=T,
+                                    output_features={"action": PolicyFeature(FeatureType.ACTION, (14,))}))
         pol.model.backbone._engine = eng          # share the loaded engine (same head dims: 14 / 14 / 1024 / 1024)
         pol.to(dev)
         pol.model.materialize(dev)

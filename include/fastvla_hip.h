@@ -272,8 +272,9 @@ int fv_op_dwconv_pair(const void* x, const void* t3, const float* b3, const void
 int fv_op_convffn(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2, const float* ls,
                   const void* res, void* out, int M, int C, fv_stream s);
 
-/* the same fused ConvFFN on v_mfma_f32_32x32x16_bf16 (the kernel the engine uses for C in {96,192,384}).  wq = fc1 (4C,C) and fc2
- * (C,4C) weights as ONE bf16 stream [4C/32 chunks][64 C]: per 32-hidden chunk the kernel's LDS slot image in staging order.
+/* the same fused ConvFFN on v_mfma_f32_32x32x16_bf16 (the kernel the engine uses for C in {96,192,384}).  wq = fc1 (4C,C) / 4 and
+ * 4 * fc2 (C,4C) (powers of two: exact; the kernel's GELU runs in y = x / 4 and takes b1 / 4 itself from the plain b1 it is given) as
+ * ONE bf16 stream [4C/32 chunks][64 C]: per 32-hidden chunk the kernel's LDS slot image in staging order.
  * Slot image T: W1 part = 32 rows x C, 8-element chunk c of row r at chunk c ^ ((r >> SH) & MASK) with (SH, MASK) = (0,15) / (1,7) /
  * (2,3) for C = 384 / 192 / 96; W2 part = C rows x 32, chunk (2s + h) ^ ((n >> 2) & 3) of row n holding hidden
  * 16s + 8(j>>2) + 4h + (j&3), j < 8 (the k order in which a 32x32 accumulator tile, converted pairwise to bf16, is the B operand

@@ -312,11 +312,11 @@ def _pack_wq(w1, w2):
     c = torch.arange(Cc // 8)
     phys1 = c[None, :] ^ ((r[:, None] >> sh) & mask)                      # (32, C/8): physical chunk of logical chunk c in row r
     t1 = torch.empty(nch, 32, Cc // 8, 8)
-    t1[:, r[:, None], phys1] = w1.view(nch, 32, Cc // 8, 8)
+    t1[:, r[:, None], phys1] = 0.25 * w1.view(nch, 32, Cc // 8, 8)           # W1 / 4 and 4 W2: exact (the GELU runs in y = x / 4)
     n = torch.arange(Cc)
     hid = torch.tensor([[16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for j in range(8)] for s in range(2) for h in range(2)])  # (4 chunks, 8)
     phys2 = torch.arange(4)[None, :] ^ ((n[:, None] >> 2) & 3)              # (C, 4)
-    w2c = w2.view(Cc, nch, 32)[:, :, hid]                                   # (C, nch, 4, 8): logical chunks
+    w2c = 4.0 * w2.view(Cc, nch, 32)[:, :, hid]                       # (C, nch, 4, 8): logical chunks
     t2 = torch.empty(nch, Cc, 4, 8)
     t2[:, n[:, None], phys2] = w2c.permute(1, 0, 2, 3)
     T = torch.cat([t1.reshape(nch, -1), t2.reshape(nch, -1)], dim=1)        # (nch, 64 C) slot images

@@ -134,6 +134,41 @@ __device__ __forceinline__ void gelu2_n7(f32x2 (&x)[N]) {
 #pragma unroll
   for (int n = 0; n < N; ++n) x[n] = x[n] * xc[n];
 }
+// GELU in the SCALED variable y = x / 4 (convffn32_kernel: W1, b1 carry the 1/4, W2 the 4 -- exact powers of two):
+//     u = clamp(y y, 0, 1);  phi = clamp(1/2 + y Q(u), 0, 1);  g = y phi = GELU(4 y) / 4
+// Q of degree 6 with 1/2 + Q(1) >= 1 (tools/gelu_fit_scaled.py), so both tails are exact without clamping y itself: max |error|
+// 1.9e-4 in x units.  10 VALU issues per PAIR, rounding to bf16 included (gelu2_n7: 13 with the bias add it no longer needs).
+template <int N>
+__device__ __forceinline__ void gelu2s_n(f32x2 (&y)[N]) {
+  static_assert(N == 1 || N == 2 || N == 4, "gelu2s_n chains");
+  f32x2 u[N], p[N];
+  if constexpr (N == 1) {
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %1 clamp\n\ts_nop 0" : "=v"(u[0]) : "v"(y[0]));
+  } else if constexpr (N == 2) {
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %2, %2 clamp\n\tv_pk_mul_f32 %1, %3, %3 clamp\n\ts_nop 0" : "=&v"(u[0]), "=&v"(u[1]) : "v"(y[0]), "v"(y[1]));
+  } else {
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %4, %4 clamp\n\tv_pk_mul_f32 %1, %5, %5 clamp\n\tv_pk_mul_f32 %2, %6, %6 clamp\n\tv_pk_mul_f32 %3, %7, %7 clamp\n\ts_nop 0"
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(u[n], (f32x2){1.52883381f, 1.52883381f}, (f32x2){-6.70501111f, -6.70501111f});
+#define FV_HORNERS(c)                                                                       \
+  _Pragma("unroll") for (int n = 0; n < N; ++n) p[n] = __builtin_elementwise_fma(p[n], u[n], (f32x2){c, c});
+  FV_HORNERS(12.571231f) FV_HORNERS(-13.3368161f) FV_HORNERS(8.98292293f) FV_HORNERS(-4.13267958f) FV_HORNERS(1.59153356f)
+#undef FV_HORNERS
+  if constexpr (N == 1) {
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %0, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0" : "+v"(p[0]) : "v"(y[0]));
+  } else if constexpr (N == 2) {
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %2, %0, 0.5 op_sel_hi:[1,1,0] clamp\n\tv_pk_fma_f32 %1, %3, %1, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0"
+        : "+v"(p[0]), "+v"(p[1]) : "v"(y[0]), "v"(y[1]));
+  } else {
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %4, %0, 0.5 op_sel_hi:[1,1,0] clamp\n\tv_pk_fma_f32 %1, %5, %1, 0.5 op_sel_hi:[1,1,0] clamp\n\t"
+        "v_pk_fma_f32 %2, %6, %2, 0.5 op_sel_hi:[1,1,0] clamp\n\tv_pk_fma_f32 %3, %7, %3, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) y[n] = y[n] * p[n];
+}
 __device__ __forceinline__ f32x2 gelu2_f(f32x2 x) {
   f32x2 v[1] = {x};
   gelu2_n<1>(v);

@@ -19,6 +19,19 @@
 //     permuted to 16 s + 8 (j >> 2) + 4 h + (j & 3) at pack time (cdna_hip_programming.md section 3, "An accumulator tile as the
 //     next MFMA's operand")
 //     out^T[32 ch x 32 px] += W2[:, chunk] . H^T  two k-steps per output tile, accumulators live across all chunks
+//
+// Round 3: two pack-time folds, both exact, take VALU work out of the chunk.
+//   * W1 and b1 are divided by 4 and W2 multiplied by 4 (powers of two: exact in bf16 / fp32).  The first product then yields
+//     y = (fc1(x) + b1) / 4 and the GELU works in y: u = clamp(y^2, 0, 1) costs one clamped multiply instead of two v_med3 + a
+//     multiply, and g = y * clamp(1/2 + y Q(u), 0, 1) = GELU(4 y) / 4 is rounded to bf16 exactly as GELU(x) would be
+//     (tools/gelu_fit_scaled.py: degree-6 Q, max |error| 1.9e-4 in x units; gelu2s_n in common.h);
+//   * b1 / 4 enters as the C operand of each hidden tile's first MFMA (its 16 registers ARE the four float4 the bias table holds
+//     for this lane half, fetched one chunk ahead), not as 16 VALU adds per tile.
+//   10 VALU issues per hidden pair instead of 13: -3.5 % / 0 / -4 % per launch at C = 384 / 192 / 96 (tools/ffn_bench.py, four rounds).
+// What was ALSO built this round and is NOT in this file (tools/experiments/convffn32_dma_staged_epilogue.patch): a row-per-lane
+// epilogue straight from the accumulators (W2 rows permuted so that a lane holds 8 consecutive channels) and one that moves
+// residual, output and the next tile's x fragments through wave-private 6 KB LDS units by LDS-DMA with hand-counted vmcnt.  Both
+// are bit-correct; neither beats the fp32 LDS turn below by more than 1 % (see the patch header for the stamps).
 #include <vector>
 
 #include "kernels.h"
@@ -58,8 +71,8 @@ __device__ __forceinline__ void mfma32_hid(f32x16& acc, const bf16x8& a, const b
   if constexpr (BA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
   else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ void mfma32_hid_init(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+__device__ __forceinline__ void mfma32_hid_init(f32x16& acc, const bf16x8& a, const bf16x8& b, const f32x16& bias) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(bias));
 }
 // XDL write -> VALU read of the hidden accumulators (8-pass MFMA: 12+ wait states), paid once per chunk behind the first
 // product's last MFMA; and VALU write -> MFMA B operand ahead of the second product
@@ -185,7 +198,10 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
     reinterpret_cast<float4*>(sb2)[i] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, b.w * l.w);
     reinterpret_cast<float4*>(sls)[i] = l;
   }
-  for (int i = tid; i < C; i += 256) reinterpret_cast<float4*>(sb1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  for (int i = tid; i < C; i += 256) {       // sb1 holds b1 / 4: the first product runs on W1 / 4 (exact), see the GELU
+    const float4 b = reinterpret_cast<const float4*>(p.b1)[i];
+    reinterpret_cast<float4*>(sb1)[i] = make_float4(0.25f * b.x, 0.25f * b.y, 0.25f * b.z, 0.25f * b.w);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-tid stores are invisible to hipcc's counters
   __syncthreads();
 
@@ -275,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
 #ifdef FFN32_GELU9
 #define F32_GELU(G) gelu2_n<4>(G);
 #else
-#define F32_GELU(G) gelu2_n7<4>(G);   /* the hidden is rounded to bf16 right behind it: 1.8e-4 is under that rounding */
+#define F32_GELU(G) gelu2s_n<4>(G);   /* y = x / 4 in, GELU(x) / 4 out: the hidden is rounded to bf16 right behind it */
 #endif
 #endif
 #ifdef FFN32_ABL_STAGE  /* ... no weight staging (global loads, LDS stores): wrong results, same MFMAs */
@@ -288,8 +304,20 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
 #else
 #define F32_ABL_FRAG 0
 #endif
+  // the chunk's bias b1 / 4 in the first product's D layout: registers 4 q .. 4 q + 3 = hidden 8 q + 4 fh + 0..3 of the chunk.
+  // Loaded one chunk ahead (behind the previous chunk's GELU, long after the MFMAs that read the old value as C have retired).
+  f32x16 bias;
+#define F32_LOAD_BIAS(HC)                                                                                    \
+  {                                                                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
+      const float4 b_ = *reinterpret_cast<const float4*>(sb1 + (HC) * 32 + 8 * q_ + 4 * fh);                 \
+      bias[4 * q_] = b_.x; bias[4 * q_ + 1] = b_.y; bias[4 * q_ + 2] = b_.z; bias[4 * q_ + 3] = b_.w;        \
+    }                                                                                                        \
+  }
+  F32_LOAD_BIAS(0)
 #define F32_CHUNK                                                                                                   \
   {                                                                                                                 \
+    const int hb = hc + 1 == nch ? 0 : hc + 1;                                                                      \
     const int cur = hc & 1;                                                                                         \
     /* weight staging two chunks deep: during chunk hc the registers loaded during chunk hc-1 (chunk hc+1's weights) */ \
     /* go to the idle slot and are refilled with chunk hc+2's; the chunk index wraps into the next tile            */ \
@@ -304,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
       if (!F32_ABL_FRAG) ring[i % PD] = i + PD < NR ? F32_FRAG(i + PD, cbase) : F32_FRAG(i + PD - NR, nbase);       \
       if (i < KS) { /* H^T += W1[chunk rows, k-step i] . x^T */                                                     \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                         \
-          if (i == 0) mfma32_hid_init(hacc[mt], a, xf[mt][0]);                                                      \
+          if (i == 0) mfma32_hid_init(hacc[mt], a, xf[mt][0], bias);                                                      \
           else if (XA && i >= KS / 2) mfma32_hid<XA>(hacc[mt], a, xf[mt][i >= KS / 2 ? i : KS - 1]);                \
           else mfma32_hid<false>(hacc[mt], a, xf[mt][i]);                                                           \
         }                                                                                                           \
@@ -314,18 +342,11 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
           else F32_PIECE_LOAD(j, hn)                                                                                \
         }                                                                                                           \
         if (i == KS - 1) { /* bias + GELU in registers -> the two B fragments of the second product */              \
-          const float4 bq0 = *reinterpret_cast<const float4*>(sb1 + hc * 32 + 4 * fh);                              \
-          const float4 bq1 = *reinterpret_cast<const float4*>(sb1 + hc * 32 + 8 + 4 * fh);                          \
-          const float4 bq2 = *reinterpret_cast<const float4*>(sb1 + hc * 32 + 16 + 4 * fh);                         \
-          const float4 bq3 = *reinterpret_cast<const float4*>(sb1 + hc * 32 + 24 + 4 * fh);                         \
           settle_hid<MT>(hacc);                                                                                     \
           _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
             _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                         \
-              const float4 ba = s ? bq2 : bq0, bb = s ? bq3 : bq1;                                                  \
-              f32x2 g[4] = {{hacc[mt][8 * s + 0] + ba.x, hacc[mt][8 * s + 1] + ba.y},                               \
-                            {hacc[mt][8 * s + 2] + ba.z, hacc[mt][8 * s + 3] + ba.w},                               \
-                            {hacc[mt][8 * s + 4] + bb.x, hacc[mt][8 * s + 5] + bb.y},                               \
-                            {hacc[mt][8 * s + 6] + bb.z, hacc[mt][8 * s + 7] + bb.w}};                              \
+              f32x2 g[4] = {{hacc[mt][8 * s + 0], hacc[mt][8 * s + 1]}, {hacc[mt][8 * s + 2], hacc[mt][8 * s + 3]}, \
+                            {hacc[mt][8 * s + 4], hacc[mt][8 * s + 5]}, {hacc[mt][8 * s + 6], hacc[mt][8 * s + 7]}}; \
               F32_GELU(g)                                                                                           \
               uint4 u;                                                                                              \
               u.x = pack_bf2(g[0].x, g[0].y); u.y = pack_bf2(g[1].x, g[1].y);                                       \
@@ -334,6 +355,7 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
               __builtin_amdgcn_sched_barrier(0); /* one group of four chains at a time */                           \
             }                                                                                                       \
           }                                                                                                         \
+          F32_LOAD_BIAS(hb)                                                                                         \
           settle_ops<MT>(hf);                                                                                       \
         }                                                                                                           \
       } else { /* out^T[tile] += W2[tile rows, chunk k-step] . H^T */                                               \
@@ -443,6 +465,7 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
 #endif
   }
 #undef F32_CHUNK
+#undef F32_LOAD_BIAS
 #undef F32_GELU
 #undef F32_LOAD_RES
 #undef F32_LOAD_X
@@ -483,7 +506,7 @@ bool convffn32_supported(int C, int ratio) { return ratio == 4 && (C == 96 || C 
 
 // fc1 weight w1 [4C][C] and fc2 weight w2 [C][4C] (row-major fp32, values already bf16-representable or to be rounded by the
 // caller) -> ONE stream out[4C/32][64 C]: per 32-hidden chunk the byte image the kernel's weight slot holds, in the order its
-// staging reads it.  Slot image T (elements of 2 bytes): W1 part = 32 rows x C with 8-element chunk c of row r at chunk
+// staging reads it.  Values: W1 / 4 and 4 W2 (exact; the kernel's GELU works in y = x / 4, see the file header).  Slot image T (elements of 2 bytes): W1 part = 32 rows x C with 8-element chunk c of row r at chunk
 // c ^ ((r >> SWS1) & SWM1); W2 part = C rows x 32 with the element j of lane half h in k-step s (hidden 16 s + 8 (j >> 2) + 4 h +
 // (j & 3): the order in which a converted 32x32 accumulator tile is the next product's B operand) in chunk (2 s + h) ^ ((n >> 2) & 3).
 // Staging moves each KB as lane l's 16 bytes -> four dwords stored 256 bytes apart, so the global image G of a KB is
@@ -495,13 +518,13 @@ void convffn32_pack(const float* w1, const float* w2, float* out, int C) {
   for (int hc = 0; hc < nch; ++hc) {
     for (int r = 0; r < 32; ++r)
       for (int c = 0; c < C / 8; ++c)
-        for (int e = 0; e < 8; ++e) T[(size_t)r * C + (size_t)(c ^ ((r >> sh1) & mask1)) * 8 + e] = w1[(size_t)(hc * 32 + r) * C + c * 8 + e];
+        for (int e = 0; e < 8; ++e) T[(size_t)r * C + (size_t)(c ^ ((r >> sh1) & mask1)) * 8 + e] = 0.25f * w1[(size_t)(hc * 32 + r) * C + c * 8 + e];
     for (int n = 0; n < C; ++n)
       for (int s = 0; s < 2; ++s)
         for (int h = 0; h < 2; ++h)
           for (int j = 0; j < 8; ++j)
             T[(size_t)32 * C + (size_t)n * 32 + (size_t)((2 * s + h) ^ ((n >> 2) & 3)) * 8 + j] =
-                w2[(size_t)n * hidden + hc * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+                4.0f * w2[(size_t)n * hidden + hc * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
     float* G = out + (size_t)hc * be;
     for (int kb = 0; kb < be / 512; ++kb)
       for (int l = 0; l < 64; ++l)

@@ -243,17 +243,19 @@ class FastVLAEngine:
                                                   pool_mode, pooled.data_ptr(), _stream()), "fv_llm_forward_pooled")
         return pooled
 
-    def backbone(self, images: torch.Tensor, ids: torch.Tensor, lens: torch.Tensor, *, splice: bool = False,
+    def backbone(self, images: Optional[torch.Tensor], ids: torch.Tensor, lens: torch.Tensor, *, splice: bool = False,
                  run_tower: bool = True, pad_value: float = 0.0, resize_with_padding: bool = True,
-                 pool_mode: int = 0) -> torch.Tensor:
+                 pool_mode: int = 0, pix: Optional[torch.Tensor] = None) -> torch.Tensor:
         """letterbox -> tower -> projector -> decoder -> pooled (B,H).  splice=False is the literal reference
-        behaviour: the image tokens are computed and not consumed."""
+        behaviour: the image tokens are computed and not consumed.  `pix`: pixels already letterboxed by
+        preprocess() ((B,S,S,4) bf16) -- then `images` is not read."""
         B, T = ids.shape
         self.ensure_workspace(B, T, splice)
         if splice or not run_tower or not self.overlap_streams:
             tok = None
             if run_tower or splice:
-                pix = self.preprocess(images, pad_value, resize_with_padding)
+                if pix is None:
+                    pix = self.preprocess(images, pad_value, resize_with_padding)
                 tok = self.vision_forward(pix)
             return self.llm_pooled(ids, lens, tok if splice else None, pool_mode)
         # literal mode: the decoder does not consume the tower's output, so the two run on separate HIP streams (their
@@ -264,7 +266,8 @@ class FastVLAEngine:
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             pooled = self.llm_pooled(ids, lens, None, pool_mode)
-        pix = self.preprocess(images, pad_value, resize_with_padding)
+        if pix is None:
+            pix = self.preprocess(images, pad_value, resize_with_padding)
         self._tok_keepalive = self.vision_forward(pix)
         cur.wait_stream(self._side)
         pooled.record_stream(cur)

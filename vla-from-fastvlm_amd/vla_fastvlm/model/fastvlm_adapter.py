@@ -364,6 +364,10 @@ class FastVLMBackbone(nn.Module):
         lens = attention_mask.to(torch.int32).sum(dim=1).to(torch.int32)
         mode = 0 if self.config.image_feature_pool == "last_token" else 1
         literal = not self.splice_image_tokens
+        if literal and not self.skip_unused_tower and not self.cache_prompt_features:
+            # the reference-literal step: tower + projector run (their output is dropped) BESIDE the decoder on
+            # a second HIP stream -- the same schedule bench.py times at the engine level
+            return eng.backbone(None, input_ids, lens, pool_mode=mode, pix=pix)
         tok = None
         if not (literal and self.skip_unused_tower):
             tok = eng.vision_forward(pix)  # computed even when not spliced: the literal reference runs the tower too
