@@ -53,9 +53,10 @@ def parse():
     ap.add_argument("--image", type=int, default=336)
     ap.add_argument("--splice", action="store_true", help="splice the 256 projected image tokens into the LLM sequence")
     ap.add_argument("--microbatch", type=int, default=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")))
-    ap.add_argument("--llm-precision", type=int, default=1, choices=(0, 1),
-                    help="1 = split-bf16 decoder operands + fp32 attention (actions within 1e-3 of the fp32 reference; default); "
-                         "0 = plain bf16 operands")
+    ap.add_argument("--llm-precision", type=int, default=None, choices=(0, 1, 2),
+                    help="1 = split-bf16 decoder operands + fp32 attention (actions ~1e-5 from the fp32 reference); "
+                         "2 (default for the 0.5B decoder; 1 for the wider ones: arch.default_llm_precision) = split-bf16 qkv / o + ONE fp16 pass for gate/up and down (actions ~4.4e-4: the cheapest policy inside "
+                         "north_star's 1e-3 with a 2x margin, tests/precision_budget.py); 0 = plain bf16 operands (~8e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-surface", action="store_true", help="skip the plugin-surface leg (FastVLAPolicy.select_action / forward)")
@@ -122,6 +123,8 @@ def main():
 
     from fastvla_hip import FastVLAEngine, arch, weights
     model = arch.preset(args.model)
+    if args.llm_precision is None:
+        args.llm_precision = arch.default_llm_precision(model)
     B, T = args.batch, args.tokens
     eng = FastVLAEngine(model, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, device=dev,
                         max_batch=max(B, args.train_batch), max_text_tokens=T, tower_microbatch=args.microbatch,
@@ -510,7 +513,8 @@ def main():
                        "parallelism": f"replicas x{world} (no collective on the inference path)",
                        "splice_image_tokens": bool(args.splice), "tower_microbatch": args.microbatch,
                        "stream_overlap": bool(eng.overlap_streams and not args.splice),
-                       "llm_precision": "split-bf16 (hi+lo) operands, fp32 attention" if args.llm_precision else "bf16 operands"},
+                       "llm_precision": {0: "bf16 operands", 1: "split-bf16 (hi+lo) operands, fp32 attention",
+                                         2: "split-bf16 qkv/o, fp16 gate/up/down (one pass), fp32 attention"}[args.llm_precision]},
             "samples_per_s": round(value * B, 2),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),

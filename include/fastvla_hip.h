@@ -59,7 +59,11 @@ typedef struct fv_model_desc {
   int32_t tower_microbatch; /* images per tower pass (0 = whole batch) */
   /* decoder arithmetic: 0 = bf16 MFMA operands (fastest; actions ~8e-3 from the fp32 reference at 0.5B),
    * 1 = split-bf16 activations (hi + lo, two MFMA passes, exact bf16 weights) + fp32 attention: 16 significant bits on
-   * every GEMM operand, actions within 1e-3 of the fp32 reference (the parity bar of north_star).  Tower unaffected. */
+   * every GEMM operand, actions within 1e-3 of the fp32 reference (the parity bar of north_star).  Tower unaffected.
+   * 2 = the per-GEMM budget of tests/precision_budget.py: qkv and o keep split-bf16 operands (12 % of the decoder's MACs), gate/up
+   * and down run ONE pass on fp16 operands (11 significant bits; fp16 copies of those weights are exact for |w| >= 6e-5 and the
+   * down projection carries a 2^4 scale against a 2^-4 on its operand), fp32 attention: actions ~5e-4 from the fp32 reference at
+   * 0.56x the MFMA work of mode 1. */
   int32_t llm_precision;
 } fv_model_desc;
 
@@ -209,13 +213,19 @@ enum fv_gemm_epilogue {
   FV_EPI_RES_F32 = 3,     /* out f32  = res_f32 + acc (+ bias)                      */
   FV_EPI_SWIGLU = 4,      /* out bf16[M,N/2] = silu(gate) * up, W rows 8-interleaved */
   FV_EPI_F32 = 5,         /* out f32  = acc + bias                                  */
-  FV_EPI_SWIGLU_SPLIT = 7 /* out bf16[M,N] = [hi | lo] of silu(gate)*up (split-bf16 operand), W rows 8-interleaved */
+  FV_EPI_SWIGLU_SPLIT = 7,/* out bf16[M,N] = [hi | lo] of silu(gate)*up (split-bf16 operand), W rows 8-interleaved */
+  FV_EPI_SWIGLU_F16 = 8   /* out f16[M,N/2] = silu(gate)*up / 16 (the fp16 operand of the down projection, whose fp16 weights carry the
+                           * 16: the power of two keeps SwiGLU outputs up to 1e6 inside fp16's range), W rows 8-interleaved */
 };
 /* out[M,N] = A[M,K] (bf16, row stride lda) x W[N,K]^T (bf16) with fp32 accumulation on MFMA */
 int fv_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const float* scale,
                const void* res, int ldr, void* out, int ldo, int epilogue, fv_stream s);
 /* the split-bf16 form the parity-mode decoder uses: A (M, 2K) carries [hi | lo] halves side by side (lda >= 2K), and
  * out = (A_hi + A_lo) . W^T in one launch with a doubled K loop; epilogues as fv_op_gemm */
+/* fp16 operands (A and W hold IEEE binary16 bits), fp32 accumulation on v_mfma_f32_16x16x32_f16; epilogues as fv_op_gemm plus
+ * FV_EPI_SWIGLU_F16 (the path of llm_precision = 2's gate/up and down projections) */
+int fv_op_gemm_f16(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr, void* out,
+                   int ldo, int epilogue, void* ws, size_t ws_bytes, fv_stream s);
 int fv_op_gemm_ksplit(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr,
                       void* out, int ldo, int epilogue, fv_stream s);
 /* fv_op_gemm_ksplit (ksplit != 0) or fv_op_gemm with a caller-owned scratch buffer for split-K partial sums: fp32 epilogues

@@ -28,7 +28,7 @@ def _cfgs(m):
     return tc, lc
 
 
-@pytest.fixture(scope="module", params=[("tiny", 1), ("tiny", 0), ("small", 1)], ids=lambda p: f"{p[0]}-prec{p[1]}")
+@pytest.fixture(scope="module", params=[("tiny", 1), ("tiny", 0), ("small", 1), ("small", 2)], ids=lambda p: f"{p[0]}-prec{p[1]}")
 def rig(request):
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a HIP device")
@@ -48,7 +48,9 @@ def _tol(eng, splice=False):
     the tower's bf16 rounding with them in either mode."""
     if eng.llm_precision == 1 and not splice:
         return 3e-4
-    return 5e-3 if eng.llm_precision == 1 else 8e-3
+    if eng.llm_precision == 2 and not splice:
+        return 1e-3     # fp16 (11-bit) operands on gate/up and down, split-bf16 on qkv / o: tests/precision_budget.py
+    return 5e-3 if eng.llm_precision >= 1 else 8e-3
 
 
 def test_tower_and_projector(rig):
@@ -216,7 +218,7 @@ def test_policy_end_to_end(rig, splice):
     print(f"[{m.name}] prec={eng.llm_precision} splice={splice} pooled rel_l2={rp:.2e} actions rel_l2={ra:.2e} loss rel={rl:.2e}")
     tol = _tol(eng, splice)
     assert rp <= tol and ra <= tol and rl <= 2 * tol
-    if eng.llm_precision == 1 and not splice:  # the reference-literal path in parity mode: north_star's 1e-3 bar
+    if eng.llm_precision >= 1 and not splice:  # the reference-literal path in the parity modes: north_star's 1e-3 bar
         assert ra <= 1e-3 and rl <= 1e-3
 
 

@@ -66,7 +66,7 @@ def full():
     torch.set_num_threads(min(16, torch.get_num_threads()))
     m = arch.preset("fastvlm-0.5b")
     w = weights.init_backbone(m, seed=2024)
-    eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=64, max_text_tokens=64)
+    eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=64, max_text_tokens=64, llm_precision=1)
     eng.load_weights(w)
     yield m, w, eng
     eng.close()
@@ -197,9 +197,11 @@ def test_c1_train_step(full, splice):
         assert bad <= max(2e-3, 1.5 / du.numel(), 0.5 * tol), (k, bad)
 
 
-def test_7b_decoder_full_width_four_layers():
+@pytest.mark.parametrize("prec,tol", [(1, 3e-4), (2, 1e-3)], ids=["split-bf16", "fp16-mlp"])
+def test_7b_decoder_full_width_four_layers(prec, tol):
     """FastVLM-7B decoder geometry at FULL width (3584 hidden, 28 q / 4 kv heads of 128, inter 18944), 4 layers, weights
-    streamed tensor by tensor onto the device (fv_load_weights_cb), vs the fp32 oracle on the same tensors."""
+    streamed tensor by tensor onto the device (fv_load_weights_cb), vs the fp32 oracle on the same tensors -- in both parity
+    modes of the decoder (llm_precision 1: split-bf16 everywhere; 2: the per-GEMM budget, fp16 gate/up/down)."""
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a HIP device")
     llm = arch.LLMConfig(hidden=3584, layers=4, heads=28, kv_heads=4, head_dim=128, inter=18944, vocab=8192)
@@ -211,7 +213,7 @@ def test_7b_decoder_full_width_four_layers():
         asked.append(name)
         return prov(name)
 
-    eng = FastVLAEngine(m, hidden_dim=64, fusion_dim=64, max_batch=4, max_text_tokens=32, llm_precision=1)
+    eng = FastVLAEngine(m, hidden_dim=64, fusion_dim=64, max_batch=4, max_text_tokens=32, llm_precision=prec)
     eng.load_weights_streaming(provider)
     lc = qwen2.Qwen2Cfg(hidden=3584, layers=4, heads=28, kv_heads=4, head_dim=128, inter=18944, vocab=8192)
     w = {n: prov(n).float().cpu() for n in asked if n.startswith("model.") and not n.startswith("model.vision_tower") and not n.startswith("model.mm_projector")}
@@ -224,8 +226,8 @@ def test_7b_decoder_full_width_four_layers():
         ref = qwen2.llm_pooled(w, ids, mask, lc)
     got = eng.llm_pooled(ids, mask.sum(1))
     torch.cuda.synchronize()
-    r, _ = check_close(got.cpu(), ref, rel=3e-4, amax=3e-3, what="7B-width 4-layer pooled (split-bf16)")
-    print(f"[7b-4layer] pooled rel_l2={r:.2e}")
+    r, _ = check_close(got.cpu(), ref, rel=tol, amax=10 * tol, what=f"7B-width 4-layer pooled (llm_precision={prec})")
+    print(f"[7b-4layer llm_precision={prec}] pooled rel_l2={r:.2e}")
     eng.close()
 
 
@@ -315,8 +317,10 @@ def test_7b_whole_preset_properties(lr7b):
     p2 = eng.llm_pooled(ids[sub], lens[sub])
     torch.cuda.synchronize()
     r = rel_l2(p2.cpu(), pooled[sub].cpu())
-    print(f"[fastvlm-7b B=16] pooled std={float(pooled.std()):.3f} rows-alone rel_l2={r:.2e}")
-    assert r <= 2e-4
+    print(f"[fastvlm-7b B=16, llm_precision={eng.llm_precision}] pooled std={float(pooled.std()):.3f} rows-alone rel_l2={r:.2e}")
+    # another tile shape accumulates K in another order: the last bits of an fp32 sum then round differently into the next GEMM's
+    # operand -- 16 significant bits in mode 1, 11 (fp16) on the MLP in mode 2 (the policy default), through 28 layers
+    assert r <= (2e-4 if eng.llm_precision == 1 else 1e-3)
     # spliced prefill at 7B width on 2 images: 256 + 64 tokens per row, finite and deterministic
     tok = eng.vision_forward(eng.preprocess(img[:2]))
     ps = eng.llm_pooled(ids[:2], lens[:2], tok)
@@ -507,3 +511,39 @@ def test_c3_rank_shape_train_step_with_dropout(full):
         du, dr = v.cpu() - p[k], ref["params"][k] - p[k]
         bad = float(((du - dr).abs() > 0.05 * 1e-4 + 4e-3 * dr.abs()).float().mean())
         assert bad <= max(2e-3, 1.5 / du.numel()), (k, bad)
+
+
+def test_decoder_precision_budget_full_size(full):
+    """VERDICT r2 #4c: the per-GEMM precision budget at full size.  Same weights, inputs and head in three engines' decoders:
+    llm_precision 1 (split-bf16 operands on every projection: 2x the MFMA work), 2 (split-bf16 on qkv / o only, ONE fp16 pass for
+    gate/up and down: 1.12x) and 0 (plain bf16: 1x) against the fp32 oracle -- the policy table of tests/precision_budget.py
+    measured on the product.  Mode 2 must meet north_star's 1e-3 on the ACTIONS; mode 0 must not be mistaken for it."""
+    m, w, eng1 = full
+    tc, lc = _cfgs(m)
+    torch.manual_seed(71)
+    B, T = 8, 64
+    ids = torch.randint(0, 151643, (B, T))
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, 23:] = 0
+    states = torch.randn(B, 14)
+    p = _head_params(lc, 72)
+    with torch.no_grad():
+        ref_pooled = qwen2.llm_pooled(w, ids, mask, lc)
+        ref_act = head.head_forward(p, ref_pooled, states)
+    out = {}
+    for prec in (1, 2, 0):
+        eng = eng1 if prec == 1 else FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=8,
+                                                   max_text_tokens=64, llm_precision=prec)
+        if prec != 1:
+            eng.load_weights(w)
+        flat = _flat_head(eng, p)
+        pooled = eng.llm_pooled(ids, mask.sum(1))
+        act, _ = eng.head_forward(flat, pooled, states.to(DEV))
+        torch.cuda.synchronize()
+        out[prec] = (rel_l2(pooled.cpu(), ref_pooled), rel_l2(act.cpu(), ref_act))
+        if prec != 1:
+            eng.close()
+    print("[decoder precision budget, fastvlm-0.5b B=8 T=64] (pooled, actions) rel_l2:  " +
+          "  ".join(f"llm_precision={k}: {v[0]:.2e}, {v[1]:.2e}" for k, v in out.items()))
+    assert out[1][1] <= 1e-4 and out[2][1] <= 1e-3 and out[2][0] <= 1.5e-3
+    assert out[0][1] > out[2][1]

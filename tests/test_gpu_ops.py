@@ -639,3 +639,46 @@ def test_gemm_splitk_down_projection_shape():
                                  _lib.EPI_RES_F32, 1, ws.data_ptr(), ws.numel() * 4, stream()), "fv_op_gemm_splitk in place")
     torch.cuda.synchronize()
     assert torch.equal(x, out)
+
+
+# ------------------------------------------------------------------------------------------------ round 3: fp16-operand GEMMs
+@pytest.mark.parametrize("M,N,K", [(100, 256, 896), (512, 1024, 896), (4096, 5120, 256), (256, 896, 4864)])
+def test_gemm_f16_operands(M, N, K):
+    """llm_precision = 2's projections: A and W hold fp16 bits, fp32 accumulation on v_mfma_f32_16x16x32_f16 -- through the
+    register-staged kernel (64- and 128-row tiles) and the 256-tile LDS-DMA kernel, plain and split-K (decoder down projection:
+    [site] transformers/models/qwen2/modeling_qwen2.py Qwen2MLP.down_proj via oracle/qwen2.py).  Operands are fp16-exact, so the
+    only difference to the float64 reference is the fp32 accumulation order."""
+    torch.manual_seed(M + N + K)
+    A = (torch.randn(M, K) * 0.7).half()
+    W = (torch.randn(N, K) / math.sqrt(K)).half()
+    res = torch.randn(M, N)
+    ref = A.double() @ W.double().t()
+    a, w = A.to(DEV).contiguous(), W.to(DEV).contiguous()
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    call(lib().fv_op_gemm_f16(a.data_ptr(), K, w.data_ptr(), M, N, K, None, None, 0, out.data_ptr(), N, _lib.EPI_F32, None, 0, stream()), "fv_op_gemm_f16")
+    torch.cuda.synchronize()
+    check_close(out.cpu(), ref.float(), rel=2e-5, amax=2e-4, what=f"f16 gemm f32 out {M}x{N}x{K}")
+    ws = torch.empty(8 * M * ((N + 255) // 256 * 256), dtype=torch.float32, device=DEV)
+    r = res.to(DEV)
+    out2 = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    call(lib().fv_op_gemm_f16(a.data_ptr(), K, w.data_ptr(), M, N, K, None, r.data_ptr(), N, out2.data_ptr(), N, _lib.EPI_RES_F32,
+                              ws.data_ptr(), ws.numel() * 4, stream()), "fv_op_gemm_f16 res_f32 (+ split-K scratch)")
+    torch.cuda.synchronize()
+    check_close(out2.cpu(), (res.double() + ref).float(), rel=2e-5, amax=2e-4, what=f"f16 gemm res_f32 {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,I,K", [(96, 128, 896), (4096, 2560, 256)])
+def test_gemm_f16_swiglu(M, I, K):
+    """FV_EPI_SWIGLU_F16: gate / up rows interleaved by 8, out = silu(gate) * up / 16 as fp16 (include/fastvla_hip.h)."""
+    torch.manual_seed(M + I)
+    A = (torch.randn(M, K) * 0.7).half()
+    Wg, Wu = (torch.randn(I, K) / math.sqrt(K)).half(), (torch.randn(I, K) / math.sqrt(K)).half()
+    Wi = torch.stack([Wg.view(I // 8, 8, K), Wu.view(I // 8, 8, K)], dim=1).reshape(2 * I, K).contiguous()
+    g, u = A.double() @ Wg.double().t(), A.double() @ Wu.double().t()
+    ref = (torch.nn.functional.silu(g) * u / 16).float()
+    a, w = A.to(DEV).contiguous(), Wi.to(DEV)
+    out = torch.full((M, I), float("nan"), dtype=torch.float16, device=DEV)
+    call(lib().fv_op_gemm_f16(a.data_ptr(), K, w.data_ptr(), M, 2 * I, K, None, None, 0, out.data_ptr(), I, _lib.EPI_SWIGLU_F16, None, 0, stream()),
+         "fv_op_gemm_f16 swiglu")
+    torch.cuda.synchronize()
+    check_close(out.float().cpu(), ref, rel=6e-4, amax=2e-3, what=f"f16 swiglu {M}x{I}x{K}")   # fp16 output rounding: 2^-11

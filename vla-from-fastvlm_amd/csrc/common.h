@@ -22,12 +22,24 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   const bf16x2 r = __builtin_convertvector((f32x2){lo, hi}, bf16x2);
   return __builtin_bit_cast(uint32_t, r);
 }
+// fp16 (11 significant bits) packing for the decoder's single-pass operand mode (llm_precision = 2): round-to-nearest-even casts
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  const f16x2 r = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, r);
+}
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
 __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
   f[0] = bf_lo(u.x); f[1] = bf_hi(u.x); f[2] = bf_lo(u.y); f[3] = bf_hi(u.y);
   f[4] = bf_lo(u.z); f[5] = bf_hi(u.z); f[6] = bf_lo(u.w); f[7] = bf_hi(u.w);
+}
+__device__ __forceinline__ uint4 pack8_h(const float* f) {
+  uint4 u;
+  u.x = pack_h2(f[0], f[1]); u.y = pack_h2(f[2], f[3]); u.z = pack_h2(f[4], f[5]); u.w = pack_h2(f[6], f[7]);
+  return u;
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 u;

@@ -358,10 +358,10 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
   p.qkv = take(rows * qkvw * 2);
   p.att = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2);
   p.act = take(rows * d.llm_inter * 2);
-  if (d.llm_precision == 1) {
+  if (d.llm_precision >= 1) {
     p.xn_lo = take(rows * d.llm_hidden * 2 * 2);                               // [hi | lo] side by side
     p.att_lo = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2 * 2);
-    p.act_lo = take(rows * d.llm_inter * 2 * 2);
+    p.act_lo = d.llm_precision == 1 ? take(rows * d.llm_inter * 2 * 2) : 0;    // mode 2: the SwiGLU output is ONE fp16 row (p.act)
     p.qkvf = take(rows * qkvw * 4);
     p.guf = 0;  // gate/up accumulators no longer round-trip through memory (SwiGLU + split fused into the GEMM epilogue)
   }
@@ -409,7 +409,7 @@ void prof_end(fv_handle* h, hipStream_t s) {
 int gemm_p(fv_handle* h, const fv::GemmArgs& g, hipStream_t s) {
   const double M = g.M, N = g.N, K = g.K;
   const bool f32o = g.epi == FV_EPI_RES_F32 || g.epi == FV_EPI_F32;
-  double bytes = (M * K + N * K) * 2 + M * (g.epi == FV_EPI_SWIGLU ? N / 2 : N) * (f32o ? 4 : 2);  // SPLIT: N bf16 columns
+  double bytes = (M * K + N * K) * 2 + M * ((g.epi == FV_EPI_SWIGLU || g.epi == FV_EPI_SWIGLU_F16) ? N / 2 : N) * (f32o ? 4 : 2);  // SPLIT: N bf16 columns
   if (g.epi == FV_EPI_LS_RES) bytes += M * N * 2;
   if (g.epi == FV_EPI_RES_F32) bytes += M * N * 4;
   // algorithmic flops (2MNK) even when ksplit executes the K loop twice for the split-bf16 operand
@@ -597,7 +597,7 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   if (d.llm_head_dim != 32 && d.llm_head_dim != 64 && d.llm_head_dim != 128) return fv_fail(FV_ERR_UNSUPPORTED, "llm head_dim must be 32/64/128");
   if (d.llm_hidden % 8 || d.llm_inter % 8 || d.llm_heads % d.llm_kv_heads) return fv_fail(FV_ERR_ARG, "llm dims must be multiples of 8 and heads %% kv_heads == 0");
   if (d.tower_out_dim != 2 * d.tower_dims[d.tower_stages - 1] && d.tower_out_dim != d.tower_dims[d.tower_stages - 1]) return fv_fail(FV_ERR_UNSUPPORTED, "tower_out_dim must be 1x or 2x the last stage dim");
-  if (d.llm_precision != 0 && d.llm_precision != 1) return fv_fail(FV_ERR_ARG, "llm_precision must be 0 (bf16) or 1 (split-bf16)");
+  if (d.llm_precision < 0 || d.llm_precision > 2) return fv_fail(FV_ERR_ARG, "llm_precision must be 0 (bf16), 1 (split-bf16) or 2 (split-bf16 qkv/o + fp16 gate/up/down)");
   if (d.state_dim <= 0 || d.action_dim <= 0 || d.hidden_dim <= 0 || d.fusion_dim <= 0) return fv_fail(FV_ERR_ARG, "head dims must be positive");
   FV_HIP_CHECK(hipSetDevice(device));
   fv_handle* h = new fv_handle();
@@ -768,6 +768,12 @@ static int load_impl(fv_handle* h, Loader& L) {
       if (u && y.gu_w) L.put_rows(u, y.gu_w + 8 * Hd, 16 * Hd, 8 * Hd, I / 8, 8 * Hd);
     }
     y.down_w = L.mat(pre + "mlp.down_proj.weight", Hd, I);
+    if (d.llm_precision == 2 && L.rc == FV_OK) {
+      // fp16 copies IN PLACE of the two projections that run on fp16 operands: exact for |w| >= 6.1e-5 (smaller weights become
+      // fp16 subnormals, absolute error <= 3e-8); down carries the 2^4 that its operand (FV_EPI_SWIGLU_F16) gives up
+      if (fv::launch_bf16_to_f16(y.gu_w, 2 * I * Hd, 1.0f, nullptr) != FV_OK || fv::launch_bf16_to_f16(y.down_w, Hd * I, 16.0f, nullptr) != FV_OK)
+        L.rc = FV_ERR_HIP;
+    }
   }
   if (L.rc != FV_OK) return L.rc;
   FV_HIP_CHECK(hipDeviceSynchronize());
@@ -928,10 +934,20 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
            fv::launch_attention_f32(qkvf, qkvw, as, as + qd, 2 * qd, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, Ni, att_scale, s, h->rope));
       fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
       FV_TRY(gemm_p(h, o1, s));
-      FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
-      fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 1};
-      FV_TRY(gemm_p(h, g1, s));  // silu(gate)*up and its hi/lo split happen in the epilogue: no fp32 round trip
       fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
+      if (d.llm_precision == 2) {
+        // the MLP in ONE pass on fp16 operands (tests/precision_budget.py): post-norm rows as fp16, SwiGLU output / 16 as fp16
+        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s, 1));
+        fv::GemmArgs g1{xn, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, act, I, FV_EPI_SWIGLU_F16, 0};
+        g1.f16 = 1;
+        FV_TRY(gemm_p(h, g1, s));
+        d1 = fv::GemmArgs{act, I, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 0};
+        d1.f16 = 1;
+      } else {
+        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
+        fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 1};
+        FV_TRY(gemm_p(h, g1, s));  // silu(gate)*up and its hi/lo split happen in the epilogue: no fp32 round trip
+      }
       d1.splitk_ws = wp.splitk_bytes ? reinterpret_cast<float*>(ws + wp.splitk) : nullptr;
       d1.splitk_bytes = wp.splitk_bytes;
       if (li + 1 < h->dec.layers.size()) {

@@ -23,15 +23,22 @@ constexpr int LDC = BN + 4;                       // fp32 epilogue image row str
 
 struct Params {
   const bf16_t* A; const bf16_t* W; const float* bias; const float* scale; const void* res; void* out;
-  int M, N, K, lda, ldr, ldo, epi, tiles_n, nwg, ksplit;
+  int M, N, K, lda, ldr, ldo, epi, tiles_n, nwg, ksplit;   // (fp16 operands are a template parameter of the kernels, not a field)
   int splits = 1, npad = 0; float* part = nullptr;   // split-K (gemm256 only): units = tiles x splits, partials [split][M][npad]
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 
+// one 16x16x32 product step; F16: the same 16-byte fragments hold IEEE binary16 (llm_precision = 2's gate/up and down projections)
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // BM = 128: 2x2 waves of 64x64.  BM = 64: 2x2 waves of 32x64, for grids that would otherwise leave CUs idle (the
 // M = B*T = 4096 decoder GEMMs) -- twice the blocks, 3 co-resident per CU.
-template <int BM>
+template <int BM, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
   constexpr int MI = BM / 32;                             // 16-row MFMA tiles per wave along M
   constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<F16>(fa[i], fb[j], acc[i][j]);
     }
   }
   __syncthreads();  // the last tile's fragment reads are done: the epilogue image reuses the staging buffers
@@ -131,9 +138,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
   __syncthreads();
 
   const int epi = p.epi;
-  if (epi == FV_EPI_SWIGLU || epi == FV_EPI_SWIGLU_SPLIT) {
+  if (epi == FV_EPI_SWIGLU || epi == FV_EPI_SWIGLU_SPLIT || epi == FV_EPI_SWIGLU_F16) {
     // W rows are interleaved [8 gate | 8 up]: 16 accumulator columns -> 8 outputs.  SPLIT also writes the bf16
-    // remainder at column offset N/2 (split-bf16 operand of the down projection: out is [M][hi N/2 | lo N/2]).
+    // remainder at column offset N/2 (split-bf16 operand of the down projection: out is [M][hi N/2 | lo N/2]); F16 writes
+    // silu(gate) * up / 16 as fp16 (the down projection's fp16 weights carry the 16).
     bf16_t* out = static_cast<bf16_t*>(p.out);
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {
@@ -145,6 +153,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = silu_f(src[e]) * src[8 + e];
+        if (epi == FV_EPI_SWIGLU_F16) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] *= 0.0625f;
+          *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (gn >> 1)) = pack8_h(o);
+          continue;
+        }
         const uint4 hv = pack8(o);
         *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (gn >> 1)) = hv;
         if (epi == FV_EPI_SWIGLU_SPLIT) {
@@ -235,7 +249,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 // straight to their fragment reads and MFMAs and run ahead.  Measured (tools/gemm_shapes.py, A/B in one session): +6 % on the decoder's
 // M = 4096 gate/up and split-K down projections, +-2 % on the tower's shapes, -15 % at 8192^3 (the staging waves' 16 pieces become the
 // critical path of a long K loop with many tiles per CU) -- launch_gemm uses it for M <= 8192 only.
-template <int MI, int WN, bool ASYM = false>
+template <int MI, int WN, bool ASYM = false, bool F16 = false>
 __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Params p) {   // <8,4> 256x256, <4,2> 128x128
   static_assert(!ASYM || WN == 4, "asymmetric staging pairs wave w with wave w + 4");
   constexpr int BMT = 32 * MI, BNT = 64 * WN, NTH = 128 * WN, BUFB = (BMT + BNT) * 128, AB = BMT * 128;
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[j][t % MI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t < MI ? fwA[j] : fwB[j], far[t % 3], acc[j][t % MI], 0, 0, 0);
+            acc[j][t % MI] = mfma16<F16>(t < MI ? fwA[j] : fwB[j], far[t % 3], acc[j][t % MI]);
           __builtin_amdgcn_sched_barrier(0);   // keep the reads where they are dealt (hipcc sinks them back to their use)
         }
 #undef G2_RD_A
@@ -419,15 +433,23 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
         asm volatile("" ::: "memory");
         continue;
       }
-      if (p.epi == FV_EPI_SWIGLU_SPLIT) {
+      if (p.epi == FV_EPI_SWIGLU_SPLIT || p.epi == FV_EPI_SWIGLU_F16) {
         // W rows are interleaved [8 gate | 8 up]: a lane takes 16 accumulator columns of one row -> 8 outputs, written as
-        // the bf16 value and, N/2 columns further, its bf16 remainder (split-bf16 operand of the down projection)
+        // the bf16 value and, N/2 columns further, its bf16 remainder (split-bf16 operand of the down projection) -- or, F16,
+        // as ONE fp16 value scaled by 1/16 (fp16 operand of the down projection)
         const int row = lane >> 2, pr = lane & 3;
         const int gm = bm + wr * (16 * MI) + i * 16 + row, go = (bn + wc * 64 + pr * 16) >> 1;
         const float* src = reinterpret_cast<const float*>(so + row * ORB) + pr * 16;
         float o8[8], h8[8], l8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o8[e] = silu_f(src[e]) * src[8 + e];
+        if (p.epi == FV_EPI_SWIGLU_F16) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] *= 0.0625f;
+          *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + go) = pack8_h(o8);
+          asm volatile("" ::: "memory");
+          continue;
+        }
         const uint4 hv = pack8(o8);
         unpack8(hv, h8);
 #pragma unroll
@@ -627,14 +649,15 @@ int gemm_glds_tile(const GemmArgs& a) {
   // 4 GiB or more go to the register-staged kernel, which addresses with size_t
   if ((size_t)a.M * a.lda * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return 0;
   const bool f32 = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
-  if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT && !f32) return 0;
-  if (a.epi == FV_EPI_SWIGLU_SPLIT && a.bias) return 0;
+  if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16 && !f32) return 0;
+  if ((a.epi == FV_EPI_SWIGLU_SPLIT || a.epi == FV_EPI_SWIGLU_F16) && a.bias) return 0;
   // (a 128 x 256 variant for shapes whose last round of 256-tiles is mostly idle -- the decoder's gate/up, 608 tiles = 2.4
   // rounds -- was measured slower, 184 vs 150 us: 64 x 64 per wave reads a third more LDS per MFMA)
   if (a.M % 256 == 0 && a.N % 256 == 0 && (long)(a.M / 256) * (a.N / 256) >= 320) return 256;
   // 128-tiles: one wave per SIMD and a K-tile of 32 MFMAs per wave cannot cover a memory latency per K-tile, so a long K
   // loop (the decoder's down projection, K = 2 x 4864) is slower here than on the 128-tile register-staged kernel at three
   // blocks per CU; short ones (qkv / o, K <= 1024) are on par
+  if (a.f16) return 0;   // fp16 operands: the 256-tile kernel or the register-staged one (no 128-tile instance is built for them)
   if (a.M % 128 == 0 && a.N % 128 == 0 && (long)(a.M / 128) * (a.N / 128) >= 128 && a.K >= 512 && a.K <= 1024) return 128;
   return 0;
 }
@@ -662,10 +685,14 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fv_fail(FV_ERR_ARG, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.K % 8 || a.lda % 8 || a.N % 8) return fv_fail(FV_ERR_ARG, "gemm: K, lda, N must be multiples of 8 (K=%d lda=%d N=%d)", a.K, a.lda, a.N);
   if (a.lda < a.K) return fv_fail(FV_ERR_ARG, "gemm: lda < K");
-  if (a.epi < FV_EPI_BIAS || (a.epi > FV_EPI_F32 && a.epi != FV_EPI_SWIGLU_SPLIT)) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
+  if (a.epi < FV_EPI_BIAS || (a.epi > FV_EPI_F32 && a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16)) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
+  if (a.f16 && a.ksplit) return fv_fail(FV_ERR_ARG, "gemm: fp16 operands are a single pass (no ksplit)");
+  if (a.epi == FV_EPI_SWIGLU_F16 && !a.f16) return fv_fail(FV_ERR_ARG, "gemm: FV_EPI_SWIGLU_F16 belongs to the fp16-operand path");
+  if (a.f16 && (a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES || a.epi == FV_EPI_SWIGLU || a.epi == FV_EPI_SWIGLU_SPLIT))
+    return fv_fail(FV_ERR_UNSUPPORTED, "gemm: fp16 operands go with the BIAS / F32 / RES_F32 / SWIGLU_F16 epilogues");
   const bool f32out = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
-  const bool swiglu = a.epi == FV_EPI_SWIGLU || a.epi == FV_EPI_SWIGLU_SPLIT;
-  const int ncols = a.epi == FV_EPI_SWIGLU ? a.N / 2 : a.N;  // SPLIT: hi and lo halves side by side -> N columns
+  const bool swiglu = a.epi == FV_EPI_SWIGLU || a.epi == FV_EPI_SWIGLU_SPLIT || a.epi == FV_EPI_SWIGLU_F16;
+  const int ncols = (a.epi == FV_EPI_SWIGLU || a.epi == FV_EPI_SWIGLU_F16) ? a.N / 2 : a.N;  // SPLIT: hi and lo halves side by side -> N columns
   if (swiglu && a.N % 16) return fv_fail(FV_ERR_ARG, "gemm: SwiGLU needs N %% 16 == 0");
   if (a.ldo < ncols || a.ldo % (f32out ? 4 : 8)) return fv_fail(FV_ERR_ARG, "gemm: bad ldo %d", a.ldo);
   if (a.epi == FV_EPI_LS_RES && (!a.res || !a.scale || a.ldr % 8 || a.ldr < a.N)) return fv_fail(FV_ERR_ARG, "gemm: LS_RES needs res/scale");
@@ -685,6 +712,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
   }
   static const bool no_asym = getenv("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
   const bool asym = !no_asym && a.M <= 8192;
@@ -701,8 +730,11 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
       p.tiles_n = tn;
       p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
       p.nwg = tiles * splits;
-      if (asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), dim3(p.nwg < cus ? p.nwg : cus / 8 * 8), dim3(512), 2 * 512 * 128, s, p);
-      else hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(p.nwg < cus ? p.nwg : cus / 8 * 8), dim3(512), 2 * 512 * 128, s, p);
+      const dim3 g2(p.nwg < cus ? p.nwg : cus / 8 * 8);
+      if (a.f16 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true, true>), g2, dim3(512), 2 * 512 * 128, s, p);
+      else if (a.f16) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, true>), g2, dim3(512), 2 * 512 * 128, s, p);
+      else if (asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), g2, dim3(512), 2 * 512 * 128, s, p);
+      else hipLaunchKernelGGL((gemm256_kernel<8, 4>), g2, dim3(512), 2 * 512 * 128, s, p);
       const long quads = (long)a.M * (a.N / 4);
       if (a.norm_w) g_norm_fused = true;
       if (a.norm_w)
@@ -717,7 +749,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     }
   }
   static const bool no_pw = getenv("FASTVLA_NO_PWCONV") != nullptr;
-  if (!no_pw && !a.ksplit && a.N == a.K && (a.K == 96 || a.K == 192) && a.lda == a.K && a.ldo == a.N && a.M % 128 == 0 &&
+  if (!no_pw && !a.ksplit && !a.f16 && a.N == a.K && (a.K == 96 || a.K == 192) && a.lda == a.K && a.ldo == a.N && a.M % 128 == 0 &&
       (a.epi == FV_EPI_BIAS || a.epi == FV_EPI_BIAS_GELU)) {
     const int tiles = a.M / 128;
     if (a.K == 96) {
@@ -739,7 +771,9 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     p.nwg = (a.M / gt) * p.tiles_n;
     const int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
     const int grid = p.nwg < slots ? p.nwg : slots;
-    if (gt == 256 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
+    if (gt == 256 && a.f16 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
+    else if (gt == 256 && a.f16) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
+    else if (gt == 256 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else if (gt == 256) hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<4, 2>), dim3(grid), dim3(256), 2 * 256 * 128, s, p);
     FV_HIP_CHECK(hipGetLastError());
@@ -750,10 +784,12 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   const long blocks128 = (long)((a.M + 127) / 128) * p.tiles_n;
   if (blocks128 >= 512) {
     p.nwg = (int)blocks128;
-    hipLaunchKernelGGL(gemm_kernel<128>, dim3(p.nwg), dim3(256), 0, s, p);
+    if (a.f16) hipLaunchKernelGGL((gemm_kernel<128, true>), dim3(p.nwg), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gemm_kernel<128>, dim3(p.nwg), dim3(256), 0, s, p);
   } else {
     p.nwg = ((a.M + 63) / 64) * p.tiles_n;
-    hipLaunchKernelGGL(gemm_kernel<64>, dim3(p.nwg), dim3(256), 0, s, p);
+    if (a.f16) hipLaunchKernelGGL((gemm_kernel<64, true>), dim3(p.nwg), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gemm_kernel<64>, dim3(p.nwg), dim3(256), 0, s, p);
   }
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;

@@ -20,6 +20,7 @@ struct GemmArgs {
   void* out; int ldo;           // bf16 or f32 by epilogue
   int epi;
   int ksplit = 0;               // 1: A holds [hi | lo] (2K columns, lda >= 2K); out = (hi + lo) . W^T in one launch
+  int f16 = 0;                  // 1: A and W hold fp16 bits (v_mfma_f32_16x16x32_f16); not together with ksplit
   float* splitk_ws = nullptr;   // optional scratch for split-K partial sums (fp32 epilogues, few output tiles, long K)
   size_t splitk_bytes = 0;
   // optional RMSNorm of the fp32 output rows (the decoder's next-layer input_layernorm): y (+ y_lo) = bf16 hi (+ lo) of
@@ -82,7 +83,10 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ldq,
 int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* img_tokens, float* x, int B, int T,
                         int Ni, int H, int vocab, hipStream_t s);
 // y_lo != null: also writes the bf16 remainder (x ~= y + y_lo), the split operand of the parity-mode decoder GEMMs
-int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s);
+int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s,
+                   int f16 = 0);   // f16 != 0: y receives fp16 bits (y_lo must be null)
+// in place: n bf16 values -> the fp16 values scale * x (weights of the fp16-operand projections, once at load time)
+int launch_bf16_to_f16(bf16_t* p, size_t n, float scale, hipStream_t s);
 int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D, hipStream_t s);
 // rope != null: qkv holds un-rotated projections; the rotate-half RoPE is fused into the MFMA kernel (head_dim 64 / 128) or applied
 // in place by a rope_f32 launch ahead of the VALU kernel (head_dim 32)

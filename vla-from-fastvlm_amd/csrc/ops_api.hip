@@ -26,6 +26,15 @@ int fv_op_gemm_splitk(const void* A, int lda, const void* W, int M, int N, int K
   return fv::launch_gemm(g, static_cast<hipStream_t>(s));
 }
 
+int fv_op_gemm_f16(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr, void* out,
+                   int ldo, int epilogue, void* ws, size_t ws_bytes, fv_stream s) {
+  fv::GemmArgs g{static_cast<const bf16_t*>(A), lda, static_cast<const bf16_t*>(W), M, N, K, bias, nullptr, res, ldr, out, ldo, epilogue};
+  g.f16 = 1;
+  g.splitk_ws = static_cast<float*>(ws);
+  g.splitk_bytes = ws_bytes;
+  return fv::launch_gemm(g, static_cast<hipStream_t>(s));
+}
+
 int fv_op_dwconv(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                  int stride, int mult, int gelu, fv_stream s) {
   return fv::launch_dwconv(static_cast<const bf16_t*>(x), w, bias, static_cast<bf16_t*>(y), B, H, W, C, k, stride, mult, gelu, static_cast<hipStream_t>(s));

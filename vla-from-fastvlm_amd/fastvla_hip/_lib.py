@@ -13,6 +13,7 @@ FV_MAX_STAGES = 8
 FV_F32, FV_BF16, FV_U8, FV_I32 = 0, 1, 2, 3
 EPI_BIAS, EPI_BIAS_GELU, EPI_LS_RES, EPI_RES_F32, EPI_SWIGLU, EPI_F32 = range(6)
 EPI_SWIGLU_SPLIT = 7
+EPI_SWIGLU_F16 = 8
 
 
 class FastVLAHipError(RuntimeError):
@@ -99,6 +100,7 @@ SIGNATURES = {
     "fv_profile_read": (_i, [_vp, C.POINTER(ProfileEntry), C.POINTER(GemmProfile), _i, C.POINTER(_i)]),
     "fv_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(AdamWHParams), _i64, _vp, _vp]),
     "fv_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "fv_op_gemm_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _vp]),
     "fv_op_gemm_ksplit": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "fv_op_gemm_splitk": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, C.c_size_t, _vp]),
     "fv_op_dwconv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -77,6 +77,15 @@ PRESETS = {
 }
 
 
+def default_llm_precision(model: ModelConfig) -> int:
+    """The cheapest decoder arithmetic VERIFIED inside north_star's 1e-3 on the actions for this model (fv_model_desc.llm_precision):
+    2 (split-bf16 qkv / o, one fp16 pass for gate/up and down) for the 0.5B-class decoder -- 4.4e-4 .. 6.2e-4 against the fp32 oracle
+    at full size (tests/test_gpu_fullsize.py::test_decoder_precision_budget_full_size, bench.py cpu_baseline); 1 (split-bf16 on every
+    projection, 1e-5) for the wider / deeper ones, where the fp16 budget measures 7.3e-4 after 4 of 28 layers at the 7B width and a
+    full-depth oracle run does not fit a test."""
+    return 2 if model.llm.hidden <= 1024 and model.llm.layers <= 24 else 1
+
+
 def preset(name: str) -> ModelConfig:
     key = name.lower()
     if key not in PRESETS:
