@@ -388,6 +388,31 @@ def main():
                    "api": "vla_fastvlm.lerobot_fastvla.FastVLAPolicy.select_action(batch) / .forward(batch)"}
         del pol
 
+    # ---- splice mode only: what the image-prefix cache changes.  joint = ONE prefill over 256 image + T text
+    # positions (the timed step above); new frames = tower + prefix pass (image positions, K / V kept) + suffix pass (text
+    # positions); cached frames = the suffix pass alone (a repeated frame, or another prompt on the same frame)
+    prefix = None
+    if args.splice and args.llm_precision >= 1 and model.llm.head_dim >= 64:
+        holder = {}
+
+        def step_new_frames():
+            tok = eng.vision_forward(eng.preprocess(images[:B]))
+            holder["kv"] = eng.llm_prefix(tok)
+            act, _ = eng.head_forward(flat, eng.llm_pooled_prefixed(ids[:B], lens[:B], holder["kv"]), states[:B])
+            return act
+
+        def step_cached_frames():
+            act, _ = eng.head_forward(flat, eng.llm_pooled_prefixed(ids[:B], lens[:B], holder["kv"]), states[:B])
+            return act
+
+        ns = max(3, args.steps // 2)
+        t_new = timed(step_new_frames, ns, 2)
+        t_hit = timed(step_cached_frames, ns, 2)
+        prefix = {"joint_prefill_ms_per_step": round(ms_per_step, 3), "new_frames_ms_per_step": round(1e3 * t_new / ns, 3),
+                  "cached_frames_ms_per_step": round(1e3 * t_hit / ns, 3), "steps": ns,
+                  "cache_mib_per_image": round(holder["kv"].numel() * 4 / B / 2 ** 20, 2),
+                  "actions_rel_l2_vs_joint": float((step_cached_frames() - step_infer()).norm() / step_infer().norm())}
+
     # ---- CPU baseline (rank 0, N=1 only): the fp32 oracle on a bounded sample of the same workload
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and w is not None:
@@ -516,7 +541,7 @@ def main():
                        "llm_precision": {0: "bf16 operands", 1: "split-bf16 (hi+lo) operands, fp32 attention",
                                          2: "split-bf16 qkv/o, fp16 gate/up/down (one pass), fp32 attention"}[args.llm_precision]},
             "samples_per_s": round(value * B, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
         }
         print(json.dumps(out))

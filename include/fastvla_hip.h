@@ -142,6 +142,20 @@ int fv_vision_forward_unit_taps(fv_handle* h, const void* pix, int B, void* img_
 int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens, const void* img_tokens, int Ni, int B,
                           int T, int pool_mode, void* pooled, fv_stream s);
 
+/* Image-prefix reuse (the call site the reference has is ONE full prefill per env step:
+ * lerobot_fastvla/modeling_fastvla.py:119-125 -> model/fastvlm_adapter.py:519-536).  With the image tokens spliced in FRONT of the
+ * text under a causal mask, the keys / values of the Ni image positions depend on the image alone:
+ *   fv_llm_prefix            runs those positions through the decoder once and writes every layer's un-rotated [k | v] rows to
+ *                            kv_out ([llm_layers][B * Ni][2 * kv_heads * head_dim] f32, caller-owned, fv_llm_prefix_bytes);
+ *   fv_llm_forward_pooled_prefixed  runs ONLY the T text positions against that cache: the same pooled rows as
+ *                            fv_llm_forward_pooled(img_tokens, Ni) up to the summation order of other tile shapes.
+ * A caller that keeps kv per image (or per camera frame) skips tower, projector and prefix for a repeated frame or for further
+ * prompts on the same image.  llm_precision 1 / 2 and head_dim 64 / 128 only; pool_mode must be 0 (last_token). */
+int fv_llm_prefix_bytes(fv_handle* h, int B, int Ni, size_t* out_bytes);
+int fv_llm_prefix(fv_handle* h, const void* img_tokens, int Ni, int B, void* kv_out, fv_stream s);
+int fv_llm_forward_pooled_prefixed(fv_handle* h, const int32_t* ids, const int32_t* lens, const void* kv, int Ni, int B, int T,
+                                   int pool_mode, void* pooled, fv_stream s);
+
 /* ---- action expert (trainable; parameters live in ONE caller-owned flat f32 buffer) --------------------------- */
 /* element offsets of the 12 head tensors inside the flat buffer, in state-dict order
  * (state_projection.0.{weight,bias}, state_projection.1.*, fusion.0.*, fusion.1.*, fusion.4.*, action_head.*);

@@ -321,3 +321,50 @@ def test_streaming_load_equals_bulk_load_bit_for_bit():
     for name, load in routes.items():
         tok, pooled = run(load)
         assert torch.equal(tok, ref[0]) and torch.equal(pooled, ref[1]), name
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+def test_image_prefix_cache_equals_joint_prefill(prec):
+    """the image tokens sit in FRONT of the text under a causal mask, so their keys / values depend on the image
+    alone.  fv_llm_prefix (image positions once, every layer's [k | v] kept) + fv_llm_forward_pooled_prefixed (text positions only)
+    must give the pooled rows of the joint spliced prefill -- and of the fp32 oracle (reference call site: one full prefill per env
+    step, lerobot_fastvla/modeling_fastvla.py:119-125 -> model/fastvlm_adapter.py:519-536).  Also: a cache row is per image --
+    sliced out and paired with another prompt batch it still serves its image."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    m = arch.preset("small")   # head_dim 64: the fp32-MFMA attention the real models use
+    w = weights.init_backbone(m, seed=23)
+    _, lc = _cfgs(m)
+    eng = FastVLAEngine(m, hidden_dim=64, fusion_dim=96, max_batch=8, max_text_tokens=32, llm_precision=prec)
+    eng.load_weights(w)
+    torch.manual_seed(24)
+    B, T = 5, 19
+    tok = eng.vision_forward(eng.preprocess(torch.rand(B, 3, 100, 140).to(DEV)))
+    ids = torch.randint(0, lc.vocab, (B, T))
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, 11:] = 0
+    mask[3, 1:] = 0
+    lens = mask.sum(1)
+    joint = eng.llm_pooled(ids, lens, tok)
+    kv = eng.llm_prefix(tok)
+    pref = eng.llm_pooled_prefixed(ids, lens, kv)
+    pref2 = eng.llm_pooled_prefixed(ids, lens, kv)
+    torch.cuda.synchronize()
+    assert kv.shape == (lc.layers, B, m.tower.num_tokens, 2 * lc.kv_heads * lc.head_dim)
+    assert torch.isfinite(pref).all() and torch.equal(pref, pref2)
+    r_joint = rel_l2(pref.cpu(), joint.cpu())
+    with torch.no_grad():
+        ref = qwen2.llm_pooled(w, ids, mask, lc, tok.cpu(), splice=True)
+    r_ref, r_ref_joint = rel_l2(pref.cpu(), ref), rel_l2(joint.cpu(), ref)
+    # image 2's cache row with two other prompts
+    sub = torch.tensor([2, 2])
+    ids2 = torch.randint(0, lc.vocab, (2, T))
+    lens2 = torch.tensor([T, 7])
+    a = eng.llm_pooled_prefixed(ids2, lens2, kv[:, sub].contiguous())
+    b = eng.llm_pooled(ids2, lens2, tok[sub].contiguous())
+    torch.cuda.synchronize()
+    r_sub = rel_l2(a.cpu(), b.cpu())
+    print(f"[prefix cache, llm_precision={prec}] prefixed vs joint {r_joint:.2e}; vs fp32 oracle {r_ref:.2e} (joint: {r_ref_joint:.2e}); re-paired row {r_sub:.2e}")
+    tol = 3e-4 if prec == 1 else 1e-3
+    assert r_joint <= (2e-5 if prec == 1 else tol) and r_sub <= (2e-5 if prec == 1 else tol) and r_ref <= tol
+    eng.close()

@@ -547,3 +547,26 @@ def test_decoder_precision_budget_full_size(full):
           "  ".join(f"llm_precision={k}: {v[0]:.2e}, {v[1]:.2e}" for k, v in out.items()))
     assert out[1][1] <= 1e-4 and out[2][1] <= 1e-3 and out[2][0] <= 1.5e-3
     assert out[0][1] > out[2][1]
+
+
+def test_image_prefix_cache_full_size(full):
+    """SURVEY.md 8f-1 at the real dimensions: fastvlm-0.5b, 256 image tokens in front of a 32-token prompt, B=4.  The prefix pass
+    (M = 1024 rows) and the suffix pass (M = 128 rows) take other GEMM tiles than the joint 288-token prefill (M = 1152), so the
+    pooled rows agree to the summation order, not bit for bit; a cached row serves its image under another prompt."""
+    m, w, eng = full
+    torch.manual_seed(81)
+    B, T = 4, 32
+    tok = eng.vision_forward(eng.preprocess(torch.rand(B, 3, 336, 336).to(DEV)))
+    ids = torch.randint(0, 151643, (B, T))
+    lens = torch.tensor([T, 9, T, 1])
+    joint = eng.llm_pooled(ids, lens, tok)
+    kv = eng.llm_prefix(tok)
+    pref = eng.llm_pooled_prefixed(ids, lens, kv)
+    sub = torch.tensor([3, 0])
+    ids2 = torch.randint(0, 151643, (2, T))
+    a = eng.llm_pooled_prefixed(ids2, lens[sub], kv[:, sub].contiguous())
+    b = eng.llm_pooled(ids2, lens[sub], tok[sub].contiguous())
+    torch.cuda.synchronize()
+    r, r2 = rel_l2(pref.cpu(), joint.cpu()), rel_l2(a.cpu(), b.cpu())
+    print(f"[prefix cache fastvlm-0.5b, Ni=256, T=32] prefixed vs joint prefill {r:.2e}; re-paired rows {r2:.2e}; cache {kv.numel() * 4 / B / 2**20:.1f} MiB per image")
+    assert torch.isfinite(pref).all() and r <= 2e-4 and r2 <= 2e-4

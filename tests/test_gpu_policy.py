@@ -359,3 +359,50 @@ def test_bench_gpus2_spawns_two_ranks_and_fills_train_dp():
     td = line["train_dp"]
     assert td["parallelism"] == "dp2" and td["global_batch"] == 8 and td["value"] > 0
     assert td["allreduce_ms"] is not None and td["ms_per_step_serial_exchange"] is not None and td["overlap_frac"] is not None
+
+
+def test_image_prefix_cache_in_the_backbone():
+    """SURVEY.md 8f-1 through the plugin-side class: FastVLMBackbone in splice mode with `cache_image_prefix` keeps every image's
+    decoder prefix (LRU keyed by a device-side hash of the image tensor).  Misses, hits, a frame repeated inside one batch and a
+    mixed batch all give the pooled rows of the uncached spliced forward; on hits neither the tower nor the prefix pass runs."""
+    from vla_fastvlm.model.fastvlm_adapter import FastVLMBackbone, FastVLMBackboneConfig
+    torch.manual_seed(8)
+    bb = FastVLMBackbone(FastVLMBackboneConfig(model_id="synthetic:small:5"))
+    bb.splice_image_tokens = True
+    eng = bb.engine()
+    B, T = 4, 12
+    vocab = eng.model.llm.vocab
+    ids = torch.randint(0, vocab, (B, T), device=eng.device, dtype=torch.int32)
+    mask = torch.ones(B, T, dtype=torch.int32, device=eng.device)
+    mask[2, 5:] = 0
+    images = torch.rand(B, 3, 60, 84, device=eng.device)
+    images[3] = images[1]                                   # the same frame twice in one batch
+    ref = bb.forward_ids(images, ids, mask).clone()
+    calls = {"n": 0, "imgs": 0}
+    vf = eng.vision_forward
+
+    def counted(pix, *a, **k):
+        calls["n"] += 1
+        calls["imgs"] += pix.shape[0]
+        return vf(pix, *a, **k)
+
+    eng.vision_forward = counted
+    bb.cache_image_prefix = True
+    first = bb.forward_ids(images, ids, mask)               # 3 distinct frames miss
+    assert calls == {"n": 1, "imgs": 3} and bb._prefix_stats == {"images": 4, "tower_runs": 3}
+    again = bb.forward_ids(images, ids, mask)               # all hits: no tower, no prefix pass
+    assert calls == {"n": 1, "imgs": 3} and bb._prefix_stats["tower_runs"] == 0
+    ids2 = torch.randint(0, vocab, (B, T), device=eng.device, dtype=torch.int32)
+    other = bb.forward_ids(images, ids2, mask)              # new prompts on cached frames
+    images2 = images.clone()
+    images2[0] = torch.rand(3, 60, 84, device=eng.device)
+    mixed = bb.forward_ids(images2, ids, mask)              # one new frame among hits
+    torch.cuda.synchronize()
+    assert calls == {"n": 2, "imgs": 4}
+    bb.cache_image_prefix = False
+    eng.vision_forward = vf
+    tol = 1e-3 if eng.llm_precision == 2 else 2e-5
+    assert rel_l2(first.cpu(), ref.cpu()) <= tol and torch.equal(first, again)
+    assert rel_l2(other.cpu(), bb.forward_ids(images, ids2, mask).cpu()) <= tol
+    assert rel_l2(mixed.cpu(), bb.forward_ids(images2, ids, mask).cpu()) <= tol
+    assert torch.equal(mixed[1:], first[1:]) and not torch.equal(mixed[0], first[0])

@@ -243,7 +243,11 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out_hi,
                                                                      bf16_t* __restrict__ out_lo, const int32_t* __restrict__ lens,
                                                                      int len_add, int ld, int ldo, int T, int heads, int kv_heads,
-                                                                     float scale, const float2* __restrict__ rope) {
+                                                                     float scale, const float2* __restrict__ rope,
+                                                                     const float* __restrict__ pre, int ldp, int Np) {
+  // pre != null (image-prefix reuse): the sequence is Np cached prefix positions + Ts = T - Np new ones.  qkv and
+  // the outputs hold ONLY the new rows (row b * Ts + t - Np); keys / values of positions < Np come from `pre`, rows
+  // (b * Np + pos) of [k (kv_heads * D) | v (kv_heads * D)] fp32, UN-rotated like qkv; queries exist for positions >= Np only.
   // rope != null: qkv holds the UN-rotated projections and the rotate-half RoPE ([site] modeling_qwen2.py:105-135) is applied
   // here, to the query fragments in registers and to the K rows on their way into LDS (position = index in the sequence;
   // table [pos][D/2] of (cos, sin)) -- one launch and one read-modify-write pass over q and k less per layer
@@ -254,7 +258,8 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
   __shared__ __attribute__((aligned(16))) float sV[KCH * LDR];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int qblocks = (T + 63) >> 6;
+  const int Ts = T - Np;                   // rows per batch entry in qkv / out (Np = 0 without a prefix)
+  const int qblocks = (Ts + 63) >> 6;
   int bid = blockIdx.x;
   const int qb = bid % qblocks; bid /= qblocks;
   const int h = bid % heads;
@@ -262,12 +267,12 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
   const int hk = h / (heads / kv_heads);
   int len = lens ? lens[b] + len_add : T;
   len = max(1, min(len, T));
-  const int q0 = qb * 64 + wid * 16, qg = q0 + fr;
+  const int q0 = Np + qb * 64 + wid * 16, qg = q0 + fr;
   const int qd = heads * D, kd = kv_heads * D;
 
   float4 fq[DT];
   {
-    const float* qp = qkv + ((size_t)b * T + min(qg, T - 1)) * ld + h * D + 4 * fg;
+    const float* qp = qkv + ((size_t)b * Ts + (min(qg, T - 1) - Np)) * ld + h * D + 4 * fg;
 #pragma unroll
     for (int c = 0; c < DT; ++c) fq[c] = *reinterpret_cast<const float4*>(qp + 16 * c);
     if (rope) {   // d = 16 c + 4 fg + e pairs with d + D/2 = 16 (c + DT/2) + 4 fg + e: the same lane
@@ -286,14 +291,16 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
   for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1e30f, l_run = 0.f;
 
-  const int kend = min(len, qb * 64 + 64);   // causal: keys beyond the block's last query are never visible
+  const int kend = min(len, Np + qb * 64 + 64);   // causal: keys beyond the block's last query are never visible
   for (int k0 = 0; k0 < kend; k0 += KCH) {
     __syncthreads();
     if (rope) {   // a thread takes the four d of the first half AND their partners d + D/2 of a key row
       for (int i = tid; i < KCH * D / 8; i += 256) {
         const int key = i / (D / 8), c4 = i % (D / 8);
         const int krow = min(k0 + key, T - 1);
-        const float* base = qkv + ((size_t)b * T + krow) * ld + qd + hk * D + c4 * 4;
+        const int kvo = krow < Np ? kv_heads * D : kd;   // distance from a row's k to its v: [k | v] in the prefix cache, q | k | v in qkv
+        const float* base = krow < Np ? pre + ((size_t)b * Np + krow) * ldp + hk * D + c4 * 4
+                                      : qkv + ((size_t)b * Ts + (krow - Np)) * ld + qd + hk * D + c4 * 4;
         const float4 a = *reinterpret_cast<const float4*>(base), bb = *reinterpret_cast<const float4*>(base + D / 2);
         const float2* t = rope + (size_t)krow * (D / 2) + c4 * 4;
         const float4 cs0 = *reinterpret_cast<const float4*>(t), cs1 = *reinterpret_cast<const float4*>(t + 2);
@@ -301,16 +308,18 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
             make_float4(a.x * cs0.x - bb.x * cs0.y, a.y * cs0.z - bb.y * cs0.w, a.z * cs1.x - bb.z * cs1.y, a.w * cs1.z - bb.w * cs1.w);
         *reinterpret_cast<float4*>(sK + key * LDR + D / 2 + c4 * 4) =
             make_float4(bb.x * cs0.x + a.x * cs0.y, bb.y * cs0.z + a.y * cs0.w, bb.z * cs1.x + a.z * cs1.y, bb.w * cs1.z + a.w * cs1.w);
-        *reinterpret_cast<float4*>(sV + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base + kd);
-        *reinterpret_cast<float4*>(sV + key * LDR + D / 2 + c4 * 4) = *reinterpret_cast<const float4*>(base + kd + D / 2);
+        *reinterpret_cast<float4*>(sV + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base + kvo);
+        *reinterpret_cast<float4*>(sV + key * LDR + D / 2 + c4 * 4) = *reinterpret_cast<const float4*>(base + kvo + D / 2);
       }
     } else {
       for (int i = tid; i < KCH * D / 4; i += 256) {
         const int key = i / (D / 4), c4 = i % (D / 4);
         const int krow = min(k0 + key, T - 1);
-        const float* base = qkv + ((size_t)b * T + krow) * ld + qd + hk * D + c4 * 4;
+        const int kvo = krow < Np ? kv_heads * D : kd;
+        const float* base = krow < Np ? pre + ((size_t)b * Np + krow) * ldp + hk * D + c4 * 4
+                                      : qkv + ((size_t)b * Ts + (krow - Np)) * ld + qd + hk * D + c4 * 4;
         *reinterpret_cast<float4*>(sK + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base);
-        *reinterpret_cast<float4*>(sV + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base + kd);
+        *reinterpret_cast<float4*>(sV + key * LDR + c4 * 4) = *reinterpret_cast<const float4*>(base + kvo);
       }
     }
     __syncthreads();
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
   l_run += __shfl_xor(l_run, 32, 64);
   if (qg >= T) return;
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-  const size_t ob = ((size_t)b * T + qg) * ldo + h * D + 4 * fg;   // lane: query qg, d = 16 dt + 4 fg + r
+  const size_t ob = ((size_t)b * Ts + (qg - Np)) * ldo + h * D + 4 * fg;   // lane: query qg, d = 16 dt + 4 fg + r
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
     float v4[4];
@@ -455,8 +464,12 @@ int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, in
 }
 
 int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
-                         int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope) {
+                         int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope,
+                         const float* pre, int ldp, int Np) {
   if (!qkv || !out_hi || !out_lo) return fv_fail(FV_ERR_ARG, "attention_f32: null pointer");
+  if (pre && (Np <= 0 || Np >= T || ldp < 2 * kv_heads * D || ldp % 4 || D < 64))
+    return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: a cached prefix needs 0 < Np < T, ldp >= 2 * kv_heads * D and head_dim 64 / 128");
+  if (!pre) Np = 0;
   if (ldo < heads * D || ldo % 8) return fv_fail(FV_ERR_ARG, "attention_f32: bad ldo");
   if (B <= 0 || T <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads || ld % 4 || ld < (heads + 2 * kv_heads) * D)
     return fv_fail(FV_ERR_ARG, "attention_f32: bad shape");
@@ -464,11 +477,11 @@ int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int
   const int NT = D == 128 ? 2 : 1;
   if (D != 32 && D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: head_dim %d not in {32,64,128}", D);
   static const bool no_mfma = getenv("FASTVLA_NO_ATTN_F32_MFMA") != nullptr;
-  if (D >= 64 && !no_mfma) {
-    const long nb = (long)B * heads * ((T + 63) / 64);
+  if (D >= 64 && (!no_mfma || pre)) {
+    const long nb = (long)B * heads * ((T - Np + 63) / 64);
     // rope given: q and k are rotated inside the kernel (no separate pass over the packed projections)
-    if (D == 64) hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope);
-    else hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope);
+    if (D == 64) hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np);
+    else hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
   }

@@ -574,6 +574,78 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
   return FV_OK;
 }
 
+
+// The parity-mode decoder stack (llm_precision 1 / 2) over rows = B * Tq residual rows already in ws.x.
+//   DEC_FULL   : the whole sequence in one pass (Tq = every position; len_add = Ni image positions in front of the text)
+//   DEC_PREFIX : the image-token prefix alone (Tq = Np positions): every layer's UN-rotated [k | v] rows go to kv
+//                ([layer][B * Np][2 * kv_heads * D] fp32) and the stack stops after the last layer's projections
+//   DEC_SUFFIX : Tq = the text positions only, attending to kv's cached prefix (Np positions) + themselves
+// (the 256 image tokens come first in the causal sequence, so their K / V depend on the image alone.)
+enum DecMode { DEC_FULL = 0, DEC_PREFIX = 1, DEC_SUFFIX = 2 };
+int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const int32_t* lens, int len_add, float* kv, int Np, int mode,
+                         hipStream_t s) {
+  const fv_model_desc& d = h->d;
+  char* ws = static_cast<char*>(h->ws);
+  float* x = reinterpret_cast<float*>(ws + wp.x);
+  bf16_t* xn = reinterpret_cast<bf16_t*>(ws + wp.xn);
+  bf16_t* act = reinterpret_cast<bf16_t*>(ws + wp.act);
+  const int rows = B * Tq, Hd = d.llm_hidden, D = d.llm_head_dim;
+  const int qd = d.llm_heads * D, kd = d.llm_kv_heads * D, qkvw = qd + 2 * kd;
+  const int Tt = mode == DEC_SUFFIX ? Np + Tq : Tq;      // positions the attention sees
+  const float att_scale = 1.0f / std::sqrt((float)D);
+  {
+    // split-bf16 activations: every GEMM operand x is carried as hi + lo (16 significant bits) and multiplied in two
+    // MFMA passes against the exact bf16 weights; qkv / gate-up accumulators and attention stay fp32.
+    // hi and lo halves sit side by side ([rows][2K]) so each projection is ONE launch with a doubled K loop (ksplit)
+    bf16_t* xs = reinterpret_cast<bf16_t*>(ws + wp.xn_lo);    // [rows][2*Hd]
+    bf16_t* as = reinterpret_cast<bf16_t*>(ws + wp.att_lo);   // [rows][2*qd]
+    bf16_t* cs = reinterpret_cast<bf16_t*>(ws + wp.act_lo);   // [rows][2*I]
+    float* qkvf = reinterpret_cast<float*>(ws + wp.qkvf);
+    const int I = d.llm_inter, I2 = 2 * I;
+    const size_t kv_layer = (size_t)B * Np * 2 * kd;          // floats per layer of the prefix cache
+    for (size_t li = 0; li < h->dec.layers.size(); ++li) {
+      const DecLayer& L = h->dec.layers[li];
+      // layer 0 norms its own input; every later layer's input_layernorm output arrives from the previous layer's down
+      // projection (fused into its split-K reducer)
+      if (li == 0) FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
+      fv::GemmArgs q1{xs, 2 * Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkvf, qkvw, FV_EPI_F32, 1};
+      FV_TRY(gemm_p(h, q1, s));
+      if (mode == DEC_PREFIX) {   // this layer's [k | v] rows of the prefix, un-rotated (RoPE rides inside the attention kernel)
+        FV_HIP_CHECK(hipMemcpy2DAsync(kv + li * kv_layer, (size_t)2 * kd * 4, qkvf + qd, (size_t)qkvw * 4, (size_t)2 * kd * 4, (size_t)rows,
+                                      hipMemcpyDeviceToDevice, s));
+        if (li + 1 == h->dec.layers.size()) break;   // nothing downstream of the last layer's K / V is ever read
+      }
+      // RoPE rides inside the attention kernel (q fragments in registers, K rows on their way into LDS)
+      FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tq * Tt * qd + 3.0 * rows * (qd + kd), 4.0 * rows * (qkvw + qd),
+           fv::launch_attention_f32(qkvf, qkvw, as, as + qd, 2 * qd, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, len_add, att_scale, s, h->rope,
+                                    mode == DEC_SUFFIX ? kv + li * kv_layer : nullptr, 2 * kd, mode == DEC_SUFFIX ? Np : 0));
+      fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
+      FV_TRY(gemm_p(h, o1, s));
+      fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
+      if (d.llm_precision == 2) {
+        // the MLP in ONE pass on fp16 operands (tests/precision_budget.py): post-norm rows as fp16, SwiGLU output / 16 as fp16
+        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s, 1));
+        fv::GemmArgs g1{xn, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, act, I, FV_EPI_SWIGLU_F16, 0};
+        g1.f16 = 1;
+        FV_TRY(gemm_p(h, g1, s));
+        d1 = fv::GemmArgs{act, I, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 0};
+        d1.f16 = 1;
+      } else {
+        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
+        fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 1};
+        FV_TRY(gemm_p(h, g1, s));  // silu(gate)*up and its hi/lo split happen in the epilogue: no fp32 round trip
+      }
+      d1.splitk_ws = wp.splitk_bytes ? reinterpret_cast<float*>(ws + wp.splitk) : nullptr;
+      d1.splitk_bytes = wp.splitk_bytes;
+      if (li + 1 < h->dec.layers.size()) {
+        d1.norm_w = h->dec.layers[li + 1].ln1; d1.norm_y = xs; d1.norm_ylo = xs + Hd; d1.norm_ld = 2 * Hd; d1.norm_eps = d.rms_eps;
+      }
+      FV_TRY(gemm_p(h, d1, s));
+    }
+  }
+  return FV_OK;
+}
+
 }  // namespace
 
 // =============================================================================================== C ABI
@@ -914,49 +986,58 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
       FV_TRY(gemm_p(h, gd, s));
     }
   } else {
-    // split-bf16 activations: every GEMM operand x is carried as hi + lo (16 significant bits) and multiplied in two
-    // MFMA passes against the exact bf16 weights; qkv / gate-up accumulators and attention stay fp32.
-    // hi and lo halves sit side by side ([rows][2K]) so each projection is ONE launch with a doubled K loop (ksplit)
-    bf16_t* xs = reinterpret_cast<bf16_t*>(ws + wp.xn_lo);    // [rows][2*Hd]
-    bf16_t* as = reinterpret_cast<bf16_t*>(ws + wp.att_lo);   // [rows][2*qd]
-    bf16_t* cs = reinterpret_cast<bf16_t*>(ws + wp.act_lo);   // [rows][2*I]
-    float* qkvf = reinterpret_cast<float*>(ws + wp.qkvf);
-    const int I = d.llm_inter, I2 = 2 * I;
-    for (size_t li = 0; li < h->dec.layers.size(); ++li) {
-      const DecLayer& L = h->dec.layers[li];
-      // layer 0 norms its own input; every later layer's input_layernorm output arrives from the previous layer's down
-      // projection (fused into its split-K reducer)
-      if (li == 0) FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
-      fv::GemmArgs q1{xs, 2 * Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkvf, qkvw, FV_EPI_F32, 1};
-      FV_TRY(gemm_p(h, q1, s));
-      // RoPE rides inside the attention kernel (q fragments in registers, K rows on their way into LDS)
-      FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tt * Tt * qd + 3.0 * rows * (qd + kd), 4.0 * rows * (qkvw + qd),
-           fv::launch_attention_f32(qkvf, qkvw, as, as + qd, 2 * qd, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, Ni, att_scale, s, h->rope));
-      fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
-      FV_TRY(gemm_p(h, o1, s));
-      fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
-      if (d.llm_precision == 2) {
-        // the MLP in ONE pass on fp16 operands (tests/precision_budget.py): post-norm rows as fp16, SwiGLU output / 16 as fp16
-        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s, 1));
-        fv::GemmArgs g1{xn, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, act, I, FV_EPI_SWIGLU_F16, 0};
-        g1.f16 = 1;
-        FV_TRY(gemm_p(h, g1, s));
-        d1 = fv::GemmArgs{act, I, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 0};
-        d1.f16 = 1;
-      } else {
-        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
-        fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 1};
-        FV_TRY(gemm_p(h, g1, s));  // silu(gate)*up and its hi/lo split happen in the epilogue: no fp32 round trip
-      }
-      d1.splitk_ws = wp.splitk_bytes ? reinterpret_cast<float*>(ws + wp.splitk) : nullptr;
-      d1.splitk_bytes = wp.splitk_bytes;
-      if (li + 1 < h->dec.layers.size()) {
-        d1.norm_w = h->dec.layers[li + 1].ln1; d1.norm_y = xs; d1.norm_ylo = xs + Hd; d1.norm_ld = 2 * Hd; d1.norm_eps = d.rms_eps;
-      }
-      FV_TRY(gemm_p(h, d1, s));
-    }
+    FV_TRY(decoder_layers_split(h, wp, B, Tt, lens, Ni, nullptr, 0, DEC_FULL, s));
   }
   FV_P(FV_FAM_ELT, 4.0 * B * Hd, 8.0 * B * Hd, fv::launch_pool_norm(x, lens, h->dec.norm, static_cast<float*>(pooled), B, Tt, Ni, Hd, d.rms_eps, pool_mode, s));
+  return FV_OK;
+}
+
+// ---- image-prefix reuse.  The spliced sequence is [Ni image tokens | T text tokens] under a causal mask: the
+// keys / values of the image positions depend on the image alone.  fv_llm_prefix runs those positions once and keeps every layer's
+// [k | v] rows; fv_llm_forward_pooled_prefixed then runs only the text positions against them -- same arithmetic as
+// fv_llm_forward_pooled(img_tokens != NULL), 1/5 of its rows at T = 64, and no tower / projector / prefix pass at all for an image
+// (or a batch of images) whose prefix is already held.
+int fv_llm_prefix_bytes(fv_handle* h, int B, int Ni, size_t* out_bytes) {
+  HandleScope _hs(h);
+  if (!h || !out_bytes || B <= 0 || Ni <= 0) return fv_fail(FV_ERR_ARG, "fv_llm_prefix_bytes: bad argument");
+  *out_bytes = (size_t)h->d.llm_layers * B * Ni * 2 * h->d.llm_kv_heads * h->d.llm_head_dim * sizeof(float);
+  return FV_OK;
+}
+
+int fv_llm_prefix(fv_handle* h, const void* img_tokens, int Ni, int B, void* kv_out, fv_stream st) {
+  HandleScope _hs(h);
+  FV_TRY(check_ready(h, true));
+  if (!img_tokens || !kv_out || B <= 0 || Ni <= 0) return fv_fail(FV_ERR_ARG, "fv_llm_prefix: bad argument");
+  const fv_model_desc& d = h->d;
+  if (d.llm_precision == 0 || d.llm_head_dim < 64) return fv_fail(FV_ERR_UNSUPPORTED, "fv_llm_prefix: needs llm_precision 1 / 2 and head_dim 64 / 128");
+  const int Pside = d.image_size >> (d.tower_stages + 1);
+  if (B > d.max_batch || Ni > Pside * Pside) return fv_fail(FV_ERR_ARG, "fv_llm_prefix: B=%d / Ni=%d exceed the handle's capacity", B, Ni);
+  const WsPlan wp = plan_ws(h, B, 1, 1);
+  if (wp.total > h->ws_bytes) return fv_fail(FV_ERR_STATE, "workspace too small (%zu > %zu)", wp.total, h->ws_bytes);
+  hipStream_t s = static_cast<hipStream_t>(st);
+  float* x = reinterpret_cast<float*>(static_cast<char*>(h->ws) + wp.x);
+  FV_HIP_CHECK(hipMemcpyAsync(x, img_tokens, (size_t)B * Ni * d.llm_hidden * 4, hipMemcpyDeviceToDevice, s));   // the prefix IS the image tokens
+  return decoder_layers_split(h, wp, B, Ni, nullptr, 0, static_cast<float*>(kv_out), Ni, DEC_PREFIX, s);
+}
+
+int fv_llm_forward_pooled_prefixed(fv_handle* h, const int32_t* ids, const int32_t* lens, const void* kv, int Ni, int B, int T,
+                                   int pool_mode, void* pooled, fv_stream st) {
+  HandleScope _hs(h);
+  FV_TRY(check_ready(h, true));
+  if (!ids || !lens || !kv || !pooled || B <= 0 || T <= 0 || Ni <= 0) return fv_fail(FV_ERR_ARG, "fv_llm_forward_pooled_prefixed: bad argument");
+  const fv_model_desc& d = h->d;
+  if (d.llm_precision == 0 || d.llm_head_dim < 64) return fv_fail(FV_ERR_UNSUPPORTED, "fv_llm_forward_pooled_prefixed: needs llm_precision 1 / 2 and head_dim 64 / 128");
+  if (pool_mode != 0) return fv_fail(FV_ERR_UNSUPPORTED, "fv_llm_forward_pooled_prefixed: mean_pool averages the image positions too, which this pass does not recompute");
+  if (T + Ni > h->rope_rows) return fv_fail(FV_ERR_ARG, "sequence of %d tokens exceeds the RoPE table (%d)", T + Ni, h->rope_rows);
+  if (B > d.max_batch) return fv_fail(FV_ERR_ARG, "B=%d exceeds max_batch=%d", B, d.max_batch);
+  const WsPlan wp = plan_ws(h, B, T, 1);
+  if (wp.total > h->ws_bytes) return fv_fail(FV_ERR_STATE, "workspace too small (%zu > %zu)", wp.total, h->ws_bytes);
+  hipStream_t s = static_cast<hipStream_t>(st);
+  float* x = reinterpret_cast<float*>(static_cast<char*>(h->ws) + wp.x);
+  const int Hd = d.llm_hidden;
+  FV_P(FV_FAM_ELT, 0.0, 6.0 * B * T * Hd, fv::launch_embed_gather(ids, h->dec.embed, nullptr, x, B, T, 0, Hd, d.llm_vocab, s));
+  FV_TRY(decoder_layers_split(h, wp, B, T, lens, Ni, const_cast<float*>(static_cast<const float*>(kv)), Ni, DEC_SUFFIX, s));
+  FV_P(FV_FAM_ELT, 4.0 * B * Hd, 8.0 * B * Hd, fv::launch_pool_norm(x, lens, h->dec.norm, static_cast<float*>(pooled), B, T, 0, Hd, d.rms_eps, 0, s));
   return FV_OK;
 }
 

@@ -91,7 +91,8 @@ int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, in
 // rope != null: qkv holds un-rotated projections; the rotate-half RoPE is fused into the MFMA kernel (head_dim 64 / 128) or applied
 // in place by a rope_f32 launch ahead of the VALU kernel (head_dim 32)
 int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
-                         int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope = nullptr);
+                         int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope = nullptr,
+                         const float* pre = nullptr, int ldp = 0, int Np = 0);   // pre: cached [k | v] rows of positions < Np (8f-1)
 // table: [>=T][D/2] (cos, sin) pairs built by rope_table_host(); position = row % T
 int launch_rope(bf16_t* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D,
                 hipStream_t s);

@@ -84,6 +84,9 @@ SIGNATURES = {
     "fv_vision_unit_info": (_i, [_vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "fv_vision_forward_unit_taps": (_i, [_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), _i, _vp]),
     "fv_llm_forward_pooled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "fv_llm_prefix_bytes": (_i, [_vp, _i, _i, C.POINTER(C.c_size_t)]),
+    "fv_llm_prefix": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "fv_llm_forward_pooled_prefixed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fv_head_layout": (_i, [_vp, C.POINTER(_i64 * 13)]),
     "fv_head_saved_bytes": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
     "fv_head_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _u64, _u64, _vp, _vp, _vp]),

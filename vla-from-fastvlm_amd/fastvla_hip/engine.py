@@ -243,6 +243,31 @@ class FastVLAEngine:
                                                   pool_mode, pooled.data_ptr(), _stream()), "fv_llm_forward_pooled")
         return pooled
 
+    # ---------------------------------------------------------------- image-prefix reuse
+    def llm_prefix(self, img_tokens: torch.Tensor) -> torch.Tensor:
+        """(B, Ni, H) f32 image tokens -> the decoder's prefix cache: every layer's un-rotated [k | v] rows of the Ni image positions,
+        (layers, B, Ni, 2 * kv_heads * head_dim) f32.  Rows of different images are independent: slices along B can be kept and
+        re-assembled per frame."""
+        B, Ni, _ = img_tokens.shape
+        l = self.model.llm
+        self.ensure_workspace(B, 1, True)
+        kv = torch.empty(l.layers, B, Ni, 2 * l.kv_heads * l.head_dim, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.fv_llm_prefix(self.h, img_tokens.contiguous().data_ptr(), Ni, B, kv.data_ptr(), _stream()), "fv_llm_prefix", self.h)
+        return kv
+
+    def llm_pooled_prefixed(self, ids: torch.Tensor, lens: torch.Tensor, kv: torch.Tensor) -> torch.Tensor:
+        """The text positions alone against a prefix cache from llm_prefix(): the pooled rows of llm_pooled(ids, lens, img_tokens)."""
+        B, T = ids.shape
+        if kv.ndim != 4 or kv.shape[1] != B:
+            raise ValueError(f"prefix cache must be (layers, B={B}, Ni, 2*kv_dim), got {tuple(kv.shape)}")
+        ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        lens = lens.to(device=self.device, dtype=torch.int32).contiguous()
+        self.ensure_workspace(B, T, True)
+        pooled = torch.empty(B, self.model.llm.hidden, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.fv_llm_forward_pooled_prefixed(self.h, ids.data_ptr(), lens.data_ptr(), kv.contiguous().data_ptr(), kv.shape[2], B, T, 0,
+                                                           pooled.data_ptr(), _stream()), "fv_llm_forward_pooled_prefixed", self.h)
+        return pooled
+
     def backbone(self, images: Optional[torch.Tensor], ids: torch.Tensor, lens: torch.Tensor, *, splice: bool = False,
                  run_tower: bool = True, pad_value: float = 0.0, resize_with_padding: bool = True,
                  pool_mode: int = 0, pix: Optional[torch.Tensor] = None) -> torch.Tensor:

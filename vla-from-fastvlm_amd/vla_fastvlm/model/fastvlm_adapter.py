@@ -166,6 +166,12 @@ class FastVLMBackbone(nn.Module):
         self.prompt_cache_size = 256
         # ... and the tower, whose output the literal reference computes and never consumes
         self.skip_unused_tower = os.environ.get("FASTVLA_SKIP_UNUSED_TOWER", "0") == "1"
+        # SPLICE mode (image tokens in front of the text): the decoder's keys / values of the image positions depend on the image
+        # alone, so they are kept per image (LRU keyed by a 128-bit hash of the image tensor, computed on the device): a repeated
+        # frame -- or further prompts on the same frame -- skips letterbox, tower, projector and the 256-token prefix pass, and
+        # even a new frame runs its text positions against the prefix instead of one joint 320-token prefill
+        self.cache_image_prefix = os.environ.get("FASTVLA_PREFIX_CACHE", "0") == "1"
+        self.prefix_cache_size = 64
         self._engine: Optional[FastVLAEngine] = None
         self._io_norm: Optional[dict] = None   # dataset statistics folded into the head kernels (set_io_normalization)
         self._head_dims = dict(state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024)
@@ -362,12 +368,15 @@ class FastVLMBackbone(nn.Module):
     def forward_ids(self, images, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
         """Pre-tokenised entry (the benchmark bypasses the host tokenizer): -> pooled (B, hidden) f32."""
         eng = self.engine()
-        pix = self._prepare_images_tensor(images, eng.device)
-        if pix.shape[0] != input_ids.shape[0]:
-            raise ValueError(f"batch mismatch: {pix.shape[0]} images vs {input_ids.shape[0]} prompts")
         lens = attention_mask.to(torch.int32).sum(dim=1).to(torch.int32)
         mode = 0 if self.config.image_feature_pool == "last_token" else 1
         literal = not self.splice_image_tokens
+        if (not literal and self.cache_image_prefix and mode == 0 and eng.llm_precision >= 1 and eng.model.llm.head_dim >= 64
+                and torch.is_tensor(images) and images.ndim == 4):
+            return self._pooled_through_prefix_cache(eng, images, input_ids, lens)
+        pix = self._prepare_images_tensor(images, eng.device)
+        if pix.shape[0] != input_ids.shape[0]:
+            raise ValueError(f"batch mismatch: {pix.shape[0]} images vs {input_ids.shape[0]} prompts")
         if literal and not self.skip_unused_tower and not self.cache_prompt_features:
             # the reference-literal step: tower + projector run (their output is dropped, SURVEY.md fact 5) BESIDE the decoder on
             # a second HIP stream -- the same schedule bench.py times at the engine level
@@ -394,6 +403,51 @@ class FastVLMBackbone(nn.Module):
             while len(cache) > max(int(self.prompt_cache_size), len(keys)):
                 cache.pop(next(iter(cache)))   # dicts keep insertion order: drop the oldest
         return torch.stack([cache[k] for k in keys], dim=0)
+
+    def _image_keys(self, images: Tensor) -> List[tuple]:
+        """One 128-bit key per image: two wrapping int64 dot products of the image's raw words with fixed odd multipliers, on the
+        device (one small D2H copy per call).  Equal tensors give equal keys; a collision needs both 64-bit sums to agree."""
+        x = images.contiguous()
+        words = x.view(x.shape[0], -1).view(torch.int16 if x.element_size() == 2 else torch.int32 if x.element_size() == 4 else torch.uint8)
+        n = words.shape[1]
+        mult = self.__dict__.setdefault("_hash_mult", {})
+        if (n, str(x.device)) not in mult:
+            g = torch.Generator().manual_seed(0x5eed)
+            mult[(n, str(x.device))] = (torch.randint(-2 ** 62, 2 ** 62, (2, n), generator=g, dtype=torch.int64) | 1).to(x.device)
+        m = mult[(n, str(x.device))]
+        w64 = words.to(torch.int64)
+        h = torch.stack([(w64 * m[0]).sum(1), (w64 * m[1]).sum(1)], dim=1).cpu()
+        return [(str(x.dtype), tuple(x.shape[1:]), int(h[b, 0]), int(h[b, 1])) for b in range(x.shape[0])]
+
+    def _pooled_through_prefix_cache(self, eng, images: Tensor, input_ids: Tensor, lens: Tensor) -> Tensor:
+        """Splice mode: per-image decoder prefixes (FastVLAEngine.llm_prefix) from the LRU, tower + prefix pass only for the images
+        that miss, then ONE suffix pass over the text positions of the whole batch (llm_pooled_prefixed)."""
+        images = images.to(eng.device)
+        if images.shape[0] != input_ids.shape[0]:
+            raise ValueError(f"batch mismatch: {images.shape[0]} images vs {input_ids.shape[0]} prompts")
+        cache = self.__dict__.setdefault("_prefix_cache", {})
+        keys = self._image_keys(images)
+        miss = [b for b, k in enumerate(keys) if k not in cache]
+        first = {}
+        for b in miss:
+            first.setdefault(keys[b], b)           # the same frame twice in one batch is computed once
+        todo = list(first.values())
+        if todo:
+            sel = torch.as_tensor(todo, device=images.device)
+            pix = self._prepare_images_tensor(images.index_select(0, sel), eng.device)
+            kv = eng.llm_prefix(eng.vision_forward(pix))
+            for j, b in enumerate(todo):
+                cache[keys[b]] = kv[:, j].clone()
+        for k in keys:                              # refresh recency, oldest first in the dict
+            cache[k] = cache.pop(k)
+        kvb = torch.stack([cache[k] for k in keys], dim=1)
+        while len(cache) > max(int(self.prefix_cache_size), len(set(keys))):
+            cache.pop(next(iter(cache)))
+        self._prefix_stats = {"images": len(keys), "tower_runs": len(todo)}
+        return eng.llm_pooled_prefixed(input_ids, lens, kvb)
+
+    def clear_prefix_cache(self) -> None:
+        self.__dict__.get("_prefix_cache", {}).clear()
 
     def clear_prompt_cache(self) -> None:
         self.__dict__.get("_prompt_cache", {}).clear()
