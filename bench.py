@@ -59,6 +59,7 @@ def parse():
                          "north_star's 1e-3 with a 2x margin, tests/precision_budget.py); 0 = plain bf16 operands (~8e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second engine that times the OTHER decoder parity mode (llm_precision 1 <-> 2)")
     ap.add_argument("--no-surface", action="store_true", help="skip the plugin-surface leg (FastVLAPolicy.select_action / forward)")
     ap.add_argument("--cpu-sample", type=int, default=6)   # ~12 s of host work on 16 threads
     ap.add_argument("--no-c1", action="store_true", help="skip the C1 (bs=4, 32-token, train step) CPU protocol of BASELINE.md section 3")
@@ -388,6 +389,27 @@ def main():
                    "api": "vla_fastvlm.lerobot_fastvla.FastVLAPolicy.select_action(batch) / .forward(batch)"}
         del pol
 
+    # ---- the other decoder parity mode on a second engine (same weights, inputs, head): the default policy (arch.default_llm_precision)
+    # trades the decoder's 1e-5 for ~5e-4 on the actions; both numbers belong in one line
+    alt = None
+    if rank == 0 and world == 1 and not args.no_alt and w is not None and args.llm_precision in (1, 2) and not args.splice:
+        ap_ = 3 - args.llm_precision
+        eng2 = FastVLAEngine(model, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, device=dev, max_batch=B, max_text_tokens=T,
+                             tower_microbatch=args.microbatch, llm_precision=ap_)
+        eng2.load_weights(w)
+
+        def step_alt():
+            pooled = eng2.backbone(images[:B], ids[:B], lens[:B])
+            return eng2.head_forward(flat, pooled, states[:B])[0]
+
+        ela = timed(step_alt, args.steps, args.warmup)
+        a_main, a_alt = step_infer(), step_alt()
+        alt = {"llm_precision": ap_, "ms_per_step": round(1e3 * ela / args.steps, 3), "value": round(args.steps / ela, 4),
+               "actions_rel_l2_vs_default_mode": float((a_alt - a_main).norm() / a_main.norm())}
+        holder_alt = a_alt[: args.cpu_sample].cpu()
+        eng2.close()
+        del eng2
+
     # ---- splice mode only: what the image-prefix cache changes.  joint = ONE prefill over 256 image + T text
     # positions (the timed step above); new frames = tower + prefix pass (image positions, K / V kept) + suffix pass (text
     # positions); cached frames = the suffix pass alone (a repeated frame, or another prompt on the same frame)
@@ -434,6 +456,8 @@ def main():
         cel = time.perf_counter() - t
         got = step_infer()[:n].cpu()
         err = float((got - ref).norm() / ref.norm())
+        if alt is not None:
+            alt["parity_actions_rel_l2"] = float((holder_alt[:n] - ref).norm() / ref.norm())
         cpu = {"value": round((n / cel) / B, 5), "unit": f"steps/s (bs={B} equivalent)", "cores": torch.get_num_threads(),
                "kind": "port", "samples_per_s": round(n / cel, 3), "seconds": round(cel, 2),
                "sample": f"{n} images {args.image}x{args.image} + {T}-token prompts, one forward "
@@ -541,7 +565,7 @@ def main():
                        "llm_precision": {0: "bf16 operands", 1: "split-bf16 (hi+lo) operands, fp32 attention",
                                          2: "split-bf16 qkv/o, fp16 gate/up/down (one pass), fp32 attention"}[args.llm_precision]},
             "samples_per_s": round(value * B, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
         }
         print(json.dumps(out))
