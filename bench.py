@@ -59,6 +59,10 @@ def parse():
                          "north_star's 1e-3 with a 2x margin, tests/precision_budget.py); 0 = plain bf16 operands (~8e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--fv-comm-check", action="store_true",
+                    help="N > 1 on the RCCL backend: also build a communicator through the library's own C ABI (fv_comm_*) and push one "
+                         "all-reduce of ones through fv_allreduce_grads (off by default: the timed path uses torch.distributed's communicator, "
+                         "and a second communicator is one more thing that can stall a scaling run)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second engine that times the OTHER decoder parity mode (llm_precision 1 <-> 2)")
     ap.add_argument("--no-surface", action="store_true", help="skip the plugin-surface leg (FastVLAPolicy.select_action / forward)")
     ap.add_argument("--cpu-sample", type=int, default=6)   # ~12 s of host work on 16 threads
@@ -142,12 +146,12 @@ def main():
         eng.load_weights(w)
     t_load = time.time() - t0
 
-    # what the communication layer itself reports (N > 1): torch.distributed's world and, on the RCCL backend, a communicator made
-    # through the library's own C ABI (fv_comm_*) with one all-reduce through fv_allreduce_grads as a live check
+    # what the communication layer itself reports (N > 1): torch.distributed's world and, with --fv-comm-check on the RCCL backend, a
+    # communicator made through the library's own C ABI (fv_comm_*) with one all-reduce through fv_allreduce_grads as a live check
     dist_info = None
     if world > 1:
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": torch.cuda.get_device_name(dev)}
-        if args.backend == "nccl" and ndev >= world:
+        if args.fv_comm_check and args.backend == "nccl" and ndev >= world:
             box = [eng.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             comm = eng.comm_init(box[0], rank, world)
