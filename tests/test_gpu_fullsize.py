@@ -525,11 +525,12 @@ def test_decoder_precision_budget_full_size(full):
     ids = torch.randint(0, 151643, (B, T))
     mask = torch.ones(B, T, dtype=torch.long)
     mask[1, 23:] = 0
-    states = torch.randn(B, 14)
+    states, tgt = torch.randn(B, 14), torch.randn(B, 14)
     p = _head_params(lc, 72)
     with torch.no_grad():
         ref_pooled = qwen2.llm_pooled(w, ids, mask, lc)
-        ref_act = head.head_forward(p, ref_pooled, states)
+        ref_act, cache = head.head_forward(p, ref_pooled, states, keep_cache=True)
+        ref_loss, ref_grads = head.head_mse_backward(p, cache, ref_act, tgt)
     out = {}
     for prec in (1, 2, 0):
         eng = eng1 if prec == 1 else FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=8,
@@ -538,9 +539,16 @@ def test_decoder_precision_budget_full_size(full):
             eng.load_weights(w)
         flat = _flat_head(eng, p)
         pooled = eng.llm_pooled(ids, mask.sum(1))
-        act, _ = eng.head_forward(flat, pooled, states.to(DEV))
+        act, saved = eng.head_forward(flat, pooled, states.to(DEV))
+        loss, grads = eng.head_backward(flat, act, tgt.to(DEV), saved)
         torch.cuda.synchronize()
         out[prec] = (rel_l2(pooled.cpu(), ref_pooled), rel_l2(act.cpu(), ref_act))
+        if prec == 2:   # the product's default mode for this model: the C1-style quantities too (loss, all 12 gradients)
+            rl = abs(float(loss) - float(ref_loss)) / float(ref_loss)
+            gv = eng.head_views(grads)
+            rg = max(rel_l2(gv[k].cpu(), ref_grads[k]) for k in head.HEAD_KEYS)
+            print(f"[llm_precision=2] loss rel {rl:.2e}, worst gradient rel_l2 {rg:.2e}")
+            assert rl <= 2e-3 and rg <= 2e-3
         if prec != 1:
             eng.close()
     print("[decoder precision budget, fastvlm-0.5b B=8 T=64] (pooled, actions) rel_l2:  " +
