@@ -136,9 +136,10 @@ def main():
                         llm_precision=args.llm_precision)
     t0 = time.time()
     big = 3 * model.llm.hidden * model.llm.inter * model.llm.layers > 2e9   # 7B: 7.6 G parameters = 30 GB as an fp32 host dict
-    if big:
+    if big or world > 1:
         # streamed: every decoder tensor is drawn on the device in bf16 when the packer asks for it (fv_load_weights_cb);
-        # identical on every rank (seeded by name).  No host copy exists, so the CPU-oracle legs are skipped for this model.
+        # identical on every rank (seeded by name).  No host copy exists, so the CPU-oracle legs are skipped for this model --
+        # and N ranks of one host do not each build a 2.5 GB fp32 dict with all host cores at once (the oracle legs are N = 1 only)
         w = None
         eng.load_weights_streaming(weights.stream_backbone(model, seed=args.seed, device=dev))
     else:
