@@ -120,6 +120,11 @@ int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hi
  * pix (B,S,S,4) bf16 -> img_tokens (B, (S/64)^2, llm_hidden) f32.  tower_out (B,(S/64)^2,tower_out_dim) bf16 may be
  * NULL. */
 int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, fv_stream s);
+/* fv_preprocess + fv_vision_forward in one (the on-device input pipeline): the stem kernel samples the SOURCE images
+ * (B,C,Hin,Win) f32 | u8 through resize_with_pad's arithmetic itself (model/fastvlm_adapter.py:36-55,479-488 then :533), so the letterboxed
+ * (B,S,S,4) frame is never written or read.  Same tokens as the two-call form, bit for bit.  Needs the fused stem (first stage width 96). */
+int fv_vision_forward_images(fv_handle* h, const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value, int resize_with_padding,
+                             void* img_tokens, void* tower_out, fv_stream s);
 /* fv_vision_forward that also copies intermediate activation maps out (parity tests name the failing stage with them):
  * taps[0] <- stem output (B,S/4,S/4,dims[0]), taps[1+i] <- output of stage i (B, S/(4<<i), S/(4<<i), dims[i]), bf16 NHWC
  * device buffers; NULL entries are skipped; n_taps <= tower_stages + 1.  The mirror of the oracle's `taps=` argument. */
@@ -260,6 +265,10 @@ int fv_op_stem_mfma(const void* pix, const void* wp, const float* bias, void* y,
  * (rounded to bf16 there exactly as the unfused pair rounds it to memory).  Cout must be 96, S % 4 == 0. */
 int fv_op_stem_fused(const void* pix, const void* wp, const float* b1, const float* w2, const float* b2, void* y, int B,
                      int S, int Cout, fv_stream s);
+/* fv_op_stem_fused reading the SOURCE images (B,C,Hin,Win) f32 | u8 through the letterbox arithmetic of fv_preprocess (the kernel behind
+ * fv_vision_forward_images): y must equal fv_op_stem_fused on fv_preprocess's output bit for bit */
+int fv_op_stem_fused_images(const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value, int resize_with_padding, const void* wp,
+                            const float* b1, const float* w2, const float* b2, void* y, int S, int Cout, fv_stream s);
 /* per-pixel LayerNorm over channels (LayerNormChannel), x,y (rows,C) bf16 */
 int fv_op_layernorm_rows(const void* x, const float* w, const float* b, void* y, int rows, int C, float eps,
                          fv_stream s);

@@ -578,3 +578,24 @@ def test_image_prefix_cache_full_size(full):
     r, r2 = rel_l2(pref.cpu(), joint.cpu()), rel_l2(a.cpu(), b.cpu())
     print(f"[prefix cache fastvlm-0.5b, Ni=256, T=32] prefixed vs joint prefill {r:.2e}; re-paired rows {r2:.2e}; cache {kv.numel() * 4 / B / 2**20:.1f} MiB per image")
     assert torch.isfinite(pref).all() and r <= 2e-4 and r2 <= 2e-4
+
+
+@pytest.mark.parametrize("kind", ["f32", "u8", "gray-odd-shape"])
+def test_fused_letterbox_stem_equals_two_call_form(full, kind):
+    """fv_vision_forward_images = fv_preprocess + fv_vision_forward with the letterbox folded into the stem kernel (the
+    1024^2 frame never reaches HBM; reference: the CPU resize + H2D of model/fastvlm_adapter.py:479-488 ahead of the VLM call at :533).
+    The stem samples the source image with letterbox_kernel's own arithmetic, so the image tokens must be BIT-identical -- for float and
+    uint8 sources, RGB and gray, square and non-square (left / top padding, fastvlm_adapter.py:36-55)."""
+    m, w, eng = full
+    g = torch.Generator().manual_seed(91)
+    if kind == "f32":
+        img = torch.rand(3, 3, 336, 336, generator=g)
+    elif kind == "u8":
+        img = torch.randint(0, 256, (2, 3, 336, 336), generator=g, dtype=torch.uint8)
+    else:
+        img = torch.rand(2, 1, 210, 333, generator=g)
+    img = img.to(DEV)
+    a, ta = eng.vision_forward(eng.preprocess(img, pad_value=0.25), return_tower_out=True)
+    b, tb = eng.vision_forward_images(img, pad_value=0.25, return_tower_out=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(b).all() and torch.equal(ta, tb) and torch.equal(a, b)

@@ -682,3 +682,28 @@ def test_gemm_f16_swiglu(M, I, K):
          "fv_op_gemm_f16 swiglu")
     torch.cuda.synchronize()
     check_close(out.float().cpu(), ref, rel=6e-4, amax=2e-3, what=f"f16 swiglu {M}x{I}x{K}")   # fp16 output rounding: 2^-11
+
+
+@pytest.mark.parametrize("dtype,Cin,Hin,Win", [("f32", 3, 84, 84), ("u8", 3, 60, 100), ("f32", 1, 97, 41)])
+def test_stem_fused_from_source_images(dtype, Cin, Hin, Win):
+    """the stem that samples the SOURCE image through the letterbox arithmetic (fv_op_stem_fused_images, the kernel
+    behind fv_vision_forward_images) against fv_preprocess + fv_op_stem_fused: bit-identical (reference: resize_with_pad,
+    model/fastvlm_adapter.py:36-55, ahead of the tower at :533) -- float and uint8 sources, RGB and gray, square and not."""
+    from fastvla_hip import FastVLAEngine, arch
+    S, B, C0 = 256, 2, 96
+    m = arch.ModelConfig("lb", arch.LLMConfig(hidden=64, layers=1, heads=2, kv_heads=1, head_dim=32, inter=64, vocab=64),
+                         arch.TowerConfig(layers=(1,), dims=(32,), attn_stages=(), image_size=S))
+    eng = FastVLAEngine(m, hidden_dim=32, fusion_dim=32, max_batch=B, max_text_tokens=8)
+    g = torch.Generator().manual_seed(Hin + Win)
+    img = (torch.rand(B, Cin, Hin, Win, generator=g) if dtype == "f32" else torch.randint(0, 256, (B, Cin, Hin, Win), generator=g, dtype=torch.uint8)).to(DEV)
+    pix = eng.preprocess(img, 0.25, True)
+    wp, b1 = dev_bf16(torch.randn(C0, 64, generator=g) / 5), dev_f32(torch.randn(C0, generator=g) * 0.1)
+    w2, b2 = dev_f32(torch.randn(9, C0, generator=g) / 3), dev_f32(torch.randn(C0, generator=g) * 0.1)
+    ya = torch.full((B, S // 4, S // 4, C0), float("nan"), dtype=torch.bfloat16, device=DEV)
+    yb = torch.full_like(ya, float("nan"))
+    call(lib().fv_op_stem_fused(pix.data_ptr(), wp.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), ya.data_ptr(), B, S, C0, stream()), "fv_op_stem_fused")
+    call(lib().fv_op_stem_fused_images(img.data_ptr(), _lib.FV_F32 if dtype == "f32" else _lib.FV_U8, B, Cin, Hin, Win, 0.25, 1, wp.data_ptr(), b1.data_ptr(),
+                                       w2.data_ptr(), b2.data_ptr(), yb.data_ptr(), S, C0, stream()), "fv_op_stem_fused_images")
+    torch.cuda.synchronize()
+    assert torch.isfinite(yb.float()).all() and torch.equal(ya, yb)
+    eng.close()

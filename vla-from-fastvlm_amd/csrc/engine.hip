@@ -124,6 +124,8 @@ struct fv_handle {
                               // buffer is only the staging area
   void* const* taps = nullptr;  // fv_vision_forward_taps: per-stage copies of the activation map (parity tests)
   int n_taps = 0;
+  struct LbSrc { const void* img; int dtype, C, Hin, Win; float pad; int letterbox; };
+  const LbSrc* lbsrc = nullptr;  // fv_vision_forward_images: the stem samples the source images itself (no letterboxed frame)
   void* const* utaps = nullptr; // fv_vision_forward_unit_taps: one copy per tower unit (stem, RepCPE, block, PatchEmbed)
   int n_utaps = 0;
   void* rccl = nullptr;       // dlopen handle of librccl (fv_comm_* / fv_allreduce_grads), resolved on first use
@@ -492,7 +494,16 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
   float* se = reinterpret_cast<float*>(ws + wp.se);
   const int S = d.image_size, C0 = d.tower_dims[0];
   static const bool fuse_stem = !getenv("FASTVLA_NO_FUSED_STEM");
-  if (fuse_stem && tw.stem0_wp && fv::stem_fused_supported(S, C0)) {
+  if (h->lbsrc) {
+    // letterbox + both stem convolutions in one kernel: neither the 1024^2 frame nor the half-resolution map exists in HBM
+    const fv_handle::LbSrc& L = *h->lbsrc;
+    if (!(tw.stem0_wp && fv::stem_fused_supported(S, C0))) return fv_fail(FV_ERR_UNSUPPORTED, "fv_vision_forward_images needs the fused stem (first stage width 96)");
+    const size_t per = (size_t)L.C * L.Hin * L.Win * (L.dtype == FV_U8 ? 1 : 4);
+    FV_P(FV_FAM_STEM, 2.0 * mb * (S / 2) * (S / 2) * 27 * C0 + dw_flops(mb, S / 4, S / 4, C0, 3) + 30.0 * mb * S * S,
+         (double)mb * per + (double)mb * (S / 4) * (S / 4) * C0 * 2,
+         fv::launch_stem_fused_lb(static_cast<const char*>(L.img) + (size_t)b0 * per, L.dtype, mb, L.C, L.Hin, L.Win, L.pad, L.letterbox, tw.stem0_wp,
+                                  tw.stem0_b, tw.stem1_w, tw.stem1_b, oth, S, C0, s));
+  } else if (fuse_stem && tw.stem0_wp && fv::stem_fused_supported(S, C0)) {
     // both convolutions in one kernel: the half-resolution 96-channel map (the path's largest tensor) never reaches HBM
     FV_P(FV_FAM_STEM, 2.0 * mb * (S / 2) * (S / 2) * 27 * C0 + dw_flops(mb, S / 4, S / 4, C0, 3),
          (double)mb * S * S * 8 + (double)mb * (S / 4) * (S / 4) * C0 * 2,
@@ -886,7 +897,7 @@ int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hi
 int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, fv_stream s) {
   HandleScope _hs(h);
   FV_TRY(check_ready(h, true));
-  if (!pix || !img_tokens || B <= 0) return fv_fail(FV_ERR_ARG, "fv_vision_forward: bad argument");
+  if ((!pix && !h->lbsrc) || !img_tokens || B <= 0) return fv_fail(FV_ERR_ARG, "fv_vision_forward: bad argument");
   if (B > h->d.max_batch) return fv_fail(FV_ERR_ARG, "fv_vision_forward: B=%d exceeds max_batch=%d", B, h->d.max_batch);
   const fv_model_desc& d = h->d;
   // the tower part of the plan does not depend on T / splice
@@ -899,7 +910,7 @@ int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, vo
   bf16_t* tout = tower_out ? static_cast<bf16_t*>(tower_out) : reinterpret_cast<bf16_t*>(static_cast<char*>(h->ws) + wp.tower_out);
   for (int b0 = 0; b0 < B; b0 += mb) {
     const int nb = std::min(mb, B - b0);
-    FV_TRY(tower_pass(h, static_cast<const bf16_t*>(pix) + (size_t)b0 * S * S * 4, b0, nb, tout + (size_t)b0 * P * d.tower_out_dim,
+    FV_TRY(tower_pass(h, pix ? static_cast<const bf16_t*>(pix) + (size_t)b0 * S * S * 4 : nullptr, b0, nb, tout + (size_t)b0 * P * d.tower_out_dim,
                       static_cast<float*>(img_tokens) + (size_t)b0 * P * d.llm_hidden, wp, static_cast<hipStream_t>(s)));
   }
   return FV_OK;
@@ -915,6 +926,17 @@ int fv_vision_forward_taps(fv_handle* h, const void* pix, int B, void* img_token
   const int rc = fv_vision_forward(h, pix, B, img_tokens, tower_out, s);
   h->taps = nullptr;
   h->n_taps = 0;
+  return rc;
+}
+
+int fv_vision_forward_images(fv_handle* h, const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value, int resize_with_padding,
+                             void* img_tokens, void* tower_out, fv_stream s) {
+  HandleScope _hs(h);
+  if (!h || !img) return fv_fail(FV_ERR_ARG, "fv_vision_forward_images: null argument");
+  const fv_handle::LbSrc src{img, dtype, C, Hin, Win, pad_value, resize_with_padding};
+  h->lbsrc = &src;
+  const int rc = fv_vision_forward(h, nullptr, B, img_tokens, tower_out, s);
+  h->lbsrc = nullptr;
   return rc;
 }
 

@@ -53,6 +53,9 @@ int launch_stem_mfma(const bf16_t* pix, const bf16_t* wp, const float* bias, bf1
 bool stem_fused_supported(int S, int C0);
 int launch_stem_fused(const bf16_t* pix, const bf16_t* wp, const float* b1, const float* w2, const float* b2, bf16_t* y, int B,
                       int S, int C0, hipStream_t s);
+// the same stem sampling the SOURCE images (B,C,Hin,Win) f32 | u8 through the letterbox arithmetic: no (B,S,S,4) frame in HBM
+int launch_stem_fused_lb(const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value, int letterbox, const bf16_t* wp,
+                         const float* b1, const float* w2, const float* b2, bf16_t* y, int S, int C0, hipStream_t s);
 int launch_dwconv(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,
                   int stride, int mult, int gelu, hipStream_t s);
 // MFMA (4x4x4, 16 channel blocks) depthwise conv for stride-1 k in {3,7} on maps with W >= 32; ttab from dwconv_toeplitz_pack

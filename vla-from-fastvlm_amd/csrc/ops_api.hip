@@ -53,6 +53,12 @@ int fv_op_stem_fused(const void* pix, const void* wp, const float* b1, const flo
                                static_cast<hipStream_t>(s));
 }
 
+int fv_op_stem_fused_images(const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value, int resize_with_padding, const void* wp,
+                            const float* b1, const float* w2, const float* b2, void* y, int S, int Cout, fv_stream s) {
+  return fv::launch_stem_fused_lb(img, dtype, B, C, Hin, Win, pad_value, resize_with_padding, static_cast<const bf16_t*>(wp), b1, w2, b2,
+                                  static_cast<bf16_t*>(y), S, Cout, static_cast<hipStream_t>(s));
+}
+
 int fv_op_layernorm_rows(const void* x, const float* w, const float* b, void* y, int rows, int C, float eps, fv_stream s) {
   return fv::launch_layernorm_rows(static_cast<const bf16_t*>(x), w, b, static_cast<bf16_t*>(y), rows, C, eps, static_cast<hipStream_t>(s));
 }

@@ -23,6 +23,49 @@ __device__ __forceinline__ float lb_fetch(const LbParams& p, size_t plane, int y
   return p.dtype == FV_U8 ? (float)static_cast<const uint8_t*>(p.img)[i] : static_cast<const float*>(p.img)[i];
 }
 
+// every product and sum is rounded on its own (fp contract off: HIP's __f*_rn are plain operators and would still fuse), so that the two
+// kernels that evaluate these expressions -- letterbox_kernel and lb_pixel inside the stem -- agree bit for bit whatever hipcc would have
+// contracted to an fma in either context
+__device__ __forceinline__ float lb_lerp(float a, float b, float w) {
+#pragma clang fp contract(off)
+  return (1.0f - w) * a + w * b;
+}
+__device__ __forceinline__ float lb_src(int d, float scale) {
+#pragma clang fp contract(off)
+  return fmaxf(((float)d + 0.5f) * scale - 0.5f, 0.0f);
+}
+__device__ __forceinline__ float lb_frac(float s, int i) {
+#pragma clang fp contract(off)
+  return s - (float)i;
+}
+
+// ONE letterboxed pixel (RGB + zero pad, bf16): the arithmetic of letterbox_kernel below, expression for expression, for the stem
+// kernel that samples the source image itself (stem_fused_kernel<true>: the 1024^2 frame then never exists in HBM)
+__device__ __forceinline__ uint2 lb_pixel(const LbParams& p, int b, int y, int x) {
+  float v[3] = {p.pad, p.pad, p.pad};
+  const int dx = x - p.pl, dy = y - p.pt;
+  if (dx >= 0 && dx < p.rw && dy >= 0 && dy < p.rh) {
+    const float sx = lb_src(dx, p.sw);
+    const int x0 = min((int)sx, p.Win - 1), x1 = min(x0 + 1, p.Win - 1);
+    const float wx = lb_frac(sx, x0);
+    const float sy = lb_src(dy, p.sh);
+    const int y0 = min((int)sy, p.Hin - 1), y1 = min(y0 + 1, p.Hin - 1);
+    const float wy = lb_frac(sy, y0);
+    const int nc = p.C >= 3 ? 3 : 1;
+    for (int c = 0; c < nc; ++c) {
+      const size_t plane = ((size_t)b * p.C + c) * p.Hin * p.Win;
+      const float t0 = lb_lerp(lb_fetch(p, plane, y0, x0), lb_fetch(p, plane, y0, x1), wx);
+      const float t1 = lb_lerp(lb_fetch(p, plane, y1, x0), lb_fetch(p, plane, y1, x1), wx);
+      v[c] = lb_lerp(t0, t1, wy);
+    }
+    if (nc == 1) v[1] = v[2] = v[0];
+  }
+  uint2 o;
+  o.x = pack_bf2(v[0], v[1]);
+  o.y = pack_bf2(v[2], 0.0f);
+  return o;
+}
+
 // One thread = one output column x LB_R consecutive output rows: when upscaling (the path's case: 336 -> 1024, ~3 output rows per
 // source row) consecutive rows share their two source rows, so the 4 taps x 3 channels are fetched again only when y0 moves -- a
 // third of the loads and of the x arithmetic of the one-pixel-per-thread form, the same values bit for bit.
@@ -33,9 +76,9 @@ __global__ __launch_bounds__(256) void letterbox_kernel(LbParams p) {
   const int dx = x - p.pl;
   const bool xin = dx >= 0 && dx < p.rw;
   // ATen area_pixel_compute_source_index, align_corners=False: src = max((dst+0.5)*scale-0.5, 0)
-  const float sx = fmaxf((dx + 0.5f) * p.sw - 0.5f, 0.0f);
+  const float sx = lb_src(dx, p.sw);
   const int x0 = min((int)sx, p.Win - 1), x1 = min(x0 + 1, p.Win - 1);
-  const float wx = sx - (float)x0;
+  const float wx = lb_frac(sx, x0);
   const int nc = p.C >= 3 ? 3 : 1;
   float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};   // the two source rows, already blended along x
   int have = -1;
@@ -46,20 +89,20 @@ __global__ __launch_bounds__(256) void letterbox_kernel(LbParams p) {
     float v[3] = {p.pad, p.pad, p.pad};
     const int dy = y - p.pt;
     if (xin && dy >= 0 && dy < p.rh) {
-      const float sy = fmaxf((dy + 0.5f) * p.sh - 0.5f, 0.0f);
+      const float sy = lb_src(dy, p.sh);
       const int y0 = min((int)sy, p.Hin - 1), y1 = min(y0 + 1, p.Hin - 1);
-      const float wy = sy - (float)y0;
+      const float wy = lb_frac(sy, y0);
       if (y0 != have) {
         have = y0;
         for (int c = 0; c < nc; ++c) {
           const size_t plane = ((size_t)b * p.C + c) * p.Hin * p.Win;
           const float p00 = lb_fetch(p, plane, y0, x0), p01 = lb_fetch(p, plane, y0, x1);
           const float p10 = lb_fetch(p, plane, y1, x0), p11 = lb_fetch(p, plane, y1, x1);
-          t0[c] = (1.0f - wx) * p00 + wx * p01;
-          t1[c] = (1.0f - wx) * p10 + wx * p11;
+          t0[c] = lb_lerp(p00, p01, wx);
+          t1[c] = lb_lerp(p10, p11, wx);
         }
       }
-      for (int c = 0; c < nc; ++c) v[c] = (1.0f - wy) * t0[c] + wy * t1[c];
+      for (int c = 0; c < nc; ++c) v[c] = lb_lerp(t0[c], t1[c], wy);
       if (nc == 1) v[1] = v[2] = v[0];  // gray -> repeat (fastvlm_adapter.py:445-446)
     }
     uint2 o;
@@ -369,10 +412,13 @@ constexpr int SF_PR = 4 * SF_TR + 3, SF_PCH = (4 * SF_TC + 4) / 2;   // input pa
 constexpr int SF_PATCH = SF_PR * SF_PCH * 16 + 16;        // 20,064 B + one zero chunk (the last row's unused fourth kernel column reads it)
 constexpr int SF_LDS = SF_S1 + 10 * SF_C * 4 + SF_PATCH;  // + depthwise taps [9][96] and bias [96] fp32 + the pixel patch
 constexpr int SF_PLD = (SF_PR * SF_PCH + 511) / 512;      // 16-byte patch chunks per thread
+// LB (the fused on-device input pipeline): the tile's input patch is not read from a letterboxed frame but SAMPLED from
+// the source image (lb_pixel: letterbox_kernel's arithmetic), so the (B,S,S,4) frame -- 537 MB at B = 64 -- is neither written nor read.
+template <bool LB>
 __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __restrict__ pix, const bf16_t* __restrict__ wp,
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
                                                              const float* __restrict__ b2, bf16_t* __restrict__ y, int B, int S,
-                                                             long ntiles) {
+                                                             long ntiles, LbParams lb) {
   extern __shared__ __attribute__((aligned(16))) char sf_smem[];
   char* s1 = sf_smem;
   float* sw2 = reinterpret_cast<float*>(sf_smem + SF_S1);   // [9][96] taps, then [96] bias
@@ -406,8 +452,16 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(const bf16_t* __rest
     for (int j = 0; j < SF_PLD; ++j) {
       const int c = tid + 512 * j, r = c / SF_PCH, cc = c % SF_PCH;
       const int iy = iy0 + r, ix = ix0 + 2 * cc;
-      pre[j] = (c < SF_PR * SF_PCH && iy >= 0 && iy < S && ix >= 0 && ix < S)
-                   ? *reinterpret_cast<const uint4*>(pix + (((size_t)b * S + iy) * S + ix) * 4) : make_uint4(0, 0, 0, 0);
+      const bool in_ = c < SF_PR * SF_PCH && iy >= 0 && iy < S && ix >= 0 && ix < S;
+      if constexpr (LB) {
+        pre[j] = make_uint4(0, 0, 0, 0);
+        if (in_) {
+          const uint2 p0 = lb_pixel(lb, (int)b, iy, ix), p1 = lb_pixel(lb, (int)b, iy, ix + 1);
+          pre[j] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+        }
+      } else {
+        pre[j] = in_ ? *reinterpret_cast<const uint4*>(pix + (((size_t)b * S + iy) * S + ix) * 4) : make_uint4(0, 0, 0, 0);
+      }
     }
   };
   auto patch_store = [&]() {
@@ -1499,13 +1553,16 @@ __global__ __launch_bounds__(256) void se_apply_gelu_kernel(const bf16_t* __rest
 
 }  // namespace
 
-int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox,
-                     bf16_t* pix, hipStream_t s) {
-  if (!img || !pix) return fv_fail(FV_ERR_ARG, "letterbox: null pointer");
+#ifndef FV_TRY_RC
+#define FV_TRY_RC(expr) do { const int rc_ = (expr); if (rc_ != FV_OK) return rc_; } while (0)
+#endif
+namespace {
+// geometry of reference resize_with_pad (model/fastvlm_adapter.py:36-55) for one call; shared by the letterbox kernel and the stem
+// that samples the source image itself
+int lb_params(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox, bf16_t* pix, LbParams& p) {
   if (B <= 0 || Hin <= 0 || Win <= 0 || S <= 0) return fv_fail(FV_ERR_ARG, "letterbox: empty shape");
   if (C != 1 && C != 3 && C != 4) return fv_fail(FV_ERR_ARG, "letterbox: C must be 1, 3 or 4 (got %d)", C);
   if (dtype != FV_F32 && dtype != FV_U8) return fv_fail(FV_ERR_ARG, "letterbox: dtype must be f32 or u8");
-  LbParams p;
   p.img = img; p.pix = pix; p.dtype = dtype; p.B = B; p.C = C; p.Hin = Hin; p.Win = Win; p.S = S; p.pad = pad_value;
   if (letterbox) {
     // reference: ratio = max(W/S, H/S); resized = int(dim / ratio) in Python double arithmetic
@@ -1519,6 +1576,15 @@ int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win,
   p.pt = S - p.rh; p.pl = S - p.rw;
   p.sh = (float)Hin / (float)p.rh;
   p.sw = (float)Win / (float)p.rw;
+  return FV_OK;
+}
+}  // namespace
+
+int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox,
+                     bf16_t* pix, hipStream_t s) {
+  if (!img || !pix) return fv_fail(FV_ERR_ARG, "letterbox: null pointer");
+  LbParams p;
+  FV_TRY_RC(lb_params(img, dtype, B, C, Hin, Win, S, pad_value, letterbox, pix, p));
   hipLaunchKernelGGL(letterbox_kernel, dim3((S + 255) / 256, (S + LB_R - 1) / LB_R, B), dim3(256), 0, s, p);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
@@ -1703,7 +1769,7 @@ int launch_stem_fused(const bf16_t* pix, const bf16_t* wp, const float* b1, cons
   if (B <= 0 || !stem_fused_supported(S, C0)) return fv_fail(FV_ERR_UNSUPPORTED, "stem_fused: bad shape S=%d C0=%d", S, C0);
   static bool attr_set = false;
   if (!attr_set) {
-    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS));
     attr_set = true;
   }
   const int S2 = S / 4;
@@ -1713,7 +1779,31 @@ int launch_stem_fused(const bf16_t* pix, const bf16_t* wp, const float* b1, cons
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const long blocks = ntiles < cus ? ntiles : cus;
-  hipLaunchKernelGGL(stem_fused_kernel, dim3((unsigned)blocks), dim3(512), SF_LDS, s, pix, wp, b1, w2, b2, y, B, S, ntiles);
+  hipLaunchKernelGGL(stem_fused_kernel<false>, dim3((unsigned)blocks), dim3(512), SF_LDS, s, pix, wp, b1, w2, b2, y, B, S, ntiles, LbParams{});
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+// the same stem reading the SOURCE images (B,C,Hin,Win) f32 | u8 through the letterbox arithmetic (fv_preprocess fused in)
+int launch_stem_fused_lb(const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value, int letterbox, const bf16_t* wp,
+                         const float* b1, const float* w2, const float* b2, bf16_t* y, int S, int C0, hipStream_t s) {
+  if (!img || !wp || !b1 || !w2 || !b2 || !y) return fv_fail(FV_ERR_ARG, "stem_fused_lb: null pointer");
+  if (B <= 0 || !stem_fused_supported(S, C0)) return fv_fail(FV_ERR_UNSUPPORTED, "stem_fused_lb: bad shape S=%d C0=%d", S, C0);
+  LbParams p;
+  FV_TRY_RC(lb_params(img, dtype, B, C, Hin, Win, S, pad_value, letterbox, nullptr, p));
+  static bool attr_set = false;
+  if (!attr_set) {
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS));
+    attr_set = true;
+  }
+  const int S2 = S / 4;
+  const long ntiles = (long)B * ((S2 + SF_TC - 1) / SF_TC) * ((S2 + SF_TR - 1) / SF_TR);
+  if (ntiles > 0x3fffffffL) return fv_fail(FV_ERR_ARG, "stem_fused_lb: too many tiles");
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const long blocks = ntiles < cus ? ntiles : cus;
+  hipLaunchKernelGGL(stem_fused_kernel<true>, dim3((unsigned)blocks), dim3(512), SF_LDS, s, nullptr, wp, b1, w2, b2, y, B, S, ntiles, p);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

@@ -80,6 +80,7 @@ SIGNATURES = {
     "fv_bind_workspace": (_i, [_vp, _vp, C.c_size_t]),
     "fv_preprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "fv_vision_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "fv_vision_forward_images": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "fv_vision_forward_taps": (_i, [_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), _i, _vp]),
     "fv_vision_unit_info": (_i, [_vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "fv_vision_forward_unit_taps": (_i, [_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), _i, _vp]),
@@ -110,6 +111,7 @@ SIGNATURES = {
     "fv_op_stem_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "fv_op_stem_mfma": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "fv_op_stem_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fv_op_stem_fused_images": (_i, [_vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fv_op_layernorm_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "fv_op_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "fv_op_rmsnorm": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),

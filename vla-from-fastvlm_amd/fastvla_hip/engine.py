@@ -62,6 +62,8 @@ class FastVLAEngine:
         self.h = h
         self._ws: Optional[torch.Tensor] = None
         self._side: Optional[torch.cuda.Stream] = None
+        # FASTVLA_FUSED_LETTERBOX=1: backbone() hands raw images to the stem (fv_vision_forward_images) instead of letterboxing first
+        self.fused_letterbox = os.environ.get("FASTVLA_FUSED_LETTERBOX", "0") == "1" and model.tower.dims[0] == 96
         self.overlap_streams = os.environ.get("FASTVLA_OVERLAP", "1") == "1"
         offs = (C.c_int64 * 13)()
         _lib.check(self.lib.fv_head_layout(self.h, C.byref(offs)), "fv_head_layout")
@@ -190,6 +192,27 @@ class FastVLAEngine:
                    "fv_vision_forward")
         return (tok, tout) if return_tower_out else tok
 
+    def vision_forward_images(self, images: torch.Tensor, pad_value: float = 0.0, resize_with_padding: bool = True,
+                              return_tower_out: bool = False):
+        """preprocess() + vision_forward() as ONE call (fv_vision_forward_images): the stem samples the source images itself, the
+        letterboxed 1024^2 frame never exists in HBM.  Same tokens, bit for bit."""
+        if images.ndim != 4:
+            raise ValueError(f"(B,C,H,W) expected, but got shape {tuple(images.shape)}")
+        if images.dtype == torch.uint8:
+            dt = _lib.FV_U8
+        else:
+            images = images.to(torch.float32)
+            dt = _lib.FV_F32
+        images = images.to(self.device).contiguous()
+        B, Cc, H, W = images.shape
+        t, l = self.model.tower, self.model.llm
+        self.ensure_workspace(B, 1, False)
+        tok = torch.empty(B, t.num_tokens, l.hidden, dtype=torch.float32, device=self.device)
+        tout = torch.empty(B, t.num_tokens, t.out_dim, dtype=torch.bfloat16, device=self.device) if return_tower_out else None
+        _lib.check(self.lib.fv_vision_forward_images(self.h, images.data_ptr(), dt, B, Cc, H, W, float(pad_value), int(resize_with_padding),
+                                                     tok.data_ptr(), _ptr(tout), _stream()), "fv_vision_forward_images", self.h)
+        return (tok, tout) if return_tower_out else tok
+
     def vision_forward_taps(self, pix: torch.Tensor):
         """-> (tokens f32, tower_out bf16, [stem, stage0, ...] NHWC bf16): per-stage activation maps for the parity tests."""
         B = pix.shape[0]
@@ -279,9 +302,12 @@ class FastVLAEngine:
         if splice or not run_tower or not self.overlap_streams:
             tok = None
             if run_tower or splice:
-                if pix is None:
-                    pix = self.preprocess(images, pad_value, resize_with_padding)
-                tok = self.vision_forward(pix)
+                if pix is None and self.fused_letterbox:
+                    tok = self.vision_forward_images(images, pad_value, resize_with_padding)
+                else:
+                    if pix is None:
+                        pix = self.preprocess(images, pad_value, resize_with_padding)
+                    tok = self.vision_forward(pix)
             return self.llm_pooled(ids, lens, tok if splice else None, pool_mode)
         # literal mode: the decoder does not consume the tower's output, so the two run on separate HIP streams (their
         # workspace regions are disjoint); the small-grid decoder kernels fill the tower kernels' tails.
@@ -291,9 +317,12 @@ class FastVLAEngine:
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             pooled = self.llm_pooled(ids, lens, None, pool_mode)
-        if pix is None:
-            pix = self.preprocess(images, pad_value, resize_with_padding)
-        self._tok_keepalive = self.vision_forward(pix)
+        if pix is None and self.fused_letterbox:
+            self._tok_keepalive = self.vision_forward_images(images, pad_value, resize_with_padding)
+        else:
+            if pix is None:
+                pix = self.preprocess(images, pad_value, resize_with_padding)
+            self._tok_keepalive = self.vision_forward(pix)
         cur.wait_stream(self._side)
         pooled.record_stream(cur)
         return pooled
