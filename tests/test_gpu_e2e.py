@@ -368,3 +368,32 @@ def test_image_prefix_cache_equals_joint_prefill(prec):
     tol = 3e-4 if prec == 1 else 1e-3
     assert r_joint <= (2e-5 if prec == 1 else tol) and r_sub <= (2e-5 if prec == 1 else tol) and r_ref <= tol
     eng.close()
+
+
+@pytest.mark.parametrize("T,ragged", [(5, False), (64, True), (33, True)])
+def test_image_prefix_cache_head_dim_128(T, ragged):
+    """the 7B decoder's attention geometry (head_dim 128, 32-key LDS chunks, GQA ratio 7) through the prefix cache: prefix lengths that
+    are not a multiple of the chunk, suffix lengths below / at / across a 64-query block, ragged prompts -- prefixed == joint prefill."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    llm = arch.LLMConfig(hidden=896, layers=2, heads=7, kv_heads=1, head_dim=128, inter=512, vocab=512)
+    m = arch.ModelConfig("d128", llm, arch.TowerConfig(layers=(1, 1, 1, 1, 1), dims=(32, 64, 128, 256, 512), image_size=384, name="d128_384"))
+    w = weights.init_backbone(m, seed=31)
+    eng = FastVLAEngine(m, hidden_dim=64, fusion_dim=64, max_batch=4, max_text_tokens=64, llm_precision=1)
+    eng.load_weights(w)
+    _, lc = _cfgs(m)
+    torch.manual_seed(T)
+    B = 3
+    tok = torch.randn(B, m.tower.num_tokens, llm.hidden, device=DEV) * 0.3      # 36 image positions: not a multiple of 32
+    ids = torch.randint(0, llm.vocab, (B, T))
+    lens = torch.tensor([T, max(1, T // 3), 1]) if ragged else torch.full((B,), T)
+    joint = eng.llm_pooled(ids, lens, tok)
+    pref = eng.llm_pooled_prefixed(ids, lens, eng.llm_prefix(tok))
+    torch.cuda.synchronize()
+    mask = (torch.arange(T)[None, :] < lens[:, None]).long()
+    with torch.no_grad():
+        ref = qwen2.llm_pooled(w, ids, mask, lc, tok.cpu(), splice=True)
+    r, rr = rel_l2(pref.cpu(), joint.cpu()), rel_l2(pref.cpu(), ref)
+    print(f"[prefix cache d=128, T={T}] prefixed vs joint {r:.2e}; vs fp32 oracle {rr:.2e}")
+    assert torch.isfinite(pref).all() and r <= 2e-5 and rr <= 3e-4
+    eng.close()
