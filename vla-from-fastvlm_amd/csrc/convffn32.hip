@@ -63,8 +63,10 @@ struct Ffn32Params {
 
 // output accumulators pinned to the accumulator half of the register file, hidden-tile accumulators to the architectural
 // half (the GELU reads them); see convffn_fused.hip for why these MFMAs are asm statements
+template <bool ACC_A = true>   // ACC_A: the accumulator half of the file (one wave per SIMD); false: plain VGPRs (two waves per SIMD share 512)
 __device__ __forceinline__ void mfma32_out(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  if constexpr (ACC_A) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 template <bool BA>  // BA: the x fragment lives in the accumulator half too
 __device__ __forceinline__ void mfma32_hid(f32x16& acc, const bf16x8& a, const bf16x8& b) {
@@ -112,7 +114,7 @@ constexpr int ring_depth32(int nr, int want) { return nr % want == 0 ? want : ri
 //   W1 chunk c of row r lives at chunk c ^ ((r >> SWS1) & SWM1); W2 chunk c (= 2 s + h) of row n at chunk c ^ ((n >> 2) & 3).
 // Both make the 16 lanes of every ds_read_b128 lane group (distinct rows mod 16, same logical chunk) hit 16 different 16-byte
 // slots of the 256-byte bank row.
-template <int C, int MT>
+template <int C, int MT, int NW = 4>
 struct Ffn32Lds {
   static constexpr int ROW1 = C * 2, ROW2 = 64;
   static constexpr int SWS1 = C == 384 ? 0 : C == 192 ? 1 : 2, SWM1 = C == 384 ? 15 : C == 192 ? 7 : 3;
@@ -121,24 +123,28 @@ struct Ffn32Lds {
   static constexpr int ORB = CQ * 4 + 16;        // fp32 row of a pass + 16 B (conflict-free 16-B column writes)
   static constexpr int EPI_WAVE = 32 * ORB;      // one pass of one wave
   static constexpr int TABLES = 2 * C * 4 + 4 * C * 4;                      // ls * b2, ls, b1 (fp32)
-  static constexpr int TOTAL = 2 * BUF + TABLES + 4 * EPI_WAVE;
+  static constexpr int TOTAL = 2 * BUF + TABLES + NW * EPI_WAVE;
   static_assert(BUF % 1024 == 0 && TOTAL <= 160 * 1024, "LDS");
 };
 
-template <int C, int MT>
-__global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
-  using L = Ffn32Lds<C, MT>;
+// NW = waves per block.  4 (C = 384, 96): one wave per SIMD with all 512 registers.  8 (C = 192): two waves per SIMD with 256 registers each,
+// no AGPRs, 32 * MT rows per wave as before -- one wave's GELU and epilogue run beside its partner's MFMAs (FFN32_NW192 = 4 restores the old shape).
+template <int C, int MT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params p) {
+  using L = Ffn32Lds<C, MT, NW>;
+  constexpr int NTH = 64 * NW, TROWS = 32 * NW * MT;   // threads per block, rows per row tile set
   constexpr int KS = C / 16;            // k-steps of the first product
   constexpr int NT = C / 32;            // output-channel tiles of the second product (two k-steps each)
   constexpr int ROW1 = L::ROW1, W1_BYTES = L::W1_BYTES, BUF = L::BUF;
-  constexpr int NLD = BUF / 1024 / 4;                         // 1 KB staging pieces per wave per chunk
-  static_assert(BUF % 4096 == 0 && NLD <= 12 && 2 * NLD == KS, "staging schedule: one store or one load per first-product step");
+  constexpr int SW = (BUF / 1024) % NW == 0 ? NW : 4;         // waves that stage the weight stream (all of them when the chunk's KBs divide evenly)
+  constexpr int NLD = BUF / 1024 / SW;                        // 1 KB staging pieces per staging wave per chunk
+  static_assert(BUF % (1024 * SW) == 0 && NLD <= 12 && 2 * NLD <= KS, "staging schedule: one store or one load per first-product step");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF] weight slots, ls*b2[C], ls[C], b1[4C], epilogue staging
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int nch = p.nchunks;                                   // C / 8: even, >= 4
-  const int ntiles = (p.M + 128 * MT - 1) / (128 * MT);
+  const int ntiles = (p.M + TROWS - 1) / TROWS;
   // the packed weight stream through a buffer descriptor: a buffer load costs a wave ~6 clk of issue beside the MFMAs where a
   // global load costs ~23 (tools/stage_micro.hip); lane offset in a VGPR (piece of wave wid, 16 B per lane), chunk and piece in
   // the scalar offset
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
   {                                                                                                          \
     int lx_ = lane;                                                                                          \
     asm volatile("" : "+v"(lx_)); /* keeps this address math out of the chunk loop's live registers */       \
-    const long mb_ = (long)(TILE) * (128 * MT) + wid * (32 * MT);                                            \
+    const long mb_ = (long)(TILE) * TROWS + wid * (32 * MT);                                                 \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                      \
       const long m_ = min(mb_ + mt * 32 + (lx_ & 31), (long)p.M - 1);                                        \
       const uint32_t xo_ = (uint32_t)m_ * (uint32_t)(C * 2) + (uint32_t)(lx_ >> 5) * 16u;                    \
@@ -175,30 +181,33 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
   // piece j of this wave: bytes [(4 j + wid) KB, +1 KB) of the chunk; each lane's 16 bytes leave as four dword stores that land
   // 256 bytes apart ([dword][lane] inside the KB) -- the packer (convffn32_pack) lays the global image out so that this IS the
   // swizzled LDS image
-#define F32_PIECE_LOAD(J, HC) F32_ST_SET(J, __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (HC) * BUF + (J) * 4096, 0)))
+#define F32_PIECE_LOAD(J, HC) F32_ST_SET(J, __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (HC) * BUF + (J) * (1024 * SW), 0)))
 #define F32_PIECE_STORE(J, SLOT)                                                                             \
   {                                                                                                          \
     const uint4 v_ = F32_ST_GET(J);                                                                          \
     asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"   \
                  "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"                     \
-                 :: "v"(v_.x), "v"(v_.y), "v"(v_.z), "v"(v_.w), "s"(wm0 + (uint32_t)((SLOT) * BUF + (J) * 4096)) : "memory"); \
+                 :: "v"(v_.x), "v"(v_.y), "v"(v_.z), "v"(v_.w), "s"(wm0 + (uint32_t)((SLOT) * BUF + (J) * (1024 * SW))) : "memory"); \
   }
+  const bool stager = SW == NW || wid < SW;   // wave-uniform
+  if (stager) {
 #pragma unroll
-  for (int j = 0; j < NLD; ++j) F32_PIECE_LOAD(j, 0)
+    for (int j = 0; j < NLD; ++j) F32_PIECE_LOAD(j, 0)
 #pragma unroll
-  for (int j = 0; j < NLD; ++j) F32_PIECE_STORE(j, 0)
+    for (int j = 0; j < NLD; ++j) F32_PIECE_STORE(j, 0)
 #pragma unroll
-  for (int j = 0; j < NLD; ++j) F32_PIECE_LOAD(j, 1)   // rides in registers through chunk 0, stored to LDS during it
+    for (int j = 0; j < NLD; ++j) F32_PIECE_LOAD(j, 1)   // rides in registers through chunk 0, stored to LDS during it
+  }
   // second-product bias, layer scale and first-product bias, staged once per block
   float* sb2 = reinterpret_cast<float*>(smem + 2 * BUF);
   float* sls = sb2 + C;
   float* sb1 = sls + C;
-  for (int i = tid; i < C / 4; i += 256) {   // sb2 holds ls * b2: out = res + (ls * acc + ls * b2), one fma per channel
+  for (int i = tid; i < C / 4; i += NTH) {   // sb2 holds ls * b2: out = res + (ls * acc + ls * b2), one fma per channel
     const float4 b = reinterpret_cast<const float4*>(p.b2)[i], l = reinterpret_cast<const float4*>(p.ls)[i];
     reinterpret_cast<float4*>(sb2)[i] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, b.w * l.w);
     reinterpret_cast<float4*>(sls)[i] = l;
   }
-  for (int i = tid; i < C; i += 256) {       // sb1 holds b1 / 4: the first product runs on W1 / 4 (exact), see the GELU
+  for (int i = tid; i < C; i += NTH) {       // sb1 holds b1 / 4: the first product runs on W1 / 4 (exact), see the GELU
     const float4 b = reinterpret_cast<const float4*>(p.b1)[i];
     reinterpret_cast<float4*>(sb1)[i] = make_float4(0.25f * b.x, 0.25f * b.y, 0.25f * b.z, 0.25f * b.w);
   }
@@ -211,7 +220,8 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
 #ifndef FFN32_PD
 #define FFN32_PD 6
 #endif
-  constexpr bool XA = true;                // upper half of the x fragments in AGPRs (MFMA reads A / B from either half)
+  constexpr bool XA = NW == 4;             // upper half of the x fragments in AGPRs (MFMA reads A / B from either half); NW = 8: no AGPRs at all
+                                           // (with any "a" operand hipcc splits a 256-register wave 128 / 128 and spills the VGPR side)
   constexpr int NR = KS + 2 * NT, PD = ring_depth32(NR, FFN32_PD < NR / 2 ? FFN32_PD : NR / 2);
   static_assert(2 * NLD <= NR - PD && NR % PD == 0, "ring");
   // swizzled fragment addresses: W1 step i reads logical chunk 2 i + fh of row fr, i.e. physical chunk (2 i + fh) ^ s1 -- the XOR
@@ -338,8 +348,10 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
         }                                                                                                           \
         if (!F32_ABL_STAGE) { /* staging: even steps store piece j to the idle slot, odd steps reload its register for the chunk after */ \
           const int j = i >> 1;                                                                                     \
-          if ((i & 1) == 0) F32_PIECE_STORE(j, cur ^ 1)                                                             \
-          else F32_PIECE_LOAD(j, hn)                                                                                \
+          if (j < NLD && stager) {                                                                                  \
+            if ((i & 1) == 0) F32_PIECE_STORE(j, cur ^ 1)                                                           \
+            else F32_PIECE_LOAD(j, hn)                                                                              \
+          }                                                                                                         \
         }                                                                                                           \
         if (i == KS - 1) { /* bias + GELU in registers -> the two B fragments of the second product */              \
           settle_hid<MT>(hacc);                                                                                     \
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
           settle_ops<MT>(hf);                                                                                       \
         }                                                                                                           \
       } else { /* out^T[tile] += W2[tile rows, chunk k-step] . H^T */                                               \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) mfma32_out(oacc[(i - KS) >> 1][mt], a, hf[mt][(i - KS) & 1]); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) mfma32_out<NW == 4>(oacc[(i - KS) >> 1][mt], a, hf[mt][(i - KS) & 1]); \
       }                                                                                                             \
     }                                                                                                               \
   }
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void convffn32_kernel(Ffn32Params p) {
   }
 #endif
   for (int tile = blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
-    const long mb = (long)tile * (128 * MT) + wid * (32 * MT);
+    const long mb = (long)tile * TROWS + wid * (32 * MT);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -485,17 +497,17 @@ int num_cus32() {
   return n;
 }
 
-template <int C, int MT>
+template <int C, int MT, int NW = 4>
 int launch_one32(const Ffn32Params& p, hipStream_t s) {
-  constexpr int LDS = Ffn32Lds<C, MT>::TOTAL;
+  constexpr int LDS = Ffn32Lds<C, MT, NW>::TOTAL;
   static bool attr_set = false;
   if (!attr_set) {
-    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn32_kernel<C, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn32_kernel<C, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  const long tiles = ((long)p.M + 128 * MT - 1) / (128 * MT);
+  const long tiles = ((long)p.M + 32 * NW * MT - 1) / (32 * NW * MT);
   const long blocks = tiles < num_cus32() ? tiles : num_cus32();   // one persistent block per CU, tiles dealt round-robin
-  hipLaunchKernelGGL((convffn32_kernel<C, MT>), dim3((unsigned)blocks), dim3(256), LDS, s, p);
+  hipLaunchKernelGGL((convffn32_kernel<C, MT, NW>), dim3((unsigned)blocks), dim3(64 * NW), LDS, s, p);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -546,8 +558,18 @@ int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const f
 #ifndef FFN32_MT96
 #define FFN32_MT96 4
 #endif
-    case 96: return launch_one32<96, FFN32_MT96>(p, s);
-    case 192: return launch_one32<192, 2>(p, s);
+#ifndef FFN32_NW96
+#define FFN32_NW96 4
+#endif
+    case 96:
+      if constexpr (FFN32_NW96 == 8) return launch_one32<96, FFN32_MT96 <= 2 ? FFN32_MT96 : 1, 8>(p, s);
+      else return launch_one32<96, FFN32_MT96>(p, s);
+#ifndef FFN32_NW192
+#define FFN32_NW192 8   /* C = 192: eight waves (two per SIMD, 32 rows each, no AGPRs): -3.5 % against four waves of 64 rows (tools/ffn_bench.py) */
+#endif
+    case 192:
+      if constexpr (FFN32_NW192 == 8) return launch_one32<192, 1, 8>(p, s);
+      else return launch_one32<192, 2>(p, s);
     case 384: return launch_one32<384, 1>(p, s);
   }
   return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: unsupported C=%d", C);
