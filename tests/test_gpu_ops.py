@@ -5,6 +5,7 @@ kernel's output (relative 2^-9): tolerances are rel-L2 <= 4e-3 and max-abs <= 2e
 1e-5-class for fp32 outputs.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -314,8 +315,12 @@ def _pack_wq(w1, w2):
     t1 = torch.empty(nch, 32, Cc // 8, 8)
     t1[:, r[:, None], phys1] = 0.25 * w1.view(nch, 32, Cc // 8, 8)           # W1 / 4 and 4 W2: exact (the GELU runs in y = x / 4)
     n = torch.arange(Cc)
-    hid = torch.tensor([[16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for j in range(8)] for s in range(2) for h in range(2)])  # (4 chunks, 8)
-    phys2 = torch.arange(4)[None, :] ^ ((n[:, None] >> 2) & 3)              # (C, 4)
+    if (int(os.environ.get("FFN32_S16_MASK", "0")) >> {384: 0, 192: 1, 96: 2}[Cc]) & 1:   # 16x16x32 form of the kernel (experiment builds)
+        hid = torch.tensor([[4 * g + j if j < 4 else 16 + 4 * g + j - 4 for j in range(8)] for g in range(4)])
+        phys2 = torch.arange(4)[None, :] ^ ((4 - ((n[:, None] >> 2) & 3)) & 3)
+    else:
+        hid = torch.tensor([[16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for j in range(8)] for s in range(2) for h in range(2)])  # (4 chunks, 8)
+        phys2 = torch.arange(4)[None, :] ^ ((n[:, None] >> 2) & 3)              # (C, 4)
     w2c = 4.0 * w2.view(Cc, nch, 32)[:, :, hid]                       # (C, nch, 4, 8): logical chunks
     t2 = torch.empty(nch, Cc, 4, 8)
     t2[:, n[:, None], phys2] = w2c.permute(1, 0, 2, 3)

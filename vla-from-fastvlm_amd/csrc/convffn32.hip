@@ -76,6 +76,20 @@ __device__ __forceinline__ void mfma32_hid(f32x16& acc, const bf16x8& a, const b
 __device__ __forceinline__ void mfma32_hid_init(f32x16& acc, const bf16x8& a, const bf16x8& b, const f32x16& bias) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(bias));
 }
+// the same three on v_mfma_f32_16x16x32_bf16 (S16 form of the kernel: a 32-pixel wave tile is two 16-pixel column tiles)
+template <bool ACC_A = true>
+__device__ __forceinline__ void mfma16_out(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (ACC_A) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <bool BA>
+__device__ __forceinline__ void mfma16_hid(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (BA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16_hid_init(f32x4& acc, const bf16x8& a, const bf16x8& b, const f32x4& bias) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(bias));
+}
 // XDL write -> VALU read of the hidden accumulators (8-pass MFMA: 12+ wait states), paid once per chunk behind the first
 // product's last MFMA; and VALU write -> MFMA B operand ahead of the second product
 template <int N>
@@ -129,20 +143,21 @@ struct Ffn32Lds {
 
 // NW = waves per block.  4 (C = 384, 96): one wave per SIMD with all 512 registers.  8 (C = 192): two waves per SIMD with 256 registers each,
 // no AGPRs, 32 * MT rows per wave as before -- one wave's GELU and epilogue run beside its partner's MFMAs (FFN32_NW192 = 4 restores the old shape).
-template <int C, int MT, int NW = 4>
+template <int C, int MT, int NW = 4, bool S16 = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params p) {
   using L = Ffn32Lds<C, MT, NW>;
   constexpr int NTH = 64 * NW, TROWS = 32 * NW * MT;   // threads per block, rows per row tile set
-  constexpr int KS = C / 16;            // k-steps of the first product
-  constexpr int NT = C / 32;            // output-channel tiles of the second product (two k-steps each)
+  constexpr int N1 = C / 16;                   // fragment reads of the first product (either MFMA shape)
+  constexpr int KS = S16 ? C / 32 : C / 16;    // k-steps of the first product (S16: two fragments -- hidden tiles -- per step)
+  constexpr int NT = S16 ? C / 16 : C / 32;    // output-channel tiles of the second product (32x32x16: two k-steps each; S16: one)
   constexpr int ROW1 = L::ROW1, W1_BYTES = L::W1_BYTES, BUF = L::BUF;
   constexpr int SW = (BUF / 1024) % NW == 0 ? NW : 4;         // waves that stage the weight stream (all of them when the chunk's KBs divide evenly)
   constexpr int NLD = BUF / 1024 / SW;                        // 1 KB staging pieces per staging wave per chunk
-  static_assert(BUF % (1024 * SW) == 0 && NLD <= 12 && 2 * NLD <= KS, "staging schedule: one store or one load per first-product step");
+  static_assert(BUF % (1024 * SW) == 0 && NLD <= 12 && 2 * NLD <= N1, "staging schedule: one store or one load per first-product read");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF] weight slots, ls*b2[C], ls[C], b1[4C], epilogue staging
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int fr = lane & 31, fh = lane >> 5;
+  const int fr = S16 ? lane & 15 : lane & 31, fh = S16 ? lane >> 4 : lane >> 5;
   const int nch = p.nchunks;                                   // C / 8: even, >= 4
   const int ntiles = (p.M + TROWS - 1) / TROWS;
   // the packed weight stream through a buffer descriptor: a buffer load costs a wave ~6 clk of issue beside the MFMAs where a
@@ -159,12 +174,23 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
   const uint32_t wm0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)smem + (uint32_t)wid * 1024u);
 
   // ---- x fragments: lane holds x[pixel m = fr][16 ks + 8 fh .. +8] for its MT pixel tiles (rows past M clamp to M - 1)
-  bf16x8 xf[MT][KS];
+  // S16: xg[mt][n][ks] = x[pixel 16 n + (lane & 15)][32 ks + 8 (lane >> 4) .. +8]
+  bf16x8 xf[S16 ? 1 : MT][S16 ? 1 : KS];
+  bf16x8 xg[S16 ? MT : 1][2][S16 ? KS : 1];
 #define F32_LOAD_X(TILE)                                                                                     \
   {                                                                                                          \
     int lx_ = lane;                                                                                          \
     asm volatile("" : "+v"(lx_)); /* keeps this address math out of the chunk loop's live registers */       \
     const long mb_ = (long)(TILE) * TROWS + wid * (32 * MT);                                                 \
+    if constexpr (S16) {                                                                                     \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                      \
+          const long m_ = min(mb_ + mt * 32 + n * 16 + (lx_ & 15), (long)p.M - 1);                           \
+          const uint32_t xo_ = (uint32_t)m_ * (uint32_t)(C * 2) + (uint32_t)(lx_ >> 4) * 16u;                \
+          _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                  \
+            xg[mt][n][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.x) + xo_ + ks * 64)); \
+        }                                                                                                    \
+    } else                                                                                                   \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                      \
       const long m_ = min(mb_ + mt * 32 + (lx_ & 31), (long)p.M - 1);                                        \
       const uint32_t xo_ = (uint32_t)m_ * (uint32_t)(C * 2) + (uint32_t)(lx_ >> 5) * 16u;                    \
@@ -174,7 +200,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
     }                                                                                                        \
   }
   F32_LOAD_X(blockIdx.x)
-  f32x16 oacc[NT][MT];
+  f32x16 oacc[S16 ? 1 : NT][S16 ? 1 : MT];
+  f32x4 oacc16[S16 ? NT : 1][S16 ? MT : 1][2];
 
   uint4 st0, st1, st2, st3, st4, st5, st6, st7, st8, st9, st10, st11;
   st0 = st1 = st2 = st3 = st4 = st5 = st6 = st7 = st8 = st9 = st10 = st11 = make_uint4(0, 0, 0, 0);
@@ -222,23 +249,29 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
 #endif
   constexpr bool XA = NW == 4;             // upper half of the x fragments in AGPRs (MFMA reads A / B from either half); NW = 8: no AGPRs at all
                                            // (with any "a" operand hipcc splits a 256-register wave 128 / 128 and spills the VGPR side)
-  constexpr int NR = KS + 2 * NT, PD = ring_depth32(NR, FFN32_PD < NR / 2 ? FFN32_PD : NR / 2);
+  constexpr int NR = N1 + C / 16, PD = ring_depth32(NR, FFN32_PD < NR / 2 ? FFN32_PD : NR / 2);
   static_assert(2 * NLD <= NR - PD && NR % PD == 0, "ring");
   // swizzled fragment addresses: W1 step i reads logical chunk 2 i + fh of row fr, i.e. physical chunk (2 i + fh) ^ s1 -- the XOR
   // touches the low bits only, so the lane part repeats every NA1 steps and the rest is an immediate offset; W2 step (t, s)
   // reads logical chunk 2 s + fh of row 32 t + fr
-  constexpr int GB1 = L::SWM1 + 1, NA1 = GB1 / 2;
+  // S16: read 2 ks + m of the first product is hidden tile m (rows 16 m + fr), logical chunk 4 ks + fh; read t of the second is
+  // W2 rows 16 t + fr, chunk fh ^ s2 with s2 = (-(row >> 2)) & 3 (the table that keeps the 16x16x32 lane groups conflict-free)
+  constexpr int GB1 = L::SWM1 + 1, NA1 = S16 ? (GB1 >= 4 ? GB1 / 4 : 1) : GB1 / 2;
   uint32_t fa1[NA1], fa2[2];
   {
-    const uint32_t s1 = (uint32_t)(fr >> L::SWS1) & L::SWM1, s2 = (uint32_t)(fr >> 2) & 3u;
+    const uint32_t s1 = (uint32_t)(fr >> L::SWS1) & L::SWM1, s2 = S16 ? (4u - ((uint32_t)fr >> 2)) & 3u : (uint32_t)(fr >> 2) & 3u;
 #pragma unroll
-    for (int m = 0; m < NA1; ++m) fa1[m] = (uint32_t)fr * ROW1 + 16u * ((((uint32_t)(2 * m + fh)) & L::SWM1) ^ s1);
+    for (int m = 0; m < NA1; ++m) fa1[m] = (uint32_t)fr * ROW1 + 16u * ((((uint32_t)((S16 ? 4 : 2) * m + fh)) & L::SWM1) ^ s1);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) fa2[q] = (uint32_t)W1_BYTES + (uint32_t)fr * 64u + 16u * ((uint32_t)(2 * q + fh) ^ s2);
+    for (int q = 0; q < 2; ++q) fa2[q] = (uint32_t)W1_BYTES + (uint32_t)fr * 64u + 16u * ((uint32_t)(S16 ? fh : 2 * q + fh) ^ s2);
   }
-#define F32_FRAG(I, SLOTP)                                                                                          \
-  ((I) < KS ? *reinterpret_cast<const uint4*>((SLOTP) + fa1[(I) % NA1] + ((I) / NA1) * (GB1 * 16))                  \
-            : *reinterpret_cast<const uint4*>((SLOTP) + fa2[((I) - KS) & 1] + (((I) - KS) >> 1) * 2048))
+#define F32_FRAG_32(I, SLOTP)                                                                                       \
+  ((I) < N1 ? *reinterpret_cast<const uint4*>((SLOTP) + fa1[(I) % NA1] + ((I) / NA1) * (GB1 * 16))                  \
+            : *reinterpret_cast<const uint4*>((SLOTP) + fa2[((I) - N1) & 1] + (((I) - N1) >> 1) * 2048))
+#define F32_FRAG_16(I, SLOTP)                                                                                       \
+  ((I) < N1 ? *reinterpret_cast<const uint4*>((SLOTP) + fa1[((I) >> 1) % NA1] + (((I) >> 1) / NA1) * (GB1 * 16) + ((I) & 1) * (16 * ROW1)) \
+            : *reinterpret_cast<const uint4*>((SLOTP) + fa2[0] + ((I) - N1) * 1024))
+#define F32_FRAG(I, SLOTP) (S16 ? F32_FRAG_16(I, SLOTP) : F32_FRAG_32(I, SLOTP))
   uint4 ring[PD];
 #pragma unroll
   for (int i = 0; i < PD; ++i) ring[i] = F32_FRAG(i, smem);
@@ -261,7 +294,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
   const uint32_t eoff = er < ERW ? (uint32_t)(er * C + ec8) * 2u : OOB;      // byte offset of the lane's chunk in row er
   const uint32_t eoff_last = (er < ERW && (RP - 1) * ERW + er < 32) ? eoff : OOB;   // last instruction: rows 30, 31 only
   char* const so = smem + 2 * BUF + L::TABLES + wid * L::EPI_WAVE;           // the wave's fp32 staging area
-  char* const sow = so + (le & 31) * ORB + (le >> 5) * 16;                   // write side: pixel fr, channel quad 4 fh
+  char* const sow = so + (S16 ? le & 15 : le & 31) * ORB + (S16 ? le >> 4 : le >> 5) * 16;   // write side: pixel fr, channel quad 4 fh
   const char* const sor = so + min(er, ERW - 1) * ORB + ec8 * 4;            // read side: row er, the lane's 8 channels
   const char* const sor_last = so + min((RP - 1) * ERW + er, 31) * ORB + ec8 * 4;
 #ifndef FFN32_XPASS   /* epilogue pass in which the next tile's x fragments are requested (default: the last) */
@@ -317,8 +350,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
   // the chunk's bias b1 / 4 in the first product's D layout: registers 4 q .. 4 q + 3 = hidden 8 q + 4 fh + 0..3 of the chunk.
   // Loaded one chunk ahead (behind the previous chunk's GELU, long after the MFMAs that read the old value as C have retired).
   f32x16 bias;
+  f32x4 bias16[2];   // S16: hidden 16 m + 4 fh + 0..3 of the chunk
 #define F32_LOAD_BIAS(HC)                                                                                    \
   {                                                                                                          \
+    if constexpr (S16) {                                                                                     \
+      _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_) {                                                     \
+        const float4 b_ = *reinterpret_cast<const float4*>(sb1 + (HC) * 32 + 16 * m_ + 4 * fh);              \
+        bias16[m_] = f32x4{b_.x, b_.y, b_.z, b_.w};                                                          \
+      }                                                                                                      \
+    } else                                                                                                   \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
       const float4 b_ = *reinterpret_cast<const float4*>(sb1 + (HC) * 32 + 8 * q_ + 4 * fh);                 \
       bias[4 * q_] = b_.x; bias[4 * q_ + 1] = b_.y; bias[4 * q_ + 2] = b_.z; bias[4 * q_ + 3] = b_.w;        \
@@ -336,15 +376,27 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
     const char* nbase = smem + (cur ^ 1) * BUF;                                                                     \
     f32x16 hacc[MT];                                                                                                \
     bf16x8 hf[MT][2];                                                                                               \
+    f32x4 hacc16[MT][2][2]; /* S16: [pixel tile n][hidden tile m] */                                                \
+    bf16x8 hf16[MT][2];                                                                                             \
     _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                                \
       if (i == NR - PD) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }                     \
       const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i % PD]);                                                    \
       if (!F32_ABL_FRAG) ring[i % PD] = i + PD < NR ? F32_FRAG(i + PD, cbase) : F32_FRAG(i + PD - NR, nbase);       \
-      if (i < KS) { /* H^T += W1[chunk rows, k-step i] . x^T */                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                         \
-          if (i == 0) mfma32_hid_init(hacc[mt], a, xf[mt][0], bias);                                                      \
-          else if (XA && i >= KS / 2) mfma32_hid<XA>(hacc[mt], a, xf[mt][i >= KS / 2 ? i : KS - 1]);                \
-          else mfma32_hid<false>(hacc[mt], a, xf[mt][i]);                                                           \
+      if (i < N1) {                                                                                                 \
+        if constexpr (S16) { /* H^T[hidden tile m] += W1[rows 16 m .., k-step ks] . x^T, both pixel tiles */         \
+          const int ks = i >> 1, m = i & 1;                                                                         \
+          _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                         \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                         \
+              if (ks == 0) mfma16_hid_init(hacc16[mt][n][m], a, xg[mt][n][0], bias16[m]);                            \
+              else if (XA && ks >= KS / 2) mfma16_hid<XA>(hacc16[mt][n][m], a, xg[mt][n][ks >= KS / 2 ? ks : KS - 1]); \
+              else mfma16_hid<false>(hacc16[mt][n][m], a, xg[mt][n][ks]);                                           \
+            }                                                                                                       \
+        } else { /* H^T += W1[chunk rows, k-step i] . x^T */                                                        \
+          _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
+            if (i == 0) mfma32_hid_init(hacc[mt], a, xf[mt][0], bias);                                              \
+            else if (XA && i >= KS / 2) mfma32_hid<XA>(hacc[mt], a, xf[mt][i >= KS / 2 ? i : KS - 1]);              \
+            else mfma32_hid<false>(hacc[mt], a, xf[mt][i]);                                                         \
+          }                                                                                                         \
         }                                                                                                           \
         if (!F32_ABL_STAGE) { /* staging: even steps store piece j to the idle slot, odd steps reload its register for the chunk after */ \
           const int j = i >> 1;                                                                                     \
@@ -353,25 +405,49 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
             else F32_PIECE_LOAD(j, hn)                                                                              \
           }                                                                                                         \
         }                                                                                                           \
-        if (i == KS - 1) { /* bias + GELU in registers -> the two B fragments of the second product */              \
-          settle_hid<MT>(hacc);                                                                                     \
-          _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
-            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                         \
-              f32x2 g[4] = {{hacc[mt][8 * s + 0], hacc[mt][8 * s + 1]}, {hacc[mt][8 * s + 2], hacc[mt][8 * s + 3]}, \
-                            {hacc[mt][8 * s + 4], hacc[mt][8 * s + 5]}, {hacc[mt][8 * s + 6], hacc[mt][8 * s + 7]}}; \
-              F32_GELU(g)                                                                                           \
-              uint4 u;                                                                                              \
-              u.x = pack_bf2(g[0].x, g[0].y); u.y = pack_bf2(g[1].x, g[1].y);                                       \
-              u.z = pack_bf2(g[2].x, g[2].y); u.w = pack_bf2(g[3].x, g[3].y);                                       \
-              hf[mt][s] = __builtin_bit_cast(bf16x8, u);                                                            \
-              __builtin_amdgcn_sched_barrier(0); /* one group of four chains at a time */                           \
+        if (i == N1 - 1) { /* bias + GELU in registers -> the B fragments of the second product */                  \
+          if constexpr (S16) {                                                                                      \
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");                                                        \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                       \
+              _Pragma("unroll") for (int n = 0; n < 2; ++n) asm volatile("" : "+v"(hacc16[mt][n][0]), "+v"(hacc16[mt][n][1])); \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                     \
+              _Pragma("unroll") for (int n = 0; n < 2; ++n) { /* k slot 8 fh + j: hidden 4 fh + j (j < 4), 16 + 4 fh + j - 4 (j >= 4) */ \
+                const f32x4 h0 = hacc16[mt][n][0], h1 = hacc16[mt][n][1];                                           \
+                f32x2 g[4] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]}};                      \
+                F32_GELU(g)                                                                                         \
+                uint4 u;                                                                                            \
+                u.x = pack_bf2(g[0].x, g[0].y); u.y = pack_bf2(g[1].x, g[1].y);                                     \
+                u.z = pack_bf2(g[2].x, g[2].y); u.w = pack_bf2(g[3].x, g[3].y);                                     \
+                hf16[mt][n] = __builtin_bit_cast(bf16x8, u);                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
+              }                                                                                                     \
             }                                                                                                       \
+            F32_LOAD_BIAS(hb)                                                                                       \
+            asm volatile("s_nop 3" ::: "memory");                                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(hf16[mt][0]), "+v"(hf16[mt][1])); \
+          } else {                                                                                                  \
+            settle_hid<MT>(hacc);                                                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                     \
+              _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                       \
+                f32x2 g[4] = {{hacc[mt][8 * s + 0], hacc[mt][8 * s + 1]}, {hacc[mt][8 * s + 2], hacc[mt][8 * s + 3]}, \
+                              {hacc[mt][8 * s + 4], hacc[mt][8 * s + 5]}, {hacc[mt][8 * s + 6], hacc[mt][8 * s + 7]}}; \
+                F32_GELU(g)                                                                                         \
+                uint4 u;                                                                                            \
+                u.x = pack_bf2(g[0].x, g[0].y); u.y = pack_bf2(g[1].x, g[1].y);                                     \
+                u.z = pack_bf2(g[2].x, g[2].y); u.w = pack_bf2(g[3].x, g[3].y);                                     \
+                hf[mt][s] = __builtin_bit_cast(bf16x8, u);                                                          \
+                __builtin_amdgcn_sched_barrier(0); /* one group of four chains at a time */                         \
+              }                                                                                                     \
+            }                                                                                                       \
+            F32_LOAD_BIAS(hb)                                                                                       \
+            settle_ops<MT>(hf);                                                                                     \
           }                                                                                                         \
-          F32_LOAD_BIAS(hb)                                                                                         \
-          settle_ops<MT>(hf);                                                                                       \
         }                                                                                                           \
+      } else if constexpr (S16) { /* out^T[tile] += W2[rows 16 t .., chunk] . H^T, both pixel tiles */               \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
+          _Pragma("unroll") for (int n = 0; n < 2; ++n) mfma16_out<NW == 4>(oacc16[i - N1][mt][n], a, hf16[mt][n]); \
       } else { /* out^T[tile] += W2[tile rows, chunk k-step] . H^T */                                               \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) mfma32_out<NW == 4>(oacc[(i - KS) >> 1][mt], a, hf[mt][(i - KS) & 1]); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) mfma32_out<NW == 4>(oacc[(i - N1) >> 1][mt], a, hf[mt][(i - N1) & 1]); \
       }                                                                                                             \
     }                                                                                                               \
   }
@@ -388,9 +464,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (S16) { oacc16[nt][mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc16[nt][mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[nt][mt][e] = 0.f;
+          for (int e = 0; e < 16; ++e) oacc[nt][mt][e] = 0.f;
+        }
+      }
     F32_STAMP(ts0)
     for (int hc = 0; hc < nch; ++hc) F32_CHUNK
     __builtin_amdgcn_sched_barrier(0);  // keep the epilogue's loads out of the chunk
@@ -427,13 +507,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
     for (int q = 0; q < NPASS * MT; ++q) {
       const int mt = q / NPASS, pass = q % NPASS;
       if (q == F32_XPASS) F32_LOAD_X(tile + (int)gridDim.x)   // the next tile's x fragments fly from this pass on
+      if constexpr (S16) {   // tile t, pixel tile n: channels 16 t + 4 fh + 0..3 of pixel 16 n + fr
 #pragma unroll
-      for (int tl = 0; tl < CQ / 32; ++tl)
+        for (int tl = 0; tl < CQ / 16; ++tl)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const f32x16& o = oacc[pass * (CQ / 32) + tl][mt];
-          *reinterpret_cast<f32x4*>(sow + (tl * 32 + qd * 8) * 4) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
-        }
+          for (int n = 0; n < 2; ++n) *reinterpret_cast<f32x4*>(sow + n * (16 * ORB) + tl * 64) = oacc16[pass * (CQ / 16) + tl][mt][n];
+      } else {
+#pragma unroll
+        for (int tl = 0; tl < CQ / 32; ++tl)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const f32x16& o = oacc[pass * (CQ / 32) + tl][mt];
+            *reinterpret_cast<f32x4*>(sow + (tl * 32 + qd * 8) * 4) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
+          }
+      }
       asm volatile("" ::: "memory");  // wave-local hand-over: LDS serves a wave's accesses in order
 #ifdef FFN32_STAMPS
       F32_STAMP(tp1_)
@@ -482,6 +569,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
 #undef F32_LOAD_RES
 #undef F32_LOAD_X
 #undef F32_FRAG
+#undef F32_FRAG_16
+#undef F32_FRAG_32
 #undef F32_PIECE_LOAD
 #undef F32_PIECE_STORE
 }
@@ -497,17 +586,17 @@ int num_cus32() {
   return n;
 }
 
-template <int C, int MT, int NW = 4>
+template <int C, int MT, int NW = 4, bool S16 = false>
 int launch_one32(const Ffn32Params& p, hipStream_t s) {
   constexpr int LDS = Ffn32Lds<C, MT, NW>::TOTAL;
   static bool attr_set = false;
   if (!attr_set) {
-    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn32_kernel<C, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn32_kernel<C, MT, NW, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const long tiles = ((long)p.M + 32 * NW * MT - 1) / (32 * NW * MT);
   const long blocks = tiles < num_cus32() ? tiles : num_cus32();   // one persistent block per CU, tiles dealt round-robin
-  hipLaunchKernelGGL((convffn32_kernel<C, MT, NW>), dim3((unsigned)blocks), dim3(64 * NW), LDS, s, p);
+  hipLaunchKernelGGL((convffn32_kernel<C, MT, NW, S16>), dim3((unsigned)blocks), dim3(64 * NW), LDS, s, p);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -515,6 +604,12 @@ int launch_one32(const Ffn32Params& p, hipStream_t s) {
 }  // namespace
 
 bool convffn32_supported(int C, int ratio) { return ratio == 4 && (C == 96 || C == 192 || C == 384); }
+
+#ifndef FFN32_S16_MASK   /* which widths run on v_mfma_f32_16x16x32_bf16: bit 0 C = 384, bit 1 C = 192, bit 2 C = 96 */
+#define FFN32_S16_MASK 0
+#endif
+constexpr bool shape16(int C) { return ((FFN32_S16_MASK) >> (C == 384 ? 0 : C == 192 ? 1 : 2)) & 1; }
+int convffn32_mfma_shape(int C) { return shape16(C) ? 16 : 32; }
 
 // fc1 weight w1 [4C][C] and fc2 weight w2 [C][4C] (row-major fp32, values already bf16-representable or to be rounded by the
 // caller) -> ONE stream out[4C/32][64 C]: per 32-hidden chunk the byte image the kernel's weight slot holds, in the order its
@@ -531,6 +626,13 @@ void convffn32_pack(const float* w1, const float* w2, float* out, int C) {
     for (int r = 0; r < 32; ++r)
       for (int c = 0; c < C / 8; ++c)
         for (int e = 0; e < 8; ++e) T[(size_t)r * C + (size_t)(c ^ ((r >> sh1) & mask1)) * 8 + e] = 0.25f * w1[(size_t)(hc * 32 + r) * C + c * 8 + e];
+    if (shape16(C)) {   // 16x16x32: one k-step; lane group g holds k slots 8 g + j = hidden 4 g + j (j < 4), 16 + 4 g + j - 4 (j >= 4)
+      for (int n = 0; n < C; ++n)
+        for (int g = 0; g < 4; ++g)
+          for (int j = 0; j < 8; ++j)
+            T[(size_t)32 * C + (size_t)n * 32 + (size_t)(g ^ ((4 - ((n >> 2) & 3)) & 3)) * 8 + j] =
+                4.0f * w2[(size_t)n * hidden + hc * 32 + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4)];
+    } else
     for (int n = 0; n < C; ++n)
       for (int s = 0; s < 2; ++s)
         for (int h = 0; h < 2; ++h)
@@ -563,14 +665,14 @@ int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const f
 #endif
     case 96:
       if constexpr (FFN32_NW96 == 8) return launch_one32<96, FFN32_MT96 <= 2 ? FFN32_MT96 : 1, 8>(p, s);
-      else return launch_one32<96, FFN32_MT96>(p, s);
+      else return launch_one32<96, FFN32_MT96, 4, shape16(96)>(p, s);
 #ifndef FFN32_NW192
 #define FFN32_NW192 8   /* C = 192: eight waves (two per SIMD, 32 rows each, no AGPRs): -3.5 % against four waves of 64 rows (tools/ffn_bench.py) */
 #endif
     case 192:
-      if constexpr (FFN32_NW192 == 8) return launch_one32<192, 1, 8>(p, s);
-      else return launch_one32<192, 2>(p, s);
-    case 384: return launch_one32<384, 1>(p, s);
+      if constexpr (FFN32_NW192 == 8) return launch_one32<192, 1, 8, shape16(192)>(p, s);
+      else return launch_one32<192, 2, 4, shape16(192)>(p, s);
+    case 384: return launch_one32<384, 1, 4, shape16(384)>(p, s);
   }
   return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: unsupported C=%d", C);
 }
