@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--image", type=int, default=336)
     ap.add_argument("--splice", action="store_true", help="splice the 256 projected image tokens into the LLM sequence")
     ap.add_argument("--microbatch", type=int, default=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")))
-    ap.add_argument("--llm-precision", type=int, default=None, choices=(0, 1, 2),
+    ap.add_argument("--llm-precision", type=int, default=None, choices=(0, 1, 2, 3, 4),
                     help="1 = split-bf16 decoder operands + fp32 attention (actions ~1e-5 from the fp32 reference); "
                          "2 (default for the 0.5B decoder; 1 for the wider ones: arch.default_llm_precision) = split-bf16 qkv / o + ONE fp16 pass for gate/up and down (actions ~4.4e-4: the cheapest policy inside "
                          "north_star's 1e-3 with a 2x margin, tests/precision_budget.py); 0 = plain bf16 operands (~8e-3)")

@@ -63,7 +63,9 @@ typedef struct fv_model_desc {
    * 2 = the per-GEMM budget of tests/precision_budget.py: qkv and o keep split-bf16 operands (12 % of the decoder's MACs), gate/up
    * and down run ONE pass on fp16 operands (11 significant bits; fp16 copies of those weights are exact for |w| >= 6e-5 and the
    * down projection carries a 2^4 scale against a 2^-4 on its operand), fp32 attention: actions ~5e-4 from the fp32 reference at
-   * 0.56x the MFMA work of mode 1. */
+   * 0.56x the MFMA work of mode 1.  3 / 4 = the two halves of mode 2 on their own (3: the fp16 pass on gate/up only, its SwiGLU output
+   * leaves as hi + lo bf16 for a split-bf16 down projection; 4: on down only): the per-family rows of the precision budget measured on
+   * the product (tools/prec_sweep.py), not defaults of any preset. */
   int32_t llm_precision;
 } fv_model_desc;
 

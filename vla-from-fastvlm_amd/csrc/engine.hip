@@ -363,7 +363,7 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
   if (d.llm_precision >= 1) {
     p.xn_lo = take(rows * d.llm_hidden * 2 * 2);                               // [hi | lo] side by side
     p.att_lo = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2 * 2);
-    p.act_lo = d.llm_precision == 1 ? take(rows * d.llm_inter * 2 * 2) : 0;    // mode 2: the SwiGLU output is ONE fp16 row (p.act)
+    p.act_lo = (d.llm_precision == 1 || d.llm_precision == 3) ? take(rows * d.llm_inter * 2 * 2) : 0;    // modes 2, 4: the SwiGLU output is ONE fp16 row (p.act)
     p.qkvf = take(rows * qkvw * 4);
     p.guf = 0;  // gate/up accumulators no longer round-trip through memory (SwiGLU + split fused into the GEMM epilogue)
   }
@@ -641,6 +641,19 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
         FV_TRY(gemm_p(h, g1, s));
         d1 = fv::GemmArgs{act, I, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 0};
         d1.f16 = 1;
+      } else if (d.llm_precision == 3) {
+        // gate/up alone in one fp16 pass; its SwiGLU output leaves as hi + lo bf16 for a split-bf16 down projection
+        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s, 1));
+        fv::GemmArgs g1{xn, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 0};
+        g1.f16 = 1;
+        FV_TRY(gemm_p(h, g1, s));
+      } else if (d.llm_precision == 4) {
+        // down alone in one fp16 pass: split-bf16 gate/up whose SwiGLU output / 16 leaves as fp16
+        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
+        fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, act, I, FV_EPI_SWIGLU_F16, 1};
+        FV_TRY(gemm_p(h, g1, s));
+        d1 = fv::GemmArgs{act, I, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 0};
+        d1.f16 = 1;
       } else {
         FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
         fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 1};
@@ -680,7 +693,8 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   if (d.llm_head_dim != 32 && d.llm_head_dim != 64 && d.llm_head_dim != 128) return fv_fail(FV_ERR_UNSUPPORTED, "llm head_dim must be 32/64/128");
   if (d.llm_hidden % 8 || d.llm_inter % 8 || d.llm_heads % d.llm_kv_heads) return fv_fail(FV_ERR_ARG, "llm dims must be multiples of 8 and heads %% kv_heads == 0");
   if (d.tower_out_dim != 2 * d.tower_dims[d.tower_stages - 1] && d.tower_out_dim != d.tower_dims[d.tower_stages - 1]) return fv_fail(FV_ERR_UNSUPPORTED, "tower_out_dim must be 1x or 2x the last stage dim");
-  if (d.llm_precision < 0 || d.llm_precision > 2) return fv_fail(FV_ERR_ARG, "llm_precision must be 0 (bf16), 1 (split-bf16) or 2 (split-bf16 qkv/o + fp16 gate/up/down)");
+  if (d.llm_precision < 0 || d.llm_precision > 4)
+    return fv_fail(FV_ERR_ARG, "llm_precision must be 0 (bf16), 1 (split-bf16), 2 (split-bf16 qkv/o + fp16 gate/up/down), 3 (fp16 gate/up only) or 4 (fp16 down only)");
   if (d.state_dim <= 0 || d.action_dim <= 0 || d.hidden_dim <= 0 || d.fusion_dim <= 0) return fv_fail(FV_ERR_ARG, "head dims must be positive");
   FV_HIP_CHECK(hipSetDevice(device));
   fv_handle* h = new fv_handle();
@@ -851,10 +865,11 @@ static int load_impl(fv_handle* h, Loader& L) {
       if (u && y.gu_w) L.put_rows(u, y.gu_w + 8 * Hd, 16 * Hd, 8 * Hd, I / 8, 8 * Hd);
     }
     y.down_w = L.mat(pre + "mlp.down_proj.weight", Hd, I);
-    if (d.llm_precision == 2 && L.rc == FV_OK) {
+    if (d.llm_precision >= 2 && L.rc == FV_OK) {
       // fp16 copies IN PLACE of the two projections that run on fp16 operands: exact for |w| >= 6.1e-5 (smaller weights become
       // fp16 subnormals, absolute error <= 3e-8); down carries the 2^4 that its operand (FV_EPI_SWIGLU_F16) gives up
-      if (fv::launch_bf16_to_f16(y.gu_w, 2 * I * Hd, 1.0f, nullptr) != FV_OK || fv::launch_bf16_to_f16(y.down_w, Hd * I, 16.0f, nullptr) != FV_OK)
+      if ((d.llm_precision != 4 && fv::launch_bf16_to_f16(y.gu_w, 2 * I * Hd, 1.0f, nullptr) != FV_OK) ||
+          (d.llm_precision != 3 && fv::launch_bf16_to_f16(y.down_w, Hd * I, 16.0f, nullptr) != FV_OK))
         L.rc = FV_ERR_HIP;
     }
   }

@@ -687,9 +687,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   if (a.lda < a.K) return fv_fail(FV_ERR_ARG, "gemm: lda < K");
   if (a.epi < FV_EPI_BIAS || (a.epi > FV_EPI_F32 && a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16)) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
   if (a.f16 && a.ksplit) return fv_fail(FV_ERR_ARG, "gemm: fp16 operands are a single pass (no ksplit)");
-  if (a.epi == FV_EPI_SWIGLU_F16 && !a.f16) return fv_fail(FV_ERR_ARG, "gemm: FV_EPI_SWIGLU_F16 belongs to the fp16-operand path");
-  if (a.f16 && (a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES || a.epi == FV_EPI_SWIGLU || a.epi == FV_EPI_SWIGLU_SPLIT))
-    return fv_fail(FV_ERR_UNSUPPORTED, "gemm: fp16 operands go with the BIAS / F32 / RES_F32 / SWIGLU_F16 epilogues");
+  if (a.f16 && (a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES || a.epi == FV_EPI_SWIGLU))
+    return fv_fail(FV_ERR_UNSUPPORTED, "gemm: fp16 operands go with the BIAS / F32 / RES_F32 / SWIGLU_SPLIT / SWIGLU_F16 epilogues");
   const bool f32out = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
   const bool swiglu = a.epi == FV_EPI_SWIGLU || a.epi == FV_EPI_SWIGLU_SPLIT || a.epi == FV_EPI_SWIGLU_F16;
   const int ncols = (a.epi == FV_EPI_SWIGLU || a.epi == FV_EPI_SWIGLU_F16) ? a.N / 2 : a.N;  // SPLIT: hi and lo halves side by side -> N columns
