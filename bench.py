@@ -24,9 +24,11 @@ Rank 0 prints ONE JSON line with the contract fields plus
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -191,25 +193,78 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed(fn, steps, warmup):
+    # board power of THIS rank's GPU while the timed region runs (amdgpu hwmon, microwatts; no subprocess): whether the step sits at
+    # the board's cap is what decides if a kernel-level cycle saving can show up as time at all
+    class PowerSampler:
+        def __init__(self):
+            self.path = self.cap = self.last = None
+            self.samples = []
+            self._stop = threading.Event()
+            self._th = None
+            try:
+                pr = torch.cuda.get_device_properties(dev)
+                slot = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+                for ue in sorted(glob.glob("/sys/class/drm/card*/device/uevent")):
+                    if f"PCI_SLOT_NAME={slot}" in open(ue).read():
+                        hw = glob.glob(os.path.join(os.path.dirname(ue), "hwmon", "hwmon*", "power1_input"))
+                        if hw:
+                            self.path = hw[0]
+                            self.cap = int(open(hw[0].replace("power1_input", "power1_cap")).read()) / 1e6
+                        break
+            except Exception:
+                self.path = None
+
+        def _run(self):
+            while not self._stop.is_set():
+                try:
+                    self.samples.append(int(open(self.path).read()) / 1e6)
+                except Exception:
+                    pass
+                self._stop.wait(0.02)
+
+        def start(self):
+            if self.path:
+                self.samples, self._th = [], threading.Thread(target=self._run, daemon=True)
+                self._stop.clear()
+                self._th.start()
+
+        def stop(self):
+            if self._th:
+                self._stop.set()
+                self._th.join()
+                self._th = None
+            if not self.samples:
+                return None
+            sm = sorted(self.samples)
+            return {"board_w_mean": round(sum(sm) / len(sm), 1), "board_w_median": round(sm[len(sm) // 2], 1), "board_w_max": round(sm[-1], 1),
+                    "cap_w": self.cap, "samples": len(sm), "source": "amdgpu hwmon power1_input of rank 0's GPU, sampled every 20 ms inside the timed region"}
+
+    power = PowerSampler() if rank == 0 else None
+
+    def timed(fn, steps, warmup, sampler=None):
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
+        if sampler:
+            sampler.start()
         t = time.perf_counter()
         for _ in range(steps):
             fn()
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t
+        if sampler:
+            sampler.last = sampler.stop()
         if world > 1:
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt)
         return el
 
-    el = timed(step_infer, args.steps, args.warmup)
+    el = timed(step_infer, args.steps, args.warmup, power)
+    power_info = power.last if power else None
     ms_per_step = 1e3 * el / args.steps
     value = world * args.steps / el
 
@@ -570,7 +625,7 @@ def main():
                        "llm_precision": {0: "bf16 operands", 1: "split-bf16 (hi+lo) operands, fp32 attention",
                                          2: "split-bf16 qkv/o, fp16 gate/up/down (one pass), fp32 attention"}[args.llm_precision]},
             "samples_per_s": round(value * B, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
+            "roofline": roofline, "power": power_info, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
         }
         print(json.dumps(out))
