@@ -10,13 +10,20 @@ def short(name):
     m = re.search(r"(\w+)(<|\()", name.replace("(anonymous namespace)::", "").replace("fv::", "").replace("void ", ""))
     return m.group(1) if m else name[:40]
 
+def instance(name):
+    """template kernels also under `name<first template argument>` (convffn32_kernel<384>: one row of the --stats table each)"""
+    m = re.search(r"(\w+)<(\d+)", name.replace("(anonymous namespace)::", "").replace("fv::", "").replace("void ", ""))
+    return f"{m.group(1)}<{m.group(2)}>" if m else None
+
 def counters(d, want):
     acc = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != want: continue
-            a = acc.setdefault(short(r["Kernel_Name"]), {})
-            a[r["Dispatch_Id"]] = a.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            for key in (short(r["Kernel_Name"]), instance(r["Kernel_Name"])):
+                if key is None: continue
+                a = acc.setdefault(key, {})
+                a[r["Dispatch_Id"]] = a.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
     return {k: (sum(v.values()) / len(v), len(v)) for k, v in acc.items()}
 
 def main(src, out):
