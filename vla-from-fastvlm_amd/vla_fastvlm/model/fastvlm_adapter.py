@@ -257,7 +257,7 @@ class FastVLMBackbone(nn.Module):
             tower = fv_arch.TowerConfig(**{**self.arch.tower.__dict__, "image_size": int(self.expected_size)})
             model = fv_arch.ModelConfig(self.arch.name, self.arch.llm, tower)
             # decoder arithmetic (include/fastvla_hip.h fv_model_desc.llm_precision): the cheapest policy verified inside north_star's
-            # 1e-3 for this model (fastvla_hip.arch.default_llm_precision); FASTVLA_LLM_PRECISION=0|1|2 overrides it
+            # 1e-3 for this model (fastvla_hip.arch.default_llm_precision); FASTVLA_LLM_PRECISION=0..4 overrides it
             prec = os.environ.get("FASTVLA_LLM_PRECISION")
             eng = FastVLAEngine(model, device=dev, max_batch=self._max_batch, max_text_tokens=self.config.tokenizer_max_length,
                                 tower_microbatch=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")),
