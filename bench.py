@@ -638,7 +638,9 @@ def main():
                        "splice_image_tokens": bool(args.splice), "tower_microbatch": args.microbatch,
                        "stream_overlap": bool(eng.overlap_streams and not args.splice),
                        "llm_precision": {0: "bf16 operands", 1: "split-bf16 (hi+lo) operands, fp32 attention",
-                                         2: "split-bf16 qkv/o, fp16 gate/up/down (one pass), fp32 attention"}[args.llm_precision]},
+                                         2: "split-bf16 qkv/o, fp16 gate/up/down (one pass), fp32 attention",
+                                         3: "split-bf16 qkv/o/down, fp16 gate/up (one pass), fp32 attention",
+                                         4: "split-bf16 qkv/o/gate/up, fp16 down (one pass), fp32 attention"}[args.llm_precision]},
             "samples_per_s": round(value * B, 2),
             "roofline": roofline, "power": power_info, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
