@@ -10,7 +10,8 @@
 // with the SAME operand traffic (a 1 KB fragment still feeds 16 K MACs), the same registers (C/2 output accumulators,
 // C/4 x-fragment registers per 32 rows) and half the MFMA instructions to interleave with.
 //
-//   per wave: MT tiles of 32 pixels; per block: 4 waves sharing the weight stream (one persistent block per CU)
+//   per wave: MT tiles of 32 pixels; per block: NW = 4 waves (one per SIMD, 512 registers each; C = 384, 96) or 8 (two per SIMD, 256
+//   registers, no AGPRs; C = 192) sharing the weight stream (one persistent block per CU)
 //   chunk of 32 hidden units:
 //     H^T[32 hid x 32 px] = W1[chunk] . x^T      A = W1 rows (lane r = hidden row, half h = k 8h..8h+7 of the 16-deep step)
 //                                                B = x fragments in registers
@@ -28,6 +29,9 @@
 //   * b1 / 4 enters as the C operand of each hidden tile's first MFMA (its 16 registers ARE the four float4 the bias table holds
 //     for this lane half, fetched one chunk ahead), not as 16 VALU adds per tile.
 //   10 VALU issues per hidden pair instead of 13: -3.5 % / 0 / -4 % per launch at C = 384 / 192 / 96 (tools/ffn_bench.py, four rounds).
+// Late round 3: the template also carries the 16x16x32 form of the same chunk (S16: a wave's 32 pixels as two 16-pixel column tiles,
+// every fragment read feeds two MFMAs, W2 packed for ONE K = 32 step) behind FFN32_S16_MASK -- bit-correct, same time as this form at
+// every width (the launch runs at the board's power cap: DESIGN.md section 5.0), so it is not enabled.
 // What was ALSO built this round and is NOT in this file (tools/experiments/convffn32_dma_staged_epilogue.patch): a row-per-lane
 // epilogue straight from the accumulators (W2 rows permuted so that a lane holds 8 consecutive channels) and one that moves
 // residual, output and the next tile's x fragments through wave-private 6 KB LDS units by LDS-DMA with hand-counted vmcnt.  Both
