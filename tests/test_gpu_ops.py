@@ -330,7 +330,8 @@ def _pack_wq(w1, w2):
 
 
 # the 32x32x16 variant the engine runs at the real tower widths; the big cases give every persistent block several row tiles
-@pytest.mark.parametrize("Cc,M", [(96, 1000), (192, 300), (384, 130), (384, 128), (96, 150013), (192, 131072 + 77), (384, 70001)])
+@pytest.mark.parametrize("Cc,M", [(96, 1000), (192, 300), (384, 130), (384, 128), (96, 150013), (192, 131072 + 77), (384, 70001),
+                                  (384, 1), (192, 5), (96, 31)])   # the last three: fewer rows than one wave's tile (rows past M are clamped / dropped)
 def test_fused_convffn32(Cc, M):
     torch.manual_seed(Cc + M + 1)
     Hd = 4 * Cc
