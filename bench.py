@@ -316,6 +316,9 @@ def main():
         "bound": "mfma", "kernel": dom,
         "achieved": round(dom_tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "practical": {"peak": 1860.0 if "32x32x16" in dom else 2050.0, "frac": round(dom_tflops / (1860.0 if "32x32x16" in dom else 2050.0), 4), "unit": "TFLOP/s",
+                      "source": "tools/mfma_ceiling.hip measured on this chip in round 2: the bare MFMA loop of this kernel's shape on random bf16 operands held in registers, "
+                                "i.e. what the board's 1.4 kW cap buys with nothing else switching (DESIGN.md 5.0, 5.5); a constant of the repo, not a quantity of this run"},
         "launches_per_step": dg["n"] // ps, "kernel_ms_per_step": round(dg["ms"] / ps, 3),
         "kernel_flops_per_launch": dg["flops"] / dg["n"], "kernel_avg_launch_ms": round(dg["ms"] / dg["n"], 4),
         "family": None if not fam else {"kernels": ffn_name + ", all channel widths, launch-weighted (the figure rounds 1-2 reported as roofline)",
