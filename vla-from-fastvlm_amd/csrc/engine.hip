@@ -369,7 +369,8 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
   }
   // split-K partial sums of the down projection (fp32, up to 4 splits of [rows][hidden padded to 256]); launch_gemm only
   // uses it when the problem has too few output tiles for the chip
-  p.splitk_bytes = rows % 256 == 0 ? (size_t)4 * rows * ((d.llm_hidden + 255) / 256 * 256) * 4 : 0;
+  // (round 3: qkv and o use it too when their 256-tiles are fewer than the CUs -- the 7B widths at M = 1024 --, so it is sized for the wider of the two outputs)
+  p.splitk_bytes = rows % 256 == 0 ? (size_t)4 * rows * ((std::max((size_t)d.llm_hidden, qkvw) + 255) / 256 * 256) * 4 : 0;
   p.splitk = take(p.splitk_bytes);
   p.head_scr = take(fv::head_bwd_scratch_bytes(h->hd, B));
   p.total = o;
@@ -620,6 +621,9 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
       // projection (fused into its split-K reducer)
       if (li == 0) FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
       fv::GemmArgs q1{xs, 2 * Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkvf, qkvw, FV_EPI_F32, 1};
+      // few output tiles and a long K (7B: 72 tiles of 256 x 256 at M = 1024): the 256-tile kernel cut along K, as the down projection
+      q1.splitk_ws = wp.splitk_bytes ? reinterpret_cast<float*>(ws + wp.splitk) : nullptr;
+      q1.splitk_bytes = wp.splitk_bytes;
       FV_TRY(gemm_p(h, q1, s));
       if (mode == DEC_PREFIX) {   // this layer's [k | v] rows of the prefix, un-rotated (RoPE rides inside the attention kernel)
         FV_HIP_CHECK(hipMemcpy2DAsync(kv + li * kv_layer, (size_t)2 * kd * 4, qkvf + qd, (size_t)qkvw * 4, (size_t)2 * kd * 4, (size_t)rows,
@@ -631,6 +635,8 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
            fv::launch_attention_f32(qkvf, qkvw, as, as + qd, 2 * qd, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, len_add, att_scale, s, h->rope,
                                     mode == DEC_SUFFIX ? kv + li * kv_layer : nullptr, 2 * kd, mode == DEC_SUFFIX ? Np : 0));
       fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
+      o1.splitk_ws = q1.splitk_ws;
+      o1.splitk_bytes = wp.splitk_bytes;
       FV_TRY(gemm_p(h, o1, s));
       fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
       if (d.llm_precision == 2) {
