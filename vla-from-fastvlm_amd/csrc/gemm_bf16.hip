@@ -25,6 +25,10 @@ struct Params {
   const bf16_t* A; const bf16_t* W; const float* bias; const float* scale; const void* res; void* out;
   int M, N, K, lda, ldr, ldo, epi, tiles_n, nwg, ksplit;   // (fp16 operands are a template parameter of the kernels, not a field)
   int splits = 1, npad = 0; float* part = nullptr;   // split-K (gemm256 only): units = tiles x splits, partials [split][M][npad]
+  // gemm256 only: tiles_m > 0 = walk the tiles column-major (the row tiles of ONE weight column tile are neighbours: same XCD, same
+  // time).  For few row tiles against many weight columns (the 7B decoder at M = 1024: 4 x 148) the row-major walk makes every XCD
+  // stream 32 different 3.7 MB weight tiles per round and each weight tile is fetched by four XCDs: 2.2 GB per launch, 4.3 TB/s.
+  int tiles_m = 0;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
@@ -270,8 +274,13 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   // decoder's down projection at M = 4096 -- one unit per CU; each unit leaves raw fp32 partial sums for splitk_reduce_kernel
   auto tile_offsets = [&](int unit, uint32_t (&oa)[4], uint32_t (&ow)[4], uint32_t (&ow2)[4], int& bm, int& bn) {
     const int logical = xcd_remap(unit, p.nwg) / p.splits;
-    bm = (logical / p.tiles_n) * BMT;
-    bn = (logical % p.tiles_n) * BNT;
+    if (p.tiles_m) {
+      bn = (logical / p.tiles_m) * BNT;
+      bm = (logical % p.tiles_m) * BMT;
+    } else {
+      bm = (logical / p.tiles_n) * BMT;
+      bn = (logical % p.tiles_n) * BNT;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int sl = j * NTH + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
@@ -714,6 +723,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
   }
+  static const bool colmajor_ok = getenv("FASTVLA_NO_GEMM_COLMAJOR") == nullptr;   // A/B
   static const bool no_asym = getenv("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
   const bool asym = !no_asym && a.M <= 8192;
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
@@ -727,6 +737,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     const size_t need = (size_t)splits * a.M * (tn * 256) * sizeof(float);
     if (splits > 1 && need <= a.splitk_bytes) {
       p.tiles_n = tn;
+      p.tiles_m = colmajor_ok && a.M / 256 <= 8 ? a.M / 256 : 0;
       p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
       p.nwg = tiles * splits;
       const dim3 g2(p.nwg < cus ? p.nwg : cus / 8 * 8);
@@ -768,6 +779,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   if (const int gt = gemm_glds_tile(a)) {
     p.tiles_n = a.N / gt;
     p.nwg = (a.M / gt) * p.tiles_n;
+    p.tiles_m = colmajor_ok && a.M / gt <= 8 ? a.M / gt : 0;
     const int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
     const int grid = p.nwg < slots ? p.nwg : slots;
     if (gt == 256 && a.f16 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
