@@ -647,6 +647,24 @@ def test_gemm_splitk_down_projection_shape():
     assert torch.equal(x, out)
 
 
+@pytest.mark.parametrize("ws_splits", [8, 3])
+def test_gemm_splitk_few_rows_many_splits(ws_splits):
+    """The 7B decoder at C5's rank shape (M = 512): 2 x 4 tiles of 256 x 256 over a long K -- up to eight K ranges per tile, and as
+    many as the scratch buffer holds when it is smaller (here: room for 8 or for 3), column-major tile walk (M <= 2048), bias in the
+    reducer; against fp64."""
+    torch.manual_seed(21 + ws_splits)
+    M, N, K = 512, 1024, 8192
+    A, W, b = bf(torch.randn(M, K)), bf(torch.randn(N, K) * 0.02), torch.randn(N)
+    ref = (A.double() @ W.double().t() + b.double()).float()
+    a, w, bd = dev_bf16(A), dev_bf16(W), dev_f32(b)
+    ws = torch.empty(ws_splits * M * 1024, dtype=torch.float32, device=DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    call(lib().fv_op_gemm_splitk(a.data_ptr(), K, w.data_ptr(), M, N, K, bd.data_ptr(), None, 0, out.data_ptr(), N,
+                                 _lib.EPI_F32, 0, ws.data_ptr(), ws.numel() * 4, stream()), "fv_op_gemm_splitk few rows")
+    torch.cuda.synchronize()
+    check_close(out.cpu(), ref, rel=2e-5, amax=2e-4, what=f"split-K few rows (scratch for {ws_splits})")
+
+
 # ------------------------------------------------------------------------------------------------ round 3: fp16-operand GEMMs
 @pytest.mark.parametrize("M,N,K", [(100, 256, 896), (512, 1024, 896), (4096, 5120, 256), (256, 896, 4864)])
 def test_gemm_f16_operands(M, N, K):

@@ -370,7 +370,8 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
   // split-K partial sums of the down projection (fp32, up to 4 splits of [rows][hidden padded to 256]); launch_gemm only
   // uses it when the problem has too few output tiles for the chip
   // (round 3: qkv and o use it too when their 256-tiles are fewer than the CUs -- the 7B widths at M = 1024 --, so it is sized for the wider of the two outputs)
-  p.splitk_bytes = rows % 256 == 0 ? (size_t)4 * rows * ((std::max((size_t)d.llm_hidden, qkvw) + 255) / 256 * 256) * 4 : 0;
+  // up to 8 splits for few rows (C5's rank shape, 7B at M = 512: 28 tiles of the down projection), 4 otherwise
+  p.splitk_bytes = rows % 256 == 0 ? (size_t)(rows <= 2048 ? 8 : 4) * rows * ((std::max((size_t)d.llm_hidden, qkvw) + 255) / 256 * 256) * 4 : 0;
   p.splitk = take(p.splitk_bytes);
   p.head_scr = take(fv::head_bwd_scratch_bytes(h->hd, B));
   p.total = o;

@@ -734,8 +734,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     int splits = tiles < cus ? cus / tiles : 1;
     if (splits > 8) splits = 8;
     while (splits > 1 && nkt / splits < 16) --splits;
-    const size_t need = (size_t)splits * a.M * (tn * 256) * sizeof(float);
-    if (splits > 1 && need <= a.splitk_bytes) {
+    while (splits > 1 && (size_t)splits * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes) --splits;   // as many as the scratch buffer holds
+    if (splits > 1) {
       p.tiles_n = tn;
       p.tiles_m = colmajor_ok && a.M / 256 <= 8 ? a.M / 256 : 0;
       p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
