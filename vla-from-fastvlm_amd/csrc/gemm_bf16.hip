@@ -662,7 +662,10 @@ int gemm_glds_tile(const GemmArgs& a) {
   if ((a.epi == FV_EPI_SWIGLU_SPLIT || a.epi == FV_EPI_SWIGLU_F16) && a.bias) return 0;
   // (a 128 x 256 variant for shapes whose last round of 256-tiles is mostly idle -- the decoder's gate/up, 608 tiles = 2.4
   // rounds -- was measured slower, 184 vs 150 us: 64 x 64 per wave reads a third more LDS per MFMA)
-  if (a.M % 256 == 0 && a.N % 256 == 0 && (long)(a.M / 256) * (a.N / 256) >= 320) return 256;
+  // few rows (M <= 2048, the column-major walk): the alternative is the register-staged kernel on 64- / 128-row tiles, and a half-filled
+  // round of 256-tiles beats it -- 7B gate/up at M = 512 (296 tiles) 10.5 -> 8.9 ms per step, 0.5B at M = 1024 (152 tiles) 0.96 -> 0.71
+  static const int min_tiles_small_m = getenv("FASTVLA_GEMM256_MIN_TILES") ? atoi(getenv("FASTVLA_GEMM256_MIN_TILES")) : 128;   // A/B
+  if (a.M % 256 == 0 && a.N % 256 == 0 && (long)(a.M / 256) * (a.N / 256) >= (a.M <= 2048 ? min_tiles_small_m : 320)) return 256;
   // 128-tiles: one wave per SIMD and a K-tile of 32 MFMAs per wave cannot cover a memory latency per K-tile, so a long K
   // loop (the decoder's down projection, K = 2 x 4864) is slower here than on the 128-tile register-staged kernel at three
   // blocks per CU; short ones (qkv / o, K <= 1024) are on par
