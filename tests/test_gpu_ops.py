@@ -557,11 +557,12 @@ def test_gemm_pointwise_square(M, C):
     check_close(_gemm(A, W, _lib.EPI_BIAS_GELU, bias=b), F.gelu(ref), what=f"pwconv gelu {M}x{C}")
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 2048, 192), (8192, 4096, 448), (4096, 5632, 192)])
+@pytest.mark.parametrize("M,N,K", [(16384, 2048, 192), (8192, 4096, 448), (4096, 5632, 192), (1024, 9216, 192), (512, 20480, 128)])
 def test_gemm_256_tile_variant(M, N, K):
-    """Shapes the 256 x 256 LDS-DMA kernel takes (M, N multiples of 256, K of 64, >= 320 tiles): all three of its epilogues,
-    plus the asymmetric-operand check that a swapped row/column map cannot pass.  The third shape has 352 tiles: a ragged second round of
-    the persistent loop."""
+    """Shapes the 256 x 256 LDS-DMA kernel takes (M, N multiples of 256, K of 64, >= 320 tiles; from 128 tiles up when M <= 2048): all
+    three of its epilogues, plus the asymmetric-operand check that a swapped row/column map cannot pass.  The third shape has 352 tiles: a
+    ragged second round of the persistent loop; the last two (4 x 36 and 2 x 80 tiles) are walked column-major (few rows, many weight
+    columns: the decoder at small batch)."""
     torch.manual_seed(M + N + K)
     A, W = bf(torch.randn(M, K)), bf(torch.randn(N, K) / math.sqrt(K))
     b, ls, res = torch.randn(N) * 0.1, torch.rand(N) * 0.3 + 0.05, bf(torch.randn(M, N))
