@@ -727,6 +727,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
   }
   static const bool colmajor_ok = getenv("FASTVLA_NO_GEMM_COLMAJOR") == nullptr;   // A/B
+  static const int cm_max = getenv("FASTVLA_GEMM_COLMAJOR_MAX_TM") ? atoi(getenv("FASTVLA_GEMM_COLMAJOR_MAX_TM")) : 8;   // A/B
   static const bool no_asym = getenv("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
   const bool asym = !no_asym && a.M <= 8192;
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
@@ -740,7 +741,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     while (splits > 1 && (size_t)splits * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes) --splits;   // as many as the scratch buffer holds
     if (splits > 1) {
       p.tiles_n = tn;
-      p.tiles_m = colmajor_ok && a.M / 256 <= 8 ? a.M / 256 : 0;
+      p.tiles_m = colmajor_ok && a.M / 256 <= cm_max ? a.M / 256 : 0;
       p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
       p.nwg = tiles * splits;
       const dim3 g2(p.nwg < cus ? p.nwg : cus / 8 * 8);
@@ -782,7 +783,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   if (const int gt = gemm_glds_tile(a)) {
     p.tiles_n = a.N / gt;
     p.nwg = (a.M / gt) * p.tiles_n;
-    p.tiles_m = colmajor_ok && a.M / gt <= 8 ? a.M / gt : 0;
+    p.tiles_m = colmajor_ok && a.M / gt <= cm_max ? a.M / gt : 0;
     const int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
     const int grid = p.nwg < slots ? p.nwg : slots;
     if (gt == 256 && a.f16 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
