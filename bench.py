@@ -85,21 +85,61 @@ def spawn_ranks(args) -> int:
     never exec()s: the parent stays a plain host process."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import threading
+    import time
+    # the rendezvous port: kept bound (SO_REUSEADDR) until just before the ranks start, so nothing else grabs it in between
+    sk = socket.socket()
+    sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0 or "")
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # drain rank 0 while polling
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("FASTVLA_BENCH_TIMEOUT_S", "1500"))
+    codes = [None] * len(procs)
+    failed = False
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        bad_now = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad_now or time.monotonic() > deadline:
+            # one rank died (OOM, bad device) or the job hangs: the others would sit in init_process_group / a barrier until the
+            # store or RCCL timeout -- end exactly the children this function started and report a fast non-zero exit
+            failed = True
+            t_grace = time.monotonic() + 3.0      # ranks that fail for the same reason report their OWN exit code
+            while time.monotonic() < t_grace and any(c is None for c in codes):
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        codes[r] = p.poll()
+                time.sleep(0.1)
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 10
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            why = f"rank(s) {bad_now} exited non-zero" if bad_now else "overall timeout"
+            print(f"bench.py: {why}; remaining ranks terminated", file=sys.stderr)
+            break
+        time.sleep(0.2)
+    reader.join(timeout=5)
+    sys.stdout.write("".join(x for x in out0 if x))
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
+    if bad or failed:
         print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr)
         return 1
     return 0

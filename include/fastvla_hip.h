@@ -149,6 +149,14 @@ int fv_vision_forward_unit_taps(fv_handle* h, const void* pix, int B, void* img_
 int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens, const void* img_tokens, int Ni, int B,
                           int T, int pool_mode, void* pooled, fv_stream s);
 
+/* llm_precision >= 2 runs gate/up and down on fp16 operands.  Weights outside the binary16 range are REFUSED at load time
+ * (fv_load_weights* returns FV_ERR_UNSUPPORTED: load with llm_precision = 1); activations are converted with SATURATING casts
+ * (an outlier channel of a real checkpoint clamps to +-65504 instead of becoming inf / NaN actions) and every clamped 8-value
+ * group is counted.  This reads the counter (0 in a healthy model; non-zero = the fp16 budget does not hold for this
+ * checkpoint / input, switch to llm_precision = 1).  A status call: synchronises the device.  Call site whose fp32 arithmetic
+ * this guards: model/fastvlm_adapter.py:183-191 (the reference loads fp32), :533. */
+int fv_llm_fp16_saturations(fv_handle* h, uint64_t* count_out, int reset);
+
 /* Image-prefix reuse (the call site the reference has is ONE full prefill per env step:
  * lerobot_fastvla/modeling_fastvla.py:119-125 -> model/fastvlm_adapter.py:519-536).  With the image tokens spliced in FRONT of the
  * text under a causal mask, the keys / values of the Ni image positions depend on the image alone:

@@ -35,6 +35,16 @@ def rel_l2(out, ref):
     return float((out - ref).norm() / ref.norm().clamp_min(1e-30))
 
 
+def worst_row(out, ref):
+    """(B, D) tensors -> the largest per-sample relative error ||out_b - ref_b|| / max(||ref_b||, rms_b' ||ref_b'|| / 4): the bound a
+    single env's action has to meet, not the batch average (a row whose own norm is unusually small is measured against a quarter of
+    the batch's typical row norm instead of blowing the ratio up)."""
+    out, ref = out.double(), ref.double()
+    rn = ref.norm(dim=1)
+    floor = 0.25 * float(rn.pow(2).mean().sqrt())
+    return float(((out - ref).norm(dim=1) / rn.clamp_min(max(floor, 1e-30))).max())
+
+
 def check_close(out, ref, *, rel=4e-3, amax=2e-2, what=""):
     """out/ref CPU fp32.  rel: relative L2 error bound; amax: max-abs error bound relative to max|ref|."""
     assert out.shape == ref.shape, (what, out.shape, ref.shape)

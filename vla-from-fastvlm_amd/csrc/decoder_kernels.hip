@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __rest
 template <bool F16>   // F16: y receives fp16 bits (11 significant bits: the single-pass operand of llm_precision = 2's gate/up GEMM)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        bf16_t* __restrict__ y, bf16_t* __restrict__ y_lo, int ldy, int rows,
-                                                       int H, float eps) {
+                                                       int H, float eps, unsigned* __restrict__ sat) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     const float o[8] = {wa.x * (a.x * r), wa.y * (a.y * r), wa.z * (a.z * r), wa.w * (a.w * r),
                         wc.x * (c.x * r), wc.y * (c.y * r), wc.z * (c.z * r), wc.w * (c.w * r)};
     if constexpr (F16) {
+      count_f16_sat8(o, sat);
       *reinterpret_cast<uint4*>(y + row * ldy + i) = pack8_h(o);
       continue;
     }
@@ -423,33 +424,39 @@ int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* im
   return FV_OK;
 }
 
-int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s, int f16) {
+int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s, int f16, unsigned* sat) {
   if (!x || !w || !y) return fv_fail(FV_ERR_ARG, "rmsnorm: null pointer");
   if (rows <= 0 || H <= 0 || H % 8 || ldy < H || ldy % 8) return fv_fail(FV_ERR_ARG, "rmsnorm: bad shape rows=%d H=%d ldy=%d", rows, H, ldy);
   if (f16 && y_lo) return fv_fail(FV_ERR_ARG, "rmsnorm: the fp16 form has no remainder output");
-  if (f16) hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, ldy, rows, H, eps);
-  else hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, ldy, rows, H, eps);
+  if (f16) hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, ldy, rows, H, eps, sat);
+  else hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, ldy, rows, H, eps, nullptr);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
 
 namespace {
-__global__ __launch_bounds__(256) void bf16_to_f16_kernel(bf16_t* __restrict__ p, size_t n8, float scale) {
+__global__ __launch_bounds__(256) void bf16_to_f16_kernel(bf16_t* __restrict__ p, size_t n8, float scale, unsigned* __restrict__ maxbits) {
+  float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     float f[8];
     unpack8(reinterpret_cast<const uint4*>(p)[i], f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] *= scale;
+    for (int e = 0; e < 8; ++e) {
+      f[e] *= scale;
+      const float af = fabsf(f[e]);
+      if (!(af <= m)) m = af == af ? af : __builtin_inff();   // a NaN weight reads as "out of range" too
+    }
     reinterpret_cast<uint4*>(p)[i] = pack8_h(f);
   }
+  if (maxbits && m > 0.f) atomicMax(maxbits, __float_as_uint(m));   // non-negative floats order like their bit patterns
 }
 }  // namespace
 
-int launch_bf16_to_f16(bf16_t* p, size_t n, float scale, hipStream_t s) {
+int launch_bf16_to_f16(bf16_t* p, size_t n, float scale, hipStream_t s, unsigned* maxbits) {
   if (!p || n == 0 || n % 8 || ((uintptr_t)p & 15)) return fv_fail(FV_ERR_ARG, "bf16_to_f16: n must be a positive multiple of 8 and p 16-byte aligned");
   const size_t n8 = n / 8;
   const unsigned blocks = (unsigned)((n8 + 255) / 256 < 65536 ? (n8 + 255) / 256 : 65536);
-  hipLaunchKernelGGL(bf16_to_f16_kernel, dim3(blocks), dim3(256), 0, s, p, n8, scale);
+  hipLaunchKernelGGL(bf16_to_f16_kernel, dim3(blocks), dim3(256), 0, s, p, n8, scale, maxbits);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

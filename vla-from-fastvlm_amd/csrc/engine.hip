@@ -135,6 +135,8 @@ struct fv_handle {
   bool no_fused_ffn = false;  // FASTVLA_NO_FUSED_FFN=1: A/B switch back to the two-GEMM ConvFFN
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
   bool no_ffn32 = false;      // FASTVLA_NO_FFN32=1: A/B switch back to the 16x16x32 fused ConvFFN
+  unsigned* f16_flags = nullptr;  // device: [0] = activation groups clamped to the fp16 range (fv_llm_fp16_saturations),
+                                  // [1] = max |scaled weight| bits seen by the loader's in-place fp16 conversion
 };
 
 namespace {
@@ -642,15 +644,15 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
       fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
       if (d.llm_precision == 2) {
         // the MLP in ONE pass on fp16 operands (tests/precision_budget.py): post-norm rows as fp16, SwiGLU output / 16 as fp16
-        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s, 1));
+        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s, 1, h->f16_flags));
         fv::GemmArgs g1{xn, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, act, I, FV_EPI_SWIGLU_F16, 0};
-        g1.f16 = 1;
+        g1.f16 = 1; g1.sat = h->f16_flags;
         FV_TRY(gemm_p(h, g1, s));
         d1 = fv::GemmArgs{act, I, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 0};
         d1.f16 = 1;
       } else if (d.llm_precision == 3) {
         // gate/up alone in one fp16 pass; its SwiGLU output leaves as hi + lo bf16 for a split-bf16 down projection
-        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s, 1));
+        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s, 1, h->f16_flags));
         fv::GemmArgs g1{xn, Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 0};
         g1.f16 = 1;
         FV_TRY(gemm_p(h, g1, s));
@@ -658,6 +660,7 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
         // down alone in one fp16 pass: split-bf16 gate/up whose SwiGLU output / 16 leaves as fp16
         FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
         fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, act, I, FV_EPI_SWIGLU_F16, 1};
+        g1.sat = h->f16_flags;
         FV_TRY(gemm_p(h, g1, s));
         d1 = fv::GemmArgs{act, I, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 0};
         d1.f16 = 1;
@@ -721,6 +724,11 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   if (rc == FV_OK && hipMemcpy(p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fv_fail(FV_ERR_HIP, "rope table upload failed");
   h->rope = static_cast<float2*>(p);
   if (rc == FV_OK) { rc = dev_alloc(h, fv::adamw_scratch_bytes(), &p); h->norm_scratch = static_cast<float*>(p); }
+  if (rc == FV_OK) {
+    rc = dev_alloc(h, 256, &p);
+    h->f16_flags = static_cast<unsigned*>(p);
+    if (rc == FV_OK && hipMemset(p, 0, 256) != hipSuccess) rc = fv_fail(FV_ERR_HIP, "fp16 flag words: memset failed");
+  }
   if (rc != FV_OK) { fv_destroy(h); return rc; }
   *out = h;
   return FV_OK;
@@ -875,13 +883,24 @@ static int load_impl(fv_handle* h, Loader& L) {
     if (d.llm_precision >= 2 && L.rc == FV_OK) {
       // fp16 copies IN PLACE of the two projections that run on fp16 operands: exact for |w| >= 6.1e-5 (smaller weights become
       // fp16 subnormals, absolute error <= 3e-8); down carries the 2^4 that its operand (FV_EPI_SWIGLU_F16) gives up
-      if ((d.llm_precision != 4 && fv::launch_bf16_to_f16(y.gu_w, 2 * I * Hd, 1.0f, nullptr) != FV_OK) ||
-          (d.llm_precision != 3 && fv::launch_bf16_to_f16(y.down_w, Hd * I, 16.0f, nullptr) != FV_OK))
+      if ((d.llm_precision != 4 && fv::launch_bf16_to_f16(y.gu_w, 2 * I * Hd, 1.0f, nullptr, h->f16_flags + 1) != FV_OK) ||
+          (d.llm_precision != 3 && fv::launch_bf16_to_f16(y.down_w, Hd * I, 16.0f, nullptr, h->f16_flags + 1) != FV_OK))
         L.rc = FV_ERR_HIP;
     }
   }
   if (L.rc != FV_OK) return L.rc;
   FV_HIP_CHECK(hipDeviceSynchronize());
+  if (d.llm_precision >= 2) {
+    // LOUD refusal instead of a silently clamped weight: the fp16 single-pass projections need every (scaled) weight inside the
+    // binary16 range.  The host side falls back to llm_precision = 1 (split-bf16, no range limit) on this error.
+    unsigned bits = 0;
+    FV_HIP_CHECK(hipMemcpy(&bits, h->f16_flags + 1, 4, hipMemcpyDeviceToHost));
+    float mx;
+    memcpy(&mx, &bits, 4);
+    if (!(mx <= 65504.0f))
+      return fv_fail(FV_ERR_UNSUPPORTED, "llm_precision=%d: a gate/up/down weight leaves the fp16 range (max |w| x scale = %g, down carries x16); "
+                     "load this checkpoint with llm_precision=1", d.llm_precision, (double)mx);
+  }
   h->loaded = true;
   return FV_OK;
 }
@@ -1041,6 +1060,18 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
 // [k | v] rows; fv_llm_forward_pooled_prefixed then runs only the text positions against them -- same arithmetic as
 // fv_llm_forward_pooled(img_tokens != NULL), 1/5 of its rows at T = 64, and no tower / projector / prefix pass at all for an image
 // (or a batch of images) whose prefix is already held.
+int fv_llm_fp16_saturations(fv_handle* h, uint64_t* count_out, int reset) {
+  HandleScope _hs(h);
+  if (!h || !count_out) return fv_fail(FV_ERR_ARG, "fv_llm_fp16_saturations: null argument");
+  FV_HIP_CHECK(hipSetDevice(h->device));
+  FV_HIP_CHECK(hipDeviceSynchronize());
+  unsigned n = 0;
+  FV_HIP_CHECK(hipMemcpy(&n, h->f16_flags, 4, hipMemcpyDeviceToHost));
+  if (reset) FV_HIP_CHECK(hipMemset(h->f16_flags, 0, 4));
+  *count_out = n;
+  return FV_OK;
+}
+
 int fv_llm_prefix_bytes(fv_handle* h, int B, int Ni, size_t* out_bytes) {
   HandleScope _hs(h);
   if (!h || !out_bytes || B <= 0 || Ni <= 0) return fv_fail(FV_ERR_ARG, "fv_llm_prefix_bytes: bad argument");

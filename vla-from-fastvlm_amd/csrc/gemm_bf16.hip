@@ -29,6 +29,7 @@ struct Params {
   // time).  For few row tiles against many weight columns (the 7B decoder at M = 1024: 4 x 148) the row-major walk makes every XCD
   // stream 32 different 3.7 MB weight tiles per round and each weight tile is fetched by four XCDs: 2.2 GB per launch, 4.3 TB/s.
   int tiles_m = 0;
+  unsigned* sat = nullptr;   // FV_EPI_SWIGLU_F16: device counter of 8-value groups clamped to the fp16 range (0 in a healthy model)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
         if (epi == FV_EPI_SWIGLU_F16) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] *= 0.0625f;
+          count_f16_sat8(o, p.sat);
           *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (gn >> 1)) = pack8_h(o);
           continue;
         }
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
         if (p.epi == FV_EPI_SWIGLU_F16) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) o8[e] *= 0.0625f;
+          count_f16_sat8(o8, p.sat);
           *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + go) = pack8_h(o8);
           asm volatile("" ::: "memory");
           continue;
@@ -714,6 +717,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   p.A = a.A; p.W = a.W; p.bias = a.bias; p.scale = a.scale; p.res = a.res; p.out = a.out;
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi;
   p.ksplit = a.ksplit ? 1 : 0;
+  p.sat = a.sat;
   if (a.ksplit && (a.K % BK || a.lda < 2 * a.K)) return fv_fail(FV_ERR_ARG, "gemm: ksplit needs K %% 64 == 0 and lda >= 2K");
   static int cus = 0;
   if (!cus) {

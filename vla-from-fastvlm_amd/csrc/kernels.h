@@ -26,6 +26,7 @@ struct GemmArgs {
   // optional RMSNorm of the fp32 output rows (the decoder's next-layer input_layernorm): y (+ y_lo) = bf16 hi (+ lo) of
   // w * out * rsqrt(mean(out^2) + eps), row stride norm_ld; fused into the split-K reducer, a separate launch otherwise
   const float* norm_w = nullptr; bf16_t* norm_y = nullptr; bf16_t* norm_ylo = nullptr; int norm_ld = 0; float norm_eps = 0.f;
+  unsigned* sat = nullptr;      // optional device counter: += 1 per 8-value group FV_EPI_SWIGLU_F16 had to clamp to the fp16 range
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -87,9 +88,10 @@ int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* im
                         int Ni, int H, int vocab, hipStream_t s);
 // y_lo != null: also writes the bf16 remainder (x ~= y + y_lo), the split operand of the parity-mode decoder GEMMs
 int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s,
-                   int f16 = 0);   // f16 != 0: y receives fp16 bits (y_lo must be null)
-// in place: n bf16 values -> the fp16 values scale * x (weights of the fp16-operand projections, once at load time)
-int launch_bf16_to_f16(bf16_t* p, size_t n, float scale, hipStream_t s);
+                   int f16 = 0, unsigned* sat = nullptr);   // f16 != 0: y receives fp16 bits (y_lo must be null), clamps counted in *sat
+// in place: n bf16 values -> the fp16 values scale * x (weights of the fp16-operand projections, once at load time); maxbits (device,
+// optional) receives max(|scale * x|) as float bits by atomicMax, so the loader can refuse weights outside the fp16 range
+int launch_bf16_to_f16(bf16_t* p, size_t n, float scale, hipStream_t s, unsigned* maxbits = nullptr);
 int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D, hipStream_t s);
 // rope != null: qkv holds un-rotated projections; the rotate-half RoPE is fused into the MFMA kernel (head_dim 64 / 128) or applied
 // in place by a rope_f32 launch ahead of the VALU kernel (head_dim 32)

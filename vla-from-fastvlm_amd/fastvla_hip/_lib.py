@@ -17,7 +17,7 @@ EPI_SWIGLU_F16 = 8
 
 
 class FastVLAHipError(RuntimeError):
-    pass
+    status = 0   # the fv_status the library returned (include/fastvla_hip.h), 0 when raised by the host side
 
 
 class ModelDesc(C.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "fv_vision_unit_info": (_i, [_vp, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "fv_vision_forward_unit_taps": (_i, [_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), _i, _vp]),
     "fv_llm_forward_pooled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "fv_llm_fp16_saturations": (_i, [_vp, C.POINTER(_u64), _i]),
     "fv_llm_prefix_bytes": (_i, [_vp, _i, _i, C.POINTER(C.c_size_t)]),
     "fv_llm_prefix": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "fv_llm_forward_pooled_prefixed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -156,4 +157,6 @@ def load():
 def check(rc: int, what: str = "", handle=None) -> None:
     if rc != 0:
         msg = load().fv_last_error(handle)
-        raise FastVLAHipError(f"{what or 'libfastvla_hip'} failed (status {rc}): {msg.decode() if msg else '?'}")
+        err = FastVLAHipError(f"{what or 'libfastvla_hip'} failed (status {rc}): {msg.decode() if msg else '?'}")
+        err.status = int(rc)
+        raise err

@@ -101,7 +101,7 @@ class FastVLAEngine:
             for j, s in enumerate(t.shape if t.ndim else (1,)):
                 descs[i].shape[j] = s
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.fv_load_weights(self.h, descs, len(state)), "fv_load_weights")
+            _lib.check(self.lib.fv_load_weights(self.h, descs, len(state)), "fv_load_weights", self.h)
         self.loaded = True
 
     def load_weights_streaming(self, provider) -> None:
@@ -265,6 +265,14 @@ class FastVLAEngine:
         _lib.check(self.lib.fv_llm_forward_pooled(self.h, ids.data_ptr(), lens.data_ptr(), _ptr(img_tokens), ni, B, T,
                                                   pool_mode, pooled.data_ptr(), _stream()), "fv_llm_forward_pooled")
         return pooled
+
+    def fp16_saturations(self, reset: bool = False) -> int:
+        """How many 8-value activation groups the fp16 single-pass projections (llm_precision >= 2) had to clamp to +-65504 since the
+        last reset (fv_llm_fp16_saturations): 0 in a healthy model; non-zero means the fp16 budget does not hold for this checkpoint /
+        input and the engine should be rebuilt with llm_precision=1.  Synchronises the device."""
+        n = C.c_uint64()
+        _lib.check(self.lib.fv_llm_fp16_saturations(self.h, C.byref(n), int(reset)), "fv_llm_fp16_saturations", self.h)
+        return int(n.value)
 
     # ---------------------------------------------------------------- image-prefix reuse (SURVEY.md 8f-1)
     def llm_prefix(self, img_tokens: torch.Tensor) -> torch.Tensor:

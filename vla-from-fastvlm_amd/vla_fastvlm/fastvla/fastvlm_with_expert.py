@@ -131,7 +131,16 @@ class FastVLMWithExpert(nn.Module):
             raise ValueError(f"states must be (B,{self.config.state_dim}), got {tuple(states.shape)}")
         params = self.head_parameters()
         differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        return _HeadFunction.apply(self, pooled, states, self.training, differentiable, *params)
+        actions = _HeadFunction.apply(self, pooled, states, self.training, differentiable, *params)
+        io = self.backbone._io_norm
+        if differentiable and not self.training and io is not None:
+            # eval mode with autograd on: the library kept the actions in normalised space (its backward differentiates the head, not
+            # the folded statistics); finish `* action_std + action_mean` here, in torch, so that predict() returns the SAME space with
+            # and without torch.no_grad() -- and the result stays differentiable
+            std = torch.as_tensor(io["action_std"], dtype=torch.float32, device=actions.device).reshape(1, -1)
+            mean = torch.as_tensor(io["action_mean"], dtype=torch.float32, device=actions.device).reshape(1, -1)
+            actions = actions * std + mean
+        return actions
 
     def head_loss(self, pooled: torch.Tensor, states: torch.Tensor, targets: torch.Tensor):
         """-> (loss 0-dim, actions): MSE of the head's prediction against `targets`, differentiable w.r.t. the 12 head

@@ -173,6 +173,7 @@ class FastVLMBackbone(nn.Module):
         self.cache_image_prefix = os.environ.get("FASTVLA_PREFIX_CACHE", "0") == "1"
         self.prefix_cache_size = 64
         self._engine: Optional[FastVLAEngine] = None
+        self._weights_override: Optional[Dict[str, Tensor]] = None   # load_backbone_state(): a checkpoint's own VLM tensors
         self._io_norm: Optional[dict] = None   # dataset statistics folded into the head kernels (set_io_normalization)
         self._head_dims = dict(state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024)
         self._max_batch = int(os.environ.get("FASTVLA_MAX_BATCH", "64"))
@@ -256,28 +257,91 @@ class FastVLMBackbone(nn.Module):
                 dev = torch.device("cuda", torch.cuda.current_device())
             tower = fv_arch.TowerConfig(**{**self.arch.tower.__dict__, "image_size": int(self.expected_size)})
             model = fv_arch.ModelConfig(self.arch.name, self.arch.llm, tower)
-            # decoder arithmetic (include/fastvla_hip.h fv_model_desc.llm_precision): the cheapest policy verified inside north_star's
-            # 1e-3 for this model (fastvla_hip.arch.default_llm_precision); FASTVLA_LLM_PRECISION=0..4 overrides it
-            prec = os.environ.get("FASTVLA_LLM_PRECISION")
-            eng = FastVLAEngine(model, device=dev, max_batch=self._max_batch, max_text_tokens=self.config.tokenizer_max_length,
-                                tower_microbatch=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")),
-                                llm_precision=int(prec) if prec is not None else fv_arch.default_llm_precision(self.arch), **self._head_dims)
+            # decoder arithmetic (include/fastvla_hip.h fv_model_desc.llm_precision): fastvla_hip.arch.default_llm_precision -- 1 for
+            # real checkpoints, the measured cheaper policy 2 only for the seeded synthetic 0.5B weights; FASTVLA_LLM_PRECISION=0..4
+            # overrides it.  A checkpoint whose gate/up/down weights leave the fp16 range is refused by the library in the fp16 modes
+            # (FV_ERR_UNSUPPORTED): warn and fall back to 1, which has no range limit.
+            env_prec = os.environ.get("FASTVLA_LLM_PRECISION")
             kind, arg = self._weights_source
+            if self._weights_override is not None:
+                kind, arg = "state", None    # a policy checkpoint's own VLM tensors (reference utils/checkpoint.py:41: load_state_dict overwrites the backbone)
+            prec = int(env_prec) if env_prec is not None else fv_arch.default_llm_precision(self.arch, kind)
             llm = self.arch.llm
             big = 3 * llm.hidden * llm.inter * llm.layers > 2e9   # 7B: 7.6 G parameters = 30 GB as an fp32 host dict
-            if kind == "synthetic" and big:
-                # every decoder tensor is drawn on the device in bf16 when the packer asks for it (fv_load_weights_cb)
-                eng.load_weights_streaming(fv_weights.stream_backbone(self.arch, seed=arg, device=dev))
-            elif kind == "synthetic":
-                eng.load_weights(fv_weights.init_backbone(self.arch, seed=arg))
-            elif kind == "hf_dir":
-                eng.load_weights_streaming(hf_checkpoint_provider(arg))   # one tensor alive at a time, bf16 stays bf16
-            else:
-                eng.load_weights(torch.load(arg, map_location="cpu") if arg.endswith(".pt") else _load_safetensors(arg))
+
+            def build(p: int) -> FastVLAEngine:
+                e = FastVLAEngine(model, device=dev, max_batch=self._max_batch, max_text_tokens=self.config.tokenizer_max_length,
+                                  tower_microbatch=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")), llm_precision=p, **self._head_dims)
+                try:
+                    if kind == "state":
+                        e.load_weights(self._weights_override)
+                    elif kind == "synthetic" and big:
+                        # every decoder tensor is drawn on the device in bf16 when the packer asks for it (fv_load_weights_cb)
+                        e.load_weights_streaming(fv_weights.stream_backbone(self.arch, seed=arg, device=dev))
+                    elif kind == "synthetic":
+                        e.load_weights(fv_weights.init_backbone(self.arch, seed=arg))
+                    elif kind == "hf_dir":
+                        prov = hf_checkpoint_provider(arg)   # one tensor alive at a time, bf16 stays bf16
+                        try:
+                            e.load_weights_streaming(prov)
+                        finally:
+                            prov.close()
+                    else:
+                        e.load_weights(torch.load(arg, map_location="cpu") if arg.endswith(".pt") else _load_safetensors(arg))
+                except Exception:
+                    e.close()
+                    raise
+                return e
+
+            try:
+                eng = build(prec)
+            except FastVLAHipError as exc:
+                if prec < 2 or exc.status != -5:   # FV_ERR_UNSUPPORTED from the fp16 weight-range check
+                    raise
+                import warnings
+                warnings.warn(f"llm_precision={prec} refused for '{self.config.model_id}' ({exc}); falling back to llm_precision=1 "
+                              "(split-bf16 operands: no range limit, 2x the decoder's MFMA work)")
+                eng = build(1)
             if self._io_norm is not None:
                 eng.set_io_norm(**self._io_norm)
             self._engine = eng
         return self._engine
+
+    def load_backbone_state(self, state: Dict[str, Tensor]) -> None:
+        """Use THESE VLM tensors (canonical checkpoint keys: `model.layers.N...`, `model.vision_tower...`, `model.mm_projector...`)
+        instead of the ones `model_id` resolves to -- what the reference's `policy.load_state_dict(state_dict)` does to
+        `model.backbone.model.*` (utils/checkpoint.py:41; trainer.py:255 writes them).  A training-form tower is folded;
+        `lm_head.*` is dropped (the path computes no logits).  The engine is (re)built on the next use."""
+        from .reparam import fold_train_form, is_train_form
+        st = {k: v for k, v in state.items() if not k.startswith("lm_head.")}
+        if is_train_form(st):
+            st = fold_train_form(st)
+        self._weights_override = st
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    def source_tensors(self):
+        """(name, tensor) of every canonical inference-form tensor this backbone packs its engine from, one at a time -- the write
+        side of the checkpoint interop (vla_fastvlm/utils/checkpoint.py save_policy_checkpoint(include_backbone=True))."""
+        if self._weights_override is not None:
+            yield from self._weights_override.items()
+            return
+        kind, arg = self._weights_source
+        if kind == "synthetic":
+            llm = self.arch.llm
+            if 3 * llm.hidden * llm.inter * llm.layers > 2e9:
+                prov = fv_weights.stream_backbone(self.arch, seed=arg, device="cpu")
+                names = list(fv_weights.init_tower(self.arch.tower, llm.hidden, torch.Generator().manual_seed(arg)))
+                names += _llm_tensor_names(llm)
+                for n in names:
+                    yield n, prov(n)
+            else:
+                yield from fv_weights.init_backbone(self.arch, seed=arg).items()
+        elif kind == "hf_dir":
+            yield from load_hf_checkpoint_dir(arg).items()
+        else:
+            yield from (torch.load(arg, map_location="cpu") if arg.endswith(".pt") else _load_safetensors(arg)).items()
 
     def set_io_normalization(self, state_mean=None, state_std=None, action_mean=None, action_std=None, eps: float = 1e-8) -> None:
         """Fold the dataset's MEAN_STD statistics of the state input and the action output into the head kernels
@@ -331,7 +395,7 @@ class FastVLMBackbone(nn.Module):
         # device in a small LRU keyed by the strings themselves, so a repeated prompt costs neither the host tokenizer nor the
         # H2D copy of its ids (tokenisation is a pure function of the strings and these settings).
         tasks = list(tasks)
-        key = (tuple(tasks), bool(self.config.pad_to_max_length), int(self.config.tokenizer_max_length), str(device))
+        key = (tuple(tasks), bool(self.config.pad_to_max_length), int(self.config.tokenizer_max_length), str(self.config.tokenizer_padding_side), str(device))
         lru = self.__dict__.setdefault("_text_lru", {})
         hit = lru.pop(key, None)
         if hit is None:
@@ -406,18 +470,29 @@ class FastVLMBackbone(nn.Module):
 
     def _image_keys(self, images: Tensor) -> List[tuple]:
         """One 128-bit key per image: two wrapping int64 dot products of the image's raw words with fixed odd multipliers, on the
-        device (one small D2H copy per call).  Equal tensors give equal keys; a collision needs both 64-bit sums to agree."""
+        device (one small D2H copy per call).  Equal tensors give equal keys; a collision needs both 64-bit sums to agree.  The
+        products are taken over bounded column chunks (2^22 words of the whole batch at a time): the transient is ~100 MB whatever
+        the frame size, not an int64 copy of the batch."""
         x = images.contiguous()
         words = x.view(x.shape[0], -1).view(torch.int16 if x.element_size() == 2 else torch.int32 if x.element_size() == 4 else torch.uint8)
-        n = words.shape[1]
+        B, n = words.shape
+        step = max(4096, (1 << 22) // max(B, 1))
         mult = self.__dict__.setdefault("_hash_mult", {})
-        if (n, str(x.device)) not in mult:
+        mk = (min(step, n), str(x.device))
+        if mk not in mult:
             g = torch.Generator().manual_seed(0x5eed)
-            mult[(n, str(x.device))] = (torch.randint(-2 ** 62, 2 ** 62, (2, n), generator=g, dtype=torch.int64) | 1).to(x.device)
-        m = mult[(n, str(x.device))]
-        w64 = words.to(torch.int64)
-        h = torch.stack([(w64 * m[0]).sum(1), (w64 * m[1]).sum(1)], dim=1).cpu()
-        return [(str(x.dtype), tuple(x.shape[1:]), int(h[b, 0]), int(h[b, 1])) for b in range(x.shape[0])]
+            mult[mk] = (torch.randint(-2 ** 62, 2 ** 62, (2, mk[0]), generator=g, dtype=torch.int64) | 1).to(x.device)
+        m = mult[mk]
+        h = torch.zeros(B, 2, dtype=torch.int64, device=x.device)
+        for ci, c0 in enumerate(range(0, n, step)):
+            w64 = words[:, c0:c0 + step].to(torch.int64)
+            k = w64.shape[1]
+            # the chunk index enters through an odd per-chunk factor, so equal chunks at different offsets do not cancel or commute
+            f = 2 * ci + 1
+            h[:, 0] += (w64 * m[0, :k]).sum(1) * f
+            h[:, 1] += (w64 * m[1, :k]).sum(1) * (f * f + 2)
+        h = h.cpu()
+        return [(str(x.dtype), tuple(x.shape[1:]), int(h[b, 0]), int(h[b, 1])) for b in range(B)]
 
     def _pooled_through_prefix_cache(self, eng, images: Tensor, input_ids: Tensor, lens: Tensor) -> Tensor:
         """Splice mode: per-image decoder prefixes (FastVLAEngine.llm_prefix) from the LRU, tower + prefix pass only for the images
@@ -456,6 +531,16 @@ class FastVLMBackbone(nn.Module):
         return self.forward(images, tasks, device=device)
 
 
+def _llm_tensor_names(llm) -> List[str]:
+    out = ["model.embed_tokens.weight"]
+    for i in range(llm.layers):
+        pre = f"model.layers.{i}."
+        out += [pre + "input_layernorm.weight", pre + "post_attention_layernorm.weight"]
+        out += [pre + f"self_attn.{n}_proj.{k}" for n in ("q", "k", "v") for k in ("weight", "bias")]
+        out += [pre + "self_attn.o_proj.weight", pre + "mlp.gate_proj.weight", pre + "mlp.up_proj.weight", pre + "mlp.down_proj.weight"]
+    return out + ["model.norm.weight"]
+
+
 def _load_safetensors(path: str):
     from safetensors.torch import load_file
     return load_file(path)
@@ -477,6 +562,10 @@ def arch_from_hf_config(config_json) -> "fv_arch.ModelConfig":
     tower_name = str(cfg.get("mm_vision_tower", "mobileclip_l_1024"))
     size = infer_size_from_tower_name(tower_name) or 1024
     tower = fv_arch.TowerConfig(image_size=int(size), name=tower_name)
+    geo = cfg.get("fastvla_tower")   # extension of THIS build: a reduced FastViT-HD geometry (test checkpoints); Apple's configs have no such key
+    if isinstance(geo, dict):
+        tower = fv_arch.TowerConfig(layers=tuple(int(v) for v in geo["layers"]), dims=tuple(int(v) for v in geo["dims"]),
+                                    attn_stages=tuple(int(v) for v in geo.get("attn_stages", tower.attn_stages)), image_size=int(size), name=tower_name)
     return fv_arch.ModelConfig(Path(config_json).parent.name or "hf-checkpoint", llm, tower)
 
 
@@ -515,6 +604,16 @@ def hf_checkpoint_provider(path):
             handles[shard] = safe_open(shard, framework="pt", device="cpu").__enter__()
         return handles[shard].get_tensor(name)
 
+    def close() -> None:
+        """release the shard handles (mmap'd files) once fv_load_weights_cb has returned"""
+        for hnd in handles.values():
+            try:
+                hnd.__exit__(None, None, None)
+            except Exception:
+                pass
+        handles.clear()
+
+    provider.close = close
     return provider
 
 

@@ -193,15 +193,19 @@ class Trainer:
         self.model.train()
         return {"eval/mse": total / max(count, 1)}
 
+    # Extension of this build (an attribute, not a TrainingConfig field: the dataclass is the reference's contract): True writes the frozen
+    # VLM tensors into policy_state_dict.pt under `model.backbone.model.*` the way the reference's state_dict() does (trainer.py:255), so
+    # its own strict loader accepts the file; False (default, or FASTVLA_SAVE_BACKBONE unset) keeps checkpoints at the head's 12 MB.
+    save_backbone_weights: bool = os.environ.get("FASTVLA_SAVE_BACKBONE", "0") == "1"
+
     def _save_checkpoint(self, suffix: str) -> None:
         """Same files as reference trainer.py:246-255: policy_config.json + policy_state_dict.pt (head tensors under the
         reference's `model.*` keys; the frozen backbone lives in the library and is not duplicated)."""
         if not self.is_main_process:
             return
-        d = Path(self.config.output_dir) / "checkpoints" / suffix
-        d.mkdir(parents=True, exist_ok=True)
-        (d / "policy_config.json").write_text(json.dumps(asdict(self.model.config), indent=2))
-        torch.save({k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}, d / "policy_state_dict.pt")
+        from ..utils.checkpoint import save_policy_checkpoint
+        d = save_policy_checkpoint(self.model, Path(self.config.output_dir) / "checkpoints" / suffix,
+                                   include_backbone=self.save_backbone_weights)
         st = getattr(self.model, "_opt_state", None)
         if st is not None:
             torch.save({"m": st["m"].cpu(), "v": st["v"].cpu(), "step": st["step"], "global_step": self.global_step,
@@ -213,7 +217,9 @@ class Trainer:
             raise FileNotFoundError(f"Checkpoint path {path} does not exist.")
         state = torch.load(p / "policy_state_dict.pt", map_location="cpu")
         own = self.model.state_dict()
-        self.model.load_state_dict({k: v for k, v in state.items() if k in own}, strict=False)
+        # `.io_norm.` keys: folded dataset statistics exist in state_dict() only while the folding is on, so a freshly built model does
+        # not list them -- let them through (FastVLMBackbone._load_from_state_dict re-applies them)
+        self.model.load_state_dict({k: v for k, v in state.items() if k in own or ".io_norm." in k}, strict=False)
         if (p / "optimizer.pt").is_file():
             self._resume_opt = torch.load(p / "optimizer.pt", map_location="cpu")  # applied by _sync_replicas()
             self.global_step = int(self._resume_opt.get("global_step", 0))

@@ -1,14 +1,27 @@
-"""Load `policy_config.json` + `policy_state_dict.pt` (reference: src/vla_fastvlm/utils/checkpoint.py:14-47).
-Only the 12 head tensors (`model.state_projection.*`, `model.fusion.*`, `model.action_head.*`) are consumed; a
-reference checkpoint's `model.backbone.model.*` entries are ignored because the frozen backbone lives in the library."""
+"""Load / write `policy_config.json` + `policy_state_dict.pt` (reference: src/vla_fastvlm/utils/checkpoint.py:14-47 reads them,
+training/trainer.py:246-255 writes them).
+
+Read side.  The 12 head tensors (`model.state_projection.*`, `model.fusion.*`, `model.action_head.*`) always come from the file.  A
+checkpoint written by the REFERENCE also carries the whole VLM under `model.backbone.model.*` (the backbone is a submodule there, so
+`state_dict()` includes it, and `load_state_dict` puts it back over whatever `from_pretrained` loaded): those tensors are handed to the
+backbone (`FastVLMBackbone.load_backbone_state`: canonical keys = the reference's keys minus the prefix, training-form towers folded,
+`lm_head.*` dropped) and packed into the engine instead of the ones `vlm_model_name` resolves to.  A checkpoint without them (what this
+build writes by default: the frozen backbone is not duplicated next to every head) keeps the `vlm_model_name` weights.
+
+Write side.  `save_policy_checkpoint(policy, dir, include_backbone=True)` writes the file the reference's own
+`load_policy_from_checkpoint(strict=True)` accepts: head tensors + every VLM tensor under `model.backbone.model.*` (+ the tied
+`lm_head.weight`)."""
 from __future__ import annotations
 
+import dataclasses
 import json
 from pathlib import Path
 
 import torch
 
 from ..fastvla import FastVLAConfig, FastVLAPolicy
+
+BACKBONE_PREFIX = "model.backbone.model."
 
 
 def load_policy_from_checkpoint(checkpoint_dir: str, device: torch.device | None = None) -> FastVLAPolicy:
@@ -21,10 +34,34 @@ def load_policy_from_checkpoint(checkpoint_dir: str, device: torch.device | None
         raise ValueError("legacy FastVLMPolicy checkpoints (nested backbone config) are not supported by the HIP path")
     policy = FastVLAPolicy(FastVLAConfig(**payload))
     state = torch.load(sd_path, map_location="cpu")
+    vlm = {k[len(BACKBONE_PREFIX):]: v for k, v in state.items() if k.startswith(BACKBONE_PREFIX)}
+    if vlm:
+        policy.model.backbone.load_backbone_state(vlm)
     own = policy.state_dict()
     missing = [k for k in own if k not in state]
     if missing:
         raise KeyError(f"checkpoint lacks head tensors: {missing}")
-    policy.load_state_dict({k: state[k] for k in own})
+    extra = {k: v for k, v in state.items() if ".io_norm." in k}   # folded dataset statistics travel with the state dict
+    policy.load_state_dict({**{k: state[k] for k in own}, **extra})
     policy.eval()
     return policy
+
+
+def save_policy_checkpoint(policy: FastVLAPolicy, checkpoint_dir: str, include_backbone: bool = False) -> Path:
+    """policy_config.json + policy_state_dict.pt under the reference's key names (trainer.py:246-255).  include_backbone=True adds
+    the VLM tensors the engine was packed from as `model.backbone.model.<canonical key>` and the tied `lm_head.weight`, which is what
+    makes the file loadable by the reference's strict `load_state_dict`."""
+    d = Path(checkpoint_dir)
+    d.mkdir(parents=True, exist_ok=True)
+    (d / "policy_config.json").write_text(json.dumps(dataclasses.asdict(policy.config), indent=2))
+    state = {k: v.detach().cpu().clone() for k, v in policy.state_dict().items()}
+    if include_backbone:
+        embed = None
+        for name, t in policy.model.backbone.source_tensors():
+            state[BACKBONE_PREFIX + name] = t.detach().cpu()
+            if name == "model.embed_tokens.weight":
+                embed = state[BACKBONE_PREFIX + name]
+        if embed is not None and BACKBONE_PREFIX + "lm_head.weight" not in state:
+            state[BACKBONE_PREFIX + "lm_head.weight"] = embed    # tied embeddings: the HF state dict lists both names
+    torch.save(state, d / "policy_state_dict.pt")
+    return d
