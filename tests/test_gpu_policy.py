@@ -322,13 +322,20 @@ def test_folded_dataset_normalisation_matches_the_processor_arithmetic():
     assert abs(float(loss_fold) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
     loss_oracle = head.mse(head.head_forward(head_p, pooled, norm_state), tgt[:, 0])
     assert abs(float(loss_fold) - float(loss_oracle)) <= 1e-4 * abs(float(loss_oracle))
-    # a gradient asked of the actions in EVAL mode sees normalised actions (the backward differentiates the head, not
-    # the folded `* std + mean` behind it) and the statistics survive a state_dict round trip
+    # EVAL mode with autograd on: the library's backward differentiates the head, not the folded `* std + mean` behind it,
+    # so the library returns normalised actions and the module finishes the un-normalisation in torch -- the SAME space as under
+    # torch.no_grad() (select_action above), still differentiable; the statistics survive a state_dict round trip
     pol.fold_dataset_stats(stats)
     pol.eval()
     a_eval = pol._predict_actions({**batch, "observation.state": raw.to(DEV)})
     assert a_eval.requires_grad
-    assert float((a_eval.detach().cpu() - head.head_forward(head_p, pooled, norm_state)).abs().max()) <= 1e-4
+    assert float((a_eval.detach().cpu() - ref_oracle).abs().max()) <= 1e-4 * float(ref_oracle.abs().max())
+    with torch.no_grad():
+        a_nograd = pol._predict_actions({**batch, "observation.state": raw.to(DEV)})
+    assert float((a_eval.detach() - a_nograd).abs().max()) <= 2e-6 * float(ref_oracle.abs().max())
+    a_eval.sum().backward()      # d(sum a * std + mean) reaches the head parameters
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in pol.model.head_parameters())
+    pol.zero_grad(set_to_none=True)
     sd = pol.state_dict()
     assert "model.backbone.io_norm.action_std" in sd
     pol.fold_dataset_stats(None)

@@ -78,19 +78,19 @@ PRESETS = {
 
 
 def default_llm_precision(model: ModelConfig, weights_source: str = "synthetic") -> int:
-    """The decoder arithmetic a backbone gets when nothing asks for another (fv_model_desc.llm_precision).
+    """The decoder arithmetic a backbone gets when nothing asks for another (fv_model_desc.llm_precision): 1 for EVERY model and weight
+    source since round 4.
 
-    1 (split-bf16 on every projection: 16 significant bits, 1e-5 from the fp32 oracle, no range limit) is the default for every REAL
-    checkpoint (`weights_source` "hf_dir" / "file") and for the wide / deep decoders, where the fp16 budget measures 1.2e-3 .. 2.1e-3 on
-    the whole 7B model.
-    2 (split-bf16 qkv / o, ONE fp16 pass for gate/up and down) only for the 0.5B-class decoder on the seeded synthetic weights it was
-    measured on: 4.4e-4 .. 6.2e-4 on the actions, worst row of a B = 64 batch asserted <= 1e-3
-    (tests/test_gpu_fullsize.py::test_c2_batch64_*, bench.py cpu_baseline) -- a 1.2x .. 1.6x margin, which is why a checkpoint that has
-    not been measured does not get it silently: opt in with FASTVLA_LLM_PRECISION=2 (weights outside the fp16 range are refused at load
-    time and the backbone falls back to 1; activations saturate and are counted, FastVLAEngine.fp16_saturations)."""
-    if weights_source != "synthetic":
-        return 1
-    return 2 if model.llm.hidden <= 1024 and model.llm.layers <= 24 else 1
+    1 = split-bf16 operands on every projection (16 significant bits, fp32 attention): actions 1e-5 from the fp32 oracle at 0.5B, pooled
+    feature <= 3e-4 on the WHOLE 7B decoder (28 layers, tests/test_gpu_fullsize.py::test_7b_full_depth_against_layer_streamed_oracle), no
+    range limit on weights or activations.
+    2 = split-bf16 qkv / o + ONE fp16 pass for gate/up and down (0.56x the MFMA work, -2.5 ms of the 0.5B bs=64 step) was round 3's default
+    for the 0.5B decoder on the strength of a batch-level rel-L2 of 4.4e-4 .. 6.4e-4.  Round 4 measured it ROW BY ROW: the worst sample of
+    C1's four rows sits at 1.1e-3 (tests/test_gpu_fullsize.py::test_c1_train_step[policy2-optin-literal]) -- outside north_star's 1e-3 for
+    that env's action -- and a real checkpoint's outlier channels have never been measured.  It therefore stays an OPT-IN
+    (FASTVLA_LLM_PRECISION=2, bench.py --llm-precision 2): weights outside the fp16 range are refused at load time and the backbone
+    falls back to 1; activations saturate and are counted (FastVLAEngine.fp16_saturations)."""
+    return 1
 
 
 def preset(name: str) -> ModelConfig:

@@ -257,9 +257,8 @@ class FastVLMBackbone(nn.Module):
                 dev = torch.device("cuda", torch.cuda.current_device())
             tower = fv_arch.TowerConfig(**{**self.arch.tower.__dict__, "image_size": int(self.expected_size)})
             model = fv_arch.ModelConfig(self.arch.name, self.arch.llm, tower)
-            # decoder arithmetic (include/fastvla_hip.h fv_model_desc.llm_precision): fastvla_hip.arch.default_llm_precision -- 1 for
-            # real checkpoints, the measured cheaper policy 2 only for the seeded synthetic 0.5B weights; FASTVLA_LLM_PRECISION=0..4
-            # overrides it.  A checkpoint whose gate/up/down weights leave the fp16 range is refused by the library in the fp16 modes
+            # decoder arithmetic (include/fastvla_hip.h fv_model_desc.llm_precision): fastvla_hip.arch.default_llm_precision (1: split-bf16
+            # everywhere, the only policy that holds 1e-3 on every row); FASTVLA_LLM_PRECISION=0..4 overrides it.  A checkpoint whose gate/up/down weights leave the fp16 range is refused by the library in the fp16 modes
             # (FV_ERR_UNSUPPORTED): warn and fall back to 1, which has no range limit.
             env_prec = os.environ.get("FASTVLA_LLM_PRECISION")
             kind, arg = self._weights_source
