@@ -224,6 +224,49 @@ int fv_comm_destroy(fv_handle* h, void* comm);
 /* ONE all-reduce (sum, in place) of the flat head gradient on stream s; the 1/world average is fv_adamw_hparams.grad_scale */
 int fv_allreduce_grads(fv_handle* h, void* comm, float* flat_grads, int64_t n, fv_stream s);
 
+/* ---- unfrozen-backbone training ------------------------------------------------------------------------
+ * The reference's knob is fastvla/configuration_fastvla.py:23 `freeze_backbone` (applied at model/fastvlm_adapter.py:170-173) and is made
+ * moot there by the unconditional no_grad at model/fastvlm_adapter.py:501; the step body is training/trainer.py:60-66,171-182 over ALL
+ * parameters.  This slice: Qwen2 decoder (embedding, every layer, final norm) + mm_projector + action expert trainable, FastViT-HD tower
+ * frozen, image tokens SPLICED in front of the text (a text-only sequence gives the projector no gradient), last_token pooling.
+ *
+ * All trainable parameters live in ONE caller-owned flat fp32 buffer (the master copy; same for gradients and Adam's m / v):
+ *   [ action expert (fv_head_layout) | projector | embedding | layer 0 .. L-1 | final norm ]
+ * with every matrix in the layout the library packs it in: q | k | v rows concatenated (packing 1), gate / up rows interleaved in blocks of
+ * 8 ([8 gate | 8 up], packing 2).  fv_train_layout lists every tensor (name, element offset, rows x cols, gradient bucket, packing). */
+typedef struct fv_train_tensor {
+  char name[104];   /* canonical checkpoint key; packed tensors: "...self_attn.qkv_proj.{weight,bias}", "...mlp.gate_up_proj.weight" */
+  int64_t offset, numel;
+  int32_t rows, cols;
+  int32_t bucket;   /* 0 = action expert, 1 = projector, 2 = embedding, 3 + l = decoder layer l, 3 + L = final norm */
+  int32_t packing;  /* 0 = plain [rows][cols], 1 = q|k|v concatenated along rows, 2 = gate/up rows interleaved by 8 */
+} fv_train_tensor;
+/* out may be NULL (sizes only).  n_buckets = 3 + llm_layers + 1. */
+int fv_train_layout(fv_handle* h, fv_train_tensor* out, int max_tensors, int* n_tensors, int64_t* total_numel, int* n_buckets);
+/* one-time: allocates the library-owned transposed bf16 weight copies the dgrad GEMMs read.  Needs llm_precision = 1, head_dim 64 / 128. */
+int fv_train_begin(fv_handle* h);
+/* backbone part of the flat master buffer <- the library's current weights (the head part is the caller's) */
+int fv_train_export_params(fv_handle* h, float* flat_params, fv_stream s);
+/* the library's MFMA operand copies <- the master, after an optimiser step: bf16 weights (RNE), their transposes, fp32 norms / biases.
+ * The frozen-path entry points (fv_llm_forward_pooled, ...) see the updated weights from then on. */
+int fv_train_commit(fv_handle* h, const float* flat_params, fv_stream s);
+int fv_train_workspace_bytes(fv_handle* h, int B, int T, size_t* out_bytes);
+/* called from inside fv_train_forward_backward, on the calling thread, right after the LAST kernel that writes bucket `bucket`'s gradient
+ * has been enqueued on the stream: flat_grads[offset, offset + numel) is final once the stream reaches this point (record an event here and
+ * start that bucket's all-reduce on a side stream: it runs under the rest of the backward pass).  Order: 0, 3 + L, 3 + L - 1, ..., 3, 2, 1. */
+typedef void (*fv_bucket_cb)(void* user, int bucket, int64_t offset, int64_t numel);
+/* ONE training step's forward + MSE + backward over every trainable tensor (replaces model.compute_loss + accelerator.backward,
+ * training/trainer.py:173-175, for an unfrozen backbone):
+ *   tower_out (B, Ni, tower_out_dim) bf16 = the frozen tower's embeddings (fv_vision_forward's tower_out); ids (B, T) int32 right-padded,
+ *   T % 8 == 0; lens (B); states (B, state_dim), targets (B, action_dim) f32; training / dropout as fv_head_forward.
+ *   -> actions (B, action_dim) (normalised space), loss (1 f32, device), flat_grads (overwritten: every tensor of fv_train_layout).
+ * ws: caller-owned scratch of fv_train_workspace_bytes(B, T) bytes (every activation the backward needs is kept there: no recompute).
+ * Asynchronous on s; allocates nothing; gradients are bit-reproducible (no float atomics). */
+int fv_train_forward_backward(fv_handle* h, const float* flat_params, const void* tower_out, const int32_t* ids, const int32_t* lens,
+                              const float* states, const float* targets, int B, int T, int training, float dropout_p, uint64_t seed,
+                              uint64_t offset, void* ws, size_t ws_bytes, float* actions, float* loss, float* flat_grads, fv_bucket_cb cb,
+                              void* user, fv_stream s);
+
 /* ---- optional per-kernel-family HIP-event timing (bench.py roofline numbers) ------------------------------------- */
 enum fv_family { FV_FAM_GEMM = 0, FV_FAM_DWCONV, FV_FAM_STEM, FV_FAM_ATTN, FV_FAM_NORM, FV_FAM_ELT, FV_FAM_HEAD, FV_FAM_COUNT };
 typedef struct fv_profile_entry { double ms, flops, bytes; int64_t launches; } fv_profile_entry;
@@ -289,6 +332,16 @@ int fv_op_attention(const void* q, const void* k, const void* v, int ldq, int ld
 int fv_op_rmsnorm(const float* x, const float* w, void* y_bf16, int rows, int H, float eps, fv_stream s);
 /* in-place rotate-half RoPE on the q and k parts of a packed qkv (rows = B*T, position = row % T) */
 int fv_op_rope(void* qkv, int ld, int rows, int T, int heads, int kv_heads, int D, float theta, fv_stream s);
+/* backward of fv_op_attention's causal GQA form in fp32 (the kernels behind fv_train_forward_backward): qkv fp32 [B*T][ld] = UN-rotated
+ * q | k | v (the rotate-half RoPE of `theta` is applied inside, as in the parity-mode forward), dO fp32 [B*T][heads*D] -> dqkv fp32 [B*T][ld]
+ * (gradients w.r.t. the un-rotated projections).  Runs the forward first (its output and row statistics are scratch).  D in {64, 128}. */
+int fv_op_attention_bwd(const float* qkv, int ld, const float* dO, float* dqkv, void* out_bf16_scratch, float* stat_scratch, int B, int T,
+                        int heads, int kv_heads, int D, const int32_t* lens, float theta, fv_stream s);
+/* backward of fv_op_rmsnorm: y = w x rsqrt(mean(x^2) + eps); dx (rows,H) f32 = dres (or 0) + dL/dx, dw (H) f32; scratch floats:
+ * ((rows + 15) / 16 + 3) / 4 * 4 * H + 64 * H */
+int fv_op_rmsnorm_bwd(const float* x, const float* w, const float* dy, const float* dres, float* dx, float* dw, float* scratch, int rows,
+                      int H, float eps, fv_stream s);
+
 /* SE + GELU tail of conv_exp: x (B,P,C) bf16 -> y = gelu(x * sigmoid(W2 relu(W1 mean_p(x) + b1) + b2)) */
 int fv_op_se_gelu(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
                   float* scratch, int B, int P, int C, int R, fv_stream s);

@@ -715,8 +715,8 @@ def test_gemm_f16_swiglu_saturates_instead_of_overflowing(M, I, K):
     leaves the binary16 range on most entries (an outlier channel of a real checkpoint): every output must be finite, the overflowing
     ones exactly +-65504, the others as the unsaturated arithmetic gives them.  Both GEMM kernels (register-staged, 256-tile)."""
     torch.manual_seed(M + I + 1)
-    A = (torch.randn(M, K) * 40).half()
-    Wg, Wu = (torch.randn(I, K) * 3 / math.sqrt(K)).half(), (torch.randn(I, K) * 3 / math.sqrt(K)).half()
+    A = (torch.randn(M, K) * 400).half()     # gate, up ~ N(0, 1600^2): silu(gate) * up / 16 reaches ~1e5 .. 1e6
+    Wg, Wu = (torch.randn(I, K) * 4 / math.sqrt(K)).half(), (torch.randn(I, K) * 4 / math.sqrt(K)).half()
     Wi = torch.stack([Wg.view(I // 8, 8, K), Wu.view(I // 8, 8, K)], dim=1).reshape(2 * I, K).contiguous()
     g, u = A.double() @ Wg.double().t(), A.double() @ Wu.double().t()
     ref = (torch.nn.functional.silu(g) * u / 16)

@@ -1,0 +1,246 @@
+"""-m gpu: the UNFROZEN decoder + projector training slice (fv_train_* in include/fastvla_hip.h).
+
+The reference's own loop would run this if model/fastvlm_adapter.py:501 were not an unconditional no_grad (`freeze_backbone`,
+fastvla/configuration_fastvla.py:23; step body training/trainer.py:171-182).  Oracle = torch.autograd over the fp32 forward that oracle/
+already states (oracle/train_unfrozen.py), on the same seeded weights, the same frozen-tower embeddings and the same inputs:
+  * op level: RMSNorm backward and the RoPE + causal-GQA attention backward (head_dim 64 / 128, ragged lengths) against autograd;
+  * the `small` preset (3 layers, spliced 36 + 16 tokens): loss, actions and EVERY tensor's gradient (<= 2e-3 rel-L2 each), the gradient
+    buckets' order and coverage, bit-identical repeats, one clip + AdamW step over all 12 + 4 + 1 + 7 L + 1 tensors, and the committed
+    bf16 operand copies afterwards;
+  * four FULL-WIDTH FastVLM-0.5B decoder layers (hidden 896, 14 q / 2 kv heads of 64, inter 4864) the same way.
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, call, lib, rel_l2, stream  # noqa: E402
+from fastvla_hip import FastVLAEngine, arch, weights  # noqa: E402
+from oracle import head, qwen2, train_unfrozen  # noqa: E402
+
+GRAD_TOL = 2e-3
+
+
+def test_rmsnorm_backward_matches_autograd():
+    torch.manual_seed(1)
+    for rows, H in ((37, 256), (300, 896), (5, 3584)):
+        x = torch.randn(rows, H, requires_grad=True)
+        w = (1 + 0.1 * torch.randn(H)).requires_grad_(True)
+        dy, dres = torch.randn(rows, H), torch.randn(rows, H)
+        y = qwen2.rmsnorm(x, w, 1e-6)
+        y.backward(dy)
+        waves = (rows + 15) // 16
+        scratch = torch.empty(((waves + 3) // 4 * 4 + 64) * H, device=DEV)
+        dx, dw = torch.full((rows, H), float("nan"), device=DEV), torch.full((H,), float("nan"), device=DEV)
+        xd, wd, dyd, dresd = x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV), dres.to(DEV)
+        call(lib().fv_op_rmsnorm_bwd(xd.data_ptr(), wd.data_ptr(), dyd.data_ptr(), dresd.data_ptr(), dx.data_ptr(), dw.data_ptr(), scratch.data_ptr(), rows, H, 1e-6, stream()),
+             "fv_op_rmsnorm_bwd")
+        torch.cuda.synchronize()
+        assert rel_l2(dx.cpu(), x.grad + dres) <= 2e-6 and rel_l2(dw.cpu(), w.grad) <= 2e-6, (rows, H)
+
+
+def _attention_autograd(qkv, B, T, heads, kv, D, lens, theta):
+    cfg = qwen2.Qwen2Cfg(hidden=heads * D, layers=1, heads=heads, kv_heads=kv, head_dim=D, rope_theta=theta)
+    qd, kd = heads * D, kv * D
+    x = qkv.view(B, T, qd + 2 * kd)
+    q = x[..., :qd].reshape(B, T, heads, D).transpose(1, 2)
+    k = x[..., qd:qd + kd].reshape(B, T, kv, D).transpose(1, 2)
+    v = x[..., qd + kd:].reshape(B, T, kv, D).transpose(1, 2)
+    pos = torch.arange(T)
+    cos, sin = qwen2.rope_tables(cfg, pos)
+    q = q * cos + qwen2._rotate_half(q) * sin
+    k = k * cos + qwen2._rotate_half(k) * sin
+    k, v = k.repeat_interleave(heads // kv, dim=1), v.repeat_interleave(heads // kv, dim=1)
+    mask = (pos[None, :] <= pos[:, None])[None, None] & (pos[None, :] < lens[:, None])[:, None, None, :]
+    s = (q @ k.transpose(-1, -2)) * D ** -0.5
+    s = s.masked_fill(~mask, torch.finfo(torch.float32).min)
+    return (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B * T, qd)
+
+
+@pytest.mark.parametrize("B,T,heads,kv,D", [(2, 52, 4, 2, 64), (3, 96, 14, 2, 64), (2, 70, 6, 2, 128), (1, 320, 14, 2, 64)])
+def test_attention_backward_matches_autograd(B, T, heads, kv, D):
+    torch.manual_seed(B * 100 + T)
+    qd, kd = heads * D, kv * D
+    ld = qd + 2 * kd
+    qkv = (torch.randn(B * T, ld) * 0.8).requires_grad_(True)
+    lens = torch.tensor([T, max(1, T - 17), max(1, T // 3)][:B])
+    dO = torch.randn(B * T, qd)
+    for b in range(B):
+        dO.view(B, T, qd)[b, int(lens[b]):] = 0   # rows past a prompt's end receive no gradient in the decoder (their outputs feed nothing)
+    out = _attention_autograd(qkv, B, T, heads, kv, D, lens, 1e6)
+    out.backward(dO)
+    ref = qkv.grad.view(B, T, ld).clone()
+    for b in range(B):
+        ref[b, int(lens[b]):] = 0
+    qd_, dod = qkv.detach().to(DEV), dO.to(DEV)
+    dq = torch.full((B * T, ld), float("nan"), device=DEV)
+    osc = torch.empty(B * T, 2 * qd, dtype=torch.bfloat16, device=DEV)
+    st = torch.empty(2 * B * heads * T, device=DEV)
+    ld_ = lens.to(torch.int32).to(DEV)
+    call(lib().fv_op_attention_bwd(qd_.data_ptr(), ld, dod.data_ptr(), dq.data_ptr(), osc.data_ptr(), st.data_ptr(), B, T, heads, kv, D, ld_.data_ptr(), 1e6, stream()),
+         "fv_op_attention_bwd")
+    torch.cuda.synchronize()
+    got = dq.cpu().view(B, T, ld)
+    # the forward the backward started from
+    o = (osc[:, :qd].float() + osc[:, qd:].float()).cpu().view(B, T, qd)
+    for b in range(B):
+        n = int(lens[b])
+        assert rel_l2(o[b, :n], out.detach().view(B, T, qd)[b, :n]) <= 1e-5
+        assert torch.isfinite(got[b, :n]).all()
+        for name, c0, c1 in (("dq", 0, qd), ("dk", qd, qd + kd), ("dv", qd + kd, ld)):
+            r = rel_l2(got[b, :n, c0:c1], ref[b, :n, c0:c1])
+            assert r <= 2e-5, (name, b, r)
+        assert float(got[b, n:, qd:].abs().max() if n < T else 0.0) == 0.0    # masked keys: exactly zero dk / dv
+    dq2 = torch.empty_like(dq)
+    call(lib().fv_op_attention_bwd(qd_.data_ptr(), ld, dod.data_ptr(), dq2.data_ptr(), osc.data_ptr(), st.data_ptr(), B, T, heads, kv, D, ld_.data_ptr(), 1e6, stream()),
+         "fv_op_attention_bwd again")
+    torch.cuda.synchronize()
+    assert torch.equal(dq2.cpu().view(B, T, ld)[0, : int(lens[0])], got[0, : int(lens[0])])   # fixed summation order
+
+
+def _rig(model, seed, head_dims, B, T):
+    w = weights.init_backbone(model, seed=seed)
+    eng = FastVLAEngine(model, state_dim=14, action_dim=14, hidden_dim=head_dims, fusion_dim=head_dims, max_batch=B, max_text_tokens=T, llm_precision=1)
+    eng.load_weights(w)
+    eng.train_begin()
+    tensors, total, nb = eng.train_layout()
+    flat = torch.zeros(total, dtype=torch.float32, device=DEV)
+    eng.train_export_params(flat)
+    lc = qwen2.Qwen2Cfg(hidden=model.llm.hidden, layers=model.llm.layers, heads=model.llm.heads, kv_heads=model.llm.kv_heads, head_dim=model.llm.head_dim,
+                        inter=model.llm.inter, vocab=model.llm.vocab, rope_theta=model.llm.rope_theta, rms_eps=model.llm.rms_eps)
+    shapes = head.head_shapes(lc.hidden, 14, 14, head_dims, head_dims)
+    g = torch.Generator().manual_seed(seed + 1)
+    hp = {k: (torch.randn(*s, generator=g) / (s[-1] ** 0.5 if len(s) > 1 else 10.0)) + (1.0 if k in ("state_projection.0.weight", "fusion.1.weight") else 0.0)
+          for k, s in shapes.items()}
+    for k, v in eng.head_views(flat).items():
+        v.copy_(hp[k])
+    return w, eng, tensors, total, nb, flat, lc, hp
+
+
+def _inputs(model, B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    tower_out = (torch.randn(B, model.tower.num_tokens, model.tower.out_dim, generator=g) * 0.7).to(torch.bfloat16)
+    ids = torch.randint(0, model.llm.vocab, (B, T), generator=g)
+    ids[0, 3] = ids[0, 1]      # a repeated id inside a row and across rows: the embedding gradient must sum them
+    ids[1, 0] = ids[0, 1]
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, T // 2 + 1:] = 0
+    if B > 2:
+        mask[2, 1:] = 0
+    states, targets = torch.randn(B, 14, generator=g), torch.randn(B, 14, generator=g)
+    return tower_out, ids, mask, states, targets
+
+
+def _check_grads(eng, grads_flat, ref, tol=GRAD_TOL):
+    got = eng.train_named_tensors(grads_flat)
+    assert set(got) == set(ref["grads"]), sorted(set(got) ^ set(ref["grads"]))[:8]
+    worst = ("", 0.0)
+    for k, g in got.items():
+        r = ref["grads"][k]
+        assert g.shape == r.shape, (k, g.shape, r.shape)
+        denom = float(r.norm())
+        if denom < 1e-12:
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        e = rel_l2(g.cpu(), r)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e <= tol, f"gradient of {k}: rel_l2 {e:.3e} > {tol}"
+    return worst
+
+
+@pytest.mark.parametrize("name,llm,tower,B,T,hd", [
+    ("small", None, "small", 3, 16, 64),
+    ("0.5b-width-4-layers", arch.LLMConfig(hidden=896, layers=4, heads=14, kv_heads=2, head_dim=64, inter=4864, vocab=8192), "tiny", 4, 32, 128),
+])
+def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    model = arch.preset("small") if llm is None else arch.ModelConfig(name, llm, arch.preset(tower).tower)
+    w, eng, tensors, total, nb, flat, lc, hp = _rig(model, 41, hd, B, T)
+    tower_out, ids, mask, states, targets = _inputs(model, B, T, 42)
+    # the exported master equals the weights the engine packed (bf16 matrices widen exactly)
+    named = eng.train_named_tensors(flat)
+    for k in train_unfrozen.trainable_backbone_keys(w):
+        assert torch.equal(named[k].cpu(), w[k].reshape(named[k].shape).float()), k
+    ws = eng.train_workspace(B, T)
+    order = []
+    act, loss, grads = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False,
+                                                  flat_grads=torch.zeros_like(flat), bucket_cb=lambda b, off, n: order.append((b, off, n)))
+    torch.cuda.synchronize()
+    ref = train_unfrozen.forward_backward(w, hp, tower_out.float(), ids, mask, states, targets, lc)
+    ra, rl = rel_l2(act.cpu(), ref["pred"]), abs(float(loss) - float(ref["loss"])) / float(ref["loss"])
+    worst = _check_grads(eng, grads, ref)
+    print(f"[unfrozen {name}] B={B} T={T} actions rel_l2={ra:.2e} loss rel={rl:.2e} worst gradient: {worst[0]} {worst[1]:.2e} ({len(ref['grads'])} tensors)")
+    assert ra <= 1e-3 and rl <= 1e-3
+    # buckets: head first, then final norm, layers last to first, embedding, projector; together they tile the flat buffer exactly once
+    L = model.llm.layers
+    assert [b for b, _, _ in order] == [0, 3 + L] + [3 + l for l in range(L - 1, -1, -1)] + [2, 1]
+    spans = sorted((off, off + n) for _, off, n in order)
+    assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    # bit-identical repeat (no float atomics anywhere in the backward)
+    act2, loss2, grads2 = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+    torch.cuda.synchronize()
+    assert torch.equal(grads, grads2) and torch.equal(act, act2) and torch.equal(loss, loss2)
+    # one clip + AdamW step over ALL tensors (reference training/trainer.py:60-66,178-180), then the operand copies follow the master
+    m, v, norm = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros(1, device=DEV)
+    new = flat.clone()
+    eng.adamw_step(new, grads, m, v, 1, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0, grad_norm_out=norm)
+    torch.cuda.synchronize()
+    params = {k: w[k].float() for k in train_unfrozen.trainable_backbone_keys(w)}
+    params.update({"head." + k: t for k, t in hp.items()})
+    ref_new, ref_norm = train_unfrozen.adamw_clip_step(params, ref["grads"], lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0)
+    assert abs(float(norm) - float(ref_norm)) <= 2e-3 * float(ref_norm)
+    got_new = eng.train_named_tensors(new)
+    coef = min(1.0, 1.0 / (float(ref_norm) + 1e-6))
+    for k, r in ref_new.items():
+        du, dr = got_new[k].cpu() - params[k].reshape(got_new[k].shape), r - params[k]
+        dr = dr.reshape(du.shape)
+        # Adam's first step is lr * g / (|g| + eps): ~lr * sign(g) wherever |g| >> eps = 1e-8, whatever the 1e-3-class noise on g; entries whose
+        # clipped gradient is within 100 eps of zero (a key bias under a nearly position-independent score, unused embedding rows) move by
+        # lr * noise / (|noise| + eps) and are compared by |update| <= lr only
+        big = (ref["grads"][k].reshape(du.shape) * coef).abs() > 1e-6
+        assert float(du.abs().max()) <= 1.0001e-3 + 1e-2 * 1e-3 * float(params[k].abs().max()), k
+        if big.any():
+            bad = float(((du - dr).abs()[big] > 0.05 * 1e-3 + 1e-2 * dr.abs()[big]).float().mean())
+            assert bad <= 5e-3, (k, bad)
+    eng.train_commit(new)
+    back = torch.zeros_like(flat)
+    eng.train_export_params(back)
+    torch.cuda.synchronize()
+    for t in tensors:
+        if t["bucket"] == 0:
+            continue
+        a, b = back[t["offset"]: t["offset"] + t["numel"]], new[t["offset"]: t["offset"] + t["numel"]]
+        if t["rows"] > 1:
+            assert torch.equal(a, b.to(torch.bfloat16).float()), t["name"]      # matrices: the master rounded to bf16 (RNE)
+        else:
+            assert torch.equal(a, b), t["name"]                                  # norms / biases stay fp32
+    # ... and the frozen-path entry points now run on the updated weights: spliced prefill vs the oracle on the bf16-rounded master
+    w2 = dict(w)
+    for k, tnew in got_new.items():
+        if k.startswith("head."):
+            continue
+        w2[k] = (tnew.cpu().to(torch.bfloat16).float() if tnew.ndim == 2 else tnew.cpu()).reshape(w[k].shape)
+    from oracle import fastvit_hd
+    with torch.no_grad():
+        tok_ref = fastvit_hd.projector_forward(w2, tower_out.float())
+        pooled_ref = qwen2.llm_pooled(w2, ids, mask, lc, image_tokens=tok_ref, splice=True)
+    pooled = eng.llm_pooled(ids, mask.sum(1), tok_ref.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(pooled.cpu(), pooled_ref) <= 3e-4
+    eng.close()
+
+
+def test_unfrozen_training_needs_split_bf16_weights():
+    from fastvla_hip import FastVLAHipError
+    m = arch.preset("small")
+    eng = FastVLAEngine(m, hidden_dim=32, fusion_dim=32, max_batch=2, max_text_tokens=8, llm_precision=2)
+    eng.load_weights(weights.init_backbone(m, seed=3))
+    with pytest.raises(FastVLAHipError, match="llm_precision = 1"):
+        eng.train_begin()
+    eng.close()

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
                                                                      bf16_t* __restrict__ out_lo, const int32_t* __restrict__ lens,
                                                                      int len_add, int ld, int ldo, int T, int heads, int kv_heads,
                                                                      float scale, const float2* __restrict__ rope,
-                                                                     const float* __restrict__ pre, int ldp, int Np) {
+                                                                     const float* __restrict__ pre, int ldp, int Np, float* __restrict__ lse) {
+  // lse != null (training, Np == 0): the row statistics max + log(sum) of every (batch, head, query) for attn_bwd_* (train_kernels.hip)
   // pre != null (image-prefix reuse): the sequence is Np cached prefix positions + Ts = T - Np new ones.  qkv and
   // the outputs hold ONLY the new rows (row b * Ts + t - Np); keys / values of positions < Np come from `pre`, rows
   // (b * Np + pos) of [k (kv_heads * D) | v (kv_heads * D)] fp32, UN-rotated like qkv; queries exist for positions >= Np only.
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
   l_run += __shfl_xor(l_run, 32, 64);
   if (qg >= T) return;
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  if (lse && fg == 0) lse[((size_t)b * heads + h) * T + qg] = m_run + __logf(fmaxf(l_run, 1e-37f));
   const size_t ob = ((size_t)b * Ts + (qg - Np)) * ldo + h * D + 4 * fg;   // lane: query qg, d = 16 dt + 4 fg + r
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
@@ -472,8 +474,9 @@ int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, in
 
 int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
                          int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope,
-                         const float* pre, int ldp, int Np) {
+                         const float* pre, int ldp, int Np, float* lse) {
   if (!qkv || !out_hi || !out_lo) return fv_fail(FV_ERR_ARG, "attention_f32: null pointer");
+  if (lse && (pre || D < 64)) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: row statistics (training) need head_dim 64 / 128 and no cached prefix");
   if (pre && (Np <= 0 || Np >= T || ldp < 2 * kv_heads * D || ldp % 4 || D < 64))
     return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: a cached prefix needs 0 < Np < T, ldp >= 2 * kv_heads * D and head_dim 64 / 128");
   if (!pre) Np = 0;
@@ -484,11 +487,11 @@ int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int
   const int NT = D == 128 ? 2 : 1;
   if (D != 32 && D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: head_dim %d not in {32,64,128}", D);
   static const bool no_mfma = getenv("FASTVLA_NO_ATTN_F32_MFMA") != nullptr;
-  if (D >= 64 && (!no_mfma || pre)) {
+  if (D >= 64 && (!no_mfma || pre || lse)) {
     const long nb = (long)B * heads * ((T - Np + 63) / 64);
     // rope given: q and k are rotated inside the kernel (no separate pass over the packed projections)
-    if (D == 64) hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np);
-    else hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np);
+    if (D == 64) hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np, lse);
+    else hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np, lse);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
   }

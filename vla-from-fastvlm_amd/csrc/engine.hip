@@ -75,6 +75,8 @@ struct Tower {
   float *exp_w = nullptr, *exp_b = nullptr, *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr, *se_b2 = nullptr;
   bf16_t *pj0_w = nullptr, *pj2_w = nullptr; float *pj0_b = nullptr, *pj2_b = nullptr;
 };
+struct TrainLayerT { bf16_t *qkvT = nullptr, *oT = nullptr, *guT = nullptr, *downT = nullptr; };   // transposed weight copies (dgrad operands)
+struct TrainState { bool ready = false; std::vector<TrainLayerT> layers; bf16_t* pj2T = nullptr; };
 struct DecLayer { float* ln1 = nullptr; bf16_t* qkv_w = nullptr; float* qkv_b = nullptr; bf16_t* o_w = nullptr; float* ln2 = nullptr; bf16_t *gu_w = nullptr, *down_w = nullptr; };
 struct Decoder { bf16_t* embed = nullptr; std::vector<DecLayer> layers; float* norm = nullptr; };
 
@@ -135,6 +137,7 @@ struct fv_handle {
   bool no_fused_ffn = false;  // FASTVLA_NO_FUSED_FFN=1: A/B switch back to the two-GEMM ConvFFN
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
   bool no_ffn32 = false;      // FASTVLA_NO_FFN32=1: A/B switch back to the 16x16x32 fused ConvFFN
+  TrainState train;               // unfrozen-backbone training (train_path.inc): library-owned transposed bf16 weight copies
   unsigned* f16_flags = nullptr;  // device: [0] = activation groups clamped to the fp16 range (fv_llm_fp16_saturations),
                                   // [1] = max |scaled weight| bits seen by the loader's in-place fp16 conversion
 };
@@ -1326,3 +1329,5 @@ int fv_allreduce_grads(fv_handle* h, void* comm, float* flat_grads, int64_t n, f
 }
 
 }  // extern "C"
+
+#include "train_path.inc"

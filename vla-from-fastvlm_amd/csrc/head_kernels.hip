@@ -343,7 +343,7 @@ int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, 
 
 int launch_head_backward(const HeadDims& d, const float* P, const float* grad_actions, const float* actions,
                          const float* targets, int B, float drop_p, const float* saved, float* loss, float* G,
-                         float* scratch, hipStream_t s) {
+                         float* scratch, hipStream_t s, float* d_pooled) {
   if (!P || !saved || !G || !scratch) return fv_fail(FV_ERR_ARG, "head_backward: null pointer");
   if (!grad_actions && (!actions || !targets || !loss)) return fv_fail(FV_ERR_ARG, "head_backward: need grad_actions or (actions, targets, loss)");
   if (B <= 0) return fv_fail(FV_ERR_ARG, "head_backward: B must be positive");
@@ -379,6 +379,8 @@ int launch_head_backward(const HeadDims& d, const float* P, const float* grad_ac
   hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv(cw, 256), d.fus), blk, 0, s, g1, sv.cat, cw, G + ho.o[4], B, d.fus, cw);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(d.fus, 256)), blk, 0, s, g1, G + ho.o[5], B, d.fus);
   hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(cw, 256), b8), blk, 0, s, g1, P + ho.o[4], g2, cw, B, d.fus, cw);
+  // dcat = [d pooled | d state branch]: the first `feat` columns are what an unfrozen backbone's backward starts from
+  if (d_pooled) hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv((long)B * d.feat, 256)), blk, 0, s, g2, cw, d_pooled, d.feat, B, d.feat);
   // state branch: ds = dcat[:, feat:], SiLU, Linear, LayerNorm
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(cdiv((long)B * d.hid, 256)), blk, 0, s, g2 + d.feat, cw, sv.z1, (const float*)nullptr, g1, B, d.hid);
   hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv(d.ds, 256), d.hid), blk, 0, s, g1, sv.n0, d.ds, G + ho.o[2], B, d.hid, d.ds);

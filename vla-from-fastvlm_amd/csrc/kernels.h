@@ -97,13 +97,36 @@ int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, in
 // in place by a rope_f32 launch ahead of the VALU kernel (head_dim 32)
 int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
                          int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope = nullptr,
-                         const float* pre = nullptr, int ldp = 0, int Np = 0);   // pre: cached [k | v] rows of positions < Np (8f-1)
+                         const float* pre = nullptr, int ldp = 0, int Np = 0,    // pre: cached [k | v] rows of positions < Np (8f-1)
+                         float* lse = nullptr);   // optional [B][heads][T] row statistics max + log(sum) for the backward pass (head_dim 64 / 128, Np = 0)
 // table: [>=T][D/2] (cos, sin) pairs built by rope_table_host(); position = row % T
 int launch_rope(bf16_t* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D,
                 hipStream_t s);
 void rope_table_host(float* cos_sin_pairs, int T, int D, float theta);
 int launch_pool_norm(const float* x, const int32_t* lens, const float* w, float* pooled, int B, int Ttot, int Ni,
                      int H, float eps, int mode, hipStream_t s);
+
+// ---- unfrozen-backbone training glue (train_kernels.hip) ------------------------------------------------------
+constexpr int RMS_BWD_RPW = 16;     // rows per wave of rmsnorm_bwd_kernel (one dw partial row per wave)
+constexpr int COLSUM_CHUNKS = 64;   // row ranges of the two-stage deterministic column sum
+int launch_split_rows(const float* in, int ldi, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);
+int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+int launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
+int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, int ldo, int lo_off, int R, int Rp, int C, hipStream_t s);
+int launch_swiglu_fwd(const float* gu, bf16_t* act, int ldo, int lo_off, long rows, int I, hipStream_t s);
+int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s);
+int launch_gelu_fwd(const float* pre, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);
+int launch_gelu_bwd(float* dh, const float* pre, size_t n, hipStream_t s);
+size_t rmsnorm_bwd_scratch_floats(long rows, int H);
+int launch_colsum(const float* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s);   // scratch >= COLSUM_CHUNKS * C floats
+int launch_rmsnorm_bwd(const float* x, const float* w, const float* dy, const float* dres, float* dx, float* dw, float* scratch, long rows, int H,
+                       float eps, hipStream_t s);
+int launch_pool_rows(float* stream, float* compact, const int32_t* lens, int B, int Tt, int Ni, int H, int scatter, hipStream_t s);
+int launch_image_rows(const float* stream, float* compact, int B, int Tt, int Ni, int H, hipStream_t s);
+int launch_embed_bwd(const int32_t* ids, const int32_t* lens, const float* dx, float* dE, int B, int T, int Ni, int H, int vocab, hipStream_t s);
+int launch_attention_bwd(const float* qkv, int ld, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, const float* dO, int lddo, const float* lse,
+                         float* delta, float* dqkv, int B, int T, int heads, int kv_heads, int D, const int32_t* lens, int len_add, float scale,
+                         const float2* rope, hipStream_t s);
 
 // action expert (all fp32)
 struct HeadDims { int feat, ds, da, hid, fus; };
@@ -117,9 +140,10 @@ int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, 
                         int training, float drop_p, uint64_t seed, uint64_t offset, float* actions, float* saved,
                         hipStream_t s, const HeadIoNorm* io = nullptr);
 // grad_actions != null: generic backward from dL/dactions (loss untouched); else fused MSE(actions, targets) + backward
+// d_pooled (optional, [B][feat]): dL/d(pooled feature) -- the gradient an UNFROZEN backbone continues from
 int launch_head_backward(const HeadDims& d, const float* P, const float* grad_actions, const float* actions,
                          const float* targets, int B, float drop_p, const float* saved, float* loss, float* G,
-                         float* scratch, hipStream_t s);
+                         float* scratch, hipStream_t s, float* d_pooled = nullptr);
 size_t head_bwd_scratch_bytes(const HeadDims& d, int B);
 size_t adamw_scratch_bytes();  // norm_scratch of launch_adamw_clip: [0] = sum of squares, [1..] per-block partials
 int launch_axpy(float* y, const float* x, int64_t n, const float* scale_dev, hipStream_t s);  // y += x, or y *= *scale_dev when x is null

@@ -1,5 +1,6 @@
 // ops_api.hip -- op-level C entry points (include/fastvla_hip.h, "op-level entry points"): one kernel each, so the
 // parity tests can check every kernel of the path against the oracle on its own.  No engine state is involved.
+#include <cmath>
 #include <vector>
 
 #include "kernels.h"
@@ -85,6 +86,34 @@ int fv_op_rope(void* qkv, int ld, int rows, int T, int heads, int kv_heads, int 
   (void)hipStreamSynchronize(static_cast<hipStream_t>(s));
   (void)hipFree(tab);
   return rc;
+}
+
+int fv_op_attention_bwd(const float* qkv, int ld, const float* dO, float* dqkv, void* out_bf16_scratch, float* stat_scratch, int B, int T,
+                        int heads, int kv_heads, int D, const int32_t* lens, float theta, fv_stream st) {
+  if (!qkv || !dO || !dqkv || !out_bf16_scratch || !stat_scratch) return fv_fail(FV_ERR_ARG, "attention_bwd: null pointer");
+  if (T <= 0 || (D != 64 && D != 128)) return fv_fail(FV_ERR_UNSUPPORTED, "attention_bwd: head_dim must be 64 or 128");
+  hipStream_t s = static_cast<hipStream_t>(st);
+  std::vector<float> cs((size_t)T * D);
+  fv::rope_table_host(cs.data(), T, D, theta);
+  float2* tab = nullptr;
+  FV_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tab), cs.size() * 4));
+  hipError_t e = hipMemcpy(tab, cs.data(), cs.size() * 4, hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? FV_OK : fv_hip_fail(e, "hipMemcpy(rope table)");
+  const int qd = heads * D;
+  bf16_t* o = static_cast<bf16_t*>(out_bf16_scratch);
+  float* lse = stat_scratch;
+  float* delta = stat_scratch + (size_t)B * heads * T;
+  const float scale = 1.0f / sqrtf((float)D);
+  if (rc == FV_OK) rc = fv::launch_attention_f32(const_cast<float*>(qkv), ld, o, o + qd, 2 * qd, B, T, heads, kv_heads, D, lens, 0, scale, s, tab, nullptr, 0, 0, lse);
+  if (rc == FV_OK) rc = fv::launch_attention_bwd(qkv, ld, o, o + qd, 2 * qd, dO, qd, lse, delta, dqkv, B, T, heads, kv_heads, D, lens, 0, scale, tab, s);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(tab);
+  return rc;
+}
+
+int fv_op_rmsnorm_bwd(const float* x, const float* w, const float* dy, const float* dres, float* dx, float* dw, float* scratch, int rows,
+                      int H, float eps, fv_stream s) {
+  return fv::launch_rmsnorm_bwd(x, w, dy, dres, dx, dw, scratch, rows, H, eps, static_cast<hipStream_t>(s));
 }
 
 int fv_op_se_gelu(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,

@@ -64,6 +64,13 @@ class GemmProfile(C.Structure):
                 ("launches", C.c_int64)]
 
 
+class TrainTensor(C.Structure):
+    _fields_ = [("name", C.c_char * 104), ("offset", C.c_int64), ("numel", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("bucket", C.c_int32), ("packing", C.c_int32)]
+
+
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int64, C.c_int64)
+
 FAMILIES = ("gemm", "dwconv", "stem", "attention", "norm", "elementwise", "head")
 
 _vp, _i, _f, _u64, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64
@@ -101,6 +108,12 @@ SIGNATURES = {
     "fv_comm_init": (_i, [_vp, C.POINTER(RcclId), _i, _i, C.POINTER(_vp)]),
     "fv_comm_destroy": (_i, [_vp, _vp]),
     "fv_allreduce_grads": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "fv_train_layout": (_i, [_vp, C.POINTER(TrainTensor), _i, C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i)]),
+    "fv_train_begin": (_i, [_vp]),
+    "fv_train_export_params": (_i, [_vp, _vp, _vp]),
+    "fv_train_commit": (_i, [_vp, _vp, _vp]),
+    "fv_train_workspace_bytes": (_i, [_vp, _i, _i, C.POINTER(C.c_size_t)]),
+    "fv_train_forward_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64, _vp, C.c_size_t, _vp, _vp, _vp, BUCKET_CB, _vp, _vp]),
     "fv_profile": (_i, [_vp, _i]),
     "fv_profile_read": (_i, [_vp, C.POINTER(ProfileEntry), C.POINTER(GemmProfile), _i, C.POINTER(_i)]),
     "fv_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(AdamWHParams), _i64, _vp, _vp]),
@@ -122,6 +135,8 @@ SIGNATURES = {
     "fv_op_dwconv_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "fv_op_convffn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fv_op_convffn32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "fv_op_attention_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "fv_op_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "fv_op_se_gelu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 

@@ -460,6 +460,101 @@ class FastVLAEngine:
         _lib.check(self.lib.fv_grad_scale(self.h, grads.data_ptr(), grads.numel(), scale_dev.data_ptr(), _stream()),
                    "fv_grad_scale", self.h)
 
+    # ---------------------------------------------------------------- unfrozen-backbone training (fv_train_*)
+    def train_begin(self) -> None:
+        """One-time set-up of the unfrozen decoder + projector training slice (library-owned transposed weight copies)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fv_train_begin(self.h), "fv_train_begin", self.h)
+
+    def train_layout(self):
+        """-> (tensors, total_numel, n_buckets): every trainable tensor of the ONE flat fp32 buffer, in order: dicts with name, offset,
+        numel, rows, cols, bucket (0 head, 1 projector, 2 embedding, 3 + l layer l, 3 + L final norm) and packing (0 plain, 1 q|k|v rows
+        concatenated, 2 gate/up rows interleaved by 8)."""
+        n, total, nb = C.c_int(), C.c_int64(), C.c_int()
+        _lib.check(self.lib.fv_train_layout(self.h, None, 0, C.byref(n), C.byref(total), C.byref(nb)), "fv_train_layout", self.h)
+        arr = (_lib.TrainTensor * n.value)()
+        _lib.check(self.lib.fv_train_layout(self.h, arr, n.value, C.byref(n), C.byref(total), C.byref(nb)), "fv_train_layout", self.h)
+        tensors = [dict(name=t.name.decode(), offset=t.offset, numel=t.numel, rows=t.rows, cols=t.cols, bucket=t.bucket, packing=t.packing) for t in arr]
+        return tensors, int(total.value), int(nb.value)
+
+    def train_export_params(self, flat: torch.Tensor) -> None:
+        """backbone part of the flat master buffer <- the library's current weights (fv_train_export_params)"""
+        _lib.check(self.lib.fv_train_export_params(self.h, flat.data_ptr(), _stream()), "fv_train_export_params", self.h)
+
+    def train_commit(self, flat: torch.Tensor) -> None:
+        """the library's bf16 operand copies (and their transposes) <- the master, after an optimiser step (fv_train_commit)"""
+        _lib.check(self.lib.fv_train_commit(self.h, flat.data_ptr(), _stream()), "fv_train_commit", self.h)
+
+    def train_workspace(self, B: int, T: int) -> torch.Tensor:
+        n = C.c_size_t()
+        _lib.check(self.lib.fv_train_workspace_bytes(self.h, B, T, C.byref(n)), "fv_train_workspace_bytes", self.h)
+        ws = torch.empty(n.value + 256, dtype=torch.uint8, device=self.device)
+        return ws
+
+    def train_named_tensors(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """canonical checkpoint key -> a COPY of that tensor taken out of a flat buffer in the library's packed layout (parameters,
+        gradients or Adam moments alike): q / k / v split back out of qkv_proj, gate / up de-interleaved, head tensors under "head.<key>"."""
+        tensors, _, _ = self.train_layout()
+        l = self.model.llm
+        qd, kd = l.heads * l.head_dim, l.kv_heads * l.head_dim
+        out = {}
+        for t in tensors:
+            v = flat[t["offset"]: t["offset"] + t["rows"] * t["cols"]]
+            v = v.view(t["rows"], t["cols"]) if t["rows"] > 1 else v
+            name = t["name"]
+            if t["bucket"] == 0:
+                out["head." + name] = v.clone()
+            elif t["packing"] == 1:
+                base, kind = name.rsplit(".qkv_proj.", 1)
+                for nm, r0, r1 in (("q", 0, qd), ("k", qd, qd + kd), ("v", qd + kd, qd + 2 * kd)):
+                    out[f"{base}.{nm}_proj.{kind}"] = v[r0:r1].clone()
+            elif t["packing"] == 2:
+                base = name.rsplit(".gate_up_proj.weight", 1)[0]
+                g = v.view(l.inter // 8, 2, 8, l.hidden)
+                out[base + ".gate_proj.weight"] = g[:, 0].reshape(l.inter, l.hidden).clone()
+                out[base + ".up_proj.weight"] = g[:, 1].reshape(l.inter, l.hidden).clone()
+            else:
+                out[name] = v.clone()
+        return out
+
+    def train_forward_backward(self, flat_params: torch.Tensor, tower_out: torch.Tensor, ids: torch.Tensor, lens: torch.Tensor, states: torch.Tensor,
+                               targets: torch.Tensor, ws: torch.Tensor, *, training: bool = True, dropout_p: float = 0.0, seed: int = 0, offset: int = 0,
+                               flat_grads: Optional[torch.Tensor] = None, bucket_cb=None):
+        """One step's forward + MSE + backward over every trainable tensor (fv_train_forward_backward).  tower_out: (B, Ni, tower_out_dim)
+        bf16 from vision_forward(..., return_tower_out=True).  bucket_cb(bucket, offset, numel) is called when a bucket's gradient has
+        been enqueued completely.  -> (actions (B, A) in normalised space, loss (1,), flat_grads)."""
+        B, T = ids.shape
+        ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        lens = lens.to(device=self.device, dtype=torch.int32).contiguous()
+        states = states.to(device=self.device, dtype=torch.float32).contiguous()
+        targets = targets.to(device=self.device, dtype=torch.float32).contiguous()
+        tower_out = tower_out.contiguous()
+        if tower_out.dtype != torch.bfloat16 or tower_out.shape != (B, self.model.tower.num_tokens, self.model.tower.out_dim):
+            raise ValueError(f"tower_out must be (B, {self.model.tower.num_tokens}, {self.model.tower.out_dim}) bf16, got {tuple(tower_out.shape)} {tower_out.dtype}")
+        if flat_grads is None:
+            flat_grads = torch.empty_like(flat_params)
+        actions = torch.empty(B, self.head_dims["da"], dtype=torch.float32, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        err = {}
+
+        def _cb(_user, bucket, off, numel):
+            if bucket_cb is not None:
+                try:
+                    bucket_cb(int(bucket), int(off), int(numel))
+                except Exception as exc:  # must not unwind through the C frames
+                    err.setdefault("exc", exc)
+
+        fn = _lib.BUCKET_CB(_cb)
+        base = ws.data_ptr()
+        pad = (-base) % 256
+        rc = self.lib.fv_train_forward_backward(self.h, flat_params.data_ptr(), tower_out.data_ptr(), ids.data_ptr(), lens.data_ptr(), states.data_ptr(),
+                                                targets.data_ptr(), B, T, int(training), float(dropout_p), seed, offset, base + pad, ws.numel() - pad,
+                                                actions.data_ptr(), loss.data_ptr(), flat_grads.data_ptr(), fn, None, _stream())
+        if "exc" in err:
+            raise err["exc"]
+        _lib.check(rc, "fv_train_forward_backward", self.h)
+        return actions, loss, flat_grads
+
     # ---------------------------------------------------------------- RCCL without torch in between (fv_comm_*)
     def comm_unique_id(self) -> bytes:
         rid = _lib.RcclId()
