@@ -161,3 +161,66 @@ def test_bench_launcher_starts_its_own_ranks_and_reports_failures():
         pytest.skip("covered by the -m gpu launcher test on a GPU box")
     assert r.returncode != 0
     assert "rank(s) failed: [(0, 1), (1, 1)]" in r.stderr and r.stderr.count("needs a HIP device") == 2
+
+
+# ------------------------------------------------------------------------------------------------ unfrozen backbone
+def _bucket_layout(L=5):
+    """the flat buffer of fv_train_layout in miniature: [head | projector | embedding | layer 0 .. L-1 | final norm] and the order in which
+    fv_train_forward_backward reports the buckets complete (head, final norm, layers last to first, embedding, projector)"""
+    sizes = [52, 40, 96] + [64] * L + [8]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    order = [0, 3 + L] + [3 + l for l in range(L - 1, -1, -1)] + [2, 1]
+    return sizes, offs, order
+
+
+def _bucket_worker(rank, world, port, out):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for p_ in (str(root), str(root / "vla-from-fastvlm_amd")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    from vla_fastvlm.training.dp import BucketedGradExchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sizes, offs, order = _bucket_layout()
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = torch.randn(offs[-1], generator=g) * (10.0 ** torch.randint(-6, 3, (offs[-1],), generator=g).float())   # wide dynamic range
+    whole = grads.clone()
+    dist.all_reduce(whole)                                        # the unbucketed exchange: ONE all-reduce of the whole buffer
+    res = {}
+    for min_numel in (0, 100, 10_000):
+        ex = BucketedGradExchange(None, min_numel=min_numel)
+        buf = grads.clone()
+        ex.begin(buf)
+        for b in order:                                           # what fv_bucket_cb drives during the backward pass
+            ex.bucket_ready(b, offs[b], sizes[b])
+        scale = ex.finish()
+        assert scale == 0.5
+        spans = sorted(ex.launched)
+        assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] == offs[-1]
+        res[min_numel] = (buf, len(ex.launched))
+    out[rank] = (whole, res)
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_exchange_equals_one_allreduce_bit_for_bit():
+    """per-layer gradient buckets all-reduced as the backward pass completes them (BucketedGradExchange, driven by the
+    library's fv_bucket_cb) == one all-reduce of the whole flat gradient, bit for bit, on 2 ranks -- with and without coalescing of
+    adjacent buckets; every element is reduced exactly once."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bucket_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in (0, 1):
+        whole, res = out[rank]
+        for min_numel, (buf, n) in res.items():
+            assert torch.equal(buf, whole), (rank, min_numel)
+        sizes, offs, order = _bucket_layout()
+        assert res[0][1] == len(order)              # one collective per bucket
+        assert res[100][1] < res[0][1]              # adjacent small buckets merged (the layers arrive last to first: each extends the held span downwards)
+        assert res[10_000][1] <= 4                  # everything that is adjacent rides in one collective
+    assert torch.equal(out[0][0], out[1][0])

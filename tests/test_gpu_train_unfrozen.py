@@ -244,3 +244,73 @@ def test_unfrozen_training_needs_split_bf16_weights():
     with pytest.raises(FastVLAHipError, match="llm_precision = 1"):
         eng.train_begin()
     eng.close()
+
+
+def test_policy_level_unfrozen_training_overfits_one_batch_and_exports_the_trained_backbone(tmp_path):
+    """The surface a trainer drives: FastVLAPolicy.enable_backbone_training() + fused_train_step (reference step body
+    training/trainer.py:171-182 over ALL parameters).  `freeze_backbone=False` alone keeps the reference's behaviour (head only);
+    after the explicit opt-in a fixed batch is overfitted, the loss of step 1 equals the oracle's, select_action runs the UPDATED spliced
+    model, gradient accumulation over two half batches gives the full batch's update, and the checkpoint written with the reference's key
+    names carries the trained decoder (model.backbone.model.*) and loads back to the same actions."""
+    from vla_fastvlm.fastvla import FastVLAConfig, FastVLAPolicy
+    from vla_fastvlm.utils import load_policy_from_checkpoint, save_policy_checkpoint
+    torch.manual_seed(5)
+    cfg = FastVLAConfig(vlm_model_name="synthetic:small:41", hidden_dim=64, fusion_dim=64, dropout=0.0, freeze_backbone=False)
+    pol = FastVLAPolicy(cfg).to(DEV)
+    pol.train()
+    g = torch.Generator().manual_seed(6)
+    B = 4
+    batch = {"images": torch.rand(B, 3, 96, 128, generator=g).to(DEV), "states": torch.randn(B, 14, generator=g).to(DEV),
+             "actions": torch.randn(B, 14, generator=g).to(DEV), "tasks": ["pick up the red cube", "open the drawer", "push", "pick up the red cube"]}
+    # the config flag alone: a head-only step, exactly as the reference would run it
+    out0 = pol.fused_train_step(batch, lr=1e-3)
+    assert pol._unfrozen is None and pol.model.backbone.splice_image_tokens is False
+    pol2 = FastVLAPolicy(cfg).to(DEV)
+    pol2.train()
+    st = pol2.enable_backbone_training()
+    assert pol2.model.backbone.splice_image_tokens is True
+    before = {k: v.clone() for k, v in st.named_backbone_tensors().items()}
+    losses = []
+    for i in range(16):
+        out = pol2.fused_train_step(batch, lr=2e-3, weight_decay=0.0)
+        losses.append(float(out["loss"]))
+    torch.cuda.synchronize()
+    print("[unfrozen policy] loss over 16 steps on one batch:", " ".join(f"{x:.4f}" for x in losses))
+    assert all(map(math.isfinite, losses)) and losses[-1] < 0.6 * losses[0] and losses[-1] < losses[7] < losses[0]
+    after = st.named_backbone_tensors()
+    moved = [k for k in before if not torch.equal(before[k], after[k])]
+    assert len(moved) >= len(before) - 1       # everything but (at most) untouched tensors moved: embedding rows count as one tensor
+    assert any("mm_projector" in k for k in moved) and any("embed_tokens" in k for k in moved)
+    # inference now runs the updated, spliced model: actions move towards the targets
+    pol2.eval()
+    with torch.no_grad():
+        a = pol2(batch["images"], batch["states"], batch["tasks"])
+    mse = float(((a - batch["actions"]) ** 2).mean())
+    assert mse < 0.7 * losses[0]
+    # the checkpoint carries the TRAINED decoder under the reference's names and loads back to the same actions
+    out_dir = save_policy_checkpoint(pol2, tmp_path / "step-16", include_backbone=True)
+    sd = torch.load(out_dir / "policy_state_dict.pt", map_location="cpu")
+    k0 = "model.backbone.model.model.layers.0.mlp.down_proj.weight"
+    assert torch.equal(sd[k0], after["model.layers.0.mlp.down_proj.weight"].cpu()) and not torch.equal(sd[k0], before["model.layers.0.mlp.down_proj.weight"].cpu())
+    again = load_policy_from_checkpoint(str(out_dir)).to(DEV)
+    again.model.backbone.splice_image_tokens = True
+    with torch.no_grad():
+        a2 = again(batch["images"], batch["states"], batch["tasks"])
+    torch.cuda.synchronize()
+    assert rel_l2(a2.cpu(), a.cpu()) <= 1e-5       # the file holds the fp32 master; both engines round it to the same bf16 operands
+    # gradient accumulation: two half batches == the full batch (reference trainer.py:96,171: accelerate sums micro-batch gradients)
+    pa, pb = FastVLAPolicy(cfg).to(DEV), FastVLAPolicy(cfg).to(DEV)
+    for p_ in (pa, pb):
+        p_.train()
+        p_.load_state_dict(pol.state_dict(), strict=False)
+    sa, sb = pa.enable_backbone_training(), pb.enable_backbone_training()
+    sb.flat.copy_(sa.flat)
+    pa.fused_train_step(batch, lr=1e-3)
+    half = lambda lo, hi: {k: (v[lo:hi] if torch.is_tensor(v) else v[lo:hi]) for k, v in batch.items()}   # noqa: E731
+    pb.fused_train_step(half(0, 2), lr=1e-3, grad_accum_steps=2)
+    pb.fused_train_step(half(2, 4), lr=1e-3, grad_accum_steps=2)
+    torch.cuda.synchronize()
+    ga, gb = sa.g, sb.acc / 2
+    assert rel_l2(gb.cpu(), ga.cpu()) <= 2e-3      # other tile shapes at other row counts: the operand roundings differ, the sums agree
+    for p_ in (pol, pol2, again, pa, pb):
+        p_.model.backbone.engine().close()

@@ -4,6 +4,7 @@ select_action / reset with the reference's signatures, plus `fused_train_step`, 
 vla_fastvlm.training.Trainer and bench.py drive."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -24,6 +25,16 @@ class FastVLAPolicy(nn.Module):
         self.model = FastVLMWithExpert(self.config)
         self.processor = FastVLAProcessor(self.config, self.model.backbone)
         self._opt_state = None
+        self._unfrozen = None   # training/unfrozen.py UnfrozenState once enable_backbone_training() ran
+
+    def enable_backbone_training(self, bucket_min_numel: int = 1 << 22):
+        """Extension of this build: fine-tune the Qwen2 decoder + mm_projector together with the action expert
+        (vision tower frozen, image tokens spliced).  Explicit on purpose: the reference's `freeze_backbone=False` trains nothing but the
+        head either (model/fastvlm_adapter.py:501), so the config flag alone must not change what a step computes."""
+        if self._unfrozen is None:
+            from ..training.unfrozen import UnfrozenState
+            self._unfrozen = UnfrozenState(self, bucket_min_numel=bucket_min_numel)
+        return self._unfrozen
 
     def forward(self, images: torch.Tensor, states: torch.Tensor, tasks: List[str] | str,
                 device: torch.device | None = None) -> torch.Tensor:
@@ -118,6 +129,13 @@ class FastVLAPolicy(nn.Module):
           between the start of the all-reduce and the optimiser kernel, so the collective runs underneath it; the
           prepared batch comes back under "next" and is passed as `prepared=` to the following call.
         """
+        if self._unfrozen is None and not self.config.freeze_backbone and os.environ.get("FASTVLA_TRAIN_BACKBONE", "0") == "1":
+            self.enable_backbone_training()
+        if self._unfrozen is not None:
+            if next_batch is not None:
+                raise ValueError("the look-ahead pipeline (next_batch) belongs to the frozen-backbone step: an unfrozen forward depends on the update")
+            return self._unfrozen.step(batch, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
+                                       process_group=process_group, prepared=prepared, grad_accum_steps=grad_accum_steps, force_sync=force_sync)
         m = self.model
         prep = prepared if prepared is not None else self.prepare_batch(batch)
         dev = prep["pooled"].device

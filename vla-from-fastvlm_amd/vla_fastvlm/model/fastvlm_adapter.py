@@ -323,6 +323,17 @@ class FastVLMBackbone(nn.Module):
     def source_tensors(self):
         """(name, tensor) of every canonical inference-form tensor this backbone packs its engine from, one at a time -- the write
         side of the checkpoint interop (vla_fastvlm/utils/checkpoint.py save_policy_checkpoint(include_backbone=True))."""
+        trained = getattr(self, "_trained_tensors", None)
+        if trained is not None:
+            # an unfrozen run (training/unfrozen.py): decoder + projector come from the fp32 master, the frozen tower from its source
+            new = {k: v.detach().cpu() for k, v in trained().items()}
+            self._trained_tensors = None
+            try:
+                for name, t in self.source_tensors():
+                    yield name, new.get(name, t).reshape(t.shape)
+            finally:
+                self._trained_tensors = trained
+            return
         if self._weights_override is not None:
             yield from self._weights_override.items()
             return

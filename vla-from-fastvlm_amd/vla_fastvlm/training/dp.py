@@ -67,6 +67,68 @@ class GradExchange:
         return self._ev[0].elapsed_time(self._ev[1])
 
 
+class BucketedGradExchange:
+    """Unfrozen-backbone training: the gradient is ~0.5 G floats, produced bucket by bucket as the backward pass
+    walks the decoder from its last layer to its first.  `bucket_ready(bucket, offset, numel)` -- the library's fv_bucket_cb, called on the
+    host right after the last kernel writing that slice of the flat gradient has been ENQUEUED -- records an event on the compute stream
+    and launches that slice's all-reduce (sum, in place) on the side stream behind it, so layer l's 60 MB travel over xGMI while layers
+    l-1 .. 0 are still being differentiated; `finish()` joins the side stream in front of the optimiser and returns 1/world for its
+    grad_scale.  Slices are disjoint and each element is reduced exactly once, so the result equals ONE all-reduce of the whole buffer
+    bit for bit (tests/test_dp_gloo.py).  `min_numel` coalesces buckets that happen to be adjacent in the buffer (layer l then l-1)
+    into fewer, larger collectives: a ring over 8 GPUs is per-link bound (7 x ~153 GB/s point to point), not NVSwitch-shaped."""
+
+    def __init__(self, device: Optional[torch.device] = None, group=None, min_numel: int = 0):
+        self.group = group
+        self.stream = torch.cuda.Stream(device=device) if device is not None and torch.device(device).type == "cuda" else None
+        self.min_numel = int(min_numel)
+        self._flat: Optional[torch.Tensor] = None
+        self._held: Optional[tuple] = None      # (offset, numel) waiting to be merged with an adjacent bucket
+        self.launched: list = []                 # (offset, numel) of every collective of the current step, in launch order
+
+    def begin(self, flat_grads: torch.Tensor) -> None:
+        self._flat, self._held, self.launched = flat_grads, None, []
+
+    def _launch(self, off: int, n: int) -> None:
+        flat = self._flat
+        self.launched.append((off, n))
+        if world_size(self.group) == 1:
+            return
+        piece = flat[off: off + n]
+        if flat.is_cuda and self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(flat.device))
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+
+    def bucket_ready(self, bucket: int, offset: int, numel: int) -> None:
+        if self._flat is None:
+            raise RuntimeError("BucketedGradExchange.begin(flat_grads) must be called before the backward pass")
+        if self._held is not None:
+            ho, hn = self._held
+            if offset + numel == ho:            # the new bucket sits right in front of the held one (layers arrive last to first)
+                offset, numel = offset, numel + hn
+            elif ho + hn == offset:
+                offset, numel = ho, hn + numel
+            else:
+                self._launch(ho, hn)
+            self._held = None
+        if numel < self.min_numel:
+            self._held = (offset, numel)
+        else:
+            self._launch(offset, numel)
+
+    def finish(self, device=None) -> float:
+        if self._held is not None:
+            self._launch(*self._held)
+            self._held = None
+        if self.stream is not None and self._flat is not None and self._flat.is_cuda and world_size(self.group) > 1:
+            torch.cuda.current_stream(device).wait_stream(self.stream)
+        return 1.0 / world_size(self.group)
+
+
 def allreduce_flat_grads(flat_grads: torch.Tensor, comm_stream: Optional["torch.cuda.Stream"] = None, group=None) -> float:
     """Sum `flat_grads` across ranks in place and join; returns the scale (1/world) the optimiser must apply.  The
     unpipelined form (start + finish back to back) for callers that have nothing to put in between."""

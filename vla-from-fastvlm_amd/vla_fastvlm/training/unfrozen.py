@@ -1,0 +1,142 @@
+"""Unfrozen-backbone training on the HIP path: decoder + mm_projector + action expert trainable, FastViT-HD
+tower frozen, image tokens spliced in front of the text.
+
+The reference exposes `freeze_backbone` (fastvla/configuration_fastvla.py:23, applied at model/fastvlm_adapter.py:170-173) but wraps the
+backbone forward in an unconditional `@torch.no_grad()` (model/fastvlm_adapter.py:501), so its own loop (training/trainer.py:171-182)
+only ever trains the head.  Because of that, `freeze_backbone=False` ALONE keeps the reference's behaviour here too (frozen backbone, head
+training); the VLM is fine-tuned only after an explicit `policy.enable_backbone_training()` (or FASTVLA_TRAIN_BACKBONE=1 together with
+`freeze_backbone=False`).  The step body is the reference's -- loss -> backward -> clip_grad_norm_(1.0) over ALL parameters -> AdamW ->
+schedule -- with every kernel in libfastvla_hip.so (fv_train_forward_backward, fv_adamw_clip_step, fv_train_commit).
+
+All trainable tensors live in ONE flat fp32 buffer (fv_train_layout: [head | projector | embedding | layers | final norm], matrices in the
+library's packed layout); gradients, Adam's m and v mirror it.  Under torch.distributed the gradient is exchanged per BUCKET while the
+backward pass is still running (training/dp.py BucketedGradExchange, driven by the library's fv_bucket_cb).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from fastvla_hip import HEAD_KEYS
+
+from .dp import BucketedGradExchange, GradExchange
+
+
+class UnfrozenState:
+    def __init__(self, policy, bucket_min_numel: int = 1 << 22):
+        m = policy.model
+        bb = m.backbone
+        self.policy = policy
+        eng = bb.engine()
+        if eng.llm_precision != 1:
+            raise RuntimeError("backbone training needs the split-bf16 decoder policy (llm_precision=1): its bf16 weight copies are refreshed "
+                               f"from the fp32 master after every step; this engine runs llm_precision={eng.llm_precision}")
+        eng.train_begin()
+        self.eng = eng
+        self.tensors, self.total, self.n_buckets = eng.train_layout()
+        dev = eng.device
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        eng.train_export_params(self.flat)
+        # the 12 head tensors move into the front of the flat buffer and the nn.Parameters are re-pointed at it, so state_dict(), a torch
+        # optimiser or LeRobot's checkpointing keep seeing the live values
+        old = m.materialize(dev)
+        hn = eng.head_numel()
+        self.flat[:hn].copy_(old)
+        views = eng.head_views(self.flat[:hn])
+        with torch.no_grad():
+            for p, k in zip(m.head_parameters(), HEAD_KEYS):
+                p.data = views[k]
+        m._flat = self.flat[:hn]
+        self.g = torch.zeros_like(self.flat)
+        self.acc: Optional[torch.Tensor] = None
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.step_count, self.micro = 0, 0
+        self.norm = torch.zeros(1, device=dev)
+        self.bucketed = BucketedGradExchange(dev, min_numel=bucket_min_numel)
+        self.whole = GradExchange(dev)
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        bb.splice_image_tokens = True          # the model being trained IS the spliced one: inference must run the same graph
+        bb._trained_tensors = self.named_backbone_tensors   # checkpoint export reads the master, not the original weight source
+        policy._opt_state = {"m": self.m, "v": self.v, "step": 0, "flat": self.flat, "norm": self.norm}
+
+    # ------------------------------------------------------------------ views / export
+    def named_backbone_tensors(self) -> Dict[str, torch.Tensor]:
+        """canonical checkpoint key -> fp32 copy of every trained decoder / projector tensor (q / k / v and gate / up unpacked)"""
+        return {k: v for k, v in self.eng.train_named_tensors(self.flat).items() if not k.startswith("head.")}
+
+    def _workspace(self, B: int, T: int) -> torch.Tensor:
+        key = (B, T)
+        if key not in self._ws:
+            self._ws.clear()                   # one shape at a time: the stash is ~0.5 GB per sample at FastVLM-0.5B
+            self._ws[key] = self.eng.train_workspace(B, T)
+        return self._ws[key]
+
+    # ------------------------------------------------------------------ one step
+    def prepare(self, batch: Dict) -> Dict:
+        """everything that does not depend on the trainable parameters: image prep + the FROZEN tower, tokenisation"""
+        pol, bb, eng = self.policy, self.policy.model.backbone, self.eng
+        dev = eng.device
+        images = pol.processor.prepare_images(batch["images"], dev)
+        states = pol.processor.prepare_states(batch["states"], dev).float()
+        tasks = pol.processor.prepare_tasks(batch["tasks"], batch_size=images.shape[0])
+        targets = batch["actions"].to(dev, torch.float32)
+        if targets.ndim == 3:
+            targets = targets[:, 0]
+        pix = bb._prepare_images_tensor(images, dev)
+        with torch.no_grad():
+            _, tower_out = eng.vision_forward(pix, return_tower_out=True)
+        text = bb._prep_text(tasks, dev)
+        ids, mask = text["input_ids"], text["attention_mask"]
+        T = ids.shape[1]
+        Tp = (T + 7) // 8 * 8                  # the training kernels want whole 16-byte rows of ids: right-pad, masked
+        if Tp != T:
+            ids = torch.nn.functional.pad(ids, (0, Tp - T))
+            mask = torch.nn.functional.pad(mask, (0, Tp - T))
+        return {"tower_out": tower_out, "ids": ids, "lens": mask.to(torch.int32).sum(1).to(torch.int32), "states": states, "targets": targets.contiguous()}
+
+    def step(self, batch: Optional[Dict] = None, *, lr: float, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-4,
+             max_grad_norm: Optional[float] = 1.0, process_group=None, prepared: Optional[Dict] = None, grad_accum_steps: int = 1,
+             force_sync: bool = False) -> Dict[str, torch.Tensor]:
+        pol, eng = self.policy, self.eng
+        prep = prepared if prepared is not None else self.prepare(batch)
+        B, T = prep["ids"].shape
+        ws = self._workspace(B, T)
+        k = max(1, int(grad_accum_steps))
+        self.micro += 1
+        sync = force_sync or self.micro % k == 0
+        p = float(pol.config.dropout) if pol.training else 0.0
+        m = pol.model
+        m._drop_calls += 1
+        overlap = k == 1 and sync              # per-bucket all-reduce under the backward pass; with accumulation the sum is exchanged once
+        if overlap:
+            self.bucketed.group = process_group
+            self.bucketed.begin(self.g)
+        actions, loss, _ = eng.train_forward_backward(self.flat, prep["tower_out"], prep["ids"], prep["lens"], prep["states"], prep["targets"], ws,
+                                                      training=pol.training, dropout_p=p, seed=m._drop_seed, offset=m._drop_calls, flat_grads=self.g,
+                                                      bucket_cb=self.bucketed.bucket_ready if overlap else None)
+        total = self.g
+        if k > 1:
+            if self.acc is None:
+                self.acc = torch.zeros_like(self.flat)
+            if self.micro == 1:
+                self.acc.copy_(self.g)
+            else:
+                eng.grad_accumulate(self.acc, self.g)
+            total = self.acc
+        out = {"loss": loss[0], "mse": loss[0].detach(), "actions": actions, "synced": sync, "next": None}
+        if sync:
+            if overlap:
+                scale = self.bucketed.finish(eng.device)
+            else:
+                self.whole.group = process_group
+                scale = self.whole.start(total) / k
+                self.whole.finish(eng.device)
+            self.step_count += 1
+            self.micro = 0
+            eng.adamw_step(self.flat, total, self.m, self.v, self.step_count, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                           max_grad_norm=max_grad_norm or 0.0, grad_scale=scale, grad_norm_out=self.norm)
+            eng.train_commit(self.flat)       # bf16 operand copies (and their transposes) follow the master
+            pol._opt_state["step"] = self.step_count
+        out["grad_norm"] = self.norm[0]
+        return out
