@@ -62,6 +62,8 @@ def parse():
                          "0 = plain bf16 operands (~8e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-train-unfrozen", action="store_true", help="skip the unfrozen decoder + projector training leg (SURVEY.md 8f-4)")
+    ap.add_argument("--unfrozen-batch", type=int, default=int(os.environ.get("FASTVLA_UNFROZEN_BATCH", "32")), help="per-GPU batch of the unfrozen training leg (C3's rank shape)")
     ap.add_argument("--fv-comm-check", action="store_true",
                     help="N > 1 on the RCCL backend: also build a communicator through the library's own C ABI (fv_comm_*) and push one "
                          "all-reduce of ones through fv_allreduce_grads (off by default: the timed path uses torch.distributed's communicator, "
@@ -458,6 +460,67 @@ def main():
                  "ms_per_step_serial_exchange": None if ser_ms is None else round(ser_ms, 3),
                  "overlap_frac": None if overlap is None else round(overlap, 3)}
 
+    # ---- unfrozen decoder + projector training (fv_train_* -- the reference's freeze_backbone=False, which its own
+    # no_grad forward makes moot): one step = letterbox + FROZEN tower + projector / spliced 320-token decoder forward with every activation
+    # kept + MSE + backward over 494 M parameters (dgrad / wgrad on the forward's GEMM kernels, split-bf16 gradient operands) + clip + AdamW +
+    # bf16 operand refresh.  Under N > 1 the gradient travels per bucket (one decoder layer = 60 MB) on a side stream while the backward
+    # pass is still running.  Its own roofline fraction: algorithmic flops (tower + 3 x (projector + decoder GEMMs) + attention fwd/bwd).
+    train_unfrozen = None
+    if not args.no_train_unfrozen and args.llm_precision == 1 and model.llm.head_dim >= 64 and w is not None:
+        from vla_fastvlm.training.dp import BucketedGradExchange
+        Bu = min(args.unfrozen_batch, B)
+        try:
+            eng.train_begin()
+            tensors_u, total_u, nb_u = eng.train_layout()
+            flat_u = torch.zeros(total_u, dtype=torch.float32, device=dev)
+            eng.train_export_params(flat_u)
+            flat_u[: flat.numel()].copy_(flat)
+            flat_u0 = flat_u.clone()              # the weights as loaded: committed back after the leg (bf16 -> fp32 -> bf16 is exact)
+            g_u, m_u, v_u = torch.zeros_like(flat_u), torch.zeros_like(flat_u), torch.zeros_like(flat_u)
+            ws_u = eng.train_workspace(Bu, T)
+            bex = BucketedGradExchange(dev, min_numel=1 << 22)
+            ust = {"step": 0}
+
+            def step_unfrozen():
+                ust["step"] += 1
+                pix_u = eng.preprocess(images[:Bu])
+                _, tower_out_u = eng.vision_forward(pix_u, return_tower_out=True)
+                bex.begin(g_u)
+                eng.train_forward_backward(flat_u, tower_out_u, ids[:Bu], lens[:Bu], states[:Bu], targets[:Bu], ws_u, training=True, dropout_p=0.1,
+                                           seed=args.seed + rank, offset=ust["step"], flat_grads=g_u, bucket_cb=bex.bucket_ready)
+                scale = bex.finish(dev)
+                eng.adamw_step(flat_u, g_u, m_u, v_u, ust["step"], lr=1e-5, weight_decay=1e-4, max_grad_norm=1.0, grad_scale=scale)
+                eng.train_commit(flat_u)
+
+            nsu = max(2, args.steps // 4)
+            elu = timed(step_unfrozen, nsu, 2)
+            Ni_u = model.tower.num_tokens
+            rows_u = Bu * (Ni_u + T)
+            ll = model.llm
+            qkvw_u = (ll.heads + 2 * ll.kv_heads) * ll.head_dim
+            dec_tok = 2.0 * ll.layers * (ll.hidden * qkvw_u + ll.heads * ll.head_dim * ll.hidden + 3 * ll.hidden * ll.inter)   # GEMM flops per token, lm_head excluded
+            dec_fl = dec_tok * rows_u
+            proj_fl = 2.0 * Bu * Ni_u * (model.tower.out_dim * ll.hidden + ll.hidden ** 2)
+            attn_fl = 2.0 * 2 * Bu * (Ni_u + T) ** 2 / 2 * ll.heads * ll.head_dim * ll.layers   # QK^T + PV, causal half
+            # the tower's algorithmic flops per image from the inference step's own per-launch accounting (literal mode: tower + projector + T-token decoder)
+            tower_fl = max(0.0, total_flops - dec_tok * B * T - 2.0 * B * Ni_u * (model.tower.out_dim * ll.hidden + ll.hidden ** 2)) / B * Bu
+            step_fl = tower_fl + 3.0 * (dec_fl + proj_fl) + 3.5 * attn_fl   # backward: dgrad + wgrad per GEMM; attention backward = 5 of the forward's 2 products
+            train_unfrozen = {"value": round(world * nsu / elu, 3), "unit": "train steps/s (whole job)", "ms_per_step": round(1e3 * elu / nsu, 3),
+                              "batch_per_gpu": Bu, "global_batch": Bu * world, "tokens_per_sample": Ni_u + T, "trainable_params": int(total_u),
+                              "grad_bytes": int(total_u * 4), "buckets": nb_u, "collectives_per_step": len(bex.launched), "parallelism": f"dp{world}",
+                              "algorithmic_tflop_per_step": round(step_fl / 1e12, 2),
+                              "roofline": {"bound": "mfma", "achieved": round(step_fl / (elu / nsu) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": round(step_fl / (elu / nsu) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                           "note": "whole step incl. the frozen tower; the backward's split-bf16 gradient operands execute 2x the algorithmic MFMA work of each dgrad / wgrad"},
+                              "workspace_gb": round(ws_u.numel() / 2 ** 30, 2)}
+            # leave the engine as it was: the legs below run on the original weights
+            eng.train_commit(flat_u0)
+            torch.cuda.synchronize()
+            del ws_u, g_u, m_u, v_u, flat_u, flat_u0
+        except Exception as exc:  # the leg must never take the headline line down with it
+            train_unfrozen = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.empty_cache()
+
     # ---- the same step through the reference's plugin surface (reference lerobot_fastvla/modeling_fastvla.py:109-133):
     # FastVLAPolicy.select_action(batch) / .forward(batch) with a LeRobot batch dict and B task strings through the tokenizer;
     # Python glue, tokenisation, the action deque and forward()'s `.item()` are inside these numbers.  The policy drives the SAME
@@ -690,7 +753,7 @@ def main():
                                          3: "split-bf16 qkv/o/down, fp16 gate/up (one pass), fp32 attention",
                                          4: "split-bf16 qkv/o/gate/up, fp16 down (one pass), fp32 attention"}[args.llm_precision]},
             "samples_per_s": round(value * B, 2),
-            "roofline": roofline, "power": power_info, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
+            "roofline": roofline, "power": power_info, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "train_unfrozen": train_unfrozen, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
         }
         print(json.dumps(out))
