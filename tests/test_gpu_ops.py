@@ -666,6 +666,41 @@ def test_gemm_splitk_few_rows_many_splits(ws_splits):
     check_close(out.cpu(), ref, rel=2e-5, amax=2e-4, what=f"split-K few rows (scratch for {ws_splits})")
 
 
+@pytest.mark.parametrize("M,N,K,ksplit,ws", [(8200, 896, 256, 0, False), (10240, 1152, 192, 1, False), (9728, 904, 128, 1, False),
+                                              (896, 4864, 2048, 1, True), (900, 904, 4096, 0, True), (1152, 896, 2048, 1, True)])
+def test_gemm_256_tile_ragged_edges_fp32_epilogues(M, N, K, ksplit, ws):
+    """Round 4: fp32-epilogue problems whose M or N is not a multiple of 256 (the decoder's N = 896 / 1152 projections at a training
+    batch, every dgrad / wgrad of the unfrozen path: M = 896, N = 4864 ...) on the 256-tile LDS-DMA kernel with ragged edge tiles --
+    plain (>= 128 tiles) and cut along K (few tiles, long K, scratch given) -- F32 with bias and RES_F32 in place, against fp64.
+    Rows / columns past the edge must not be written (the outputs are embedded in NaN-guarded buffers)."""
+    torch.manual_seed(M + N + K)
+    Kt = (2 if ksplit else 1) * K
+    A = bf(torch.randn(M, Kt) * (0.5 if not ksplit else 1.0))
+    if ksplit:
+        A[:, K:] = bf(A[:, K:] * 2 ** -8)     # a lo half: hi + lo is the operand
+    W, b, res = bf(torch.randn(N, K) / math.sqrt(K)), torch.randn(N), torch.randn(M, N)
+    Aeff = (A[:, :K] + A[:, K:]) if ksplit else A
+    ref = Aeff.double() @ W.double().t()
+    a, w, bd = dev_bf16(A), dev_bf16(W), dev_f32(b)
+    wsb = torch.empty(8 * 1024 * 1024, dtype=torch.float32, device=DEV) if ws else None
+    guard = 8
+    out = torch.full((M + guard, N + guard), float("nan"), dtype=torch.float32, device=DEV)
+    call(lib().fv_op_gemm_splitk(a.data_ptr(), Kt, w.data_ptr(), M, N, K, bd.data_ptr(), None, 0, out.data_ptr(), N + guard, _lib.EPI_F32, ksplit,
+                                 wsb.data_ptr() if ws else None, wsb.numel() * 4 if ws else 0, stream()), "ragged F32")
+    torch.cuda.synchronize()
+    o = out.cpu()
+    check_close(o[:M, :N], (ref + b.double()).float(), rel=2e-5, amax=2e-4, what=f"ragged gemm F32 {M}x{N}x{K}")
+    assert torch.isnan(o[M:]).all() and torch.isnan(o[:, N:]).all(), "wrote past the edge"
+    x = torch.full((M + guard, N + guard), float("nan"), dtype=torch.float32, device=DEV)
+    x[:M, :N] = res.to(DEV)
+    call(lib().fv_op_gemm_splitk(a.data_ptr(), Kt, w.data_ptr(), M, N, K, None, x.data_ptr(), N + guard, x.data_ptr(), N + guard, _lib.EPI_RES_F32, ksplit,
+                                 wsb.data_ptr() if ws else None, wsb.numel() * 4 if ws else 0, stream()), "ragged RES_F32 in place")
+    torch.cuda.synchronize()
+    o = x.cpu()
+    check_close(o[:M, :N], (ref + res.double()).float(), rel=2e-5, amax=2e-4, what=f"ragged gemm RES_F32 {M}x{N}x{K}")
+    assert torch.isnan(o[M:]).all() and torch.isnan(o[:, N:]).all(), "wrote past the edge"
+
+
 # ------------------------------------------------------------------------------------------------ round 3: fp16-operand GEMMs
 @pytest.mark.parametrize("M,N,K", [(100, 256, 896), (512, 1024, 896), (4096, 5120, 256), (256, 896, 4864)])
 def test_gemm_f16_operands(M, N, K):

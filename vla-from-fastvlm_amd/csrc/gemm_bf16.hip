@@ -286,7 +286,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int sl = j * NTH + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
-      oa[j] = j < SA ? (uint32_t)(((size_t)(bm + row) * p.lda + chunk * 8) * 2) : 0u;
+      oa[j] = j < SA ? (uint32_t)(((size_t)min(bm + row, p.M - 1) * p.lda + chunk * 8) * 2) : 0u;   // rows past M (ragged last row tile, fp32 epilogues) repeat the last
       ow[j] = j < SW ? (uint32_t)(((size_t)min(bn + row, p.N - 1) * p.K + chunk * 8) * 2) : 0u;   // rows past N (padded last tile) repeat the last
       if (ASYM) ow2[j] = j < SW ? (uint32_t)(((size_t)min(bn + row + 32, p.N - 1) * p.K + chunk * 8) * 2) : 0u;
     }
@@ -418,11 +418,12 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
     float bs[8], sc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bs[e] = 0.f; sc[e] = 1.f; }
-    if (p.bias && p.splits == 1) {
+    const bool col_ok = gn < p.N;                  // ragged last column tile (N % 8 == 0: a lane's 8 columns are in or out together)
+    if (p.bias && p.splits == 1 && col_ok) {
       const float4 lo = *reinterpret_cast<const float4*>(p.bias + gn), hi = *reinterpret_cast<const float4*>(p.bias + gn + 4);
       bs[0] = lo.x; bs[1] = lo.y; bs[2] = lo.z; bs[3] = lo.w; bs[4] = hi.x; bs[5] = hi.y; bs[6] = hi.z; bs[7] = hi.w;
     }
-    if (p.epi == FV_EPI_LS_RES) {
+    if (p.epi == FV_EPI_LS_RES && col_ok) {
       const float4 lo = *reinterpret_cast<const float4*>(p.scale + gn), hi = *reinterpret_cast<const float4*>(p.scale + gn + 4);
       sc[0] = lo.x; sc[1] = lo.y; sc[2] = lo.z; sc[3] = lo.w; sc[4] = hi.x; sc[5] = hi.y; sc[6] = hi.z; sc[7] = hi.w;
     }
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
         for (int it = 0; it < 2; ++it) {
           const int row = it * 8 + (lane >> 3);
           const int gm = bm + wr * (16 * MI) + i * 16 + row;
+          if (gm >= p.M) continue;                 // ragged last row tile
           float* pp = p.part + ((size_t)sp * p.M + gm) * p.npad + gn;
           *reinterpret_cast<float4*>(pp) = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
           *reinterpret_cast<float4*>(pp + 4) = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       for (int it = 0; it < 2; ++it) {
         const int row = it * 8 + (lane >> 3);
         const int gm = bm + wr * (16 * MI) + i * 16 + row;
+        if (gm >= p.M || !col_ok) continue;        // ragged edge tiles (fp32 epilogues only: launch_gemm keeps the others on whole tiles)
         const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
         const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
         float v[8] = {y0.x + bs[0], y0.y + bs[1], y0.z + bs[2], y0.w + bs[3], y1.x + bs[4], y1.y + bs[5], y1.z + bs[6], y1.w + bs[7]};
@@ -669,6 +672,15 @@ int gemm_glds_tile(const GemmArgs& a) {
   // round of 256-tiles beats it -- 7B gate/up at M = 512 (296 tiles) 10.5 -> 8.9 ms per step, 0.5B at M = 1024 (152 tiles) 0.96 -> 0.71
   static const int min_tiles_small_m = getenv("FASTVLA_GEMM256_MIN_TILES") ? atoi(getenv("FASTVLA_GEMM256_MIN_TILES")) : 128;   // A/B
   if (a.M % 256 == 0 && a.N % 256 == 0 && (long)(a.M / 256) * (a.N / 256) >= (a.M <= 2048 ? min_tiles_small_m : 320)) return 256;
+  // fp32 epilogues (the decoder's projections and every dgrad / wgrad of the unfrozen training path: N = 896, 1152, 4864, M = 896 ...)
+  // take RAGGED edge tiles on the 256-tile kernel -- staging clamps rows past M / N, the epilogue drops them -- when the edge waste is
+  // small: the register-staged kernel they fell to runs at ~0.45 PF against ~0.9 here
+  static const bool no_ragged = getenv("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
+  if (!no_ragged && f32 && !a.f16 && a.N % 8 == 0) {
+    const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
+    const double fill = (double)a.M * a.N / ((double)tm * tn * 65536.0);
+    if (tm * tn >= 128 && fill >= 0.75) return 256;
+  }
   // 128-tiles: one wave per SIMD and a K-tile of 32 MFMAs per wave cannot cover a memory latency per K-tile, so a long K
   // loop (the decoder's down projection, K = 2 x 4864) is slower here than on the 128-tile register-staged kernel at three
   // blocks per CU; short ones (qkv / o, K <= 1024) are on par
@@ -733,19 +745,21 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   static const bool colmajor_ok = getenv("FASTVLA_NO_GEMM_COLMAJOR") == nullptr;   // A/B
   static const int cm_max = getenv("FASTVLA_GEMM_COLMAJOR_MAX_TM") ? atoi(getenv("FASTVLA_GEMM_COLMAJOR_MAX_TM")) : 8;   // A/B
   static const bool no_asym = getenv("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
-  const bool asym = !no_asym && a.M <= 8192;
+  const bool asym = !no_asym && a.M <= 8192 && a.M % 256 == 0;   // the asymmetric staging addresses row + 32 from a (clamped) base row: whole row tiles only
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
   static const bool no_splitk = getenv("FASTVLA_NO_SPLITK") != nullptr, no_g256 = getenv("FASTVLA_NO_GEMM256") != nullptr;
-  if (!no_splitk && a.splitk_ws && f32out && !no_g256 && a.M % 256 == 0 && a.K % 64 == 0 && a.N % 4 == 0 &&
+  static const bool no_ragged_sk = getenv("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
+  if (!no_splitk && a.splitk_ws && f32out && !no_g256 && (a.M % 256 == 0 || (!no_ragged_sk && !a.f16 && a.N % 8 == 0)) && a.K % 64 == 0 && a.N % 4 == 0 &&
       (size_t)a.M * a.lda * 2 < ((size_t)1 << 32) && (size_t)a.N * a.K * 2 < ((size_t)1 << 32)) {
-    const int tn = (a.N + 255) / 256, tiles = (a.M / 256) * tn, nkt = (a.ksplit ? 2 : 1) * (a.K / 64);
+    const int tmr = (a.M + 255) / 256;            // a ragged last row tile: staging clamps its rows, the partial-sum stores skip them
+    const int tn = (a.N + 255) / 256, tiles = tmr * tn, nkt = (a.ksplit ? 2 : 1) * (a.K / 64);
     int splits = tiles < cus ? cus / tiles : 1;
     if (splits > 8) splits = 8;
     while (splits > 1 && nkt / splits < 16) --splits;
     while (splits > 1 && (size_t)splits * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes) --splits;   // as many as the scratch buffer holds
     if (splits > 1) {
       p.tiles_n = tn;
-      p.tiles_m = colmajor_ok && a.M / 256 <= cm_max ? a.M / 256 : 0;
+      p.tiles_m = colmajor_ok && tmr <= cm_max ? tmr : 0;
       p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
       p.nwg = tiles * splits;
       const dim3 g2(p.nwg < cus ? p.nwg : cus / 8 * 8);
@@ -785,9 +799,10 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     return FV_OK;
   }
   if (const int gt = gemm_glds_tile(a)) {
-    p.tiles_n = a.N / gt;
-    p.nwg = (a.M / gt) * p.tiles_n;
-    p.tiles_m = colmajor_ok && a.M / gt <= cm_max ? a.M / gt : 0;
+    const int tmr = (a.M + gt - 1) / gt;        // ragged edge tiles only come back from gemm_glds_tile for fp32 epilogues
+    p.tiles_n = (a.N + gt - 1) / gt;
+    p.nwg = tmr * p.tiles_n;
+    p.tiles_m = colmajor_ok && tmr <= cm_max ? tmr : 0;
     const int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
     const int grid = p.nwg < slots ? p.nwg : slots;
     if (gt == 256 && a.f16 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
