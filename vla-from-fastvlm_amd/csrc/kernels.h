@@ -114,7 +114,7 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
 int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, int ldo, int lo_off, int R, int Rp, int C, hipStream_t s);
 int launch_swiglu_fwd(const float* gu, bf16_t* act, int ldo, int lo_off, long rows, int I, hipStream_t s);
-int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s);
+int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s, bf16_t* out_split = nullptr);   // out_split: [rows][4I] = [hi | lo] bf16 instead of fp32 in place
 int launch_gelu_fwd(const float* pre, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);
 int launch_gelu_bwd(float* dh, const float* pre, size_t n, hipStream_t s);
 size_t rmsnorm_bwd_scratch_floats(long rows, int H);
@@ -126,7 +126,8 @@ int launch_image_rows(const float* stream, float* compact, int B, int Tt, int Ni
 int launch_embed_bwd(const int32_t* ids, const int32_t* lens, const float* dx, float* dE, int B, int T, int Ni, int H, int vocab, hipStream_t s);
 int launch_attention_bwd(const float* qkv, int ld, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, const float* dO, int lddo, const float* lse,
                          float* delta, float* dqkv, int B, int T, int heads, int kv_heads, int D, const int32_t* lens, int len_add, float scale,
-                         const float2* rope, hipStream_t s);
+                         const float2* rope, hipStream_t s, float* part = nullptr);   // part: optional scratch of (heads / kv_heads) * B * T * 2 * kv_heads * D floats
+                                                                                       // -> dK / dV per q head in parallel, then summed in a fixed order
 
 // action expert (all fp32)
 struct HeadDims { int feat, ds, da, hid, fus; };

@@ -122,8 +122,9 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const float* __restrict
     *reinterpret_cast<uint4*>(act + r * ldo + lo_off + 8 * j) = pack8(l);
   }
 }
-// dgu (written over gu, same interleaved layout) from dact [rows][I]:  dgate = dact * up * silu'(gate), dup = dact * silu(gate)
-__global__ __launch_bounds__(256) void swiglu_bwd_kernel(float* __restrict__ gu, const float* __restrict__ dact, long rows, int I) {
+// dgu (same interleaved layout) from dact [rows][I]:  dgate = dact * up * silu'(gate), dup = dact * silu(gate).  out_split == null: fp32,
+// written over gu; else split bf16 [rows][4I] = [hi 2I | lo 2I]: the dgrad GEMM's operand as it is, and (transposed) the wgrad's
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(float* __restrict__ gu, const float* __restrict__ dact, long rows, int I, bf16_t* __restrict__ out_split) {
   const int j8 = I >> 3;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * j8; i += (long)gridDim.x * 256) {
     const long r = i / j8;
@@ -139,8 +140,25 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(float* __restrict__ gu,
       dg[e] = d[e] * u[e] * sg * (1.0f + g[e] * (1.0f - sg));
       du[e] = d[e] * g[e] * sg;
     }
-    store8(gp, dg);
-    store8(gp + 8, du);
+    if (out_split) {
+      bf16_t* op = out_split + r * 4 * I + 16 * j;
+      float h[8], l[8];
+      uint4 hv = pack8(dg);
+      *reinterpret_cast<uint4*>(op) = hv;
+      unpack8(hv, h);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) l[e] = dg[e] - h[e];
+      *reinterpret_cast<uint4*>(op + 2 * I) = pack8(l);
+      hv = pack8(du);
+      *reinterpret_cast<uint4*>(op + 8) = hv;
+      unpack8(hv, h);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) l[e] = du[e] - h[e];
+      *reinterpret_cast<uint4*>(op + 2 * I + 8) = pack8(l);
+    } else {
+      store8(gp, dg);
+      store8(gp + 8, du);
+    }
   }
 }
 
@@ -476,11 +494,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
   store_unrotated<D>(dqkv + ((size_t)b * T + qg) * ld + h * D, dq, rope, qg, fg);
 }
 
-template <int D>
+// PART: one block per (batch, kv head, key block, q head OF THE GROUP): the block writes that head's share of dK / dV to
+// part[hh][row][2 kd] (k | v of every kv head side by side), summed over hh in a fixed order by attn_dkv_reduce_kernel -- 7x the blocks of
+// the looped form at 14 q / 2 kv heads (320 -> 2240 at B = 32, T = 320: the looped form left the chip 1.25 rounds of unbalanced blocks)
+template <int D, bool PART>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dO, int lddo,
                                                                const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                                const int32_t* __restrict__ lens, int len_add, int T, int heads, int kv_heads,
-                                                               float scale, const float2* __restrict__ rope) {
+                                                               float scale, const float2* __restrict__ rope, float* __restrict__ part, long part_stride) {
   constexpr int DT = D / 16;
   constexpr int QCH = D == 64 ? 64 : 32;
   constexpr int LDR = D + 4;
@@ -490,11 +511,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int kblocks = (T + 63) >> 6;
+  const int grp = heads / kv_heads;
   int bid = blockIdx.x;
+  int hh0 = 0, hh1 = grp;
+  if constexpr (PART) { hh0 = bid % grp; hh1 = hh0 + 1; bid /= grp; }
   const int kbk = bid % kblocks; bid /= kblocks;
   const int hk = bid % kv_heads;
   const int b = bid / kv_heads;
-  const int grp = heads / kv_heads;
   int len = lens ? lens[b] + len_add : T;
   len = max(1, min(len, T));
   const int k0w = kbk * 64 + wid * 16, kg = k0w + fr, kc = min(kg, T - 1);
@@ -510,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
 
   const int qstart = (kbk * 64) / QCH * QCH;       // causal: queries before the block's first key never see it
   if (kbk * 64 < len) {
-    for (int hh = 0; hh < grp; ++hh) {
+    for (int hh = hh0; hh < hh1; ++hh) {
       const int h = hk * grp + hh;
       for (int qc0 = qstart; qc0 < len; qc0 += QCH) {
         __syncthreads();
@@ -560,9 +583,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
     }
   }
   if (kg >= T) return;
-  float* drow = dqkv + ((size_t)b * T + kg) * ld;
-  store_unrotated<D>(drow + qd + hk * D, dk, rope, kg, fg);
-  store_unrotated<D>(drow + qd + kd + hk * D, dv, nullptr, 0, fg);
+  if constexpr (PART) {
+    float* prow = part + (size_t)hh0 * part_stride + ((size_t)b * T + kg) * (2 * kd);
+    store_unrotated<D>(prow + hk * D, dk, rope, kg, fg);
+    store_unrotated<D>(prow + kd + hk * D, dv, nullptr, 0, fg);
+  } else {
+    float* drow = dqkv + ((size_t)b * T + kg) * ld;
+    store_unrotated<D>(drow + qd + hk * D, dk, rope, kg, fg);
+    store_unrotated<D>(drow + qd + kd + hk * D, dv, nullptr, 0, fg);
+  }
+}
+
+// dqkv[row][qd ..] = sum over the group's q heads (fixed order) of part[hh][row][2 kd]
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const float* __restrict__ part, long part_stride, int grp, float* __restrict__ dqkv, int ld, int qd,
+                                                               int w2, long n4) {
+  const int c4 = w2 >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long row = i / c4;
+    const int c = (int)(i % c4) * 4;
+    float4 a = *reinterpret_cast<const float4*>(part + row * w2 + c);
+    for (int g = 1; g < grp; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)g * part_stride + row * w2 + c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dqkv + row * ld + qd + c) = a;
+  }
 }
 
 inline unsigned grid_for(long work, int per_block = 256, unsigned cap = 4096) {
@@ -614,9 +659,9 @@ int launch_swiglu_fwd(const float* gu, bf16_t* act, int ldo, int lo_off, long ro
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
-int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s) {
+int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s, bf16_t* out_split) {
   if (!gu || !dact || rows <= 0 || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_bwd: bad arguments");
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (I / 8))), dim3(256), 0, s, gu, dact, rows, I);
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (I / 8))), dim3(256), 0, s, gu, dact, rows, I, out_split);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -691,22 +736,27 @@ int launch_embed_bwd(const int32_t* ids, const int32_t* lens, const float* dx, f
 // [B][heads][T].  head_dim 64 / 128.
 int launch_attention_bwd(const float* qkv, int ld, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, const float* dO, int lddo, const float* lse,
                          float* delta, float* dqkv, int B, int T, int heads, int kv_heads, int D, const int32_t* lens, int len_add, float scale,
-                         const float2* rope, hipStream_t s) {
+                         const float2* rope, hipStream_t s, float* part) {
   if (!qkv || !o_hi || !o_lo || !dO || !lse || !delta || !dqkv) return fv_fail(FV_ERR_ARG, "attention_bwd: null pointer");
   if (D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention_bwd: head_dim must be 64 or 128 (got %d)", D);
   if (B <= 0 || T <= 0 || heads % kv_heads || ld % 4 || ld < (heads + 2 * kv_heads) * D || ldo % 8 || ldo < heads * D || lddo % 4 || lddo < heads * D)
     return fv_fail(FV_ERR_ARG, "attention_bwd: bad shape");
-  const int blocks = (T + 63) / 64;
+  const int blocks = (T + 63) / 64, grp = heads / kv_heads, kd = kv_heads * D;
+  const long pstride = (long)B * T * 2 * kd;      // floats per q-head share: part >= grp * pstride floats
+  const bool parts = part != nullptr && grp > 1;
+  const dim3 gq(B * heads * blocks), gk(B * kv_heads * blocks * (parts ? grp : 1));
   if (D == 64) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3(B * heads * blocks), dim3(256), 0, s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T,
-                       heads, kv_heads, scale, rope);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(B * kv_heads * blocks), dim3(256), 0, s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads,
-                       kv_heads, scale, rope);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope);
+    if (parts) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, dim3(256), 0, s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), gk, dim3(256), 0, s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, dim3(B * heads * blocks), dim3(256), 0, s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T,
-                       heads, kv_heads, scale, rope);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, dim3(B * kv_heads * blocks), dim3(256), 0, s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads,
-                       kv_heads, scale, rope);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope);
+    if (parts) hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), gk, dim3(256), 0, s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, false>), gk, dim3(256), 0, s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
+  }
+  if (parts) {
+    const long n4 = (long)B * T * (2 * kd / 4);
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3(grid_for(n4)), dim3(256), 0, s, part, pstride, grp, dqkv, ld, heads * D, 2 * kd, n4);
   }
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
