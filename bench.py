@@ -330,8 +330,7 @@ def main():
     # the MFMA family is two kernels: the fused ConvFFN (epi 6: 4*M*C*4C flop) and the plain GEMM (2*M*N*|K|)
     def _fl(r):
         return (4.0 if r["epi"] == 6 else 2.0) * r["m"] * r["n"] * abs(r["k"]) * r["launches"]
-    ffn_name = ("convffn_kernel (fused fc1+GELU+fc2, bf16 MFMA 16x16x32)" if os.environ.get("FASTVLA_NO_FFN32", "0") == "1"
-                else "convffn32_kernel (fused fc1+GELU+fc2, bf16 MFMA 32x32x16)")
+    ffn_name = "convffn32_kernel (fused fc1+GELU+fc2, bf16 MFMA 32x32x16)"
     # `roofline` is ONE kernel as rocprofv3 lists it: the fused ConvFFN is a template with one instance per channel width, each its own
     # row of the --stats table, so the dominant kernel is the instance with the most time (C = 384 at the 0.5B tower), not the three
     # pooled; the pooled, launch-weighted figure of rounds 1-2 stays beside it as "family"

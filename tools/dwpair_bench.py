@@ -47,8 +47,8 @@ for C, H in ((384, 64), (192, 128), (96, 256)):
         rows = [r for r in rows if r[12]]
         names = ["bar1", "3x3+x'->lds", "bar2", "wait+x->lds", "x loads", "x' emit", "7x7", "bar3", "t->lds", "bar4", "t emit", "loop"]
         med = [statistics.median(r[z] / r[12] for r in rows) for z in range(12)]
-        chb = 64 if C % 64 == 0 and os.environ.get("FASTVLA_DWPAIR_GEO", "1") == "1" else 32
-        tw = 16 if chb == 64 or os.environ.get("FASTVLA_DWPAIR_GEO") == "2" else 32
+        chb = 64 if C % 64 == 0 else 32       # the library's one geometry per shape (the FASTVLA_DWPAIR_GEO switch is gone: round 4)
+        tw = 16 if chb == 64 else 32
         nblk = B * ((H + tw - 1) // tw) * (C // chb)
         occ = 3 if (chb, tw) == (32, 16) else 2
         per_block_s = min(ts) * 1e-3 / max(1.0, nblk / (256.0 * occ))          # a block's lifetime if the rounds were equal

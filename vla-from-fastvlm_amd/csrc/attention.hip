@@ -307,7 +307,7 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ldq,
   const dim3 grid((unsigned)blocks), blk(256);
   const bool masked = causal || lens || (T & 63);
   if (D != 32 && D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention: head_dim %d not in {32,64,128}", D);
-  static const bool no32 = getenv("FASTVLA_NO_ATTN32") != nullptr;
+  static const bool no32 = fv_ab_env("FASTVLA_NO_ATTN32") != nullptr;
   if (D == 32 && !masked && !no32) {
     hipLaunchKernelGGL(attention32_kernel, grid, blk, 0, s, p);
     FV_HIP_CHECK(hipGetLastError());

@@ -219,6 +219,19 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+// A/B switches (FASTVLA_NO_GEMM256, FASTVLA_NO_FFN32, ...) exist ONLY in the tools build (`make AB=1` -> -DFASTVLA_AB_SWITCHES ->
+// tools/bin/libfastvla_hip_ab.so, used by tools/*.sh): in the product library every shape has exactly ONE dispatch path, so no
+// environment variable can route a user onto a kernel the -m gpu suite does not cover.
+#include <stdlib.h>
+inline const char* fv_ab_env(const char* name) {
+#ifdef FASTVLA_AB_SWITCHES
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 #define FV_HIP_CHECK(expr)                                  \
   do {                                                      \
     hipError_t _e = (expr);                                 \

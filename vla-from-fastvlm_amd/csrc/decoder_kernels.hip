@@ -486,7 +486,7 @@ int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int
   const int G = heads / kv_heads;
   const int NT = D == 128 ? 2 : 1;
   if (D != 32 && D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: head_dim %d not in {32,64,128}", D);
-  static const bool no_mfma = getenv("FASTVLA_NO_ATTN_F32_MFMA") != nullptr;
+  static const bool no_mfma = fv_ab_env("FASTVLA_NO_ATTN_F32_MFMA") != nullptr;
   if (D >= 64 && (!no_mfma || pre || lse)) {
     const long nb = (long)B * heads * ((T - Np + 63) / 64);
     // rope given: q and k are rotated inside the kernel (no separate pass over the packed projections)

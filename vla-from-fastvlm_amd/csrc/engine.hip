@@ -500,7 +500,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
   bf16_t* hid = reinterpret_cast<bf16_t*>(ws + wp.bufH);
   float* se = reinterpret_cast<float*>(ws + wp.se);
   const int S = d.image_size, C0 = d.tower_dims[0];
-  static const bool fuse_stem = !getenv("FASTVLA_NO_FUSED_STEM");
+  static const bool fuse_stem = !fv_ab_env("FASTVLA_NO_FUSED_STEM");
   if (h->lbsrc) {
     // letterbox + both stem convolutions in one kernel: neither the 1024^2 frame nor the half-resolution map exists in HBM
     const fv_handle::LbSrc& L = *h->lbsrc;
@@ -540,7 +540,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
     }
     for (const Block& b : tw.stages[i]) {
       if (!d.tower_is_attn[i]) {
-        static const bool pair_ok = !getenv("FASTVLA_NO_DW_PAIR");
+        static const bool pair_ok = !fv_ab_env("FASTVLA_NO_DW_PAIR");
         if (pair_ok && !h->no_mfma_dw && !h->no_fused_ffn && b.mix_t && b.ffn.dw_t && b.ffn.w2p && fv::dwconv_pair_supported(mb, H, H, C)) {
           // token mixer and the ConvFFN's 7x7 in one marching kernel: cur -> oth (x') and hid (t); then oth += ls * ffn(t)
           FV_P(FV_FAM_DWCONV, dw_flops(mb, H, H, C, 3) + dw_flops(mb, H, H, C, 7), 6.0 * M * C,
@@ -714,9 +714,9 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   h->d = d;
   h->device = device;
   h->hd = fv::HeadDims{d.llm_hidden, d.state_dim, d.action_dim, d.hidden_dim, d.fusion_dim};
-  if (const char* e = getenv("FASTVLA_NO_FUSED_FFN")) h->no_fused_ffn = e[0] == '1';
-  if (const char* e = getenv("FASTVLA_NO_MFMA_DW")) h->no_mfma_dw = e[0] == '1';
-  if (const char* e = getenv("FASTVLA_NO_FFN32")) h->no_ffn32 = e[0] == '1';
+  if (const char* e = fv_ab_env("FASTVLA_NO_FUSED_FFN")) h->no_fused_ffn = e[0] == '1';
+  if (const char* e = fv_ab_env("FASTVLA_NO_MFMA_DW")) h->no_mfma_dw = e[0] == '1';
+  if (const char* e = fv_ab_env("FASTVLA_NO_FFN32")) h->no_ffn32 = e[0] == '1';
   // RoPE table for every position the path can see (text + spliced image tokens)
   const int P = (d.image_size >> (d.tower_stages + 1)) * (d.image_size >> (d.tower_stages + 1));
   h->rope_rows = d.max_text_tokens + P + 8;

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256, C == 96 ? 3 : 1) void pwconv_kernel(Params p) 
 // which glds kernel (0 = none, 256 or 128) takes the problem.  256-tiles when there are enough of them to keep one block per
 // CU busy; otherwise 128-tiles (two blocks per CU) if the shape allows.
 int gemm_glds_tile(const GemmArgs& a) {
-  static const bool off = getenv("FASTVLA_NO_GEMM256") != nullptr;
+  static const bool off = fv_ab_env("FASTVLA_NO_GEMM256") != nullptr;
   if (off || a.K % 64 || a.K < 128) return 0;
   // gemm256_kernel keeps per-lane source byte offsets in 32 bits ((row * lda) * 2 for A, (row * K) * 2 for W): operands of
   // 4 GiB or more go to the register-staged kernel, which addresses with size_t
@@ -670,12 +670,12 @@ int gemm_glds_tile(const GemmArgs& a) {
   // rounds -- was measured slower, 184 vs 150 us: 64 x 64 per wave reads a third more LDS per MFMA)
   // few rows (M <= 2048, the column-major walk): the alternative is the register-staged kernel on 64- / 128-row tiles, and a half-filled
   // round of 256-tiles beats it -- 7B gate/up at M = 512 (296 tiles) 10.5 -> 8.9 ms per step, 0.5B at M = 1024 (152 tiles) 0.96 -> 0.71
-  static const int min_tiles_small_m = getenv("FASTVLA_GEMM256_MIN_TILES") ? atoi(getenv("FASTVLA_GEMM256_MIN_TILES")) : 128;   // A/B
+  constexpr int min_tiles_small_m = 128;
   if (a.M % 256 == 0 && a.N % 256 == 0 && (long)(a.M / 256) * (a.N / 256) >= (a.M <= 2048 ? min_tiles_small_m : 320)) return 256;
   // fp32 epilogues (the decoder's projections and every dgrad / wgrad of the unfrozen training path: N = 896, 1152, 4864, M = 896 ...)
   // take RAGGED edge tiles on the 256-tile kernel -- staging clamps rows past M / N, the epilogue drops them -- when the edge waste is
   // small: the register-staged kernel they fell to runs at ~0.45 PF against ~0.9 here
-  static const bool no_ragged = getenv("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
+  static const bool no_ragged = fv_ab_env("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
   if (!no_ragged && f32 && !a.f16 && a.N % 8 == 0) {
     const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
     const double fill = (double)a.M * a.N / ((double)tm * tn * 65536.0);
@@ -742,13 +742,13 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
   }
-  static const bool colmajor_ok = getenv("FASTVLA_NO_GEMM_COLMAJOR") == nullptr;   // A/B
-  static const int cm_max = getenv("FASTVLA_GEMM_COLMAJOR_MAX_TM") ? atoi(getenv("FASTVLA_GEMM_COLMAJOR_MAX_TM")) : 8;   // A/B
-  static const bool no_asym = getenv("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
+  static const bool colmajor_ok = fv_ab_env("FASTVLA_NO_GEMM_COLMAJOR") == nullptr;   // A/B
+  constexpr int cm_max = 8;   // (16 measured at the headline shape in round 3: gate/up -3.5 %, split-K down +9 %, step unchanged)
+  static const bool no_asym = fv_ab_env("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
   const bool asym = !no_asym && a.M <= 8192 && a.M % 256 == 0;   // the asymmetric staging addresses row + 32 from a (clamped) base row: whole row tiles only
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
-  static const bool no_splitk = getenv("FASTVLA_NO_SPLITK") != nullptr, no_g256 = getenv("FASTVLA_NO_GEMM256") != nullptr;
-  static const bool no_ragged_sk = getenv("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
+  static const bool no_splitk = fv_ab_env("FASTVLA_NO_SPLITK") != nullptr, no_g256 = fv_ab_env("FASTVLA_NO_GEMM256") != nullptr;
+  static const bool no_ragged_sk = fv_ab_env("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
   if (!no_splitk && a.splitk_ws && f32out && !no_g256 && (a.M % 256 == 0 || (!no_ragged_sk && !a.f16 && a.N % 8 == 0)) && a.K % 64 == 0 && a.N % 4 == 0 &&
       (size_t)a.M * a.lda * 2 < ((size_t)1 << 32) && (size_t)a.N * a.K * 2 < ((size_t)1 << 32)) {
     const int tmr = (a.M + 255) / 256;            // a ragged last row tile: staging clamps its rows, the partial-sum stores skip them
@@ -780,7 +780,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
       return FV_OK;
     }
   }
-  static const bool no_pw = getenv("FASTVLA_NO_PWCONV") != nullptr;
+  static const bool no_pw = fv_ab_env("FASTVLA_NO_PWCONV") != nullptr;
   if (!no_pw && !a.ksplit && !a.f16 && a.N == a.K && (a.K == 96 || a.K == 192) && a.lda == a.K && a.ldo == a.N && a.M % 128 == 0 &&
       (a.epi == FV_EPI_BIAS || a.epi == FV_EPI_BIAS_GELU)) {
     const int tiles = a.M / 128;

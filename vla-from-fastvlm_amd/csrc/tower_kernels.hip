@@ -1828,8 +1828,7 @@ int launch_dwconv_pair(const bf16_t* x, const bf16_t* t3, const float* b3, const
     attr_set = true;
   }
   // geometry: 0 = 32 columns x 32 channels (two blocks per CU), 1 = 16 x 64 (full cache lines), 2 = 16 x 32 (three blocks per CU)
-  static const int force = getenv("FASTVLA_DWPAIR_GEO") ? atoi(getenv("FASTVLA_DWPAIR_GEO")) : -1;
-  int geo = force >= 0 ? force : DP_DEFAULT_GEO;
+  int geo = DP_DEFAULT_GEO;
   if (geo == 1 && C % 64) geo = 0;
   const int chb = geo == 1 ? 64 : 32, tw = geo == 0 ? 32 : 16;
   const int tiles_x = (W + tw - 1) / tw, nsl = C / chb;
