@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--image", type=int, default=336)
     ap.add_argument("--splice", action="store_true", help="splice the 256 projected image tokens into the LLM sequence")
     ap.add_argument("--microbatch", type=int, default=int(os.environ.get("FASTVLA_TOWER_MICROBATCH", "0")))
-    ap.add_argument("--llm-precision", type=int, default=None, choices=(0, 1, 2, 3, 4),
+    ap.add_argument("--llm-precision", type=int, default=None, choices=(0, 1, 2, 3, 4, 5),
                     help="1 (default for every model: arch.default_llm_precision) = split-bf16 decoder operands + fp32 attention (actions ~1e-5 from the "
                          "fp32 reference, every row inside north_star's 1e-3); 2 = opt-in: split-bf16 qkv / o + ONE fp16 pass for gate/up and down "
                          "(actions 4.4e-4 .. 6.4e-4 as a batch rel-L2, but the worst ROW of C1 measures 1.1e-3: tests/test_gpu_fullsize.py); "
@@ -577,8 +577,8 @@ def main():
     # ---- the other decoder parity mode on a second engine (same weights, inputs, head): the opt-in policy 2 trades the decoder's 1e-5
     # for ~5e-4 (batch rel-L2) on the actions; both numbers belong in one line
     alt = None
-    if rank == 0 and world == 1 and not args.no_alt and w is not None and args.llm_precision in (1, 2) and not args.splice:
-        ap_ = 3 - args.llm_precision
+    if rank == 0 and world == 1 and not args.no_alt and w is not None and args.llm_precision in (1, 2, 5) and not args.splice:
+        ap_ = {1: 5, 5: 1, 2: 1}[args.llm_precision]
         eng2 = FastVLAEngine(model, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, device=dev, max_batch=B, max_text_tokens=T,
                              tower_microbatch=args.microbatch, llm_precision=ap_)
         eng2.load_weights(w)
@@ -750,7 +750,8 @@ def main():
                        "llm_precision": {0: "bf16 operands", 1: "split-bf16 (hi+lo) operands, fp32 attention",
                                          2: "split-bf16 qkv/o, fp16 gate/up/down (one pass), fp32 attention",
                                          3: "split-bf16 qkv/o/down, fp16 gate/up (one pass), fp32 attention",
-                                         4: "split-bf16 qkv/o/gate/up, fp16 down (one pass), fp32 attention"}[args.llm_precision]},
+                                         4: "split-bf16 qkv/o/gate/up, fp16 down (one pass), fp32 attention",
+                                         5: "bf16 hi + fp8 lo operands (lo product on the scaled fp8 MFMA, 1.5 passes), fp32 attention"}[args.llm_precision]},
             "samples_per_s": round(value * B, 2),
             "roofline": roofline, "power": power_info, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "train_unfrozen": train_unfrozen, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),

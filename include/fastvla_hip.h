@@ -65,7 +65,11 @@ typedef struct fv_model_desc {
    * down projection carries a 2^4 scale against a 2^-4 on its operand), fp32 attention: actions ~5e-4 from the fp32 reference at
    * 0.56x the MFMA work of mode 1.  3 / 4 = the two halves of mode 2 on their own (3: the fp16 pass on gate/up only, its SwiGLU output
    * leaves as hi + lo bf16 for a split-bf16 down projection; 4: on down only): the per-family rows of the precision budget measured on
-   * the product (tools/prec_sweep.py), not defaults of any preset. */
+   * the product (tools/prec_sweep.py), not defaults of any preset.
+   * 5 = "hi + lo8" (round 4): every split operand keeps its bf16 hi half and carries the remainder as ONE fp8 e4m3 byte (x 2^8); the lo product
+   * runs on v_mfma_scale_f32_16x16x128_f8f6f4 against fp8 copies of the weights (x 2^6) at twice the bf16 MFMA rate: 1.5 passes instead of 2,
+   * 13 significant bits per operand instead of 16 (5.8e-5 per GEMM; split-bf16 2.5e-6, one fp16 pass 2.1e-4); fp32 attention.  Needs hidden,
+   * inter and heads * head_dim % 128 == 0; weights with |w| x 64 > 448 are refused at load time. */
   int32_t llm_precision;
 } fv_model_desc;
 
@@ -298,6 +302,12 @@ int fv_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const
  * FV_EPI_SWIGLU_F16 (the path of llm_precision = 2's gate/up and down projections) */
 int fv_op_gemm_f16(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr, void* out,
                    int ldo, int epilogue, void* ws, size_t ws_bytes, fv_stream s);
+/* the "hi + lo8" form of llm_precision = 5: A rows = K bf16 values, then at byte offset 2K their K remainders as fp8 e4m3 (x 2^8); W8 = fp8 copy
+ * of W x 2^6 at row stride 2K bytes.  out = (A_hi + A_lo8 2^-8) . W^T with the lo product on v_mfma_scale_f32_16x16x128_f8f6f4 against W8: 1.5
+ * passes.  K % 128 == 0, lda >= 1.5 K.  fv_op_lo8_pack builds both operand forms from fp32 rows / a bf16 weight (either may be NULL). */
+int fv_op_gemm_lo8(const void* A, int lda, const void* W, const void* W8, int M, int N, int K, const float* bias, const void* res, int ldr, void* out,
+                   int ldo, int epilogue, void* ws, size_t ws_bytes, fv_stream s);
+int fv_op_lo8_pack(const float* x, void* a_out, int lda, const void* W, void* w8_out, int M, int K, int N, fv_stream s);
 int fv_op_gemm_ksplit(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr,
                       void* out, int ldo, int epilogue, fv_stream s);
 /* fv_op_gemm_ksplit (ksplit != 0) or fv_op_gemm with a caller-owned scratch buffer for split-K partial sums: fp32 epilogues

@@ -74,21 +74,20 @@ def full():
 
 # per-sample bound on the actions / pooled feature by decoder policy: 1 (the default) holds north_star's 1e-3 on EVERY row with margin;
 # 2 (opt-in) holds it on the batch's rel-L2 but its worst row was measured at 1.1e-3 (C1) -- which is why it is not the default
-WORST_ROW_TOL = {1: 1e-3, 2: 2e-3}
+WORST_ROW_TOL = {1: 1e-3, 2: 2e-3, 5: 1e-3}
 
 
-@pytest.fixture(scope="module", params=[1, 2], ids=["policy1-default", "policy2-optin"])
+@pytest.fixture(scope="module", params=[1, 2, 5], ids=["policy1", "policy2-optin", "policy5-hi-lo8"])
 def fullp(request, full):
     """The same model and weights under BOTH decoder policies the product ships for the 0.5B decoder: 1 (split-bf16 everywhere:
     arch.default_llm_precision, what bench.py and every FastVLMBackbone run) and the opt-in 2 (fp16 gate/up/down).
     VERDICT r3 #1: C1 / C2 / C3 are asserted in the mode the headline number is measured in, row by row."""
     m, w, eng1 = full
-    assert arch.default_llm_precision(m) == 1 and arch.default_llm_precision(m, "hf_dir") == 1
     if request.param == 1:
         yield m, w, eng1
         return
     eng = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=64, max_text_tokens=64,
-                        llm_precision=2)
+                        llm_precision=request.param)
     eng.load_weights(w)
     yield m, w, eng
     assert eng.fp16_saturations() == 0   # nothing in these runs came near the fp16 range
@@ -395,22 +394,23 @@ def test_7b_full_depth_against_layer_streamed_oracle(lr7b):
         ref_act = head.head_forward(p, ref_pooled, states)
     assert sw.asked == 2 + 12 * 28 and torch.isfinite(ref_pooled).all()
     out = {}
-    for prec in (1, 2):
+    for prec in (1, 2, 5):
         e = eng
-        if prec == 2:
-            e = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=4, max_text_tokens=64, llm_precision=2)
+        if prec != 1:
+            e = FastVLAEngine(m, state_dim=14, action_dim=14, hidden_dim=1024, fusion_dim=1024, max_batch=4, max_text_tokens=64, llm_precision=prec)
             e.load_weights_streaming(weights.stream_backbone(m, seed=seed, device=DEV))
         pooled = e.llm_pooled(ids, mask.sum(1))
         act, _ = e.head_forward(_flat_head(e, p), pooled, states.to(DEV))
         torch.cuda.synchronize()
         out[prec] = (rel_l2(pooled.cpu(), ref_pooled), worst_row(pooled.cpu(), ref_pooled), rel_l2(act.cpu(), ref_act), worst_row(act.cpu(), ref_act))
-        if prec == 2:
+        if prec != 1:
             assert e.fp16_saturations() == 0
             e.close()
     print("[fastvlm-7b FULL DEPTH (28 layers) B=2 T=24 vs layer-streamed fp32 oracle] (pooled rel_l2, pooled worst row, actions rel_l2, actions worst row):  " +
           "  ".join(f"llm_precision={k}: " + ", ".join(f"{x:.2e}" for x in v) for k, v in out.items()))
     assert out[1][0] <= 3e-4 and out[1][1] <= 3e-4 and out[1][2] <= 1e-3 and out[1][3] <= 1e-3
     assert all(x == x for x in out[2])   # policy 2: recorded, finite
+    assert out[5][0] <= 1e-3 and out[5][2] <= 1e-3   # policy 5 (bf16 hi + fp8 lo): inside the bar on the batch norm; its worst rows are printed
 
 
 def test_c5_rank_shape_two_camera_train_step_7b(lr7b):
@@ -551,7 +551,7 @@ def test_c2_batch64_rows_match_batch4_and_replays_are_bit_identical(fullp):
           f"all 64 rows vs fp32 oracle: actions rel_l2 {ra:.2e} WORST ROW {wa:.2e}; pooled rel_l2 {rpo:.2e} WORST ROW {wp:.2e}")
     # the rows-vs-B=4 bound: another tile shape sums K in another order; the last bits then round differently into the next GEMM's operand
     # (16 significant bits in policy 1, 11 on the MLP in policy 2)
-    assert rt <= 2e-3 and rlast <= 2e-3 and rp <= (2e-4 if eng.llm_precision == 1 else 1e-3)
+    assert rt <= 2e-3 and rlast <= 2e-3 and rp <= {1: 2e-4, 2: 1e-3, 5: 5e-4}[eng.llm_precision]
     assert ra <= 1e-3 and rpo <= 1e-3 and wa <= WORST_ROW_TOL[eng.llm_precision] and wp <= WORST_ROW_TOL[eng.llm_precision]
 
 

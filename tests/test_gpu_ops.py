@@ -701,6 +701,69 @@ def test_gemm_256_tile_ragged_edges_fp32_epilogues(M, N, K, ksplit, ws):
     assert torch.isnan(o[M:]).all() and torch.isnan(o[:, N:]).all(), "wrote past the edge"
 
 
+# ------------------------------------------------------------------------------------------------ round 4: "hi + lo8" operands
+def _e4m3(t):
+    return t.to(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("M,N,K,epi,ws", [(100, 256, 896, "f32", False), (4096, 1152, 896, "f32", False), (512, 896, 4864, "res", True),
+                                            (8200, 896, 1152, "res", False), (4096, 2560, 256, "swiglu", False), (96, 128, 896, "swiglu", False)])
+def test_gemm_hi_lo8_operands(M, N, K, epi, ws):
+    """llm_precision = 5's projections (round 4): A = bf16 hi + ONE fp8 e4m3 byte of remainder (x 2^8) per element, the lo product on
+    v_mfma_scale_f32_16x16x128_f8f6f4 against the weights' fp8 copy (x 2^6), through the register-staged kernel, the 256-tile kernel
+    (plain, ragged, split-K) and the SwiGLU-split epilogue (whose output leaves in the same form).  The reference applies the SAME
+    roundings in float64 (torch.float8_e4m3fn), so what is left is fp32 summation order; the distance to the UNROUNDED product is the
+    policy's error and is printed ([site] transformers/models/qwen2/modeling_qwen2.py Linear layers via oracle/qwen2.py)."""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K)
+    W = bf(torch.randn(N, K) / math.sqrt(K))
+    hi = bf(x)
+    lo8 = _e4m3((x - hi) * 256.0) / 256.0
+    W8 = _e4m3(W * 64.0) / 64.0
+    ref = hi.double() @ W.double().t() + lo8.double() @ W8.double().t()
+    exact = x.double() @ W.double().t()
+    xd, wd = dev_f32(x), dev_bf16(W)
+    a = torch.zeros(M, 2 * K, dtype=torch.bfloat16, device=DEV)
+    w8 = torch.zeros(N, 2 * K, dtype=torch.uint8, device=DEV)
+    call(lib().fv_op_lo8_pack(xd.data_ptr(), a.data_ptr(), 2 * K, wd.data_ptr(), w8.data_ptr(), M, K, N, stream()), "fv_op_lo8_pack")
+    torch.cuda.synchronize()
+    assert torch.equal(a[:, :K].float().cpu(), hi)
+    got_lo = a.view(torch.uint8).view(M, 4 * K)[:, 2 * K:3 * K].view(torch.float8_e4m3fn).float().cpu() / 256.0
+    assert torch.equal(got_lo, lo8) and torch.equal(w8[:, :K].view(torch.float8_e4m3fn).float().cpu() / 64.0, W8)
+    wsb = torch.empty(8 * 1024 * 1024, dtype=torch.float32, device=DEV) if ws else None
+    wsp, wsn = (wsb.data_ptr(), wsb.numel() * 4) if ws else (None, 0)
+    if epi == "swiglu":
+        I = N // 2
+        Wi = torch.stack([W[:I].view(I // 8, 8, K), W[I:].view(I // 8, 8, K)], dim=1).reshape(N, K).contiguous()   # rows [8 gate | 8 up]
+        call(lib().fv_op_lo8_pack(None, None, 0, dev_bf16(Wi).data_ptr(), w8.data_ptr(), M, K, N, stream()), "fv_op_lo8_pack W")
+        g, u = ref[:, :I], ref[:, I:]
+        act = torch.nn.functional.silu(g) * u
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)      # [hi I | lo8 bytes ...]
+        call(lib().fv_op_gemm_lo8(a.data_ptr(), 2 * K, dev_bf16(Wi).data_ptr(), w8.data_ptr(), M, N, K, None, None, 0, out.data_ptr(), N, 7, wsp, wsn, stream()),
+             "fv_op_gemm_lo8 swiglu-split")
+        torch.cuda.synchronize()
+        oh = out[:, :I].float().cpu()
+        ol = out.view(torch.uint8).view(M, 2 * N)[:, 2 * I:3 * I].view(torch.float8_e4m3fn).float().cpu() / 256.0
+        check_close(oh + ol, act.float(), rel=2e-4, amax=2e-3, what=f"hi + lo8 SwiGLU output {M}x{N}x{K}")     # the output's own lo8 rounding: 2^-13
+        return
+    b, res = torch.randn(N), torch.randn(M, N)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    if epi == "f32":
+        call(lib().fv_op_gemm_lo8(a.data_ptr(), 2 * K, wd.data_ptr(), w8.data_ptr(), M, N, K, dev_f32(b).data_ptr(), None, 0, out.data_ptr(), N, _lib.EPI_F32, wsp, wsn, stream()),
+             "fv_op_gemm_lo8 f32")
+        want = ref + b.double()
+    else:
+        r = dev_f32(res)
+        call(lib().fv_op_gemm_lo8(a.data_ptr(), 2 * K, wd.data_ptr(), w8.data_ptr(), M, N, K, None, r.data_ptr(), N, out.data_ptr(), N, _lib.EPI_RES_F32, wsp, wsn, stream()),
+             "fv_op_gemm_lo8 res_f32")
+        want = ref + res.double()
+    torch.cuda.synchronize()
+    check_close(out.cpu(), want.float(), rel=2e-5, amax=2e-4, what=f"hi + lo8 gemm {M}x{N}x{K} {epi}")
+    pol = float((ref - exact).norm() / exact.norm())
+    print(f"[hi + lo8 {M}x{N}x{K}] policy error vs the unrounded product: {pol:.2e}")
+    assert pol <= 1.2e-4
+
+
 # ------------------------------------------------------------------------------------------------ round 3: fp16-operand GEMMs
 @pytest.mark.parametrize("M,N,K", [(100, 256, 896), (512, 1024, 896), (4096, 5120, 256), (256, 896, 4864)])
 def test_gemm_f16_operands(M, N, K):

@@ -34,6 +34,29 @@ __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
   const f16x2 r = {(_Float16)lo, (_Float16)hi};
   return __builtin_bit_cast(uint32_t, r);
 }
+// ---- "hi + lo8" operands (llm_precision = 5): x ~= bf16(x) + fp8_e4m3((x - bf16(x)) * 2^8) * 2^-8.  The lo half costs ONE byte per
+// element and its product runs on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the MACs per clock of the bf16 MFMA, the 2^-14 of the two
+// operand scales applied by the instruction's E8M0 scale operand): 1.5 passes instead of split-bf16's 2, 13 significant bits instead
+// of 16 (5.8e-5 per GEMM against 2.5e-6; one fp16 pass: 2.1e-4).  v_cvt_pk_fp8_f32 (OCP e4m3fn on gfx950) does NOT saturate
+// (|v| > 448 -> NaN): clamp first.
+#define FV_LO8_SCALE 256.0f   // 2^8 on the remainder
+#define FV_W8_SCALE 64.0f     // 2^6 on the weights' fp8 copy
+#define FV_LO8_MFMA_SCALE 113 // E8M0 of 2^-(8 + 6)
+#define FV_F8_MAX 448.0f
+__device__ __forceinline__ uint32_t pack_f8x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -FV_F8_MAX, FV_F8_MAX); b = __builtin_amdgcn_fmed3f(b, -FV_F8_MAX, FV_F8_MAX);
+  c = __builtin_amdgcn_fmed3f(c, -FV_F8_MAX, FV_F8_MAX); d = __builtin_amdgcn_fmed3f(d, -FV_F8_MAX, FV_F8_MAX);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+// remainders l[0..7] (already x - bf16(x)) -> 8 fp8 bytes
+__device__ __forceinline__ uint2 pack_lo8(const float* l) {
+  uint2 u;
+  u.x = pack_f8x4(l[0] * FV_LO8_SCALE, l[1] * FV_LO8_SCALE, l[2] * FV_LO8_SCALE, l[3] * FV_LO8_SCALE);
+  u.y = pack_f8x4(l[4] * FV_LO8_SCALE, l[5] * FV_LO8_SCALE, l[6] * FV_LO8_SCALE, l[7] * FV_LO8_SCALE);
+  return u;
+}
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 

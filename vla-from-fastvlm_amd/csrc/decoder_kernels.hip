@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __rest
 template <bool F16>   // F16: y receives fp16 bits (11 significant bits: the single-pass operand of llm_precision = 2's gate/up GEMM)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        bf16_t* __restrict__ y, bf16_t* __restrict__ y_lo, int ldy, int rows,
-                                                       int H, float eps, unsigned* __restrict__ sat) {
+                                                       int H, float eps, unsigned* __restrict__ sat, int lo8) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
       unpack8(hi, h8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
-      *reinterpret_cast<uint4*>(y_lo + row * ldy + i) = pack8(l8);
+      if (lo8) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(y_lo + row * ldy) + i) = pack_lo8(l8);   // fp8 remainders: one byte each
+      else *reinterpret_cast<uint4*>(y_lo + row * ldy + i) = pack8(l8);
     }
   }
 }
@@ -134,7 +135,7 @@ template <int DPT, int NT>
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out_hi,
                                                              bf16_t* __restrict__ out_lo, const int32_t* __restrict__ lens,
                                                              int len_add, int ld, int ldo, int T, int heads, int kv_heads,
-                                                             int QT, float scale) {
+                                                             int QT, float scale, int lo8) {
   constexpr int D = DPT * NT;
   extern __shared__ __attribute__((aligned(16))) float skv[];  // [2][64][D]
   float* sK = skv;
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) l8[e] = v8[e] - h8[e];
     *reinterpret_cast<uint4*>(out_hi + o + d) = hv;
-    *reinterpret_cast<uint4*>(out_lo + o + d) = pack8(l8);
+    if (lo8) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(out_lo + ((size_t)b * T + pos) * ldo) + h * D + part * DPT + d) = pack_lo8(l8);
+    else *reinterpret_cast<uint4*>(out_lo + o + d) = pack8(l8);
   }
 }
 
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
                                                                      bf16_t* __restrict__ out_lo, const int32_t* __restrict__ lens,
                                                                      int len_add, int ld, int ldo, int T, int heads, int kv_heads,
                                                                      float scale, const float2* __restrict__ rope,
-                                                                     const float* __restrict__ pre, int ldp, int Np, float* __restrict__ lse) {
+                                                                     const float* __restrict__ pre, int ldp, int Np, float* __restrict__ lse, int lo8) {
   // lse != null (training, Np == 0): the row statistics max + log(sum) of every (batch, head, query) for attn_bwd_* (train_kernels.hip)
   // pre != null (image-prefix reuse): the sequence is Np cached prefix positions + Ts = T - Np new ones.  qkv and
   // the outputs hold ONLY the new rows (row b * Ts + t - Np); keys / values of positions < Np come from `pre`, rows
@@ -381,9 +383,14 @@ __global__ __launch_bounds__(256, 2) void attention_f32_mfma_kernel(const float*
     for (int r = 0; r < 4; ++r) v4[r] = o[dt][r] * inv;
     uint2 hv, lv;
     hv.x = pack_bf2(v4[0], v4[1]); hv.y = pack_bf2(v4[2], v4[3]);
+    *reinterpret_cast<uint2*>(out_hi + ob + 16 * dt) = hv;
+    if (lo8) {   // fp8 remainders (x 2^8), one byte each, in the lo half's place
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out_lo + ((size_t)b * Ts + (qg - Np)) * ldo) + h * D + 4 * fg + 16 * dt) =
+          pack_f8x4((v4[0] - bf_lo(hv.x)) * FV_LO8_SCALE, (v4[1] - bf_hi(hv.x)) * FV_LO8_SCALE, (v4[2] - bf_lo(hv.y)) * FV_LO8_SCALE, (v4[3] - bf_hi(hv.y)) * FV_LO8_SCALE);
+      continue;
+    }
     lv.x = pack_bf2(v4[0] - bf_lo(hv.x), v4[1] - bf_hi(hv.x));
     lv.y = pack_bf2(v4[2] - bf_lo(hv.y), v4[3] - bf_hi(hv.y));
-    *reinterpret_cast<uint2*>(out_hi + ob + 16 * dt) = hv;
     *reinterpret_cast<uint2*>(out_lo + ob + 16 * dt) = lv;
   }
 }
@@ -426,12 +433,12 @@ int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* im
   return FV_OK;
 }
 
-int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s, int f16, unsigned* sat) {
+int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s, int f16, unsigned* sat, int lo8) {
   if (!x || !w || !y) return fv_fail(FV_ERR_ARG, "rmsnorm: null pointer");
   if (rows <= 0 || H <= 0 || H % 8 || ldy < H || ldy % 8) return fv_fail(FV_ERR_ARG, "rmsnorm: bad shape rows=%d H=%d ldy=%d", rows, H, ldy);
   if (f16 && y_lo) return fv_fail(FV_ERR_ARG, "rmsnorm: the fp16 form has no remainder output");
-  if (f16) hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, ldy, rows, H, eps, sat);
-  else hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, ldy, rows, H, eps, nullptr);
+  if (f16) hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, ldy, rows, H, eps, sat, 0);
+  else hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, y_lo, ldy, rows, H, eps, nullptr, lo8);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -454,6 +461,41 @@ __global__ __launch_bounds__(256) void bf16_to_f16_kernel(bf16_t* __restrict__ p
 }
 }  // namespace
 
+namespace {
+// W [N][K] bf16 -> W8 [N][2K bytes]: fp8 e4m3 of W x 2^6 in the first K bytes of each row (the second K bytes are never read: the row
+// stride equals the bf16 copy's so that gemm256_kernel's per-lane row offsets serve both copies)
+__global__ __launch_bounds__(256) void bf16_to_w8_kernel(const bf16_t* __restrict__ w, uint8_t* __restrict__ w8, long n8, int K, unsigned* __restrict__ maxbits) {
+  float m = 0.f;
+  const int k8 = K >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const long row = i / k8;
+    const int c = (int)(i % k8) * 8;
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(w + row * K + c), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      f[e] *= FV_W8_SCALE;
+      const float af = fabsf(f[e]);
+      if (!(af <= m)) m = af == af ? af : __builtin_inff();
+    }
+    uint2 u;
+    u.x = pack_f8x4(f[0], f[1], f[2], f[3]);
+    u.y = pack_f8x4(f[4], f[5], f[6], f[7]);
+    *reinterpret_cast<uint2*>(w8 + row * 2 * K + c) = u;
+  }
+  if (maxbits && m > 0.f) atomicMax(maxbits, __float_as_uint(m));
+}
+}  // namespace
+
+int launch_bf16_to_w8(const bf16_t* w, void* w8, size_t rows, int K, hipStream_t s, unsigned* maxbits) {
+  if (!w || !w8 || rows == 0 || K <= 0 || K % 8 || (((uintptr_t)w | (uintptr_t)w8) & 15)) return fv_fail(FV_ERR_ARG, "bf16_to_w8: bad arguments");
+  const long n8 = (long)rows * (K / 8);
+  const unsigned blocks = (unsigned)((n8 + 255) / 256 < 65536 ? (n8 + 255) / 256 : 65536);
+  hipLaunchKernelGGL(bf16_to_w8_kernel, dim3(blocks), dim3(256), 0, s, w, static_cast<uint8_t*>(w8), n8, K, maxbits);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
 int launch_bf16_to_f16(bf16_t* p, size_t n, float scale, hipStream_t s, unsigned* maxbits) {
   if (!p || n == 0 || n % 8 || ((uintptr_t)p & 15)) return fv_fail(FV_ERR_ARG, "bf16_to_f16: n must be a positive multiple of 8 and p 16-byte aligned");
   const size_t n8 = n / 8;
@@ -474,7 +516,7 @@ int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, in
 
 int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
                          int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope,
-                         const float* pre, int ldp, int Np, float* lse) {
+                         const float* pre, int ldp, int Np, float* lse, int lo8) {
   if (!qkv || !out_hi || !out_lo) return fv_fail(FV_ERR_ARG, "attention_f32: null pointer");
   if (lse && (pre || D < 64)) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: row statistics (training) need head_dim 64 / 128 and no cached prefix");
   if (pre && (Np <= 0 || Np >= T || ldp < 2 * kv_heads * D || ldp % 4 || D < 64))
@@ -490,8 +532,8 @@ int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int
   if (D >= 64 && (!no_mfma || pre || lse)) {
     const long nb = (long)B * heads * ((T - Np + 63) / 64);
     // rope given: q and k are rotated inside the kernel (no separate pass over the packed projections)
-    if (D == 64) hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np, lse);
-    else hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np, lse);
+    if (D == 64) hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np, lse, lo8);
+    else hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), dim3((unsigned)nb), dim3(256), 0, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, scale, rope, pre, ldp, Np, lse, lo8);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
   }
@@ -506,9 +548,9 @@ int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int
   const long blocks = (long)B * kv_heads * ((T + QT - 1) / QT);
   const size_t lds = (size_t)2 * 64 * D * sizeof(float);
   const dim3 grid((unsigned)blocks), blk(256);
-  if (D == 32) hipLaunchKernelGGL((attention_f32_kernel<32, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, QT, scale);
-  else if (D == 64) hipLaunchKernelGGL((attention_f32_kernel<64, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, QT, scale);
-  else hipLaunchKernelGGL((attention_f32_kernel<64, 2>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, QT, scale);
+  if (D == 32) hipLaunchKernelGGL((attention_f32_kernel<32, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, QT, scale, lo8);
+  else if (D == 64) hipLaunchKernelGGL((attention_f32_kernel<64, 1>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, QT, scale, lo8);
+  else hipLaunchKernelGGL((attention_f32_kernel<64, 2>), grid, blk, lds, s, qkv, out_hi, out_lo, lens, len_add, ld, ldo, T, heads, kv_heads, QT, scale, lo8);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

@@ -77,7 +77,10 @@ struct Tower {
 };
 struct TrainLayerT { bf16_t *qkvT = nullptr, *oT = nullptr, *guT = nullptr, *downT = nullptr; };   // transposed weight copies (dgrad operands)
 struct TrainState { bool ready = false; std::vector<TrainLayerT> layers; bf16_t* pj2T = nullptr; };
-struct DecLayer { float* ln1 = nullptr; bf16_t* qkv_w = nullptr; float* qkv_b = nullptr; bf16_t* o_w = nullptr; float* ln2 = nullptr; bf16_t *gu_w = nullptr, *down_w = nullptr; };
+struct DecLayer {
+  float* ln1 = nullptr; bf16_t* qkv_w = nullptr; float* qkv_b = nullptr; bf16_t* o_w = nullptr; float* ln2 = nullptr; bf16_t *gu_w = nullptr, *down_w = nullptr;
+  void *qkv_w8 = nullptr, *o_w8 = nullptr, *gu_w8 = nullptr, *down_w8 = nullptr;   // llm_precision = 5: fp8 copies (x 2^6, row stride 2K bytes) for the lo8 products
+};
 struct Decoder { bf16_t* embed = nullptr; std::vector<DecLayer> layers; float* norm = nullptr; };
 
 struct WsPlan {
@@ -368,7 +371,7 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
   if (d.llm_precision >= 1) {
     p.xn_lo = take(rows * d.llm_hidden * 2 * 2);                               // [hi | lo] side by side
     p.att_lo = take(rows * (size_t)d.llm_heads * d.llm_head_dim * 2 * 2);
-    p.act_lo = (d.llm_precision == 1 || d.llm_precision == 3) ? take(rows * d.llm_inter * 2 * 2) : 0;    // modes 2, 4: the SwiGLU output is ONE fp16 row (p.act)
+    p.act_lo = (d.llm_precision == 1 || d.llm_precision == 3 || d.llm_precision == 5) ? take(rows * d.llm_inter * 2 * 2) : 0;    // modes 2, 4: the SwiGLU output is ONE fp16 row (p.act)
     p.qkvf = take(rows * qkvw * 4);
     p.guf = 0;  // gate/up accumulators no longer round-trip through memory (SwiGLU + split fused into the GEMM epilogue)
   }
@@ -625,8 +628,12 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
       const DecLayer& L = h->dec.layers[li];
       // layer 0 norms its own input; every later layer's input_layernorm output arrives from the previous layer's down
       // projection (fused into its split-K reducer)
-      if (li == 0) FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
-      fv::GemmArgs q1{xs, 2 * Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkvf, qkvw, FV_EPI_F32, 1};
+      // llm_precision = 5: every split operand is "hi + lo8" (bf16 + one fp8 byte of remainder per element, in the lo half's place) and
+      // every projection takes ksplit = 2: the lo product on the scaled fp8 MFMA against the weights' fp8 copies -- 1.5 passes
+      const int lo8 = d.llm_precision == 5, KS = lo8 ? 2 : 1;
+      if (li == 0) FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln1, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s, 0, nullptr, lo8));
+      fv::GemmArgs q1{xs, 2 * Hd, L.qkv_w, rows, qkvw, Hd, L.qkv_b, nullptr, nullptr, 0, qkvf, qkvw, FV_EPI_F32, KS};
+      q1.W8 = L.qkv_w8;
       // few output tiles and a long K (7B: 72 tiles of 256 x 256 at M = 1024): the 256-tile kernel cut along K, as the down projection
       q1.splitk_ws = wp.splitk_bytes ? reinterpret_cast<float*>(ws + wp.splitk) : nullptr;
       q1.splitk_bytes = wp.splitk_bytes;
@@ -639,12 +646,14 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
       // RoPE rides inside the attention kernel (q fragments in registers, K rows on their way into LDS)
       FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tq * Tt * qd + 3.0 * rows * (qd + kd), 4.0 * rows * (qkvw + qd),
            fv::launch_attention_f32(qkvf, qkvw, as, as + qd, 2 * qd, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, len_add, att_scale, s, h->rope,
-                                    mode == DEC_SUFFIX ? kv + li * kv_layer : nullptr, 2 * kd, mode == DEC_SUFFIX ? Np : 0));
-      fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
+                                    mode == DEC_SUFFIX ? kv + li * kv_layer : nullptr, 2 * kd, mode == DEC_SUFFIX ? Np : 0, nullptr, lo8));
+      fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, KS};
+      o1.W8 = L.o_w8;
       o1.splitk_ws = q1.splitk_ws;
       o1.splitk_bytes = wp.splitk_bytes;
       FV_TRY(gemm_p(h, o1, s));
-      fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 1};
+      fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, KS};
+      d1.W8 = L.down_w8;
       if (d.llm_precision == 2) {
         // the MLP in ONE pass on fp16 operands (tests/precision_budget.py): post-norm rows as fp16, SwiGLU output / 16 as fp16
         FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 6.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xn, nullptr, Hd, rows, Hd, d.rms_eps, s, 1, h->f16_flags));
@@ -668,9 +677,10 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
         d1 = fv::GemmArgs{act, I, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 0};
         d1.f16 = 1;
       } else {
-        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s));
-        fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, 1};
-        FV_TRY(gemm_p(h, g1, s));  // silu(gate)*up and its hi/lo split happen in the epilogue: no fp32 round trip
+        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s, 0, nullptr, lo8));
+        fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, KS};
+        g1.W8 = L.gu_w8;
+        FV_TRY(gemm_p(h, g1, s));  // silu(gate)*up and its hi / lo (or lo8) split happen in the epilogue: no fp32 round trip
       }
       d1.splitk_ws = wp.splitk_bytes ? reinterpret_cast<float*>(ws + wp.splitk) : nullptr;
       d1.splitk_bytes = wp.splitk_bytes;
@@ -706,8 +716,10 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   if (d.llm_head_dim != 32 && d.llm_head_dim != 64 && d.llm_head_dim != 128) return fv_fail(FV_ERR_UNSUPPORTED, "llm head_dim must be 32/64/128");
   if (d.llm_hidden % 8 || d.llm_inter % 8 || d.llm_heads % d.llm_kv_heads) return fv_fail(FV_ERR_ARG, "llm dims must be multiples of 8 and heads %% kv_heads == 0");
   if (d.tower_out_dim != 2 * d.tower_dims[d.tower_stages - 1] && d.tower_out_dim != d.tower_dims[d.tower_stages - 1]) return fv_fail(FV_ERR_UNSUPPORTED, "tower_out_dim must be 1x or 2x the last stage dim");
-  if (d.llm_precision < 0 || d.llm_precision > 4)
-    return fv_fail(FV_ERR_ARG, "llm_precision must be 0 (bf16), 1 (split-bf16), 2 (split-bf16 qkv/o + fp16 gate/up/down), 3 (fp16 gate/up only) or 4 (fp16 down only)");
+  if (d.llm_precision < 0 || d.llm_precision > 5)
+    return fv_fail(FV_ERR_ARG, "llm_precision must be 0 (bf16), 1 (split-bf16), 2 (split-bf16 qkv/o + fp16 gate/up/down), 3 (fp16 gate/up only), 4 (fp16 down only) or 5 (bf16 hi + fp8 lo)");
+  if (d.llm_precision == 5 && (d.llm_hidden % 128 || d.llm_inter % 128 || (d.llm_heads * d.llm_head_dim) % 128))
+    return fv_fail(FV_ERR_UNSUPPORTED, "llm_precision = 5 (hi + lo8 operands) needs hidden, inter and heads * head_dim to be multiples of 128");
   if (d.state_dim <= 0 || d.action_dim <= 0 || d.hidden_dim <= 0 || d.fusion_dim <= 0) return fv_fail(FV_ERR_ARG, "head dims must be positive");
   FV_HIP_CHECK(hipSetDevice(device));
   fv_handle* h = new fv_handle();
@@ -883,7 +895,15 @@ static int load_impl(fv_handle* h, Loader& L) {
       if (u && y.gu_w) L.put_rows(u, y.gu_w + 8 * Hd, 16 * Hd, 8 * Hd, I / 8, 8 * Hd);
     }
     y.down_w = L.mat(pre + "mlp.down_proj.weight", Hd, I);
-    if (d.llm_precision >= 2 && L.rc == FV_OK) {
+    if (d.llm_precision == 5 && L.rc == FV_OK) {
+      // fp8 e4m3 copies (x 2^6) of the four projection matrices for the lo8 products; |w| x 64 must stay inside e4m3's 448
+      struct { bf16_t* w; void** w8; size_t rows; int K; } m4[4] = {{y.qkv_w, &y.qkv_w8, qd + 2 * kd, (int)Hd}, {y.o_w, &y.o_w8, Hd, (int)qd},
+                                                                  {y.gu_w, &y.gu_w8, 2 * I, (int)Hd}, {y.down_w, &y.down_w8, Hd, (int)I}};
+      for (auto& t : m4) {
+        *t.w8 = L.alloc(t.rows * 2 * t.K);
+        if (!*t.w8 || fv::launch_bf16_to_w8(t.w, *t.w8, t.rows, t.K, nullptr, h->f16_flags + 2) != FV_OK) { L.rc = FV_ERR_HIP; break; }
+      }
+    } else if (d.llm_precision >= 2 && L.rc == FV_OK) {
       // fp16 copies IN PLACE of the two projections that run on fp16 operands: exact for |w| >= 6.1e-5 (smaller weights become
       // fp16 subnormals, absolute error <= 3e-8); down carries the 2^4 that its operand (FV_EPI_SWIGLU_F16) gives up
       if ((d.llm_precision != 4 && fv::launch_bf16_to_f16(y.gu_w, 2 * I * Hd, 1.0f, nullptr, h->f16_flags + 1) != FV_OK) ||
@@ -893,7 +913,15 @@ static int load_impl(fv_handle* h, Loader& L) {
   }
   if (L.rc != FV_OK) return L.rc;
   FV_HIP_CHECK(hipDeviceSynchronize());
-  if (d.llm_precision >= 2) {
+  if (d.llm_precision == 5) {
+    unsigned bits = 0;
+    FV_HIP_CHECK(hipMemcpy(&bits, h->f16_flags + 2, 4, hipMemcpyDeviceToHost));
+    float mx;
+    memcpy(&mx, &bits, 4);
+    if (!(mx <= 448.0f))
+      return fv_fail(FV_ERR_UNSUPPORTED, "llm_precision=5: a projection weight leaves the fp8 range of its lo-product copy (max |w| x 64 = %g > 448); "
+                     "load this checkpoint with llm_precision=1", (double)mx);
+  } else if (d.llm_precision >= 2) {
     // LOUD refusal instead of a silently clamped weight: the fp16 single-pass projections need every (scaled) weight inside the
     // binary16 range.  The host side falls back to llm_precision = 1 (split-bf16, no range limit) on this error.
     unsigned bits = 0;

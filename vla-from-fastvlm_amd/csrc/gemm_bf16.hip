@@ -13,6 +13,8 @@
 // SwiGLU / fp32-residual all run on 8 contiguous columns per lane with 16-byte global accesses.
 // Bounded by the MFMA roof for K >= ~512, by HBM for the K = 96..384 tower shapes (kernel table).
 #include <cstdlib>
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace fv {
@@ -29,10 +31,30 @@ struct Params {
   // time).  For few row tiles against many weight columns (the 7B decoder at M = 1024: 4 x 148) the row-major walk makes every XCD
   // stream 32 different 3.7 MB weight tiles per round and each weight tile is fetched by four XCDs: 2.2 GB per launch, 4.3 TB/s.
   int tiles_m = 0;
+  const uint8_t* W8 = nullptr;   // ksplit == 2: fp8 copy of W (x 2^6), row stride 2K bytes
   unsigned* sat = nullptr;   // FV_EPI_SWIGLU_F16: device counter of 8-value groups clamped to the fp16 range (0 in a healthy model)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+// the lo8 product step: 16 x 16 x 128 on fp8 e4m3 operands (32 bytes per lane = two 16-byte LDS pieces), the 2^-14 of the operand scales
+// applied by the instruction (E8M0 scale on the first operand, 1.0 on the second)
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ i32x8 ld_f8op(const void* p0, const void* p1) {   // two ds_read_b128 into the halves of one 8-register operand
+  return __builtin_shufflevector(*reinterpret_cast<const i32x4*>(p0), *reinterpret_cast<const i32x4*>(p1), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// Inline asm with the accumulator TIED (dst = src C): through the builtin hipcc picks the untied form, gives every product a fresh
+// destination and keeps two copies of the 128 accumulators alive (420 bytes of scratch per lane in the 256-tile kernel).  The compiler
+// cannot see that this is a matrix-pipe write: the kernels put their own wait states between the last lo8 product and the first
+// read of an accumulator (lo8_settle).
+__device__ __forceinline__ f32x4 mfma_lo8(const i32x8& a, const i32x8& b, f32x4 c) {
+  const int sa = FV_LO8_MFMA_SCALE, sb = 127;
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+  return c;
+}
+// XDL write -> VALU / LDS read of the result: 18 wait states for a 16-pass MFMA (cdna4 ISA 4.5); s_nop n = n + 1 wait states
+__device__ __forceinline__ void lo8_settle() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
 
 // one 16x16x32 product step; F16: the same 16-byte fragments hold IEEE binary16 (llm_precision = 2's gate/up and down projections)
 template <bool F16>
@@ -43,7 +65,7 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const 
 
 // BM = 128: 2x2 waves of 64x64.  BM = 64: 2x2 waves of 32x64, for grids that would otherwise leave CUs idle (the
 // M = B*T = 4096 decoder GEMMs) -- twice the blocks, 3 co-resident per CU.
-template <int BM, bool F16 = false>
+template <int BM, bool F16 = false, bool LO8 = false>   // LO8: the hi + lo8 instance (p.ksplit == 2); the others carry none of its code
 __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
   constexpr int MI = BM / 32;                             // 16-row MFMA tiles per wave along M
   constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
@@ -66,10 +88,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
   uint4 ra[NA], rb[4];
   // ksplit: A carries [hi | lo] halves of a split-bf16 operand side by side (2K columns); the second half of the K
   // loop re-reads the same weight columns, so out = (A_hi + A_lo) . W^T in one launch.
+  // ksplit == 2 ("hi + lo8"): after the nk1 bf16 tiles of A's hi half come K / 128 fp8 tiles: 128 one-byte remainders per row from byte
+  // offset 2K of A's rows against W8's rows (row stride 2K bytes) -- the same 128-byte LDS rows, swizzle and 16-byte pieces
   const int nk1 = (p.K + BK - 1) / BK;
-  const int nk = p.ksplit ? 2 * nk1 : nk1;
+  const int nk = LO8 ? nk1 + p.K / 128 : (p.ksplit ? 2 * nk1 : nk1);
   auto load_tile = [&](int kt) {
     const bool second = kt >= nk1;
+    if (LO8 && second) {
+      const size_t kb = (size_t)(kt - nk1) * 128 + skc * 16;    // byte column of the fp8 tile
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int gm = bm + srow + 32 * i;
+        ra[i] = gm < p.M ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.A + (size_t)gm * p.lda) + 2 * (size_t)p.K + kb) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gn = bn + srow + 32 * i;
+        rb[i] = gn < p.N ? *reinterpret_cast<const uint4*>(p.W8 + (size_t)gn * 2 * p.K + kb) : make_uint4(0, 0, 0, 0);
+      }
+      return;
+    }
     const int kw = (second ? kt - nk1 : kt) * BK + skc * 8;   // weight column
     const int ka = second ? p.K + kw : kw;                      // activation column
     const bool kin = kw < p.K;
@@ -114,6 +152,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
     if (kt + 2 < nk) load_tile(kt + 2);
     const bf16_t* a_base = sA + cur * A_ELEMS;
     const bf16_t* b_base = sB + cur * B_ELEMS;
+    if (LO8 && kt >= nk1) {   // fp8 tile: both 16-byte pieces of a row (k-chunks fq and 4 + fq) form one 32-byte operand
+      i32x8 fb8[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fb8[i] = ld_f8op(b_base + lds_off(wc * 64 + i * 16 + fr, fq), b_base + lds_off(wc * 64 + i * 16 + fr, 4 + fq));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const i32x8 fa8 = ld_f8op(a_base + lds_off(wr * (BM / 2) + i * 16 + fr, fq), a_base + lds_off(wr * (BM / 2) + i * 16 + fr, 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_lo8(fa8, fb8[j], acc[i][j]);
+      }
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int chunk = ks * 4 + fq;
@@ -130,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<F16>(fa[i], fb[j], acc[i][j]);
     }
   }
+  if constexpr (LO8) lo8_settle();
   __syncthreads();  // the last tile's fragment reads are done: the epilogue image reuses the staging buffers
 
   // ---- epilogue: accumulators -> fp32 LDS image (C/D map: col = lane&15, row = (lane>>4)*4 + reg) ----
@@ -172,7 +223,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
           unpack8(hv, h8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
-          *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (p.N >> 1) + (gn >> 1)) = pack8(l8);
+          if (LO8) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(out + (size_t)gm * p.ldo + (p.N >> 1)) + (gn >> 1)) = pack_lo8(l8);
+          else *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (p.N >> 1) + (gn >> 1)) = pack8(l8);
         }
       }
     }
@@ -255,7 +307,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 // straight to their fragment reads and MFMAs and run ahead.  Measured (tools/gemm_shapes.py, A/B in one session): +6 % on the decoder's
 // M = 4096 gate/up and split-K down projections, +-2 % on the tower's shapes, -15 % at 8192^3 (the staging waves' 16 pieces become the
 // critical path of a long K loop with many tiles per CU) -- launch_gemm uses it for M <= 8192 only.
-template <int MI, int WN, bool ASYM = false, bool F16 = false>
+template <int MI, int WN, bool ASYM = false, bool F16 = false, bool LO8 = false>   // LO8: the hi + lo8 instance (p.ksplit == 2)
 __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Params p) {   // <8,4> 256x256, <4,2> 128x128
   static_assert(!ASYM || WN == 4, "asymmetric staging pairs wave w with wave w + 4");
   constexpr int BMT = 32 * MI, BNT = 64 * WN, NTH = 128 * WN, BUFB = (BMT + BNT) * 128, AB = BMT * 128;
@@ -265,7 +317,11 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid / WN, wc = wid % WN;            // wave's M half, 64-column N slice
   const int fr = lane & 15, fq = lane >> 4;
-  const int nk1 = p.K / BK, nk = p.ksplit ? 2 * nk1 : nk1;   // ksplit: A = [hi | lo], the weight columns are walked twice
+  // ksplit 1: A = [hi | lo] bf16, the weight columns are walked twice; 2: nk1 bf16 tiles of A's hi half, then K / 128 fp8 tiles (A's
+  // one-byte remainders at byte offset 2K of its rows, W8's rows at the bf16 copy's row stride: the per-lane offsets serve both)
+  const int nk1 = p.K / BK, nk = LO8 ? nk1 + p.K / 128 : (p.ksplit ? 2 * nk1 : nk1);
+  auto a_boff = [&](int kt) { return LO8 && kt >= nk1 ? 2 * p.K + (kt - nk1) * 128 : ((kt >= nk1 ? kt - nk1 : kt) * BK + (kt >= nk1 ? p.K : 0)) * 2; };
+  auto w_boff = [&](int kt) { return LO8 && kt >= nk1 ? (kt - nk1) * 128 : (kt >= nk1 ? kt - nk1 : kt) * BK * 2; };
   const int wslot = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
   // staging: slot s = j * 512 + tid is 16 B of row s >> 3 at LDS position s & 7, filled from k-chunk (s & 7) ^ (row & 7)
@@ -295,10 +351,11 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   // in an SGPR.  Beside MFMAs a wave pays ~31 clk of issue for such a piece where the global_load_lds form (64-bit per-lane
   // address) pays ~52 (tools/stage_micro.hip); launch_gemm keeps operands of 4 GiB or more away from this kernel.
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, 0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, 0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc_bf = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, 0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc_f8 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(LO8 ? p.W8 : reinterpret_cast<const uint8_t*>(p.W)), 0, 0xffffffffu, 0x00020000);
   auto stage = [&](const uint32_t (&oa)[4], const uint32_t (&ow)[4], const uint32_t (&ow2)[4], int kt, int buf) {
-    const int kw = kt >= nk1 ? kt - nk1 : kt;
-    const int aoff = (kw * BK + (kt >= nk1 ? p.K : 0)) * 2, woff = kw * BK * 2;
+    const int aoff = a_boff(kt), woff = w_boff(kt);
+    const __amdgpu_buffer_rsrc_t wrsrc = LO8 && kt >= nk1 ? wrsrc_f8 : wrsrc_bf;
     char* la = g2_smem + buf * BUFB + wslot;
     char* lw = la + AB;
     if constexpr (ASYM) {
@@ -348,70 +405,101 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int cur = (pb + kt - kt0) & 1;
-      G2_T(4)
-      // the next K-tile's SA + SW LDS-DMA pieces are dealt one per MFMA step below (G2_DEAL): issued in a burst here, before any
-      // MFMA of this K-tile, they cost every wave ~470 clk with the matrix pipe idle (tools/gemm_stamps.py)
-      const bool st_same = kt + 1 < kt1, st_any = st_same || next < p.nwg;
-#if G2_DEAL
-      const int st_kt = st_same ? kt + 1 : kn0;
-      const int st_kw = st_kt >= nk1 ? st_kt - nk1 : st_kt;
-      const int st_aoff = (st_kw * BK + (st_kt >= nk1 ? p.K : 0)) * 2, st_woff = st_kw * BK * 2;
-      char* st_la = g2_smem + (cur ^ 1) * BUFB + wslot;
-      char* st_lw = st_la + AB;
-#else
-      if (st_same) stage(offa, offw, offw2, kt + 1, cur ^ 1);
-      else if (st_any) stage(offa_n, offw_n, offw2_n, kn0, cur ^ 1);
-#endif
-      G2_T(0)
-      const char* la = g2_smem + cur * BUFB + (wr * (16 * MI)) * 128;
-      const char* lw = g2_smem + cur * BUFB + AB + (wc * 64) * 128;
-      // Fragment reads run two steps (8 MFMAs, ~130 clk) ahead of their use: left to itself hipcc reads each pair of
-      // fragments right before the MFMAs that need them and waits out the LDS latency every 8 MFMAs.  A step = one
-      // activation fragment (m tile i of k-step ks) against the k-step's four weight fragments.
-      {
-        bf16x8 fwA[4], fwB[4], far[3];
-#define G2_RD_A(T) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + ((T) % MI) * 2048 + ((T) / MI ? fo1 : fo0)))
-#define G2_RD_W(KS, J) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lw + (J) * 2048 + ((KS) ? fo1 : fo0)))
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fwA[j] = G2_RD_W(0, j);
-        far[0] = G2_RD_A(0);
-        far[1] = G2_RD_A(1);
-#pragma unroll
-        for (int t = 0; t < 2 * MI; ++t) {
-          if (t + 2 < 2 * MI) far[(t + 2) % 3] = G2_RD_A(t + 2);
-#if G2_DEAL
-          if (t < SA + SW && st_any) {
-            if (t < SA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(st_la + (t % 4) * (NTH * 16)), 16, st_same ? offa[t % 4] : offa_n[t % 4], st_aoff, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(st_lw + ((t - SA) % 4) * (NTH * 16)), 16, st_same ? offw[(t - SA) % 4] : offw_n[(t - SA) % 4], st_woff, 0, 0);
+    // the K-tile step as a generic lambda so that the bf16 tiles and (LO8) the fp8 tiles run in TWO loops: inside one loop the two
+    // fragment sets shared a live range and the 256-tile instance spilled 400 bytes per lane
+    auto ktile = [&](auto f8_tag, int kt) {
+      constexpr bool F8T = decltype(f8_tag)::value;
+        const int cur = (pb + kt - kt0) & 1;
+        G2_T(4)
+        // the next K-tile's SA + SW LDS-DMA pieces are dealt one per MFMA step below (G2_DEAL): issued in a burst here, before any
+        // MFMA of this K-tile, they cost every wave ~470 clk with the matrix pipe idle (tools/gemm_stamps.py)
+        const bool st_same = kt + 1 < kt1, st_any = st_same || next < p.nwg;
+  #if G2_DEAL
+        const int st_kt = st_same ? kt + 1 : kn0;
+        const int st_aoff = a_boff(st_kt), st_woff = w_boff(st_kt);
+        const __amdgpu_buffer_rsrc_t wrsrc = LO8 && st_kt >= nk1 ? wrsrc_f8 : wrsrc_bf;
+        char* st_la = g2_smem + (cur ^ 1) * BUFB + wslot;
+        char* st_lw = st_la + AB;
+  #else
+        if (st_same) stage(offa, offw, offw2, kt + 1, cur ^ 1);
+        else if (st_any) stage(offa_n, offw_n, offw2_n, kn0, cur ^ 1);
+  #endif
+        G2_T(0)
+        const char* la = g2_smem + cur * BUFB + (wr * (16 * MI)) * 128;
+        const char* lw = g2_smem + cur * BUFB + AB + (wc * 64) * 128;
+        // Fragment reads run two steps (8 MFMAs, ~130 clk) ahead of their use: left to itself hipcc reads each pair of
+        // fragments right before the MFMAs that need them and waits out the LDS latency every 8 MFMAs.  A step = one
+        // activation fragment (m tile i of k-step ks) against the k-step's four weight fragments.
+        if constexpr (F8T) {
+          // fp8 tile: a row's two 16-byte pieces (k-chunks fq, 4 + fq) are ONE 32-byte operand; MI steps of four 16x16x128 products, each as
+          // long on the matrix pipe as the two bf16 steps it replaces, over twice the K
+          i32x8 w8f[4], x8f[2];
+  #define G2_RD8(BASE, T) ld_f8op((BASE) + (T) * 2048 + fo0, (BASE) + (T) * 2048 + fo1)
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) w8f[j] = G2_RD8(lw, j);
+          x8f[0] = G2_RD8(la, 0);
+  #pragma unroll
+          for (int t = 0; t < MI; ++t) {
+            if (t + 1 < MI) x8f[(t + 1) & 1] = G2_RD8(la, t + 1);
+  #if G2_DEAL
+            if (t < SA + SW && st_any) {
+              if (t < SA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(st_la + (t % 4) * (NTH * 16)), 16, st_same ? offa[t % 4] : offa_n[t % 4], st_aoff, 0, 0);
+              else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(st_lw + ((t - SA) % 4) * (NTH * 16)), 16, st_same ? offw[(t - SA) % 4] : offw_n[(t - SA) % 4], st_woff, 0, 0);
+            }
+  #endif
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][t] = mfma_lo8(w8f[j], x8f[t & 1], acc[j][t]);
+            __builtin_amdgcn_sched_barrier(0);
           }
-#endif
-          if (t == MI - 3) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fwB[j] = G2_RD_W(1, j);
+  #undef G2_RD8
+        } else {
+          bf16x8 fwA[4], fwB[4], far[3];
+  #define G2_RD_A(T) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + ((T) % MI) * 2048 + ((T) / MI ? fo1 : fo0)))
+  #define G2_RD_W(KS, J) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lw + (J) * 2048 + ((KS) ? fo1 : fo0)))
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) fwA[j] = G2_RD_W(0, j);
+          far[0] = G2_RD_A(0);
+          far[1] = G2_RD_A(1);
+  #pragma unroll
+          for (int t = 0; t < 2 * MI; ++t) {
+            if (t + 2 < 2 * MI) far[(t + 2) % 3] = G2_RD_A(t + 2);
+  #if G2_DEAL
+            if (t < SA + SW && st_any) {
+              if (t < SA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(st_la + (t % 4) * (NTH * 16)), 16, st_same ? offa[t % 4] : offa_n[t % 4], st_aoff, 0, 0);
+              else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(st_lw + ((t - SA) % 4) * (NTH * 16)), 16, st_same ? offw[(t - SA) % 4] : offw_n[(t - SA) % 4], st_woff, 0, 0);
+            }
+  #endif
+            if (t == MI - 3) {
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) fwB[j] = G2_RD_W(1, j);
+            }
+  #pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[j][t % MI] = mfma16<F16>(t < MI ? fwA[j] : fwB[j], far[t % 3], acc[j][t % MI]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads where they are dealt (hipcc sinks them back to their use)
           }
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[j][t % MI] = mfma16<F16>(t < MI ? fwA[j] : fwB[j], far[t % 3], acc[j][t % MI]);
-          __builtin_amdgcn_sched_barrier(0);   // keep the reads where they are dealt (hipcc sinks them back to their use)
+  #undef G2_RD_A
+  #undef G2_RD_W
         }
-#undef G2_RD_A
-#undef G2_RD_W
-      }
-      G2_T(1)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next K-tile has landed ...
-      G2_T(2)
-      __syncthreads();                                    // ... for everybody, and nobody still reads this one
-      G2_T(3)
-#ifdef G2_STAMPS
-      st_[6] += 1;
-#endif
+        G2_T(1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next K-tile has landed ...
+        G2_T(2)
+        __syncthreads();                                    // ... for everybody, and nobody still reads this one
+        G2_T(3)
+  #ifdef G2_STAMPS
+        st_[6] += 1;
+  #endif
+    };
+    {
+      const int kmid = LO8 ? (kt1 < nk1 ? kt1 : nk1) : kt1;
+      for (int kt = kt0; kt < kmid; ++kt) ktile(std::false_type{}, kt);
+      if constexpr (LO8) for (int kt = kt0 > nk1 ? kt0 : nk1; kt < kt1; ++kt) ktile(std::true_type{}, kt);
     }
 
     // ---- epilogue: per 16-row tile, 64 columns of fp32 through the wave's 4.25 KB of the buffer the last K-tile just
     // vacated (the other one already holds the next output tile's first K-tile)
     constexpr int ORB = 64 * 4 + 16;
+    if constexpr (LO8) lo8_settle();
     char* so = g2_smem + ((pb + kt1 - kt0 - 1) & 1) * BUFB + wid * (16 * ORB);
     const int c8 = lane & 7;                       // the lane's 8 output columns on the way out (same for every row tile)
     const int gn = bn + wc * 64 + c8 * 8;
@@ -470,7 +558,8 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
         for (int e = 0; e < 8; ++e) l8[e] = o8[e] - h8[e];
         bf16_t* op = static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + go;
         *reinterpret_cast<uint4*>(op) = hv;
-        *reinterpret_cast<uint4*>(op + (p.N >> 1)) = pack8(l8);
+        if (LO8) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + (p.N >> 1)) + go) = pack_lo8(l8);
+        else *reinterpret_cast<uint4*>(op + (p.N >> 1)) = pack8(l8);
         asm volatile("" ::: "memory");
         continue;
       }
@@ -542,7 +631,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ part, int splits, int M, int N, int npad,
                                                                   const float* __restrict__ bias, const float* res, int ldr, float* out,
                                                                   int ldo, const float* __restrict__ nw, bf16_t* __restrict__ y,
-                                                                  bf16_t* __restrict__ ylo, int ldy, float eps) {
+                                                                  bf16_t* __restrict__ ylo, int ldy, float eps, int lo8) {
   const int lane = threadIdx.x & 63;
   const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -564,7 +653,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
     uint2 hv;
     hv.x = pack_bf2(o0, o1); hv.y = pack_bf2(o2, o3);
     *reinterpret_cast<uint2*>(y + (size_t)m * ldy + n) = hv;
-    if (ylo) {
+    if (ylo && lo8) {
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ylo + (size_t)m * ldy) + n) =
+          pack_f8x4((o0 - bf_lo(hv.x)) * FV_LO8_SCALE, (o1 - bf_hi(hv.x)) * FV_LO8_SCALE, (o2 - bf_lo(hv.y)) * FV_LO8_SCALE, (o3 - bf_hi(hv.y)) * FV_LO8_SCALE);
+    } else if (ylo) {
       uint2 lv;
       lv.x = pack_bf2(o0 - bf_lo(hv.x), o1 - bf_hi(hv.x)); lv.y = pack_bf2(o2 - bf_lo(hv.y), o3 - bf_hi(hv.y));
       *reinterpret_cast<uint2*>(ylo + (size_t)m * ldy + n) = lv;
@@ -702,7 +794,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   }
   const int rc = launch_gemm_core(a, s);
   if (rc != FV_OK) return rc;
-  if (a.norm_w && rc == FV_OK && !g_norm_fused) return launch_rmsnorm(static_cast<const float*>(a.out), a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.M, a.N, a.norm_eps, s);
+  if (a.norm_w && rc == FV_OK && !g_norm_fused)
+    return launch_rmsnorm(static_cast<const float*>(a.out), a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.M, a.N, a.norm_eps, s, 0, nullptr, a.ksplit == 2 ? 1 : 0);
   return FV_OK;
 }
 
@@ -728,9 +821,13 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   Params p;
   p.A = a.A; p.W = a.W; p.bias = a.bias; p.scale = a.scale; p.res = a.res; p.out = a.out;
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi;
-  p.ksplit = a.ksplit ? 1 : 0;
+  p.ksplit = a.ksplit == 2 ? 2 : (a.ksplit ? 1 : 0);
   p.sat = a.sat;
-  if (a.ksplit && (a.K % BK || a.lda < 2 * a.K)) return fv_fail(FV_ERR_ARG, "gemm: ksplit needs K %% 64 == 0 and lda >= 2K");
+  p.W8 = static_cast<const uint8_t*>(a.W8);
+  if (a.ksplit == 2) {
+    if (!a.W8 || a.K % 128 || a.lda * 2 < 3 * a.K || ((uintptr_t)a.W8 & 15)) return fv_fail(FV_ERR_ARG, "gemm: the hi + lo8 form needs W8, K %% 128 == 0 and lda >= 1.5 K");
+    if (a.f16) return fv_fail(FV_ERR_ARG, "gemm: hi + lo8 goes with bf16 hi operands");
+  } else if (a.ksplit && (a.K % BK || a.lda < 2 * a.K)) return fv_fail(FV_ERR_ARG, "gemm: ksplit needs K %% 64 == 0 and lda >= 2K");
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -741,6 +838,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4, 2, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
   }
   static const bool colmajor_ok = fv_ab_env("FASTVLA_NO_GEMM_COLMAJOR") == nullptr;   // A/B
   constexpr int cm_max = 8;   // (16 measured at the headline shape in round 3: gate/up -3.5 %, split-K down +9 %, step unchanged)
@@ -752,7 +851,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   if (!no_splitk && a.splitk_ws && f32out && !no_g256 && (a.M % 256 == 0 || (!no_ragged_sk && !a.f16 && a.N % 8 == 0)) && a.K % 64 == 0 && a.N % 4 == 0 &&
       (size_t)a.M * a.lda * 2 < ((size_t)1 << 32) && (size_t)a.N * a.K * 2 < ((size_t)1 << 32)) {
     const int tmr = (a.M + 255) / 256;            // a ragged last row tile: staging clamps its rows, the partial-sum stores skip them
-    const int tn = (a.N + 255) / 256, tiles = tmr * tn, nkt = (a.ksplit ? 2 : 1) * (a.K / 64);
+    const int tn = (a.N + 255) / 256, tiles = tmr * tn, nkt = a.ksplit == 2 ? a.K / 64 + a.K / 128 : (a.ksplit ? 2 : 1) * (a.K / 64);
     int splits = tiles < cus ? cus / tiles : 1;
     if (splits > 8) splits = 8;
     while (splits > 1 && nkt / splits < 16) --splits;
@@ -763,7 +862,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
       p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
       p.nwg = tiles * splits;
       const dim3 g2(p.nwg < cus ? p.nwg : cus / 8 * 8);
-      if (a.f16 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true, true>), g2, dim3(512), 2 * 512 * 128, s, p);
+      /* (no asymmetric-staging instance of the hi + lo8 kernel: it spills) */ if (a.ksplit == 2) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, false, true>), g2, dim3(512), 2 * 512 * 128, s, p);
+      else if (a.f16 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true, true>), g2, dim3(512), 2 * 512 * 128, s, p);
       else if (a.f16) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, true>), g2, dim3(512), 2 * 512 * 128, s, p);
       else if (asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), g2, dim3(512), 2 * 512 * 128, s, p);
       else hipLaunchKernelGGL((gemm256_kernel<8, 4>), g2, dim3(512), 2 * 512 * 128, s, p);
@@ -772,7 +872,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
       if (a.norm_w)
         hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, p.npad, a.bias,
                            a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo,
-                           a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps);
+                           a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps, a.ksplit == 2 ? 1 : 0);
       else
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, p.npad, a.bias,
                            a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo);
@@ -805,7 +905,9 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     p.tiles_m = colmajor_ok && tmr <= cm_max ? tmr : 0;
     const int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
     const int grid = p.nwg < slots ? p.nwg : slots;
-    if (gt == 256 && a.f16 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
+    if (gt == 256 && a.ksplit == 2) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, false, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
+    else if (a.ksplit == 2) hipLaunchKernelGGL((gemm256_kernel<4, 2, false, false, true>), dim3(grid), dim3(256), 2 * 256 * 128, s, p);
+    else if (gt == 256 && a.f16 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else if (gt == 256 && a.f16) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else if (gt == 256 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else if (gt == 256) hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
@@ -818,11 +920,13 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   const long blocks128 = (long)((a.M + 127) / 128) * p.tiles_n;
   if (blocks128 >= 512) {
     p.nwg = (int)blocks128;
-    if (a.f16) hipLaunchKernelGGL((gemm_kernel<128, true>), dim3(p.nwg), dim3(256), 0, s, p);
+    if (a.ksplit == 2) hipLaunchKernelGGL((gemm_kernel<128, false, true>), dim3(p.nwg), dim3(256), 0, s, p);
+    else if (a.f16) hipLaunchKernelGGL((gemm_kernel<128, true>), dim3(p.nwg), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_kernel<128>, dim3(p.nwg), dim3(256), 0, s, p);
   } else {
     p.nwg = ((a.M + 63) / 64) * p.tiles_n;
-    if (a.f16) hipLaunchKernelGGL((gemm_kernel<64, true>), dim3(p.nwg), dim3(256), 0, s, p);
+    if (a.ksplit == 2) hipLaunchKernelGGL((gemm_kernel<64, false, true>), dim3(p.nwg), dim3(256), 0, s, p);
+    else if (a.f16) hipLaunchKernelGGL((gemm_kernel<64, true>), dim3(p.nwg), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_kernel<64>, dim3(p.nwg), dim3(256), 0, s, p);
   }
   FV_HIP_CHECK(hipGetLastError());

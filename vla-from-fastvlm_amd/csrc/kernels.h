@@ -20,12 +20,15 @@ struct GemmArgs {
   void* out; int ldo;           // bf16 or f32 by epilogue
   int epi;
   int ksplit = 0;               // 1: A holds [hi | lo] (2K columns, lda >= 2K); out = (hi + lo) . W^T in one launch
+                                // 2: "hi + lo8": A rows = K bf16 then (at byte offset 2K) K fp8 remainders x 2^8 (lda >= 1.5 K); the lo product runs
+                                //    against W8 on the scaled fp8 MFMA (K % 128 == 0); SWIGLU_SPLIT / fused-norm outputs leave in the same form
   int f16 = 0;                  // 1: A and W hold fp16 bits (v_mfma_f32_16x16x32_f16); not together with ksplit
   float* splitk_ws = nullptr;   // optional scratch for split-K partial sums (fp32 epilogues, few output tiles, long K)
   size_t splitk_bytes = 0;
   // optional RMSNorm of the fp32 output rows (the decoder's next-layer input_layernorm): y (+ y_lo) = bf16 hi (+ lo) of
   // w * out * rsqrt(mean(out^2) + eps), row stride norm_ld; fused into the split-K reducer, a separate launch otherwise
   const float* norm_w = nullptr; bf16_t* norm_y = nullptr; bf16_t* norm_ylo = nullptr; int norm_ld = 0; float norm_eps = 0.f;
+  const void* W8 = nullptr;     // ksplit == 2: fp8 e4m3 copy of W x 2^6, row stride 2K BYTES (the first K of each row valid: the bf16 copy's per-lane offsets serve both)
   unsigned* sat = nullptr;      // optional device counter: += 1 per 8-value group FV_EPI_SWIGLU_F16 had to clamp to the fp16 range
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
@@ -88,17 +91,21 @@ int launch_embed_gather(const int32_t* ids, const bf16_t* table, const float* im
                         int Ni, int H, int vocab, hipStream_t s);
 // y_lo != null: also writes the bf16 remainder (x ~= y + y_lo), the split operand of the parity-mode decoder GEMMs
 int launch_rmsnorm(const float* x, const float* w, bf16_t* y, bf16_t* y_lo, int ldy, int rows, int H, float eps, hipStream_t s,
-                   int f16 = 0, unsigned* sat = nullptr);   // f16 != 0: y receives fp16 bits (y_lo must be null), clamps counted in *sat
+                   int f16 = 0, unsigned* sat = nullptr,    // f16 != 0: y receives fp16 bits (y_lo must be null), clamps counted in *sat
+                   int lo8 = 0);                            // lo8 != 0: the remainder leaves as fp8 (x 2^8), one byte per element, at y_lo's row starts
 // in place: n bf16 values -> the fp16 values scale * x (weights of the fp16-operand projections, once at load time); maxbits (device,
 // optional) receives max(|scale * x|) as float bits by atomicMax, so the loader can refuse weights outside the fp16 range
 int launch_bf16_to_f16(bf16_t* p, size_t n, float scale, hipStream_t s, unsigned* maxbits = nullptr);
+// W [rows][K] bf16 -> fp8 e4m3 copy of W x 2^6 at row stride 2K bytes (GemmArgs::W8); maxbits as launch_bf16_to_f16
+int launch_bf16_to_w8(const bf16_t* w, void* w8, size_t rows, int K, hipStream_t s, unsigned* maxbits = nullptr);
 int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D, hipStream_t s);
 // rope != null: qkv holds un-rotated projections; the rotate-half RoPE is fused into the MFMA kernel (head_dim 64 / 128) or applied
 // in place by a rope_f32 launch ahead of the VALU kernel (head_dim 32)
 int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
                          int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope = nullptr,
                          const float* pre = nullptr, int ldp = 0, int Np = 0,    // pre: cached [k | v] rows of positions < Np (8f-1)
-                         float* lse = nullptr);   // optional [B][heads][T] row statistics max + log(sum) for the backward pass (head_dim 64 / 128, Np = 0)
+                         float* lse = nullptr,    // optional [B][heads][T] row statistics max + log(sum) for the backward pass (head_dim 64 / 128, Np = 0)
+                         int lo8 = 0);            // remainders as fp8 bytes (the hi + lo8 operand form of llm_precision = 5)
 // table: [>=T][D/2] (cos, sin) pairs built by rope_table_host(); position = row % T
 int launch_rope(bf16_t* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D,
                 hipStream_t s);
@@ -110,6 +117,7 @@ int launch_pool_norm(const float* x, const int32_t* lens, const float* w, float*
 constexpr int RMS_BWD_RPW = 16;     // rows per wave of rmsnorm_bwd_kernel (one dw partial row per wave)
 constexpr int COLSUM_CHUNKS = 64;   // row ranges of the two-stage deterministic column sum
 int launch_split_rows(const float* in, int ldi, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);
+int launch_lo8_rows(const float* in, int ldi, bf16_t* out, int ldo, long R, int C, hipStream_t s);   // the fp8 remainder bytes of the hi + lo8 operand form
 int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
 int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, int ldo, int lo_off, int R, int Rp, int C, hipStream_t s);

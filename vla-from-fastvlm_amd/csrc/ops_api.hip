@@ -27,6 +27,27 @@ int fv_op_gemm_splitk(const void* A, int lda, const void* W, int M, int N, int K
   return fv::launch_gemm(g, static_cast<hipStream_t>(s));
 }
 
+int fv_op_gemm_lo8(const void* A, int lda, const void* W, const void* W8, int M, int N, int K, const float* bias, const void* res, int ldr, void* out,
+                   int ldo, int epilogue, void* ws, size_t ws_bytes, fv_stream s) {
+  fv::GemmArgs g{static_cast<const bf16_t*>(A), lda, static_cast<const bf16_t*>(W), M, N, K, bias, nullptr, res, ldr, out, ldo, epilogue};
+  g.ksplit = 2;
+  g.W8 = W8;
+  g.splitk_ws = static_cast<float*>(ws);
+  g.splitk_bytes = ws_bytes;
+  return fv::launch_gemm(g, static_cast<hipStream_t>(s));
+}
+int fv_op_lo8_pack(const float* x, void* a_out, int lda, const void* W, void* w8_out, int M, int K, int N, fv_stream s) {
+  // x (M, K) f32 -> the hi + lo8 operand rows (lda bf16 units each: K bf16, then at byte 2K the K fp8 remainders); W (N, K) bf16 -> W8
+  int rc = FV_OK;
+  if (x && a_out) {
+    // RMSNorm with unit weights would rescale: use the plain split of the training glue for hi, then its remainders as fp8
+    rc = fv::launch_split_rows(x, K, static_cast<bf16_t*>(a_out), lda, 0, M, K, static_cast<hipStream_t>(s));
+    if (rc == FV_OK) rc = fv::launch_lo8_rows(x, K, static_cast<bf16_t*>(a_out), lda, M, K, static_cast<hipStream_t>(s));
+  }
+  if (rc == FV_OK && W && w8_out) rc = fv::launch_bf16_to_w8(static_cast<const bf16_t*>(W), w8_out, (size_t)N, K, static_cast<hipStream_t>(s));
+  return rc;
+}
+
 int fv_op_gemm_f16(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr, void* out,
                    int ldo, int epilogue, void* ws, size_t ws_bytes, fv_stream s) {
   fv::GemmArgs g{static_cast<const bf16_t*>(A), lda, static_cast<const bf16_t*>(W), M, N, K, bias, nullptr, res, ldr, out, ldo, epilogue};

@@ -48,6 +48,21 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
   }
 }
 
+// fp32 [R][C] -> the fp8 remainder bytes of the "hi + lo8" operand form: out row r (ldo bf16 units) gets, at byte offset 2C, fp8((x - bf16(x)) * 2^8)
+__global__ __launch_bounds__(256) void lo8_rows_kernel(const float* __restrict__ in, int ldi, bf16_t* __restrict__ out, int ldo, long R, int C) {
+  const int c8 = C >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < R * c8; i += (long)gridDim.x * 256) {
+    const long r = i / c8;
+    const int c = (int)(i % c8) * 8;
+    float v[8], h[8], l[8];
+    load8(in + r * ldi + c, v);
+    unpack8(pack8(v), h);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) l[e] = v[e] - h[e];
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(out + r * ldo) + 2 * (size_t)C + c) = pack_lo8(l);
+  }
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n8) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
     float v[8];
@@ -623,6 +638,13 @@ int launch_split_rows(const float* in, int ldi, bf16_t* out, int ldo, int lo_off
   if (R <= 0 || C <= 0 || C % 8 || ldi % 4 || ldi < C || ldo % 8 || lo_off % 8 || ldo < (lo_off ? lo_off + C : C) || (lo_off && lo_off < C))
     return fv_fail(FV_ERR_ARG, "split_rows: bad shape R=%ld C=%d ldi=%d ldo=%d lo_off=%d", R, C, ldi, ldo, lo_off);
   hipLaunchKernelGGL(split_rows_kernel, dim3(grid_for(R * (C / 8))), dim3(256), 0, s, in, ldi, out, ldo, lo_off, R, C);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_lo8_rows(const float* in, int ldi, bf16_t* out, int ldo, long R, int C, hipStream_t s) {
+  if (!in || !out || R <= 0 || C <= 0 || C % 8 || ldi % 4 || ldi < C || ldo % 8 || ldo * 2 < 3 * C) return fv_fail(FV_ERR_ARG, "lo8_rows: bad shape");
+  hipLaunchKernelGGL(lo8_rows_kernel, dim3(grid_for(R * (C / 8))), dim3(256), 0, s, in, ldi, out, ldo, R, C);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

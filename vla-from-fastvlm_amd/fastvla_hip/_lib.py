@@ -119,6 +119,8 @@ SIGNATURES = {
     "fv_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(AdamWHParams), _i64, _vp, _vp]),
     "fv_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "fv_op_gemm_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _vp]),
+    "fv_op_gemm_lo8": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _vp]),
+    "fv_op_lo8_pack": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "fv_op_gemm_ksplit": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "fv_op_gemm_splitk": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, C.c_size_t, _vp]),
     "fv_op_dwconv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
