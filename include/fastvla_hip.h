@@ -254,6 +254,10 @@ int fv_train_export_params(fv_handle* h, float* flat_params, fv_stream s);
 /* the library's MFMA operand copies <- the master, after an optimiser step: bf16 weights (RNE), their transposes, fp32 norms / biases.
  * The frozen-path entry points (fv_llm_forward_pooled, ...) see the updated weights from then on. */
 int fv_train_commit(fv_handle* h, const float* flat_params, fv_stream s);
+/* grad_split 1 (default): the gradient operand of every dgrad / wgrad GEMM is split bf16 (hi + lo: 16 significant bits; per-tensor gradients within
+ * 2e-3 of fp32 autograd: the parity mode).  0: its bf16 hi half alone -- the usual mixed-precision recipe, half the backward's MFMA work, gradients
+ * ~3e-3 from fp32 (outside this repo's gradient bar; an explicit speed knob, never a default). */
+int fv_train_set_options(fv_handle* h, int grad_split);
 int fv_train_workspace_bytes(fv_handle* h, int B, int T, size_t* out_bytes);
 /* called from inside fv_train_forward_backward, on the calling thread, right after the LAST kernel that writes bucket `bucket`'s gradient
  * has been enqueued on the stream: flat_grads[offset, offset + numel) is final once the stream reaches this point (record an event here and

@@ -236,6 +236,30 @@ def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
     eng.close()
 
 
+def test_plain_bf16_gradient_operands_are_a_labelled_speed_knob():
+    """fv_train_set_options(grad_split=0): the backward's gradient operands as their bf16 hi half alone (the usual mixed-precision recipe, half the
+    backward's MFMA work).  Same loss and actions (the forward is untouched); gradients a few 1e-3 from autograd -- printed, bounded at 8e-3, and
+    NOT inside the 2e-3 bar the default mode is held to, which is why it is an option and not the default."""
+    model = arch.preset("small")
+    B, T = 3, 16
+    w, eng, tensors, total, nb, flat, lc, hp = _rig(model, 41, 64, B, T)
+    tower_out, ids, mask, states, targets = _inputs(model, B, T, 42)
+    ws = eng.train_workspace(B, T)
+    ref = train_unfrozen.forward_backward(w, hp, tower_out.float(), ids, mask, states, targets, lc)
+    a1, l1, g1 = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+    eng.train_set_options(grad_split=False)
+    a0, l0, g0 = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+    torch.cuda.synchronize()
+    assert torch.equal(a0, a1) and torch.equal(l0, l1) and not torch.equal(g0, g1)
+    worst = _check_grads(eng, g0, ref, tol=8e-3)
+    print(f"[unfrozen small, plain-bf16 gradient operands] worst gradient: {worst[0]} {worst[1]:.2e} (split-bf16 mode: 1.8e-3)")
+    eng.train_set_options(grad_split=True)
+    _, _, g2 = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+    torch.cuda.synchronize()
+    assert torch.equal(g2, g1)
+    eng.close()
+
+
 def test_unfrozen_training_needs_split_bf16_weights():
     from fastvla_hip import FastVLAHipError
     m = arch.preset("small")

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-tower", action="store_true", help="reuse one tower output (times the trainable part alone)")
+    ap.add_argument("--grad-bf16", action="store_true", help="fv_train_set_options(grad_split=0): plain bf16 gradient operands (speed knob, outside the 2e-3 gradient bar)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     model = arch.preset(args.model)
@@ -31,6 +32,7 @@ def main():
     eng = FastVLAEngine(model, max_batch=B, max_text_tokens=T, llm_precision=1)
     eng.load_weights(weights.init_backbone(model, seed=1234))
     eng.train_begin()
+    eng.train_set_options(grad_split=not args.grad_bf16)
     _, total, nb = eng.train_layout()
     flat = torch.zeros(total, device=dev)
     eng.train_export_params(flat)
@@ -64,7 +66,7 @@ def main():
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
     print(json.dumps({"model": args.model, "batch": B, "tokens": model.tower.num_tokens + T, "ms_per_step": round(ms, 2), "loss": float(loss), "trainable_params": total,
-                      "buckets": nb, "tower_in_step": not args.no_tower}))
+                      "buckets": nb, "tower_in_step": not args.no_tower, "grad_operands": "bf16 hi only" if args.grad_bf16 else "split bf16 (hi + lo)"}))
 
 
 if __name__ == "__main__":

@@ -76,7 +76,10 @@ struct Tower {
   bf16_t *pj0_w = nullptr, *pj2_w = nullptr; float *pj0_b = nullptr, *pj2_b = nullptr;
 };
 struct TrainLayerT { bf16_t *qkvT = nullptr, *oT = nullptr, *guT = nullptr, *downT = nullptr; };   // transposed weight copies (dgrad operands)
-struct TrainState { bool ready = false; std::vector<TrainLayerT> layers; bf16_t* pj2T = nullptr; };
+struct TrainState {
+  bool ready = false; std::vector<TrainLayerT> layers; bf16_t* pj2T = nullptr;
+  int grad_split = 1;   // 1: gradient operands of dgrad / wgrad as split bf16 (hi + lo; the parity mode), 0: their bf16 hi half alone (fv_train_set_options)
+};
 struct DecLayer {
   float* ln1 = nullptr; bf16_t* qkv_w = nullptr; float* qkv_b = nullptr; bf16_t* o_w = nullptr; float* ln2 = nullptr; bf16_t *gu_w = nullptr, *down_w = nullptr;
   void *qkv_w8 = nullptr, *o_w8 = nullptr, *gu_w8 = nullptr, *down_w8 = nullptr;   // llm_precision = 5: fp8 copies (x 2^6, row stride 2K bytes) for the lo8 products

@@ -466,6 +466,10 @@ class FastVLAEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fv_train_begin(self.h), "fv_train_begin", self.h)
 
+    def train_set_options(self, grad_split: bool = True) -> None:
+        """grad_split=False: the backward's gradient operands as plain bf16 (half its MFMA work, ~3e-3 gradients: an explicit speed knob)."""
+        _lib.check(self.lib.fv_train_set_options(self.h, int(bool(grad_split))), "fv_train_set_options", self.h)
+
     def train_layout(self):
         """-> (tensors, total_numel, n_buckets): every trainable tensor of the ONE flat fp32 buffer, in order: dicts with name, offset,
         numel, rows, cols, bucket (0 head, 1 projector, 2 embedding, 3 + l layer l, 3 + L final norm) and packing (0 plain, 1 q|k|v rows
