@@ -158,11 +158,12 @@ class Trainer:
             self.global_step += 1
             if out["synced"]:
                 self.update_step += 1
-                self._last_grad_norm = float(out["grad_norm"])   # a norm exists only for micro-batches that closed an update
+                gn = out["grad_norm"]   # a device scalar on the HIP path (kept as one: no host sync here); a norm exists only for micro-batches that closed an update
+                self._last_grad_norm = gn.detach().clone() if torch.is_tensor(gn) else float(gn)
             if self.is_main_process and self.global_step % cfg.logging_steps == 0:
                 rec = {"train/loss": float(out["loss"]), "train/mse": float(out["mse"]), "train/lr": self.last_lr, "train/epoch": self.epoch}
-                if out["synced"]:
-                    rec["train/grad_norm"] = self._last_grad_norm
+                if getattr(self, "_last_grad_norm", None) is not None:   # the LAST closed update's norm, also on logging steps that fall between two updates
+                    rec["train/grad_norm"] = float(self._last_grad_norm)
                 self._log(rec)
             if self.global_step % cfg.eval_steps == 0 and self.eval_dataloader is not None:
                 metrics = self.evaluate()
