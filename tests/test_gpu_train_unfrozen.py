@@ -156,6 +156,8 @@ def _check_grads(eng, grads_flat, ref, tol=GRAD_TOL):
 @pytest.mark.parametrize("name,llm,tower,B,T,hd", [
     ("small", None, "small", 3, 16, 64),
     ("0.5b-width-4-layers", arch.LLMConfig(hidden=896, layers=4, heads=14, kv_heads=2, head_dim=64, inter=4864, vocab=8192), "tiny", 4, 32, 128),
+    # FastVLM-7B's decoder geometry at full width (C5's model): head_dim 128 through the attention backward, GQA group 7, K = 18944 contractions
+    ("7b-width-2-layers", arch.LLMConfig(hidden=3584, layers=2, heads=28, kv_heads=4, head_dim=128, inter=18944, vocab=4096), "tiny", 2, 16, 128),
 ])
 def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
     if not torch.cuda.is_available():

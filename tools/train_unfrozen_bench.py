@@ -30,7 +30,10 @@ def main():
     model = arch.preset(args.model)
     B, T = args.batch, args.tokens
     eng = FastVLAEngine(model, max_batch=B, max_text_tokens=T, llm_precision=1)
-    eng.load_weights(weights.init_backbone(model, seed=1234))
+    if 3 * model.llm.hidden * model.llm.inter * model.llm.layers > 2e9:   # 7B: 30 GB as an fp32 host dict -- stream it, drawn on the device
+        eng.load_weights_streaming(weights.stream_backbone(model, seed=1234, device=dev))
+    else:
+        eng.load_weights(weights.init_backbone(model, seed=1234))
     eng.train_begin()
     eng.train_set_options(grad_split=not args.grad_bf16)
     _, total, nb = eng.train_layout()
