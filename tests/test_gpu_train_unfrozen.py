@@ -340,3 +340,46 @@ def test_policy_level_unfrozen_training_overfits_one_batch_and_exports_the_train
     assert rel_l2(gb.cpu(), ga.cpu()) <= 2e-3      # other tile shapes at other row counts: the operand roundings differ, the sums agree
     for p_ in (pol, pol2, again, pa, pb):
         p_.model.backbone.engine().close()
+
+
+def test_two_rank_unfrozen_step_equals_the_full_batch_step(tmp_path):
+    """Data-parallel unfrozen training on DEVICE tensors: two rank processes (gloo: this pool gives one GPU, so RCCL cannot form a
+    communicator; under RCCL the same worker is one rank per GPU) each take half of one fixed batch, differentiate it, and let the gradient
+    leave bucket by bucket -- fv_bucket_cb -> BucketedGradExchange: event on the compute stream, all-reduce of that slice on the side
+    stream -- under the rest of the backward pass.  The reduced, averaged gradient must equal the single-process full-batch gradient (the
+    MSE is a mean over samples: reference fastvla/modeling_fastvla.py:56; accelerate/DDP averaging: training/trainer.py:68-78,175), both
+    ranks must end with bit-identical parameters, and the clipped update must match the full-batch one."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    worker = str(root / "tools" / "unfrozen_dp_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    one = tmp_path / "w1"
+    one.mkdir()
+    r = subprocess.run([sys.executable, worker, "--out", str(one)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = tmp_path / "w2"
+    two.mkdir()
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, worker, "--out", str(two)], env=dict(env, RANK=str(k), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                                                                                   MASTER_PORT=str(port)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    full = torch.load(one / "rank0.pt")
+    r0, r1 = torch.load(two / "rank0.pt"), torch.load(two / "rank1.pt")
+    assert r0["world"] == 2 and len(r0["collectives"]) >= 3          # head, final norm + layers (coalesced), embedding, projector ...
+    spans = sorted(r0["collectives"])
+    assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] == full["grads"].numel()
+    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["flat"], r1["flat"])      # replicas stay identical
+    e = rel_l2(r0["grads"], full["grads"])
+    print(f"[unfrozen dp2 vs full batch] reduced gradient rel_l2 {e:.2e}; grad norm {r0['grad_norm']:.4f} vs {full['grad_norm']:.4f}; "
+          f"{len(r0['collectives'])} collectives per step")
+    assert e <= 2e-3 and abs(r0["grad_norm"] - full["grad_norm"]) <= 2e-3 * full["grad_norm"]
+    # the half-batch losses average to the full-batch loss
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - full["loss"]) <= 1e-4 * abs(full["loss"])
