@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-train-unfrozen", action="store_true", help="skip the unfrozen decoder + projector training leg (SURVEY.md 8f-4)")
+    ap.add_argument("--train-unfrozen-dp", action="store_true", help="N > 1: run the unfrozen training leg too (per-bucket all-reduce under the backward pass); off by default at N > 1 so that "
+                                                                    "a failure of ONE rank inside this secondary leg can never hang the collectives of a scaling run before its JSON line is out")
     ap.add_argument("--unfrozen-batch", type=int, default=int(os.environ.get("FASTVLA_UNFROZEN_BATCH", "32")), help="per-GPU batch of the unfrozen training leg (C3's rank shape)")
     ap.add_argument("--fv-comm-check", action="store_true",
                     help="N > 1 on the RCCL backend: also build a communicator through the library's own C ABI (fv_comm_*) and push one "
@@ -465,7 +467,7 @@ def main():
     # bf16 operand refresh.  Under N > 1 the gradient travels per bucket (one decoder layer = 60 MB) on a side stream while the backward
     # pass is still running.  Its own roofline fraction: algorithmic flops (tower + 3 x (projector + decoder GEMMs) + attention fwd/bwd).
     train_unfrozen = None
-    if not args.no_train_unfrozen and args.llm_precision == 1 and model.llm.head_dim >= 64 and w is not None:
+    if not args.no_train_unfrozen and (world == 1 or args.train_unfrozen_dp) and args.llm_precision == 1 and model.llm.head_dim >= 64 and w is not None:
         from vla_fastvlm.training.dp import BucketedGradExchange
         Bu = min(args.unfrozen_batch, B)
         try:
