@@ -490,14 +490,16 @@ def main():
                 eng.train_forward_backward(flat_u, tower_out_u, ids[:Bu], lens[:Bu], states[:Bu], targets[:Bu], ws_u, training=True, dropout_p=0.1,
                                            seed=args.seed + rank, offset=ust["step"], flat_grads=g_u, bucket_cb=bex.bucket_ready)
                 scale = bex.finish(dev)
-                eng.adamw_step(flat_u, g_u, m_u, v_u, ust["step"], lr=1e-5, weight_decay=1e-4, max_grad_norm=1.0, grad_scale=scale)
+                eng.adamw_step(flat_u, g_u, m_u, v_u, ust["step"], lr=1e-5, weight_decay=1e-4, max_grad_norm=1.0, grad_scale=scale / eng.train_loss_scale())
                 eng.train_commit(flat_u)
 
             nsu = max(2, args.steps // 4)
             elu = timed(step_unfrozen, nsu, 2)
-            eng.train_set_options(grad_split=False)     # the labelled speed knob: plain bf16 gradient operands (outside the 2e-3 gradient bar)
+            eng.train_set_options(grad_split=False)     # the labelled speed knob: plain bf16 dgrad operands (outside the 2e-3 gradient bar)
             elu_bf = timed(step_unfrozen, nsu, 1)
-            eng.train_set_options(grad_split=True)
+            eng.train_set_options(grad_split=True, wgrad_f16=False)   # round 4's first form: weight gradients as split-bf16 gradient x bf16 activation (two passes)
+            elu_w2 = timed(step_unfrozen, nsu, 1)
+            eng.train_set_options()
             Ni_u = model.tower.num_tokens
             rows_u = Bu * (Ni_u + T)
             ll = model.llm
@@ -517,7 +519,9 @@ def main():
                                            "frac": round(step_fl / (elu / nsu) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                            "note": "whole step incl. the frozen tower; the backward's split-bf16 gradient operands execute 2x the algorithmic MFMA work of each dgrad / wgrad"},
                               "workspace_gb": round(ws_u.numel() / 2 ** 30, 2),
-                              "ms_per_step_plain_bf16_gradient_operands": round(1e3 * elu_bf / nsu, 3)}
+                              "ms_per_step_plain_bf16_dgrad_operands": round(1e3 * elu_bf / nsu, 3),
+                              "ms_per_step_two_pass_bf16_wgrad": round(1e3 * elu_w2 / nsu, 3),
+                              "backward_arithmetic": "dgrad: split-bf16 gradient x exact-bf16 transposed weight (2 passes); wgrad: ONE fp16 pass, loss scale 2^12"}
             # leave the engine as it was: the legs below run on the original weights
             eng.train_commit(flat_u0)
             torch.cuda.synchronize()

@@ -254,10 +254,17 @@ int fv_train_export_params(fv_handle* h, float* flat_params, fv_stream s);
 /* the library's MFMA operand copies <- the master, after an optimiser step: bf16 weights (RNE), their transposes, fp32 norms / biases.
  * The frozen-path entry points (fv_llm_forward_pooled, ...) see the updated weights from then on. */
 int fv_train_commit(fv_handle* h, const float* flat_params, fv_stream s);
-/* grad_split 1 (default): the gradient operand of every dgrad / wgrad GEMM is split bf16 (hi + lo: 16 significant bits; per-tensor gradients within
- * 2e-3 of fp32 autograd: the parity mode).  0: its bf16 hi half alone -- the usual mixed-precision recipe, half the backward's MFMA work, gradients
- * ~3e-3 from fp32 (outside this repo's gradient bar; an explicit speed knob, never a default). */
-int fv_train_set_options(fv_handle* h, int grad_split);
+/* Arithmetic of the backward's contractions (defaults 1, 1, 12):
+ *   grad_split 1: the gradient operand of every dgrad GEMM is split bf16 (hi + lo, 16 significant bits) against the exact-bf16 transposed weights;
+ *              0: its bf16 hi half alone (the usual mixed-precision recipe: half the dgrad work, gradients ~3e-3 from fp32 -- outside this repo's
+ *                 2e-3 gradient bar; an explicit speed knob).
+ *   wgrad_f16  1: every weight gradient in ONE fp16 pass -- the gradient and the activation each rounded once to 11 significant bits;
+ *              0: the split-bf16 gradient against the activation's bf16 hi half (two passes; the activation's 8 bits bound the result at ~1.8e-3).
+ *   loss_scale_log2: dL/dactions is multiplied by 2^k, so EVERY gradient fv_train_forward_backward writes carries that factor (it keeps the wgrad's
+ *              fp16 gradient operand inside binary16's range; saturating casts, clamps counted by fv_llm_fp16_saturations); pass
+ *              grad_scale = 2^-k / world to fv_adamw_clip_step (fv_train_loss_scale returns 2^k).  The loss itself is not scaled. */
+int fv_train_set_options(fv_handle* h, int grad_split, int wgrad_f16, int loss_scale_log2);
+int fv_train_loss_scale(fv_handle* h, float* scale_out);
 int fv_train_workspace_bytes(fv_handle* h, int B, int T, size_t* out_bytes);
 /* called from inside fv_train_forward_backward, on the calling thread, right after the LAST kernel that writes bucket `bucket`'s gradient
  * has been enqueued on the stream: flat_grads[offset, offset + numel) is final once the stream reaches this point (record an event here and
@@ -267,7 +274,8 @@ typedef void (*fv_bucket_cb)(void* user, int bucket, int64_t offset, int64_t num
  * training/trainer.py:173-175, for an unfrozen backbone):
  *   tower_out (B, Ni, tower_out_dim) bf16 = the frozen tower's embeddings (fv_vision_forward's tower_out); ids (B, T) int32 right-padded,
  *   T % 8 == 0; lens (B); states (B, state_dim), targets (B, action_dim) f32; training / dropout as fv_head_forward.
- *   -> actions (B, action_dim) (normalised space), loss (1 f32, device), flat_grads (overwritten: every tensor of fv_train_layout).
+ *   -> actions (B, action_dim) (normalised space), loss (1 f32, device), flat_grads (overwritten: every tensor of fv_train_layout, TIMES the
+ *      loss scale of fv_train_set_options -- 2^12 by default).
  * ws: caller-owned scratch of fv_train_workspace_bytes(B, T) bytes (every activation the backward needs is kept there: no recompute).
  * Asynchronous on s; allocates nothing; gradients are bit-reproducible (no float atomics). */
 int fv_train_forward_backward(fv_handle* h, const float* flat_params, const void* tower_out, const int32_t* ids, const int32_t* lens,

@@ -136,7 +136,7 @@ def _inputs(model, B, T, seed):
 
 
 def _check_grads(eng, grads_flat, ref, tol=GRAD_TOL):
-    got = eng.train_named_tensors(grads_flat)
+    got = eng.train_named_tensors(grads_flat / eng.train_loss_scale())    # every gradient carries the loss scale (a power of two: the division is exact)
     assert set(got) == set(ref["grads"]), sorted(set(got) ^ set(ref["grads"]))[:8]
     worst = ("", 0.0)
     for k, g in got.items():
@@ -191,7 +191,7 @@ def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
     # one clip + AdamW step over ALL tensors (reference training/trainer.py:60-66,178-180), then the operand copies follow the master
     m, v, norm = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros(1, device=DEV)
     new = flat.clone()
-    eng.adamw_step(new, grads, m, v, 1, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0, grad_norm_out=norm)
+    eng.adamw_step(new, grads, m, v, 1, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0, grad_norm_out=norm, grad_scale=1.0 / eng.train_loss_scale())
     torch.cuda.synchronize()
     params = {k: w[k].float() for k in train_unfrozen.trainable_backbone_keys(w)}
     params.update({"head." + k: t for k, t in hp.items()})
@@ -238,27 +238,45 @@ def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
     eng.close()
 
 
-def test_plain_bf16_gradient_operands_are_a_labelled_speed_knob():
-    """fv_train_set_options(grad_split=0): the backward's gradient operands as their bf16 hi half alone (the usual mixed-precision recipe, half the
-    backward's MFMA work).  Same loss and actions (the forward is untouched); gradients a few 1e-3 from autograd -- printed, bounded at 8e-3, and
-    NOT inside the 2e-3 bar the default mode is held to, which is why it is an option and not the default."""
+def test_backward_arithmetic_options():
+    """fv_train_set_options: the default (split-bf16 dgrad operands, weight gradients in ONE fp16 pass, loss scale 2^12) against the two-pass
+    split-bf16 wgrad it replaced and against the plain-bf16 dgrad speed knob.  Same loss and actions in every mode (the forward is untouched);
+    the worst per-tensor gradient error of each mode is printed: the default must hold the 2e-3 bar WITH margin (<= 1e-3), the legacy wgrad holds
+    it barely (the activation operand's 8 bits), plain-bf16 dgrad operands do not (bounded at 8e-3: an option, never the default).  Another loss
+    scale gives the same gradients up to the fp16 rounding of the scaled operand, and no cast saturates."""
     model = arch.preset("small")
     B, T = 3, 16
     w, eng, tensors, total, nb, flat, lc, hp = _rig(model, 41, 64, B, T)
     tower_out, ids, mask, states, targets = _inputs(model, B, T, 42)
     ws = eng.train_workspace(B, T)
     ref = train_unfrozen.forward_backward(w, hp, tower_out.float(), ids, mask, states, targets, lc)
-    a1, l1, g1 = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
-    eng.train_set_options(grad_split=False)
-    a0, l0, g0 = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
-    torch.cuda.synchronize()
-    assert torch.equal(a0, a1) and torch.equal(l0, l1) and not torch.equal(g0, g1)
-    worst = _check_grads(eng, g0, ref, tol=8e-3)
-    print(f"[unfrozen small, plain-bf16 gradient operands] worst gradient: {worst[0]} {worst[1]:.2e} (split-bf16 mode: 1.8e-3)")
-    eng.train_set_options(grad_split=True)
-    _, _, g2 = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
-    torch.cuda.synchronize()
-    assert torch.equal(g2, g1)
+
+    def run():
+        a, l, g = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+        torch.cuda.synchronize()
+        return a, l, g
+
+    assert eng.train_loss_scale() == 4096.0
+    a1, l1, g1 = run()
+    worst_default = _check_grads(eng, g1, ref, tol=1e-3)
+    eng.train_set_options(grad_split=True, wgrad_f16=False)
+    a2, l2, g2 = run()
+    worst_legacy = _check_grads(eng, g2, ref, tol=GRAD_TOL)
+    eng.train_set_options(grad_split=False, wgrad_f16=True)
+    a3, l3, g3 = run()
+    worst_plain = _check_grads(eng, g3, ref, tol=8e-3)
+    eng.train_set_options(grad_split=True, wgrad_f16=True, loss_scale_log2=8)
+    a4, l4, g4 = run()
+    assert eng.train_loss_scale() == 256.0
+    worst_ls8 = _check_grads(eng, g4, ref, tol=1e-3)
+    print(f"[unfrozen small, backward arithmetic] worst gradient -- default (split dgrad + fp16 wgrad): {worst_default[0]} {worst_default[1]:.2e}; "
+          f"two-pass split-bf16 wgrad: {worst_legacy[1]:.2e}; plain-bf16 dgrad operands: {worst_plain[1]:.2e}; loss scale 2^8: {worst_ls8[1]:.2e}")
+    for a, l in ((a2, l2), (a3, l3), (a4, l4)):
+        assert torch.equal(a, a1) and torch.equal(l, l1)
+    assert eng.fp16_saturations() == 0
+    eng.train_set_options()
+    _, _, g5 = run()
+    assert torch.equal(g5, g1)
     eng.close()
 
 

@@ -24,7 +24,8 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-tower", action="store_true", help="reuse one tower output (times the trainable part alone)")
-    ap.add_argument("--grad-bf16", action="store_true", help="fv_train_set_options(grad_split=0): plain bf16 gradient operands (speed knob, outside the 2e-3 gradient bar)")
+    ap.add_argument("--grad-bf16", action="store_true", help="fv_train_set_options(grad_split=0): plain bf16 dgrad operands (speed knob, outside the 2e-3 gradient bar)")
+    ap.add_argument("--wgrad-bf16", action="store_true", help="fv_train_set_options(wgrad_f16=0): weight gradients as split-bf16 gradient x bf16 activation (two passes)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     model = arch.preset(args.model)
@@ -35,7 +36,7 @@ def main():
     else:
         eng.load_weights(weights.init_backbone(model, seed=1234))
     eng.train_begin()
-    eng.train_set_options(grad_split=not args.grad_bf16)
+    eng.train_set_options(grad_split=not args.grad_bf16, wgrad_f16=not args.wgrad_bf16)
     _, total, nb = eng.train_layout()
     flat = torch.zeros(total, device=dev)
     eng.train_export_params(flat)
@@ -56,7 +57,7 @@ def main():
         if st["tower_out"] is None or not args.no_tower:
             _, st["tower_out"] = eng.vision_forward(eng.preprocess(images), return_tower_out=True)
         _, loss, _ = eng.train_forward_backward(flat, st["tower_out"], ids, lens, states, targets, ws, training=True, dropout_p=0.1, seed=7, offset=st["n"], flat_grads=grads)
-        eng.adamw_step(flat, grads, m, v, st["n"], lr=1e-5, weight_decay=1e-4, max_grad_norm=1.0)
+        eng.adamw_step(flat, grads, m, v, st["n"], lr=1e-5, weight_decay=1e-4, max_grad_norm=1.0, grad_scale=1.0 / eng.train_loss_scale())
         eng.train_commit(flat)
         return loss
 
@@ -69,7 +70,7 @@ def main():
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
     print(json.dumps({"model": args.model, "batch": B, "tokens": model.tower.num_tokens + T, "ms_per_step": round(ms, 2), "loss": float(loss), "trainable_params": total,
-                      "buckets": nb, "tower_in_step": not args.no_tower, "grad_operands": "bf16 hi only" if args.grad_bf16 else "split bf16 (hi + lo)"}))
+                      "buckets": nb, "tower_in_step": not args.no_tower, "dgrad_operands": "bf16 hi only" if args.grad_bf16 else "split bf16 (hi + lo)", "wgrad": "split-bf16 x bf16, two passes" if args.wgrad_bf16 else "one fp16 pass"}))
 
 
 if __name__ == "__main__":

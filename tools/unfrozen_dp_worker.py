@@ -47,7 +47,7 @@ def main():
     mine = {k: v[rank * per:(rank + 1) * per] for k, v in batch.items()}
     out = pol.fused_train_step(mine, lr=1e-3, weight_decay=0.0)
     torch.cuda.synchronize()
-    torch.save({"grads": st.g.cpu() / world, "flat": st.flat.cpu(), "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
+    torch.save({"grads": st.g.cpu() / world / st.eng.train_loss_scale(), "flat": st.flat.cpu(), "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
                 "collectives": list(st.bucketed.launched), "world": world}, Path(args.out) / f"rank{rank}.pt")
     if world > 1:
         dist.barrier()

@@ -78,7 +78,9 @@ struct Tower {
 struct TrainLayerT { bf16_t *qkvT = nullptr, *oT = nullptr, *guT = nullptr, *downT = nullptr; };   // transposed weight copies (dgrad operands)
 struct TrainState {
   bool ready = false; std::vector<TrainLayerT> layers; bf16_t* pj2T = nullptr;
-  int grad_split = 1;   // 1: gradient operands of dgrad / wgrad as split bf16 (hi + lo; the parity mode), 0: their bf16 hi half alone (fv_train_set_options)
+  int grad_split = 1;   // 1: gradient operand of every dgrad as split bf16 (hi + lo; the parity mode), 0: its bf16 hi half alone (fv_train_set_options)
+  int wgrad_f16 = 1;    // 1: the weight gradients in ONE fp16 pass (both operands 11 significant bits, the gradient carrying the loss scale); 0: split-bf16 gradient x bf16 activation
+  int loss_scale_log2 = 12;   // every gradient the backward produces is multiplied by 2^this (the optimiser's grad_scale takes it out again): fp16's range for the wgrad operands
 };
 struct DecLayer {
   float* ln1 = nullptr; bf16_t* qkv_w = nullptr; float* qkv_b = nullptr; bf16_t* o_w = nullptr; float* ln2 = nullptr; bf16_t *gu_w = nullptr, *down_w = nullptr;

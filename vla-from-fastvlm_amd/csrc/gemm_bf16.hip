@@ -768,7 +768,7 @@ int gemm_glds_tile(const GemmArgs& a) {
   // take RAGGED edge tiles on the 256-tile kernel -- staging clamps rows past M / N, the epilogue drops them -- when the edge waste is
   // small: the register-staged kernel they fell to runs at ~0.45 PF against ~0.9 here
   static const bool no_ragged = fv_ab_env("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
-  if (!no_ragged && f32 && !a.f16 && a.N % 8 == 0) {
+  if (!no_ragged && f32 && a.N % 8 == 0) {
     const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
     const double fill = (double)a.M * a.N / ((double)tm * tn * 65536.0);
     if (tm * tn >= 128 && fill >= 0.75) return 256;
@@ -848,7 +848,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
   static const bool no_splitk = fv_ab_env("FASTVLA_NO_SPLITK") != nullptr, no_g256 = fv_ab_env("FASTVLA_NO_GEMM256") != nullptr;
   static const bool no_ragged_sk = fv_ab_env("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
-  if (!no_splitk && a.splitk_ws && f32out && !no_g256 && (a.M % 256 == 0 || (!no_ragged_sk && !a.f16 && a.N % 8 == 0)) && a.K % 64 == 0 && a.N % 4 == 0 &&
+  if (!no_splitk && a.splitk_ws && f32out && !no_g256 && (a.M % 256 == 0 || (!no_ragged_sk && a.N % 8 == 0)) && a.K % 64 == 0 && a.N % 4 == 0 &&
       (size_t)a.M * a.lda * 2 < ((size_t)1 << 32) && (size_t)a.N * a.K * 2 < ((size_t)1 << 32)) {
     const int tmr = (a.M + 255) / 256;            // a ragged last row tile: staging clamps its rows, the partial-sum stores skip them
     const int tn = (a.N + 255) / 256, tiles = tmr * tn, nkt = a.ksplit == 2 ? a.K / 64 + a.K / 128 : (a.ksplit ? 2 : 1) * (a.K / 64);

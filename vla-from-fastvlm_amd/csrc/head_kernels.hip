@@ -157,13 +157,13 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict_
 
 // single block: loss = mean((a-t)^2), g = 2 (a-t) / (B*A)
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ t,
-                                                   float* __restrict__ loss, float* __restrict__ g, int n) {
+                                                   float* __restrict__ loss, float* __restrict__ g, int n, float loss_scale) {
   __shared__ float red[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) {
     const float d = a[i] - t[i];
     s += d * d;
-    g[i] = 2.0f * d / (float)n;
+    g[i] = loss_scale * 2.0f * d / (float)n;   // loss_scale (a power of two, 1 by default) scales every gradient downstream; the loss itself is not scaled
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -343,7 +343,7 @@ int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, 
 
 int launch_head_backward(const HeadDims& d, const float* P, const float* grad_actions, const float* actions,
                          const float* targets, int B, float drop_p, const float* saved, float* loss, float* G,
-                         float* scratch, hipStream_t s, float* d_pooled) {
+                         float* scratch, hipStream_t s, float* d_pooled, float loss_scale) {
   if (!P || !saved || !G || !scratch) return fv_fail(FV_ERR_ARG, "head_backward: null pointer");
   if (!grad_actions && (!actions || !targets || !loss)) return fv_fail(FV_ERR_ARG, "head_backward: need grad_actions or (actions, targets, loss)");
   if (B <= 0) return fv_fail(FV_ERR_ARG, "head_backward: B must be positive");
@@ -359,7 +359,7 @@ int launch_head_backward(const HeadDims& d, const float* P, const float* grad_ac
   const unsigned b8 = cdiv(B, 8);
   const float* ga = grad_actions;
   if (!ga) {
-    hipLaunchKernelGGL(mse_kernel, dim3(1), blk, 0, s, actions, targets, loss, ga_own, B * d.da);
+    hipLaunchKernelGGL(mse_kernel, dim3(1), blk, 0, s, actions, targets, loss, ga_own, B * d.da, loss_scale);
     ga = ga_own;
   }
   // action_head

@@ -121,6 +121,8 @@ int launch_lo8_rows(const float* in, int ldi, bf16_t* out, int ldo, long R, int 
 int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
 int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, int ldo, int lo_off, int R, int Rp, int C, hipStream_t s);
+// the same transpose to fp16 (saturating; clamps counted in *sat): in_kind 0 = fp32, 1 = bf16, 2 = split bf16 (value = in[c] + in[lo_in + c]: both halves summed before rounding)
+int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, int R, int Rp, int C, unsigned* sat, hipStream_t s);
 int launch_swiglu_fwd(const float* gu, bf16_t* act, int ldo, int lo_off, long rows, int I, hipStream_t s);
 int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s, bf16_t* out_split = nullptr);   // out_split: [rows][4I] = [hi | lo] bf16 instead of fp32 in place
 int launch_gelu_fwd(const float* pre, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);
@@ -152,7 +154,7 @@ int launch_head_forward(const HeadDims& d, const float* P, const float* pooled, 
 // d_pooled (optional, [B][feat]): dL/d(pooled feature) -- the gradient an UNFROZEN backbone continues from
 int launch_head_backward(const HeadDims& d, const float* P, const float* grad_actions, const float* actions,
                          const float* targets, int B, float drop_p, const float* saved, float* loss, float* G,
-                         float* scratch, hipStream_t s, float* d_pooled = nullptr);
+                         float* scratch, hipStream_t s, float* d_pooled = nullptr, float loss_scale = 1.0f);   // loss_scale: the fused MSE's dL/dactions times a power of two
 size_t head_bwd_scratch_bytes(const HeadDims& d, int B);
 size_t adamw_scratch_bytes();  // norm_scratch of launch_adamw_clip: [0] = sum of squares, [1..] per-block partials
 int launch_axpy(float* y, const float* x, int64_t n, const float* scale_dev, hipStream_t s);  // y += x, or y *= *scale_dev when x is null

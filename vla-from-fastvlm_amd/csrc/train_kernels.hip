@@ -117,6 +117,46 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ 
   }
 }
 
+// the same tile transpose with fp16 output (11 significant bits: the wgrad operands): KIND 0 = fp32 input, 1 = bf16, 2 = split bf16 whose halves
+// (lo_in columns apart) are summed before the one rounding; saturating casts, clamps counted
+template <int KIND>
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const void* __restrict__ in_v, int ldi, int lo_in, bf16_t* __restrict__ out, int ldo, int R, int Rp, int C,
+                                                             unsigned* __restrict__ sat) {
+  __shared__ float tile[TP][TP + 1];
+  const int r0 = blockIdx.x * TP, c0 = blockIdx.y * TP, tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int r = (tid >> 3) + 32 * k, c = (tid & 7) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r0 + r < R && c0 + c < C) {
+      if constexpr (KIND == 0) load8(static_cast<const float*>(in_v) + (size_t)(r0 + r) * ldi + c0 + c, v);
+      else {
+        const bf16_t* p = static_cast<const bf16_t*>(in_v) + (size_t)(r0 + r) * ldi + c0 + c;
+        unpack8(*reinterpret_cast<const uint4*>(p), v);
+        if constexpr (KIND == 2) {
+          float l[8];
+          unpack8(*reinterpret_cast<const uint4*>(p + lo_in), l);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += l[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r][c + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = (tid >> 3) + 32 * k, r = (tid & 7) * 8;
+    if (c0 + c >= C || r0 + r >= Rp) continue;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[r + e][c];
+    count_f16_sat8(v, sat);
+    *reinterpret_cast<uint4*>(out + (size_t)(c0 + c) * ldo + r0 + r) = pack8_h(v);
+  }
+}
+
 // SwiGLU on the gate/up accumulators.  gu fp32 [rows][2I], columns in the packed weight's order: 16-column groups [8 gate | 8 up]
 // of the outputs 8j .. 8j+7.  act = silu(gate) * up as split bf16: [rows][ldo] with hi at column i, lo at lo_off + i.
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const float* __restrict__ gu, bf16_t* __restrict__ act, int ldo, int lo_off, long rows, int I) {
@@ -671,6 +711,18 @@ int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, 
   const dim3 g((Rp + TP - 1) / TP, (C + TP - 1) / TP);
   if (in_bf16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, g, dim3(256), 0, s, static_cast<const bf16_t*>(in), ldi, out, ldo, 0, R, Rp, C);
   else hipLaunchKernelGGL(transpose_kernel<float>, g, dim3(256), 0, s, static_cast<const float*>(in), ldi, out, ldo, lo_off, R, Rp, C);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, int R, int Rp, int C, unsigned* sat, hipStream_t s) {
+  if (!in || !out) return fv_fail(FV_ERR_ARG, "transpose_f16: null pointer");
+  if (R <= 0 || C <= 0 || C % 8 || Rp < R || Rp % 8 || ldi < C || ldi % (in_kind ? 8 : 4) || ldo % 8 || ldo < Rp || in_kind < 0 || in_kind > 2 || (in_kind == 2 && (lo_in % 8 || lo_in < C)))
+    return fv_fail(FV_ERR_ARG, "transpose_f16: bad shape R=%d Rp=%d C=%d ldi=%d ldo=%d kind=%d", R, Rp, C, ldi, ldo, in_kind);
+  const dim3 g((Rp + TP - 1) / TP, (C + TP - 1) / TP);
+  if (in_kind == 0) hipLaunchKernelGGL(transpose_f16_kernel<0>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
+  else if (in_kind == 1) hipLaunchKernelGGL(transpose_f16_kernel<1>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
+  else hipLaunchKernelGGL(transpose_f16_kernel<2>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

@@ -466,9 +466,16 @@ class FastVLAEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fv_train_begin(self.h), "fv_train_begin", self.h)
 
-    def train_set_options(self, grad_split: bool = True) -> None:
-        """grad_split=False: the backward's gradient operands as plain bf16 (half its MFMA work, ~3e-3 gradients: an explicit speed knob)."""
-        _lib.check(self.lib.fv_train_set_options(self.h, int(bool(grad_split))), "fv_train_set_options", self.h)
+    def train_set_options(self, grad_split: bool = True, wgrad_f16: bool = True, loss_scale_log2: int = 12) -> None:
+        """Arithmetic of the backward's contractions (fv_train_set_options).  grad_split=False: dgrad gradient operands as plain bf16 (speed knob,
+        ~3e-3 gradients); wgrad_f16=False: weight gradients as split-bf16 gradient x bf16 activation (two passes) instead of ONE fp16 pass;
+        loss_scale_log2: every gradient of train_forward_backward carries 2^k (train_loss_scale()): divide it out in the optimiser's grad_scale."""
+        _lib.check(self.lib.fv_train_set_options(self.h, int(bool(grad_split)), int(bool(wgrad_f16)), int(loss_scale_log2)), "fv_train_set_options", self.h)
+
+    def train_loss_scale(self) -> float:
+        v = C.c_float()
+        _lib.check(self.lib.fv_train_loss_scale(self.h, C.byref(v)), "fv_train_loss_scale", self.h)
+        return float(v.value)
 
     def train_layout(self):
         """-> (tensors, total_numel, n_buckets): every trainable tensor of the ONE flat fp32 buffer, in order: dicts with name, offset,
@@ -526,7 +533,7 @@ class FastVLAEngine:
                                flat_grads: Optional[torch.Tensor] = None, bucket_cb=None):
         """One step's forward + MSE + backward over every trainable tensor (fv_train_forward_backward).  tower_out: (B, Ni, tower_out_dim)
         bf16 from vision_forward(..., return_tower_out=True).  bucket_cb(bucket, offset, numel) is called when a bucket's gradient has
-        been enqueued completely.  -> (actions (B, A) in normalised space, loss (1,), flat_grads)."""
+        been enqueued completely.  -> (actions (B, A) in normalised space, loss (1,), flat_grads TIMES train_loss_scale())."""
         B, T = ids.shape
         ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
         lens = lens.to(device=self.device, dtype=torch.int32).contiguous()

@@ -134,6 +134,7 @@ class UnfrozenState:
                 self.whole.finish(eng.device)
             self.step_count += 1
             self.micro = 0
+            scale /= eng.train_loss_scale()      # every gradient of fv_train_forward_backward carries the loss scale (2^12 by default)
             eng.adamw_step(self.flat, total, self.m, self.v, self.step_count, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                            max_grad_norm=max_grad_norm or 0.0, grad_scale=scale, grad_norm_out=self.norm)
             eng.train_commit(self.flat)       # bf16 operand copies (and their transposes) follow the master
