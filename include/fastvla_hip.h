@@ -254,10 +254,13 @@ int fv_train_export_params(fv_handle* h, float* flat_params, fv_stream s);
 /* the library's MFMA operand copies <- the master, after an optimiser step: bf16 weights (RNE), their transposes, fp32 norms / biases.
  * The frozen-path entry points (fv_llm_forward_pooled, ...) see the updated weights from then on. */
 int fv_train_commit(fv_handle* h, const float* flat_params, fv_stream s);
-/* Arithmetic of the backward's contractions (defaults 1, 1, 12):
+/* Arithmetic of the backward's contractions (defaults 2, 1, 12: every dgrad and wgrad ONE fp16 pass -- worst per-tensor gradient 6.2e-4 from fp32 autograd
+ * through the whole 24-layer 0.5B decoder, 5.8e-4 at the 7B width):
  *   grad_split 1: the gradient operand of every dgrad GEMM is split bf16 (hi + lo, 16 significant bits) against the exact-bf16 transposed weights;
  *              0: its bf16 hi half alone (the usual mixed-precision recipe: half the dgrad work, gradients ~3e-3 from fp32 -- outside this repo's
- *                 2e-3 gradient bar; an explicit speed knob).
+ *                 2e-3 gradient bar; an explicit speed knob);
+ *              2: ONE fp16 pass -- the loss-scaled gradient rounded once to 11 significant bits against an fp16 copy of the transposed weight (exact:
+ *                 bf16 widens into fp16): the same single pass as 0 at 8x its precision.
  *   wgrad_f16  1: every weight gradient in ONE fp16 pass -- the gradient and the activation each rounded once to 11 significant bits;
  *              0: the split-bf16 gradient against the activation's bf16 hi half (two passes; the activation's 8 bits bound the result at ~1.8e-3).
  *   loss_scale_log2: dL/dactions is multiplied by 2^k, so EVERY gradient fv_train_forward_backward writes carries that factor (it keeps the wgrad's

@@ -156,13 +156,16 @@ def _check_grads(eng, grads_flat, ref, tol=GRAD_TOL):
 @pytest.mark.parametrize("name,llm,tower,B,T,hd", [
     ("small", None, "small", 3, 16, 64),
     ("0.5b-width-4-layers", arch.LLMConfig(hidden=896, layers=4, heads=14, kv_heads=2, head_dim=64, inter=4864, vocab=8192), "tiny", 4, 32, 128),
+    # the WHOLE FastVLM-0.5B decoder (24 layers, 151936-row embedding) behind the real tower's 256 image tokens: the gradient error through the full depth
+    ("0.5b-full-depth", arch.preset("fastvlm-0.5b").llm, "full", 2, 8, 256),
     # FastVLM-7B's decoder geometry at full width (C5's model): head_dim 128 through the attention backward, GQA group 7, K = 18944 contractions
     ("7b-width-2-layers", arch.LLMConfig(hidden=3584, layers=2, heads=28, kv_heads=4, head_dim=128, inter=18944, vocab=4096), "tiny", 2, 16, 128),
 ])
 def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a HIP device")
-    model = arch.preset("small") if llm is None else arch.ModelConfig(name, llm, arch.preset(tower).tower)
+    model = arch.preset("small") if llm is None else arch.ModelConfig(name, llm, arch.preset("fastvlm-0.5b" if tower == "full" else tower).tower)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
     w, eng, tensors, total, nb, flat, lc, hp = _rig(model, 41, hd, B, T)
     tower_out, ids, mask, states, targets = _inputs(model, B, T, 42)
     # the exported master equals the weights the engine packed (bf16 matrices widen exactly)
@@ -176,8 +179,15 @@ def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
     torch.cuda.synchronize()
     ref = train_unfrozen.forward_backward(w, hp, tower_out.float(), ids, mask, states, targets, lc)
     ra, rl = rel_l2(act.cpu(), ref["pred"]), abs(float(loss) - float(ref["loss"])) / float(ref["loss"])
-    worst = _check_grads(eng, grads, ref)
+    worst = _check_grads(eng, grads, ref, tol=1e-3)    # the bar is 2e-3; the default arithmetic holds it with >= 2x margin at every size tested
     print(f"[unfrozen {name}] B={B} T={T} actions rel_l2={ra:.2e} loss rel={rl:.2e} worst gradient: {worst[0]} {worst[1]:.2e} ({len(ref['grads'])} tensors)")
+    if name in ("0.5b-full-depth", "7b-width-2-layers"):   # the split-bf16 dgrad (two passes) through the full depth / at the 7B width, for the record
+        eng.train_set_options(grad_split=1)
+        _, _, g1s = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+        torch.cuda.synchronize()
+        w1s = _check_grads(eng, g1s, ref, tol=GRAD_TOL)
+        print(f"[unfrozen {name}] split-bf16 dgrad operands: worst gradient {w1s[0]} {w1s[1]:.2e}")
+        eng.train_set_options()
     assert ra <= 1e-3 and rl <= 1e-3
     # buckets: head first, then final norm, layers last to first, embedding, projector; together they tile the flat buffer exactly once
     L = model.llm.layers
@@ -239,7 +249,7 @@ def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
 
 
 def test_backward_arithmetic_options():
-    """fv_train_set_options: the default (split-bf16 dgrad operands, weight gradients in ONE fp16 pass, loss scale 2^12) against the two-pass
+    """fv_train_set_options: the default (dgrad and wgrad each ONE fp16 pass, loss scale 2^12) against the two-pass
     split-bf16 wgrad it replaced and against the plain-bf16 dgrad speed knob.  Same loss and actions in every mode (the forward is untouched);
     the worst per-tensor gradient error of each mode is printed: the default must hold the 2e-3 bar WITH margin (<= 1e-3), the legacy wgrad holds
     it barely (the activation operand's 8 bits), plain-bf16 dgrad operands do not (bounded at 8e-3: an option, never the default).  Another loss
@@ -257,20 +267,25 @@ def test_backward_arithmetic_options():
         return a, l, g
 
     assert eng.train_loss_scale() == 4096.0
-    a1, l1, g1 = run()
+    a1, l1, g1 = run()                                     # default: dgrad and wgrad each ONE fp16 pass
     worst_default = _check_grads(eng, g1, ref, tol=1e-3)
-    eng.train_set_options(grad_split=True, wgrad_f16=False)
+    eng.train_set_options(grad_split=1, wgrad_f16=True)    # split-bf16 dgrad operands (two passes): the most exact form
+    a6, l6, g6 = run()
+    worst_split = _check_grads(eng, g6, ref, tol=1e-3)
+    assert torch.equal(a6, a1) and torch.equal(l6, l1)
+    eng.train_set_options(grad_split=1, wgrad_f16=False)   # round 4's first form: split-bf16 gradient x bf16 activation for the weight gradients
     a2, l2, g2 = run()
     worst_legacy = _check_grads(eng, g2, ref, tol=GRAD_TOL)
-    eng.train_set_options(grad_split=False, wgrad_f16=True)
+    eng.train_set_options(grad_split=0, wgrad_f16=True)    # plain-bf16 dgrad operands: one pass at 8 bits
     a3, l3, g3 = run()
     worst_plain = _check_grads(eng, g3, ref, tol=8e-3)
-    eng.train_set_options(grad_split=True, wgrad_f16=True, loss_scale_log2=8)
+    eng.train_set_options(loss_scale_log2=8)
     a4, l4, g4 = run()
     assert eng.train_loss_scale() == 256.0
     worst_ls8 = _check_grads(eng, g4, ref, tol=1e-3)
-    print(f"[unfrozen small, backward arithmetic] worst gradient -- default (split dgrad + fp16 wgrad): {worst_default[0]} {worst_default[1]:.2e}; "
-          f"two-pass split-bf16 wgrad: {worst_legacy[1]:.2e}; plain-bf16 dgrad operands: {worst_plain[1]:.2e}; loss scale 2^8: {worst_ls8[1]:.2e}")
+    print(f"[unfrozen small, backward arithmetic] worst gradient -- default (fp16 dgrad + fp16 wgrad, one pass each): {worst_default[0]} {worst_default[1]:.2e}; "
+          f"split-bf16 dgrad: {worst_split[1]:.2e}; + two-pass split-bf16 wgrad: {worst_legacy[1]:.2e}; plain-bf16 dgrad operands: {worst_plain[1]:.2e}; "
+          f"loss scale 2^8: {worst_ls8[1]:.2e}")
     for a, l in ((a2, l2), (a3, l3), (a4, l4)):
         assert torch.equal(a, a1) and torch.equal(l, l1)
     assert eng.fp16_saturations() == 0

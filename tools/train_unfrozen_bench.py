@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-tower", action="store_true", help="reuse one tower output (times the trainable part alone)")
     ap.add_argument("--grad-bf16", action="store_true", help="fv_train_set_options(grad_split=0): plain bf16 dgrad operands (speed knob, outside the 2e-3 gradient bar)")
+    ap.add_argument("--dgrad-split", action="store_true", help="fv_train_set_options(grad_split=1): split-bf16 dgrad operands (two passes) instead of ONE fp16 pass")
     ap.add_argument("--wgrad-bf16", action="store_true", help="fv_train_set_options(wgrad_f16=0): weight gradients as split-bf16 gradient x bf16 activation (two passes)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -36,7 +37,7 @@ def main():
     else:
         eng.load_weights(weights.init_backbone(model, seed=1234))
     eng.train_begin()
-    eng.train_set_options(grad_split=not args.grad_bf16, wgrad_f16=not args.wgrad_bf16)
+    eng.train_set_options(grad_split=1 if args.dgrad_split else (0 if args.grad_bf16 else 2), wgrad_f16=not args.wgrad_bf16)
     _, total, nb = eng.train_layout()
     flat = torch.zeros(total, device=dev)
     eng.train_export_params(flat)
@@ -70,7 +71,7 @@ def main():
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
     print(json.dumps({"model": args.model, "batch": B, "tokens": model.tower.num_tokens + T, "ms_per_step": round(ms, 2), "loss": float(loss), "trainable_params": total,
-                      "buckets": nb, "tower_in_step": not args.no_tower, "dgrad_operands": "bf16 hi only" if args.grad_bf16 else "split bf16 (hi + lo)", "wgrad": "split-bf16 x bf16, two passes" if args.wgrad_bf16 else "one fp16 pass"}))
+                      "buckets": nb, "tower_in_step": not args.no_tower, "dgrad_operands": "split bf16 (hi + lo)" if args.dgrad_split else ("bf16 hi only" if args.grad_bf16 else "fp16, one pass"), "wgrad": "split-bf16 x bf16, two passes" if args.wgrad_bf16 else "one fp16 pass"}))
 
 
 if __name__ == "__main__":

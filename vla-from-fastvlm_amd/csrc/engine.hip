@@ -75,10 +75,13 @@ struct Tower {
   float *exp_w = nullptr, *exp_b = nullptr, *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr, *se_b2 = nullptr;
   bf16_t *pj0_w = nullptr, *pj2_w = nullptr; float *pj0_b = nullptr, *pj2_b = nullptr;
 };
-struct TrainLayerT { bf16_t *qkvT = nullptr, *oT = nullptr, *guT = nullptr, *downT = nullptr; };   // transposed weight copies (dgrad operands)
+struct TrainLayerT {   // transposed weight copies (dgrad operands): bf16, and fp16 for the one-pass fp16 dgrad
+  bf16_t *qkvT = nullptr, *oT = nullptr, *guT = nullptr, *downT = nullptr;
+  bf16_t *qkvT16 = nullptr, *oT16 = nullptr, *guT16 = nullptr, *downT16 = nullptr;
+};
 struct TrainState {
-  bool ready = false; std::vector<TrainLayerT> layers; bf16_t* pj2T = nullptr;
-  int grad_split = 1;   // 1: gradient operand of every dgrad as split bf16 (hi + lo; the parity mode), 0: its bf16 hi half alone (fv_train_set_options)
+  bool ready = false; std::vector<TrainLayerT> layers; bf16_t *pj2T = nullptr, *pj2T16 = nullptr;
+  int grad_split = 2;   // dgrad's gradient operand: 1 split bf16 (hi + lo, two passes), 0 its bf16 hi half alone, 2 ONE fp16 pass against fp16 transposed weights (fv_train_set_options)
   int wgrad_f16 = 1;    // 1: the weight gradients in ONE fp16 pass (both operands 11 significant bits, the gradient carrying the loss scale); 0: split-bf16 gradient x bf16 activation
   int loss_scale_log2 = 12;   // every gradient the backward produces is multiplied by 2^this (the optimiser's grad_scale takes it out again): fp16's range for the wgrad operands
 };

@@ -123,6 +123,7 @@ int launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
 int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, int ldo, int lo_off, int R, int Rp, int C, hipStream_t s);
 // the same transpose to fp16 (saturating; clamps counted in *sat): in_kind 0 = fp32, 1 = bf16, 2 = split bf16 (value = in[c] + in[lo_in + c]: both halves summed before rounding)
 int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, int R, int Rp, int C, unsigned* sat, hipStream_t s);
+int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, long R, int C, unsigned* sat, hipStream_t s);   // row-major fp16 rows (in_kind as above)
 int launch_swiglu_fwd(const float* gu, bf16_t* act, int ldo, int lo_off, long rows, int I, hipStream_t s);
 int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s, bf16_t* out_split = nullptr);   // out_split: [rows][4I] = [hi | lo] bf16 instead of fp32 in place
 int launch_gelu_fwd(const float* pre, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);

@@ -157,6 +157,31 @@ __global__ __launch_bounds__(256) void transpose_f16_kernel(const void* __restri
   }
 }
 
+// rows -> fp16 rows (the dgrad's gradient operand in its one-pass fp16 form): KIND as transpose_f16_kernel; saturating, clamps counted
+template <int KIND>
+__global__ __launch_bounds__(256) void rows_f16_kernel(const void* __restrict__ in_v, int ldi, int lo_in, bf16_t* __restrict__ out, int ldo, long R, int C,
+                                                        unsigned* __restrict__ sat) {
+  const int c8 = C >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < R * c8; i += (long)gridDim.x * 256) {
+    const long r = i / c8;
+    const int c = (int)(i % c8) * 8;
+    float v[8];
+    if constexpr (KIND == 0) load8(static_cast<const float*>(in_v) + r * ldi + c, v);
+    else {
+      const bf16_t* p = static_cast<const bf16_t*>(in_v) + r * ldi + c;
+      unpack8(*reinterpret_cast<const uint4*>(p), v);
+      if constexpr (KIND == 2) {
+        float l[8];
+        unpack8(*reinterpret_cast<const uint4*>(p + lo_in), l);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += l[e];
+      }
+    }
+    count_f16_sat8(v, sat);
+    *reinterpret_cast<uint4*>(out + r * ldo + c) = pack8_h(v);
+  }
+}
+
 // SwiGLU on the gate/up accumulators.  gu fp32 [rows][2I], columns in the packed weight's order: 16-column groups [8 gate | 8 up]
 // of the outputs 8j .. 8j+7.  act = silu(gate) * up as split bf16: [rows][ldo] with hi at column i, lo at lo_off + i.
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const float* __restrict__ gu, bf16_t* __restrict__ act, int ldo, int lo_off, long rows, int I) {
@@ -723,6 +748,17 @@ int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf1
   if (in_kind == 0) hipLaunchKernelGGL(transpose_f16_kernel<0>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
   else if (in_kind == 1) hipLaunchKernelGGL(transpose_f16_kernel<1>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
   else hipLaunchKernelGGL(transpose_f16_kernel<2>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, long R, int C, unsigned* sat, hipStream_t s) {
+  if (!in || !out || R <= 0 || C <= 0 || C % 8 || ldi < C || ldi % (in_kind ? 8 : 4) || ldo % 8 || ldo < C || in_kind < 0 || in_kind > 2 || (in_kind == 2 && (lo_in % 8 || lo_in < C)))
+    return fv_fail(FV_ERR_ARG, "rows_to_f16: bad arguments");
+  const dim3 g(grid_for(R * (C / 8)));
+  if (in_kind == 0) hipLaunchKernelGGL(rows_f16_kernel<0>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, C, sat);
+  else if (in_kind == 1) hipLaunchKernelGGL(rows_f16_kernel<1>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, C, sat);
+  else hipLaunchKernelGGL(rows_f16_kernel<2>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, C, sat);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

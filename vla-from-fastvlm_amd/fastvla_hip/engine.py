@@ -466,11 +466,23 @@ class FastVLAEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fv_train_begin(self.h), "fv_train_begin", self.h)
 
-    def train_set_options(self, grad_split: bool = True, wgrad_f16: bool = True, loss_scale_log2: int = 12) -> None:
-        """Arithmetic of the backward's contractions (fv_train_set_options).  grad_split=False: dgrad gradient operands as plain bf16 (speed knob,
-        ~3e-3 gradients); wgrad_f16=False: weight gradients as split-bf16 gradient x bf16 activation (two passes) instead of ONE fp16 pass;
-        loss_scale_log2: every gradient of train_forward_backward carries 2^k (train_loss_scale()): divide it out in the optimiser's grad_scale."""
-        _lib.check(self.lib.fv_train_set_options(self.h, int(bool(grad_split)), int(bool(wgrad_f16)), int(loss_scale_log2)), "fv_train_set_options", self.h)
+    _TRAIN_OPTION_DEFAULTS = {"grad_split": 2, "wgrad_f16": True, "loss_scale_log2": 12}
+
+    def train_set_options(self, grad_split: Optional[int] = None, wgrad_f16: Optional[bool] = None, loss_scale_log2: Optional[int] = None,
+                          keep: bool = False) -> None:
+        """Arithmetic of the backward's contractions (fv_train_set_options).  grad_split: dgrad's gradient operand -- 2 (default) ONE fp16 pass against
+        fp16 transposed weights, 1 split bf16 (two passes, the most exact), 0 plain bf16 (one pass at 8 bits: ~3e-3 gradients, outside the bar);
+        wgrad_f16=False: weight gradients as split-bf16 gradient x bf16 activation (two passes) instead of ONE fp16 pass;
+        loss_scale_log2: every gradient of train_forward_backward carries 2^k (train_loss_scale()): divide it out in the optimiser's grad_scale.
+        An argument left None takes its default -- or, with keep=True, the value of the previous call (to change one knob only)."""
+        base = getattr(self, "_train_options", None) if keep else None
+        opts = dict(base or self._TRAIN_OPTION_DEFAULTS)
+        for k, v in (("grad_split", grad_split), ("wgrad_f16", wgrad_f16), ("loss_scale_log2", loss_scale_log2)):
+            if v is not None:
+                opts[k] = v
+        _lib.check(self.lib.fv_train_set_options(self.h, int(opts["grad_split"]), int(bool(opts["wgrad_f16"])), int(opts["loss_scale_log2"])),
+                   "fv_train_set_options", self.h)
+        self._train_options = opts
 
     def train_loss_scale(self) -> float:
         v = C.c_float()

@@ -53,6 +53,8 @@ class UnfrozenState:
         self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         self.step_count, self.micro = 0, 0
         self.norm = torch.zeros(1, device=dev)
+        self.loss_scale_log2 = 12
+        self.saturation_check_every = 50
         self.bucketed = BucketedGradExchange(dev, min_numel=bucket_min_numel)
         self.whole = GradExchange(dev)
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -139,5 +141,14 @@ class UnfrozenState:
                            max_grad_norm=max_grad_norm or 0.0, grad_scale=scale, grad_norm_out=self.norm)
             eng.train_commit(self.flat)       # bf16 operand copies (and their transposes) follow the master
             pol._opt_state["step"] = self.step_count
+            if self.step_count % self.saturation_check_every == 0:
+                # the backward's fp16 operands carry the gradient x 2^loss_scale: a clamp means the scale is too large for this model / loss
+                # -- say so and halve it (every 50 optimiser steps: the read synchronises)
+                n = eng.fp16_saturations(reset=True)
+                if n and self.loss_scale_log2 > 0:
+                    import warnings
+                    self.loss_scale_log2 -= 1
+                    eng.train_set_options(loss_scale_log2=self.loss_scale_log2, keep=True)
+                    warnings.warn(f"{n} fp16 gradient-operand groups saturated in the last {self.saturation_check_every} steps: loss scale lowered to 2^{self.loss_scale_log2}")
         out["grad_norm"] = self.norm[0]
         return out
