@@ -33,6 +33,7 @@ struct Params {
   int tiles_m = 0;
   const uint8_t* W8 = nullptr;   // ksplit == 2: fp8 copy of W (x 2^6), row stride 2K bytes
   unsigned* sat = nullptr;   // FV_EPI_SWIGLU_F16: device counter of 8-value groups clamped to the fp16 range (0 in a healthy model)
+  float* stash = nullptr;    // FV_EPI_SWIGLU_SPLIT: raw fp32 gate/up accumulators, [M][N]
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
@@ -209,6 +210,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = silu_f(src[e]) * src[8 + e];
+        if (p.stash) {
+          float* sp = p.stash + (size_t)gm * p.N + gn;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sp + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
+        }
         if (epi == FV_EPI_SWIGLU_F16) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] *= 0.0625f;
@@ -541,9 +547,15 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
         const int row = lane >> 2, pr = lane & 3;
         const int gm = bm + wr * (16 * MI) + i * 16 + row, go = (bn + wc * 64 + pr * 16) >> 1;
         const float* src = reinterpret_cast<const float*>(so + row * ORB) + pr * 16;
+        if (gm >= p.M) { asm volatile("" ::: "memory"); continue; }   // ragged last row tile (the unfrozen training path's row counts)
         float o8[8], h8[8], l8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o8[e] = silu_f(src[e]) * src[8 + e];
+        if (p.stash) {
+          float* sp = p.stash + (size_t)gm * p.N + (bn + wc * 64 + pr * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sp + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
+        }
         if (p.epi == FV_EPI_SWIGLU_F16) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) o8[e] *= 0.0625f;
@@ -768,7 +780,7 @@ int gemm_glds_tile(const GemmArgs& a) {
   // take RAGGED edge tiles on the 256-tile kernel -- staging clamps rows past M / N, the epilogue drops them -- when the edge waste is
   // small: the register-staged kernel they fell to runs at ~0.45 PF against ~0.9 here
   static const bool no_ragged = fv_ab_env("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
-  if (!no_ragged && f32 && a.N % 8 == 0) {
+  if (!no_ragged && ((f32 && a.N % 8 == 0) || (a.epi == FV_EPI_SWIGLU_SPLIT && a.N % 256 == 0))) {   // (SwiGLU: ragged rows only)
     const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
     const double fill = (double)a.M * a.N / ((double)tm * tn * 65536.0);
     if (tm * tn >= 128 && fill >= 0.75) return 256;
@@ -823,6 +835,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi;
   p.ksplit = a.ksplit == 2 ? 2 : (a.ksplit ? 1 : 0);
   p.sat = a.sat;
+  p.stash = a.stash;
+  if (a.stash && (a.epi != FV_EPI_SWIGLU_SPLIT || ((uintptr_t)a.stash & 15))) return fv_fail(FV_ERR_ARG, "gemm: stash goes with FV_EPI_SWIGLU_SPLIT (16-byte aligned)");
   p.W8 = static_cast<const uint8_t*>(a.W8);
   if (a.ksplit == 2) {
     if (!a.W8 || a.K % 128 || a.lda * 2 < 3 * a.K || ((uintptr_t)a.W8 & 15)) return fv_fail(FV_ERR_ARG, "gemm: the hi + lo8 form needs W8, K %% 128 == 0 and lda >= 1.5 K");

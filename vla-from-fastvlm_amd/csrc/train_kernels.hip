@@ -242,6 +242,52 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(float* __restrict__ gu,
   }
 }
 
+// The same backward with BOTH of its consumers' operands written directly (the one-pass fp16 arithmetic, fv_train_set_options defaults): dgu as fp16
+// rows [rows][2I] (the dgrad's A operand) and as fp16 columns outT [2I][Rp] (the wgrad's, rows in [rows, Rp) zero) -- no fp32 or split copy of
+// dgu, no separate rounding and transposing passes.  A block owns 64 rows x 64 dgu columns (4 [8 gate | 8 up] groups); thread -> (row tid / 4,
+// group tid % 4) on the way in, (column tid / 8 + 32 k, 8 rows) on the way out through a 64 x 64 fp32 LDS tile.
+__global__ __launch_bounds__(256) void swiglu_bwd_f16_kernel(const float* __restrict__ gu, const float* __restrict__ dact, int rows, int Rp, int I,
+                                                              bf16_t* __restrict__ out_rows, bf16_t* __restrict__ outT, unsigned* __restrict__ sat) {
+  __shared__ float tile[TP][TP + 1];
+  const int r0 = blockIdx.x * TP, c0 = blockIdx.y * TP, tid = threadIdx.x, C = 2 * I;
+  {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    float dg[8], du[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dg[e] = du[e] = 0.f;
+    if (r0 + r < rows && c0 + c < C) {
+      float g[8], u[8], d[8];
+      const float* gp = gu + (size_t)(r0 + r) * C + c0 + c;
+      load8(gp, g);
+      load8(gp + 8, u);
+      load8(dact + (size_t)(r0 + r) * I + ((c0 + c) >> 1), d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sg = 1.0f / (1.0f + __expf(-g[e]));
+        dg[e] = d[e] * u[e] * sg * (1.0f + g[e] * (1.0f - sg));
+        du[e] = d[e] * g[e] * sg;
+      }
+      count_f16_sat8(dg, sat);
+      count_f16_sat8(du, sat);
+      bf16_t* op = out_rows + (size_t)(r0 + r) * C + c0 + c;
+      *reinterpret_cast<uint4*>(op) = pack8_h(dg);
+      *reinterpret_cast<uint4*>(op + 8) = pack8_h(du);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { tile[r][c + e] = dg[e]; tile[r][c + 8 + e] = du[e]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = (tid >> 3) + 32 * k, r = (tid & 7) * 8;
+    if (c0 + c >= C || r0 + r >= Rp) continue;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[r + e][c];
+    *reinterpret_cast<uint4*>(outT + (size_t)(c0 + c) * Rp + r0 + r) = pack8_h(v);
+  }
+}
+
 // exact-erf GELU (nn.GELU default; [site] fast_vlm/modeling_fast_vlm.py:47): h = gelu(pre) as split bf16, and its backward in place
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ pre, bf16_t* __restrict__ out, int ldo, int lo_off, long R, int C) {
   const int c8 = C >> 3;
@@ -772,6 +818,12 @@ int launch_swiglu_fwd(const float* gu, bf16_t* act, int ldo, int lo_off, long ro
 int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s, bf16_t* out_split) {
   if (!gu || !dact || rows <= 0 || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_bwd: bad arguments");
   hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (I / 8))), dim3(256), 0, s, gu, dact, rows, I, out_split);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+int launch_swiglu_bwd_f16(const float* gu, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s) {
+  if (!gu || !dact || !out_rows || !outT || !sat || rows <= 0 || Rp < rows || Rp % 8 || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_bwd_f16: bad arguments");
+  hipLaunchKernelGGL(swiglu_bwd_f16_kernel, dim3((Rp + TP - 1) / TP, (2 * I + TP - 1) / TP), dim3(256), 0, s, gu, dact, rows, Rp, I, out_rows, outT, sat);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
