@@ -516,7 +516,7 @@ int launch_rope_f32(float* qkv, const float2* table, int ld, int rows, int T, in
 
 int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads,
                          int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope,
-                         const float* pre, int ldp, int Np, float* lse, int lo8) {
+                         const float* pre, int ldp, int Np, float* lse, int lo8, void* split_scratch) {
   if (!qkv || !out_hi || !out_lo) return fv_fail(FV_ERR_ARG, "attention_f32: null pointer");
   if (lse && (pre || D < 64)) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: row statistics (training) need head_dim 64 / 128 and no cached prefix");
   if (pre && (Np <= 0 || Np >= T || ldp < 2 * kv_heads * D || ldp % 4 || D < 64))
@@ -529,6 +529,10 @@ int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int
   const int NT = D == 128 ? 2 : 1;
   if (D != 32 && D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention_f32: head_dim %d not in {32,64,128}", D);
   static const bool no_mfma = fv_ab_env("FASTVLA_NO_ATTN_F32_MFMA") != nullptr;
+  static const bool no_split = fv_ab_env("FASTVLA_NO_ATTN_SPLIT") != nullptr;   // A/B: the fp32-MFMA kernels of round 4's first version
+  // training (lse wanted): the split-bf16 kernel -- 5x the fp32 pipe's rate at 16 significant bits per operand (attention_split.hip)
+  if (D >= 64 && lse && !pre && !lo8 && !no_split && split_scratch)
+    return launch_attention_split_fwd(qkv, ld, out_hi, out_lo, ldo, B, T, heads, kv_heads, D, lens, len_add, scale, rope, lse, split_scratch, s);
   if (D >= 64 && (!no_mfma || pre || lse)) {
     const long nb = (long)B * heads * ((T - Np + 63) / 64);
     // rope given: q and k are rotated inside the kernel (no separate pass over the packed projections)

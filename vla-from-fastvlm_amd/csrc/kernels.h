@@ -107,7 +107,8 @@ int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int
                          int kv_heads, int D, const int32_t* lens, int len_add, float scale, hipStream_t s, const float2* rope = nullptr,
                          const float* pre = nullptr, int ldp = 0, int Np = 0,    // pre: cached [k | v] rows of positions < Np (8f-1)
                          float* lse = nullptr,    // optional [B][heads][T] row statistics max + log(sum) for the backward pass (head_dim 64 / 128, Np = 0)
-                         int lo8 = 0);            // remainders as fp8 bytes (the hi + lo8 operand form of llm_precision = 5)
+                         int lo8 = 0,             // remainders as fp8 bytes (the hi + lo8 operand form of llm_precision = 5)
+                         void* split_scratch = nullptr);   // with lse: attention_split_scratch_bytes() bytes -> the split-bf16 kernel (attention_split.hip)
 // table: [>=T][D/2] (cos, sin) pairs built by rope_table_host(); position = row % T
 int launch_rope(bf16_t* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D,
                 hipStream_t s);
@@ -141,8 +142,19 @@ int launch_image_rows(const float* stream, float* compact, int B, int Tt, int Ni
 int launch_embed_bwd(const int32_t* ids, const int32_t* lens, const float* dx, float* dE, int B, int T, int Ni, int H, int vocab, hipStream_t s);
 int launch_attention_bwd(const float* qkv, int ld, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, const float* dO, int lddo, const float* lse,
                          float* delta, float* dqkv, int B, int T, int heads, int kv_heads, int D, const int32_t* lens, int len_add, float scale,
-                         const float2* rope, hipStream_t s, float* part = nullptr);   // part: optional scratch of (heads / kv_heads) * B * T * 2 * kv_heads * D floats
+                         const float2* rope, hipStream_t s, float* part = nullptr,    // part: optional scratch of (heads / kv_heads) * B * T * 2 * kv_heads * D floats
+                         void* split_scratch = nullptr);   // attention_split_scratch_bytes() bytes -> the split-bf16 kernels (attention_split.hip)
                                                                                        // -> dK / dV per q head in parallel, then summed in a fixed order
+
+// attention_split.hip: the same forward (training: with lse) and backward on the bf16 matrix core with split (hi + lo) operands, three passes per product
+// scratch: attention_split_scratch_bytes(B, T, kv_heads, D) bytes -- K (rotated) and V of every kv head as split bf16 in both operand forms, written once
+// per call by a small pre-pass and copied flat into LDS by every q head's / query block's thread block
+size_t attention_split_scratch_bytes(int B, int T, int kv_heads, int D);
+int launch_attention_split_fwd(const float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int ldo, int B, int T, int heads, int kv_heads, int D,
+                               const int32_t* lens, int len_add, float scale, const float2* rope, float* lse, void* scratch, hipStream_t s);
+int launch_attention_split_bwd(const float* qkv, int ld, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, const float* dO, int lddo, const float* lse,
+                               float* delta, float* dqkv, int B, int T, int heads, int kv_heads, int D, const int32_t* lens, int len_add, float scale,
+                               const float2* rope, hipStream_t s, float* part, long pstride, void* scratch);
 
 // action expert (all fp32)
 struct HeadDims { int feat, ds, da, hid, fus; };

@@ -125,10 +125,13 @@ int fv_op_attention_bwd(const float* qkv, int ld, const float* dO, float* dqkv, 
   float* lse = stat_scratch;
   float* delta = stat_scratch + (size_t)B * heads * T;
   const float scale = 1.0f / sqrtf((float)D);
-  if (rc == FV_OK) rc = fv::launch_attention_f32(const_cast<float*>(qkv), ld, o, o + qd, 2 * qd, B, T, heads, kv_heads, D, lens, 0, scale, s, tab, nullptr, 0, 0, lse);
-  if (rc == FV_OK) rc = fv::launch_attention_bwd(qkv, ld, o, o + qd, 2 * qd, dO, qd, lse, delta, dqkv, B, T, heads, kv_heads, D, lens, 0, scale, tab, s);
+  void* scr = nullptr;   // the split-bf16 kernels' K / V records (the training path keeps this in its workspace)
+  if (rc == FV_OK) { e = hipMalloc(&scr, fv::attention_split_scratch_bytes(B, T, kv_heads, D)); if (e != hipSuccess) rc = fv_hip_fail(e, "hipMalloc(attention scratch)"); }
+  if (rc == FV_OK) rc = fv::launch_attention_f32(const_cast<float*>(qkv), ld, o, o + qd, 2 * qd, B, T, heads, kv_heads, D, lens, 0, scale, s, tab, nullptr, 0, 0, lse, 0, scr);
+  if (rc == FV_OK) rc = fv::launch_attention_bwd(qkv, ld, o, o + qd, 2 * qd, dO, qd, lse, delta, dqkv, B, T, heads, kv_heads, D, lens, 0, scale, tab, s, nullptr, scr);
   (void)hipStreamSynchronize(s);
   (void)hipFree(tab);
+  if (scr) (void)hipFree(scr);
   return rc;
 }
 

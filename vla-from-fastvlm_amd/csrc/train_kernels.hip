@@ -14,6 +14,10 @@
 // bucketed-equals-unbucketed tests rely on).
 #include "kernels.h"
 
+#ifndef FV_TRY_RC
+#define FV_TRY_RC(expr) do { const int rc_ = (expr); if (rc_ != FV_OK) return rc_; } while (0)
+#endif
+
 namespace fv {
 namespace {
 
@@ -898,7 +902,7 @@ int launch_embed_bwd(const int32_t* ids, const int32_t* lens, const float* dx, f
 // [B][heads][T].  head_dim 64 / 128.
 int launch_attention_bwd(const float* qkv, int ld, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, const float* dO, int lddo, const float* lse,
                          float* delta, float* dqkv, int B, int T, int heads, int kv_heads, int D, const int32_t* lens, int len_add, float scale,
-                         const float2* rope, hipStream_t s, float* part) {
+                         const float2* rope, hipStream_t s, float* part, void* split_scratch) {
   if (!qkv || !o_hi || !o_lo || !dO || !lse || !delta || !dqkv) return fv_fail(FV_ERR_ARG, "attention_bwd: null pointer");
   if (D != 64 && D != 128) return fv_fail(FV_ERR_UNSUPPORTED, "attention_bwd: head_dim must be 64 or 128 (got %d)", D);
   if (B <= 0 || T <= 0 || heads % kv_heads || ld % 4 || ld < (heads + 2 * kv_heads) * D || ldo % 8 || ldo < heads * D || lddo % 4 || lddo < heads * D)
@@ -907,7 +911,10 @@ int launch_attention_bwd(const float* qkv, int ld, const bf16_t* o_hi, const bf1
   const long pstride = (long)B * T * 2 * kd;      // floats per q-head share: part >= grp * pstride floats
   const bool parts = part != nullptr && grp > 1;
   const dim3 gq(B * heads * blocks), gk(B * kv_heads * blocks * (parts ? grp : 1));
-  if (D == 64) {
+  static const bool no_split = fv_ab_env("FASTVLA_NO_ATTN_SPLIT") != nullptr;   // A/B: the fp32-MFMA kernels below
+  if (!no_split && split_scratch) {
+    FV_TRY_RC(launch_attention_split_bwd(qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, B, T, heads, kv_heads, D, lens, len_add, scale, rope, s, part, pstride, split_scratch));
+  } else if (D == 64) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope);
     if (parts) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, dim3(256), 0, s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), gk, dim3(256), 0, s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
