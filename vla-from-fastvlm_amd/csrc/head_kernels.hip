@@ -81,21 +81,33 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   }
 }
 
-// dx[b][k] = sum_n dy[b][n] W[n][k]; thread per k, 8 batch rows per pass
+// dx[b][k] = sum_n dy[b][n] W[n][k].  Block = 32 k x 8 batch rows; its 256 threads are 8 n-lanes x 32 k: lane j sums n = j, j + 8, ... (N / 8
+// steps instead of N: the first version's 32 blocks of N-long dependent loops took 196 us per call at B = 32, N = 1024, K = 1920 -- 3 % of
+// the C3 rank-shape train step for 126 MFLOP), the eight partial sums are folded through LDS in a fixed order (bit-repeatable).
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W,
                                                              float* __restrict__ dx, int lddx, int B, int N, int K) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float part[8][8][32];   // [n-lane][batch row][k]
+  const int tid = threadIdx.x, kl = tid & 31, nl = tid >> 5;
+  const int k = blockIdx.x * 32 + kl, kc = min(k, K - 1);
   const int b0 = blockIdx.y * 8;
-  if (k >= K) return;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int n = 0; n < N; ++n) {
-    const float wv = W[(size_t)n * K + k];
+  const float* dyr[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += dy[(size_t)min(b0 + j, B - 1) * N + n] * wv;
+  for (int j = 0; j < 8; ++j) dyr[j] = dy + (size_t)min(b0 + j, B - 1) * N;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+  for (int n = nl; n < N; n += 8) {
+    const float wv = W[(size_t)n * K + kc];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += dyr[j][n] * wv;
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (b0 + j < B) dx[(size_t)(b0 + j) * lddx + k] = acc[j];
+  for (int j = 0; j < 8; ++j) part[nl][j][kl] = acc[j];
+  __syncthreads();
+  const int j = tid >> 5;   // one (batch row, k) per thread
+  float sum = 0.f;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) sum += part[l][j][kl];
+  if (k < K && b0 + j < B) dx[(size_t)(b0 + j) * lddx + k] = sum;
 }
 
 // dW[n][k] = sum_b dy[b][n] x[b][k]; block = one n, 256 k
@@ -365,12 +377,12 @@ int launch_head_backward(const HeadDims& d, const float* P, const float* grad_ac
   // action_head
   hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv(d.fus, 256), d.da), blk, 0, s, ga, sv.a3, d.fus, G + ho.o[10], B, d.da, d.fus);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(d.da, 256)), blk, 0, s, ga, G + ho.o[11], B, d.da);
-  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(d.fus, 256), b8), blk, 0, s, ga, P + ho.o[10], g1, d.fus, B, d.da, d.fus);
+  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(d.fus, 32), b8), blk, 0, s, ga, P + ho.o[10], g1, d.fus, B, d.da, d.fus);
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(cdiv((long)B * d.fus, 256)), blk, 0, s, g1, d.fus, sv.z3, (const float*)nullptr, g1, B, d.fus);
   // fusion.4
   hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv(d.fus, 256), d.fus), blk, 0, s, g1, sv.d2, d.fus, G + ho.o[8], B, d.fus, d.fus);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(d.fus, 256)), blk, 0, s, g1, G + ho.o[9], B, d.fus);
-  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(d.fus, 256), b8), blk, 0, s, g1, P + ho.o[8], g2, d.fus, B, d.fus, d.fus);
+  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(d.fus, 32), b8), blk, 0, s, g1, P + ho.o[8], g2, d.fus, B, d.fus, d.fus);
   // dropout multiplier, SiLU, LayerNorm (fusion.1)
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(cdiv((long)B * d.fus, 256)), blk, 0, s, g2, d.fus, sv.n2, sv.mask, g2, B, d.fus);
   hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3(cdiv(d.fus, 256)), blk, 0, s, g2, sv.xh2, G + ho.o[6], G + ho.o[7], B, d.fus);
@@ -378,14 +390,14 @@ int launch_head_backward(const HeadDims& d, const float* P, const float* grad_ac
   // fusion.0
   hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv(cw, 256), d.fus), blk, 0, s, g1, sv.cat, cw, G + ho.o[4], B, d.fus, cw);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(d.fus, 256)), blk, 0, s, g1, G + ho.o[5], B, d.fus);
-  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(cw, 256), b8), blk, 0, s, g1, P + ho.o[4], g2, cw, B, d.fus, cw);
+  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(cw, 32), b8), blk, 0, s, g1, P + ho.o[4], g2, cw, B, d.fus, cw);
   // dcat = [d pooled | d state branch]: the first `feat` columns are what an unfrozen backbone's backward starts from
   if (d_pooled) hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv((long)B * d.feat, 256)), blk, 0, s, g2, cw, d_pooled, d.feat, B, d.feat);
   // state branch: ds = dcat[:, feat:], SiLU, Linear, LayerNorm
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(cdiv((long)B * d.hid, 256)), blk, 0, s, g2 + d.feat, cw, sv.z1, (const float*)nullptr, g1, B, d.hid);
   hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv(d.ds, 256), d.hid), blk, 0, s, g1, sv.n0, d.ds, G + ho.o[2], B, d.hid, d.ds);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(d.hid, 256)), blk, 0, s, g1, G + ho.o[3], B, d.hid);
-  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(d.ds, 256), b8), blk, 0, s, g1, P + ho.o[2], g2, d.ds, B, d.hid, d.ds);
+  hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(d.ds, 32), b8), blk, 0, s, g1, P + ho.o[2], g2, d.ds, B, d.hid, d.ds);
   hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3(cdiv(d.ds, 256)), blk, 0, s, g2, sv.xh0, G + ho.o[0], G + ho.o[1], B, d.ds);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;

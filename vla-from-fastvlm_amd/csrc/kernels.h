@@ -117,7 +117,7 @@ int launch_pool_norm(const float* x, const int32_t* lens, const float* w, float*
                      int H, float eps, int mode, hipStream_t s);
 
 // ---- unfrozen-backbone training glue (train_kernels.hip) ------------------------------------------------------
-constexpr int RMS_BWD_RPW = 16;     // rows per wave of rmsnorm_bwd_kernel (one dw partial row per wave)
+constexpr int RMS_BWD_RPW = 4;      // rows per wave of rmsnorm_bwd_kernel (one dw partial row per wave)
 constexpr int COLSUM_CHUNKS = 64;   // row ranges of the two-stage deterministic column sum
 int launch_split_rows(const float* in, int ldi, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);
 int launch_lo8_rows(const float* in, int ldi, bf16_t* out, int ldo, long R, int C, hipStream_t s);   // the fp8 remainder bytes of the hi + lo8 operand form
@@ -145,6 +145,20 @@ int launch_attention_bwd(const float* qkv, int ld, const bf16_t* o_hi, const bf1
                          const float2* rope, hipStream_t s, float* part = nullptr,    // part: optional scratch of (heads / kv_heads) * B * T * 2 * kv_heads * D floats
                          void* split_scratch = nullptr);   // attention_split_scratch_bytes() bytes -> the split-bf16 kernels (attention_split.hip)
                                                                                        // -> dK / dV per q head in parallel, then summed in a fixed order
+
+// fv_train_commit in ONE launch: every trainable tensor of the flat fp32 master -> the library's operand copies.  One descriptor per tensor
+// (device array, sorted by tile0); a block takes one 64 x 64 tile of a matrix (bf16 rows + the transposed dgrad copy, fp16 or bf16) or 4096
+// floats of a vector
+struct CommitDesc {
+  long long src_off;     // offset into the flat master (floats)
+  void* dst;             // bf16 [rows][cols] (matrix) or fp32 [numel] (vector)
+  void* dstT16;          // fp16 [cols][rows] or null
+  void* dstTb;           // bf16 [cols][rows] or null
+  int rows, cols;        // vector: rows = 1, cols = numel
+  int is_mat;
+  int tile0;             // first tile of this tensor in the launch's tile numbering
+};
+int launch_commit(const CommitDesc* desc_dev, int ndesc, int ntiles, const float* flat, int f16_transposes, unsigned* sat, hipStream_t s);
 
 // attention_split.hip: the same forward (training: with lse) and backward on the bf16 matrix core with split (hi + lo) operands, three passes per product
 // scratch: attention_split_scratch_bytes(B, T, kv_heads, D) bytes -- K (rotated) and V of every kv head as split bf16 in both operand forms, written once

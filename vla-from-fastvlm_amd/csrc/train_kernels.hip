@@ -186,6 +186,64 @@ __global__ __launch_bounds__(256) void rows_f16_kernel(const void* __restrict__ 
   }
 }
 
+// fv_train_commit as one launch (CommitDesc, kernels.h): the 99 f32->bf16 casts, 72 weight transposes and 167 vector copies of one optimiser step were
+// ~340 launches of 3-10 us and read the bf16 weights back for the transposes; here the fp32 master is read once
+__global__ __launch_bounds__(256) void commit_kernel(const CommitDesc* __restrict__ desc, int ndesc, const float* __restrict__ flat, int f16t,
+                                                      unsigned* __restrict__ sat) {
+  __shared__ float tile[TP][TP + 1];
+  const int tid = threadIdx.x, bt = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;          // the last descriptor whose tile0 <= bt
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile0 <= bt) lo = mid; else hi = mid - 1;
+  }
+  const CommitDesc d = desc[lo];
+  const int lt = bt - d.tile0;
+  const float* src = flat + d.src_off;
+  if (!d.is_mat) {
+    const long base = (long)lt * (TP * TP);
+    float* dst = static_cast<float*>(d.dst);
+    for (int i = tid; i < TP * TP; i += 256)
+      if (base + i < d.cols) dst[base + i] = src[base + i];
+    return;
+  }
+  const int tcols = (d.cols + TP - 1) / TP;
+  const int r0 = (lt / tcols) * TP, c0 = (lt % tcols) * TP;
+  bf16_t* dst = static_cast<bf16_t*>(d.dst);
+  const bool tr = d.dstT16 != nullptr;   // (both transposed forms exist or neither)
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int r = (tid >> 3) + 32 * k, c = (tid & 7) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r0 + r < d.rows && c0 + c < d.cols) {
+      load8(src + (size_t)(r0 + r) * d.cols + c0 + c, v);
+      const uint4 hv = pack8(v);
+      *reinterpret_cast<uint4*>(dst + (size_t)(r0 + r) * d.cols + c0 + c) = hv;
+      unpack8(hv, v);   // the transposed copy holds the ROUNDED weight (what the forward multiplies by)
+    }
+    if (tr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tile[r][c + e] = v[e];
+    }
+  }
+  if (!tr) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = (tid >> 3) + 32 * k, r = (tid & 7) * 8;
+    if (c0 + c >= d.cols || r0 + r >= d.rows) continue;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[r + e][c];
+    if (f16t) {
+      count_f16_sat8(v, sat);
+      *reinterpret_cast<uint4*>(static_cast<bf16_t*>(d.dstT16) + (size_t)(c0 + c) * d.rows + r0 + r) = pack8_h(v);
+    } else {
+      *reinterpret_cast<uint4*>(static_cast<bf16_t*>(d.dstTb) + (size_t)(c0 + c) * d.rows + r0 + r) = pack8(v);
+    }
+  }
+}
+
 // SwiGLU on the gate/up accumulators.  gu fp32 [rows][2I], columns in the packed weight's order: 16-column groups [8 gate | 8 up]
 // of the outputs 8j .. 8j+7.  act = silu(gate) * up as split bf16: [rows][ldo] with hi at column i, lo at lo_off + i.
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const float* __restrict__ gu, bf16_t* __restrict__ act, int ldo, int lo_off, long rows, int I) {
@@ -326,32 +384,37 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(float* __restrict__ dh, c
 }
 
 // RMSNorm backward.  y = w x r, r = rsqrt(mean(x^2) + eps):  dx = dres + r w dy - (r^3 / H) x sum_i(w_i dy_i x_i);  dw_i = sum_rows dy_i x_i r.
-// One wave per row, `rpw` consecutive rows per wave; a lane keeps the dw partial sums of its columns in registers across its rows and
-// every WAVE writes one partial row dw_part[wave][H] (summed in a fixed order by colsum_kernel).  H <= 4096.
+// One wave per row, `rpw` consecutive rows per wave (4: 2560 waves at 10 240 rows -- with 16 the launch was 160 blocks of serial, latency-exposed
+// rows: 57 us for 147 MB); the row's x and dy stay in registers between the two passes; a lane keeps the dw partial sums of its columns in
+// registers across its rows and every WAVE writes one partial row dw_part[wave][H] (summed in a fixed order by colsum_kernel).  H <= 512 NCH.
+template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
                                                            const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ dw_part,
                                                            long rows, int H, float eps, int rpw) {
   const int lane = threadIdx.x & 63;
   const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  float acc[8][8];
+  float acc[NCH][8], wv8[NCH][8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
+  for (int c = 0; c < NCH; ++c) {
+    const int i = lane * 8 + 512 * c;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+    for (int e = 0; e < 8; ++e) { acc[c][e] = 0.f; wv8[c][e] = 0.f; }
+    if (i < H) load8(w + i, wv8[c]);
+  }
   for (int k = 0; k < rpw; ++k) {
     const long row = wv * rpw + k;
     if (row >= rows) break;
     const float* xr = x + row * H;
     const float* dyr = dy + row * H;
+    float xv[NCH][8], dv[NCH][8];
     float ss = 0.f, sd = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int i = lane * 8 + 512 * c;
       if (i < H) {
-        float xv[8], dv[8], wv8[8];
-        load8(xr + i, xv); load8(dyr + i, dv); load8(w + i, wv8);
+        load8(xr + i, xv[c]); load8(dyr + i, dv[c]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ss += xv[e] * xv[e]; sd += wv8[e] * dv[e] * xv[e]; }
+        for (int e = 0; e < 8; ++e) { ss += xv[c][e] * xv[c][e]; sd += wv8[c][e] * dv[c][e] * xv[c][e]; }
       }
     }
     ss = wave_sum(ss);
@@ -359,11 +422,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     const float r = rsqrtf(ss / (float)H + eps);
     const float coef = r * r * r * sd / (float)H;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int i = lane * 8 + 512 * c;
       if (i < H) {
-        float xv[8], dv[8], wv8[8], o[8];
-        load8(xr + i, xv); load8(dyr + i, dv); load8(w + i, wv8);
+        float o[8];
         if (dres) load8(dres + row * H + i, o);
         else {
 #pragma unroll
@@ -371,8 +433,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          o[e] += r * wv8[e] * dv[e] - coef * xv[e];
-          acc[c][e] += dv[e] * xv[e] * r;
+          o[e] += r * wv8[c][e] * dv[c][e] - coef * xv[c][e];
+          acc[c][e] += dv[c][e] * xv[c][e] * r;
         }
         store8(dx + row * H + i, o);
       }
@@ -380,7 +442,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   }
   if (dw_part) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int i = lane * 8 + 512 * c;
       if (i < H) store8(dw_part + wv * H + i, acc[c]);
     }
@@ -825,6 +887,12 @@ int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
+int launch_commit(const CommitDesc* desc_dev, int ndesc, int ntiles, const float* flat, int f16_transposes, unsigned* sat, hipStream_t s) {
+  if (!desc_dev || !flat || ndesc <= 0 || ntiles <= 0 || (f16_transposes && !sat)) return fv_fail(FV_ERR_ARG, "commit: bad arguments");
+  hipLaunchKernelGGL(commit_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, desc_dev, ndesc, flat, f16_transposes, sat);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
 int launch_swiglu_bwd_f16(const float* gu, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s) {
   if (!gu || !dact || !out_rows || !outT || !sat || rows <= 0 || Rp < rows || Rp % 8 || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_bwd_f16: bad arguments");
   hipLaunchKernelGGL(swiglu_bwd_f16_kernel, dim3((Rp + TP - 1) / TP, (2 * I + TP - 1) / TP), dim3(256), 0, s, gu, dact, rows, Rp, I, out_rows, outT, sat);
@@ -871,7 +939,11 @@ int launch_rmsnorm_bwd(const float* x, const float* w, const float* dy, const fl
   const long waves = (rows + RMS_BWD_RPW - 1) / RMS_BWD_RPW;
   const long wpad = (waves + 3) / 4 * 4;
   // (waves of the last block that own no row write zero partial rows themselves)
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)(wpad / 4)), dim3(256), 0, s, x, w, dy, dres, dx, dw ? scratch : nullptr, rows, H, eps, RMS_BWD_RPW);
+  const dim3 g((unsigned)(wpad / 4));
+  float* part = dw ? scratch : nullptr;
+  if (H <= 1024) hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, g, dim3(256), 0, s, x, w, dy, dres, dx, part, rows, H, eps, RMS_BWD_RPW);
+  else if (H <= 2048) hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, g, dim3(256), 0, s, x, w, dy, dres, dx, part, rows, H, eps, RMS_BWD_RPW);
+  else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, g, dim3(256), 0, s, x, w, dy, dres, dx, part, rows, H, eps, RMS_BWD_RPW);
   FV_HIP_CHECK(hipGetLastError());
   if (dw) return launch_colsum(scratch, H, wpad, H, dw, scratch + wpad * H, s);
   return FV_OK;
