@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ 
 
 // the same tile transpose with fp16 output (11 significant bits: the wgrad operands): KIND 0 = fp32 input, 1 = bf16, 2 = split bf16 whose halves
 // (lo_in columns apart) are summed before the one rounding; saturating casts, clamps counted
+// (rows_out != null: the same values also as fp16 ROWS [R][ldro] -- a gradient's dgrad and wgrad operands from one read)
 template <int KIND>
 __global__ __launch_bounds__(256) void transpose_f16_kernel(const void* __restrict__ in_v, int ldi, int lo_in, bf16_t* __restrict__ out, int ldo, int R, int Rp, int C,
-                                                             unsigned* __restrict__ sat) {
+                                                             unsigned* __restrict__ sat, bf16_t* __restrict__ rows_out, int ldro) {
   __shared__ float tile[TP][TP + 1];
   const int r0 = blockIdx.x * TP, c0 = blockIdx.y * TP, tid = threadIdx.x;
 #pragma unroll
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void transpose_f16_kernel(const void* __restri
           for (int e = 0; e < 8; ++e) v[e] += l[e];
         }
       }
+      if (rows_out) *reinterpret_cast<uint4*>(rows_out + (size_t)(r0 + r) * ldro + c0 + c) = pack8_h(v);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) tile[r][c + e] = v[e];
@@ -309,14 +311,18 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(float* __restrict__ gu,
 // dgu, no separate rounding and transposing passes.  A block owns 64 rows x 64 dgu columns (4 [8 gate | 8 up] groups); thread -> (row tid / 4,
 // group tid % 4) on the way in, (column tid / 8 + 32 k, 8 rows) on the way out through a 64 x 64 fp32 LDS tile.
 __global__ __launch_bounds__(256) void swiglu_bwd_f16_kernel(const float* __restrict__ gu, const float* __restrict__ dact, int rows, int Rp, int I,
-                                                              bf16_t* __restrict__ out_rows, bf16_t* __restrict__ outT, unsigned* __restrict__ sat) {
+                                                              bf16_t* __restrict__ out_rows, bf16_t* __restrict__ outT, unsigned* __restrict__ sat,
+                                                              bf16_t* __restrict__ actT) {
+  // actT != null: also act = silu(gate) * up of the same tile as fp16 columns [I][Rp] -- the down projection's wgrad operand, recomputed here
+  // from the accumulators this kernel reads anyway instead of transposed from a kept copy by a pass of its own
   __shared__ float tile[TP][TP + 1];
+  __shared__ float tact[TP][TP / 2 + 1];
   const int r0 = blockIdx.x * TP, c0 = blockIdx.y * TP, tid = threadIdx.x, C = 2 * I;
   {
     const int r = tid >> 2, c = (tid & 3) * 16;
-    float dg[8], du[8];
+    float dg[8], du[8], av[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dg[e] = du[e] = 0.f;
+    for (int e = 0; e < 8; ++e) dg[e] = du[e] = av[e] = 0.f;
     if (r0 + r < rows && c0 + c < C) {
       float g[8], u[8], d[8];
       const float* gp = gu + (size_t)(r0 + r) * C + c0 + c;
@@ -328,6 +334,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_f16_kernel(const float* __rest
         const float sg = 1.0f / (1.0f + __expf(-g[e]));
         dg[e] = d[e] * u[e] * sg * (1.0f + g[e] * (1.0f - sg));
         du[e] = d[e] * g[e] * sg;
+        av[e] = silu_f(g[e]) * u[e];   // exactly the forward's value (the epilogue's silu_f on the same accumulators)
       }
       count_f16_sat8(dg, sat);
       count_f16_sat8(du, sat);
@@ -337,8 +344,22 @@ __global__ __launch_bounds__(256) void swiglu_bwd_f16_kernel(const float* __rest
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { tile[r][c + e] = dg[e]; tile[r][c + 8 + e] = du[e]; }
+    if (actT) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tact[r][(c >> 1) + e] = av[e];
+    }
   }
   __syncthreads();
+  if (actT) {   // 32 act columns x 64 rows: thread -> (column tid / 8, 8 rows)
+    const int c = tid >> 3, r = (tid & 7) * 8, ac = (c0 >> 1) + c;
+    if (ac < I && r0 + r < Rp) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tact[r + e][c];
+      count_f16_sat8(v, sat);
+      *reinterpret_cast<uint4*>(actT + (size_t)ac * Rp + r0 + r) = pack8_h(v);
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int c = (tid >> 3) + 32 * k, r = (tid & 7) * 8;
@@ -852,14 +873,16 @@ int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, 
   return FV_OK;
 }
 
-int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, int R, int Rp, int C, unsigned* sat, hipStream_t s) {
+int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, int R, int Rp, int C, unsigned* sat, hipStream_t s,
+                            bf16_t* rows_out, int ldro) {
   if (!in || !out) return fv_fail(FV_ERR_ARG, "transpose_f16: null pointer");
+  if (rows_out && (ldro < C || ldro % 8)) return fv_fail(FV_ERR_ARG, "transpose_f16: bad row output stride %d", ldro);
   if (R <= 0 || C <= 0 || C % 8 || Rp < R || Rp % 8 || ldi < C || ldi % (in_kind ? 8 : 4) || ldo % 8 || ldo < Rp || in_kind < 0 || in_kind > 2 || (in_kind == 2 && (lo_in % 8 || lo_in < C)))
     return fv_fail(FV_ERR_ARG, "transpose_f16: bad shape R=%d Rp=%d C=%d ldi=%d ldo=%d kind=%d", R, Rp, C, ldi, ldo, in_kind);
   const dim3 g((Rp + TP - 1) / TP, (C + TP - 1) / TP);
-  if (in_kind == 0) hipLaunchKernelGGL(transpose_f16_kernel<0>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
-  else if (in_kind == 1) hipLaunchKernelGGL(transpose_f16_kernel<1>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
-  else hipLaunchKernelGGL(transpose_f16_kernel<2>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
+  if (in_kind == 0) hipLaunchKernelGGL(transpose_f16_kernel<0>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat, rows_out, ldro);
+  else if (in_kind == 1) hipLaunchKernelGGL(transpose_f16_kernel<1>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat, rows_out, ldro);
+  else hipLaunchKernelGGL(transpose_f16_kernel<2>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat, rows_out, ldro);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -893,9 +916,9 @@ int launch_commit(const CommitDesc* desc_dev, int ndesc, int ntiles, const float
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
-int launch_swiglu_bwd_f16(const float* gu, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s) {
+int launch_swiglu_bwd_f16(const float* gu, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s, bf16_t* actT) {
   if (!gu || !dact || !out_rows || !outT || !sat || rows <= 0 || Rp < rows || Rp % 8 || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_bwd_f16: bad arguments");
-  hipLaunchKernelGGL(swiglu_bwd_f16_kernel, dim3((Rp + TP - 1) / TP, (2 * I + TP - 1) / TP), dim3(256), 0, s, gu, dact, rows, Rp, I, out_rows, outT, sat);
+  hipLaunchKernelGGL(swiglu_bwd_f16_kernel, dim3((Rp + TP - 1) / TP, (2 * I + TP - 1) / TP), dim3(256), 0, s, gu, dact, rows, Rp, I, out_rows, outT, sat, actT);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
