@@ -69,6 +69,11 @@ __device__ __forceinline__ uint4 pack8_h(const float* f) {
   u.x = pack_h2(f[0], f[1]); u.y = pack_h2(f[2], f[3]); u.z = pack_h2(f[4], f[5]); u.w = pack_h2(f[6], f[7]);
   return u;
 }
+__device__ __forceinline__ void unpack8_h(const uint4& u, float* f) {
+  const f16x8 h = __builtin_bit_cast(f16x8, u);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+}
 // how many of the 8 values pack8_h will clamp (0 in a healthy model: the callers add it to the handle's saturation counter)
 __device__ __forceinline__ void count_f16_sat8(const float* f, unsigned* counter) {
   float m = 0.f;

@@ -33,7 +33,8 @@ struct Params {
   int tiles_m = 0;
   const uint8_t* W8 = nullptr;   // ksplit == 2: fp8 copy of W (x 2^6), row stride 2K bytes
   unsigned* sat = nullptr;   // FV_EPI_SWIGLU_F16: device counter of 8-value groups clamped to the fp16 range (0 in a healthy model)
-  float* stash = nullptr;    // FV_EPI_SWIGLU_SPLIT: raw fp32 gate/up accumulators, [M][N]
+  void* stash = nullptr;     // FV_EPI_SWIGLU_SPLIT: raw gate/up accumulators, [M][N] fp32 or (stash_f16) fp16
+  int stash_f16 = 0;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
@@ -211,9 +212,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = silu_f(src[e]) * src[8 + e];
         if (p.stash) {
-          float* sp = p.stash + (size_t)gm * p.N + gn;
+          if (p.stash_f16) {
+            float gv[8], uv[8];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sp + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
+            for (int e = 0; e < 8; ++e) { gv[e] = src[e]; uv[e] = src[8 + e]; }
+            count_f16_sat8(gv, p.sat); count_f16_sat8(uv, p.sat);
+            bf16_t* sp = static_cast<bf16_t*>(p.stash) + (size_t)gm * p.N + gn;
+            *reinterpret_cast<uint4*>(sp) = pack8_h(gv);
+            *reinterpret_cast<uint4*>(sp + 8) = pack8_h(uv);
+          } else {
+            float* sp = static_cast<float*>(p.stash) + (size_t)gm * p.N + gn;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sp + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
+          }
         }
         if (epi == FV_EPI_SWIGLU_F16) {
 #pragma unroll
@@ -552,9 +563,19 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 #pragma unroll
         for (int e = 0; e < 8; ++e) o8[e] = silu_f(src[e]) * src[8 + e];
         if (p.stash) {
-          float* sp = p.stash + (size_t)gm * p.N + (bn + wc * 64 + pr * 16);
+          if (p.stash_f16) {
+            float gv[8], uv[8];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sp + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
+            for (int e = 0; e < 8; ++e) { gv[e] = src[e]; uv[e] = src[8 + e]; }
+            count_f16_sat8(gv, p.sat); count_f16_sat8(uv, p.sat);
+            bf16_t* sp = static_cast<bf16_t*>(p.stash) + (size_t)gm * p.N + (bn + wc * 64 + pr * 16);
+            *reinterpret_cast<uint4*>(sp) = pack8_h(gv);
+            *reinterpret_cast<uint4*>(sp + 8) = pack8_h(uv);
+          } else {
+            float* sp = static_cast<float*>(p.stash) + (size_t)gm * p.N + (bn + wc * 64 + pr * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sp + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
+          }
         }
         if (p.epi == FV_EPI_SWIGLU_F16) {
 #pragma unroll
@@ -835,8 +856,9 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi;
   p.ksplit = a.ksplit == 2 ? 2 : (a.ksplit ? 1 : 0);
   p.sat = a.sat;
-  p.stash = a.stash;
-  if (a.stash && (a.epi != FV_EPI_SWIGLU_SPLIT || ((uintptr_t)a.stash & 15))) return fv_fail(FV_ERR_ARG, "gemm: stash goes with FV_EPI_SWIGLU_SPLIT (16-byte aligned)");
+  p.stash = a.stash; p.stash_f16 = a.stash_f16;
+  if (a.stash && (a.epi != FV_EPI_SWIGLU_SPLIT || ((uintptr_t)a.stash & 15) || (a.stash_f16 && !a.sat)))
+    return fv_fail(FV_ERR_ARG, "gemm: stash goes with FV_EPI_SWIGLU_SPLIT (16-byte aligned; the fp16 form with a saturation counter)");
   p.W8 = static_cast<const uint8_t*>(a.W8);
   if (a.ksplit == 2) {
     if (!a.W8 || a.K % 128 || a.lda * 2 < 3 * a.K || ((uintptr_t)a.W8 & 15)) return fv_fail(FV_ERR_ARG, "gemm: the hi + lo8 form needs W8, K %% 128 == 0 and lda >= 1.5 K");
@@ -866,10 +888,21 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
       (size_t)a.M * a.lda * 2 < ((size_t)1 << 32) && (size_t)a.N * a.K * 2 < ((size_t)1 << 32)) {
     const int tmr = (a.M + 255) / 256;            // a ragged last row tile: staging clamps its rows, the partial-sum stores skip them
     const int tn = (a.N + 255) / 256, tiles = tmr * tn, nkt = a.ksplit == 2 ? a.K / 64 + a.K / 128 : (a.ksplit ? 2 : 1) * (a.K / 64);
-    int splits = tiles < cus ? cus / tiles : 1;
-    if (splits > 8) splits = 8;
-    while (splits > 1 && nkt / splits < 16) --splits;
-    while (splits > 1 && (size_t)splits * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes) --splits;   // as many as the scratch buffer holds
+    // K ranges per tile: the count that minimises (rounds of `cus` units, each 1 / s of a tile's K loop) + the partial sums' trip through memory
+    // (s x M x npad floats written and read back: ~0.5 of a 2048-deep K loop per range at 10 240 x 1024) -- 160 tiles (the unfrozen path's
+    // 10 240 x 896 projections) take 3 ranges = 480 units = 1.9 rounds instead of 0.6 of one
+    int splits = 1;
+    {
+      const double tile_us = (double)nkt * 64.0 * 131072.0 / 1.0e6 / 4.0;                 // ~a 256 x 256 x (64 nkt) tile on one CU at ~4 GF/us/CU
+      const double part_us = 2.0 * (double)a.M * (tn * 256) * 4.0 / 4.0e6;               // one range's partials written + read at ~4 TB/s
+      double best = 1e30;
+      for (int sN = 1; sN <= 8; ++sN) {
+        if (sN > 1 && (nkt / sN < 16 || (size_t)sN * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes)) break;
+        const long units = (long)tiles * sN, rounds = (units + cus - 1) / cus;
+        const double t = (double)rounds * tile_us / sN + (sN > 1 ? sN * part_us : 0.0);
+        if (t < best * 0.97) { best = t; splits = sN; }
+      }
+    }
     if (splits > 1) {
       p.tiles_n = tn;
       p.tiles_m = colmajor_ok && tmr <= cm_max ? tmr : 0;

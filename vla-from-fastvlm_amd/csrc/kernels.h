@@ -30,8 +30,9 @@ struct GemmArgs {
   const float* norm_w = nullptr; bf16_t* norm_y = nullptr; bf16_t* norm_ylo = nullptr; int norm_ld = 0; float norm_eps = 0.f;
   const void* W8 = nullptr;     // ksplit == 2: fp8 e4m3 copy of W x 2^6, row stride 2K BYTES (the first K of each row valid: the bf16 copy's per-lane offsets serve both)
   unsigned* sat = nullptr;      // optional device counter: += 1 per 8-value group FV_EPI_SWIGLU_F16 had to clamp to the fp16 range
-  float* stash = nullptr;       // FV_EPI_SWIGLU_SPLIT only: also keep the raw fp32 gate/up accumulators [M][N] (row stride N, the packed column order):
-                                // what the SwiGLU backward of the unfrozen training path differentiates
+  void* stash = nullptr;        // FV_EPI_SWIGLU_SPLIT only: also keep the raw gate/up accumulators [M][N] (row stride N, the packed column order):
+                                // what the SwiGLU backward of the unfrozen training path differentiates; fp32, or
+  int stash_f16 = 0;            // 1: fp16 (saturating, clamps counted in *sat): half the bytes of a launch whose epilogue is write-bound
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -131,8 +132,8 @@ int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* 
 int launch_swiglu_fwd(const float* gu, bf16_t* act, int ldo, int lo_off, long rows, int I, hipStream_t s);
 int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s, bf16_t* out_split = nullptr);   // out_split: [rows][4I] = [hi | lo] bf16 instead of fp32 in place
 // dgu straight into the two fp16 operands of its consumers: rows [rows][2I] and columns [2I][Rp] (zero for rows in [rows, Rp)); clamps counted in *sat
-int launch_swiglu_bwd_f16(const float* gu, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s,
-                          bf16_t* actT = nullptr);   // actT: also silu(gate) * up as fp16 columns [I][Rp] (the down projection's wgrad operand)
+int launch_swiglu_bwd_f16(const void* gu, int gu_f16, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s,
+                          bf16_t* actT = nullptr);   // gu_f16: the kept accumulators are fp16 (GemmArgs::stash_f16)   // actT: also silu(gate) * up as fp16 columns [I][Rp] (the down projection's wgrad operand)
 int launch_gelu_fwd(const float* pre, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);
 int launch_gelu_bwd(float* dh, const float* pre, size_t n, hipStream_t s);
 size_t rmsnorm_bwd_scratch_floats(long rows, int H);

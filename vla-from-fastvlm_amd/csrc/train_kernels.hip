@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(float* __restrict__ gu,
 // rows [rows][2I] (the dgrad's A operand) and as fp16 columns outT [2I][Rp] (the wgrad's, rows in [rows, Rp) zero) -- no fp32 or split copy of
 // dgu, no separate rounding and transposing passes.  A block owns 64 rows x 64 dgu columns (4 [8 gate | 8 up] groups); thread -> (row tid / 4,
 // group tid % 4) on the way in, (column tid / 8 + 32 k, 8 rows) on the way out through a 64 x 64 fp32 LDS tile.
-__global__ __launch_bounds__(256) void swiglu_bwd_f16_kernel(const float* __restrict__ gu, const float* __restrict__ dact, int rows, int Rp, int I,
+template <bool G16>   // G16: the kept gate/up accumulators are fp16 (GemmArgs::stash_f16)
+__global__ __launch_bounds__(256) void swiglu_bwd_f16_kernel(const void* __restrict__ gu_v, const float* __restrict__ dact, int rows, int Rp, int I,
                                                               bf16_t* __restrict__ out_rows, bf16_t* __restrict__ outT, unsigned* __restrict__ sat,
                                                               bf16_t* __restrict__ actT) {
   // actT != null: also act = silu(gate) * up of the same tile as fp16 columns [I][Rp] -- the down projection's wgrad operand, recomputed here
@@ -325,9 +326,15 @@ __global__ __launch_bounds__(256) void swiglu_bwd_f16_kernel(const float* __rest
     for (int e = 0; e < 8; ++e) dg[e] = du[e] = av[e] = 0.f;
     if (r0 + r < rows && c0 + c < C) {
       float g[8], u[8], d[8];
-      const float* gp = gu + (size_t)(r0 + r) * C + c0 + c;
-      load8(gp, g);
-      load8(gp + 8, u);
+      if constexpr (G16) {
+        const bf16_t* gp = static_cast<const bf16_t*>(gu_v) + (size_t)(r0 + r) * C + c0 + c;
+        unpack8_h(*reinterpret_cast<const uint4*>(gp), g);
+        unpack8_h(*reinterpret_cast<const uint4*>(gp + 8), u);
+      } else {
+        const float* gp = static_cast<const float*>(gu_v) + (size_t)(r0 + r) * C + c0 + c;
+        load8(gp, g);
+        load8(gp + 8, u);
+      }
       load8(dact + (size_t)(r0 + r) * I + ((c0 + c) >> 1), d);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -916,9 +923,11 @@ int launch_commit(const CommitDesc* desc_dev, int ndesc, int ntiles, const float
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
-int launch_swiglu_bwd_f16(const float* gu, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s, bf16_t* actT) {
+int launch_swiglu_bwd_f16(const void* gu, int gu_f16, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s, bf16_t* actT) {
   if (!gu || !dact || !out_rows || !outT || !sat || rows <= 0 || Rp < rows || Rp % 8 || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_bwd_f16: bad arguments");
-  hipLaunchKernelGGL(swiglu_bwd_f16_kernel, dim3((Rp + TP - 1) / TP, (2 * I + TP - 1) / TP), dim3(256), 0, s, gu, dact, rows, Rp, I, out_rows, outT, sat, actT);
+  const dim3 g((Rp + TP - 1) / TP, (2 * I + TP - 1) / TP);
+  if (gu_f16) hipLaunchKernelGGL(swiglu_bwd_f16_kernel<true>, g, dim3(256), 0, s, gu, dact, rows, Rp, I, out_rows, outT, sat, actT);
+  else hipLaunchKernelGGL(swiglu_bwd_f16_kernel<false>, g, dim3(256), 0, s, gu, dact, rows, Rp, I, out_rows, outT, sat, actT);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
