@@ -254,8 +254,8 @@ int fv_train_export_params(fv_handle* h, float* flat_params, fv_stream s);
 /* the library's MFMA operand copies <- the master, after an optimiser step: bf16 weights (RNE), their transposes, fp32 norms / biases.
  * The frozen-path entry points (fv_llm_forward_pooled, ...) see the updated weights from then on. */
 int fv_train_commit(fv_handle* h, const float* flat_params, fv_stream s);
-/* Arithmetic of the backward's contractions (defaults 2, 1, 12: every dgrad and wgrad ONE fp16 pass -- worst per-tensor gradient 6.2e-4 from fp32 autograd
- * through the whole 24-layer 0.5B decoder, 5.8e-4 at the 7B width):
+/* Arithmetic of the backward's contractions (defaults 2, 1, 12: every dgrad and wgrad ONE fp16 pass -- worst per-tensor gradient 8.4e-4 from fp32 autograd
+ * through the whole 24-layer 0.5B decoder, 6.7e-4 at the 7B width; in this mode the gate/up accumulators are kept as fp16 for the backward):
  *   grad_split 1: the gradient operand of every dgrad GEMM is split bf16 (hi + lo, 16 significant bits) against the exact-bf16 transposed weights;
  *              0: its bf16 hi half alone (the usual mixed-precision recipe: half the dgrad work, gradients ~3e-3 from fp32 -- outside this repo's
  *                 2e-3 gradient bar; an explicit speed knob);

