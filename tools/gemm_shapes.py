@@ -48,6 +48,10 @@ def main():
         ("4096^2 K=16384", 4096, 4096, 16384, _lib.EPI_BIAS, 0, False),
         ("4096^2 K=4160 (row stride not a power of two)", 4096, 4096, 4160, _lib.EPI_BIAS, 0, False),
         ("4096^2 K=8256 (row stride not a power of two)", 4096, 4096, 8256, _lib.EPI_BIAS, 0, False),
+        ("2048x4096 K=4096 (128 tiles)", 2048, 4096, 4096, _lib.EPI_BIAS, 0, False),
+        ("4096x2048 K=4096 (128 tiles)", 4096, 2048, 4096, _lib.EPI_BIAS, 0, False),
+        ("8192x4096 K=4096 (512 tiles)", 8192, 4096, 4096, _lib.EPI_BIAS, 0, False),
+        ("12288x4096 K=4096 (768 tiles)", 12288, 4096, 4096, _lib.EPI_BIAS, 0, False),
         ("16384x4096 K=4096", 16384, 4096, 4096, _lib.EPI_BIAS, 0, False),
         ("65536x1024 K=4096", 65536, 1024, 4096, _lib.EPI_BIAS, 0, False),
         ("7B gate/up M=1024", 1024, 37888, 3584, _lib.EPI_SWIGLU_SPLIT, 1, False),

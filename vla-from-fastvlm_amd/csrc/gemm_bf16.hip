@@ -31,12 +31,19 @@ struct Params {
   // time).  For few row tiles against many weight columns (the 7B decoder at M = 1024: 4 x 148) the row-major walk makes every XCD
   // stream 32 different 3.7 MB weight tiles per round and each weight tile is fetched by four XCDs: 2.2 GB per launch, 4.3 TB/s.
   int tiles_m = 0;
+  // gemm256 only: group_m > 0 = walk the tiles in groups of group_m tile ROWS, column-major inside a group (tiles_mt = row tiles in all): the 32 CUs
+  // of an XCD work on ~32 consecutive tiles of the walk, which row-major are 1 row x 32 columns = 33 operand panels through that XCD's L2 and
+  // grouped by 4 are 4 x 8 = 12 (a 4096^3 problem, 16 x 16 tiles, sat at 790 TF whatever the grid: L2 fill, not the K loop)
+  int group_m = 0, tiles_mt = 0;
   const uint8_t* W8 = nullptr;   // ksplit == 2: fp8 copy of W (x 2^6), row stride 2K bytes
   unsigned* sat = nullptr;   // FV_EPI_SWIGLU_F16: device counter of 8-value groups clamped to the fp16 range (0 in a healthy model)
   void* stash = nullptr;     // FV_EPI_SWIGLU_SPLIT: raw gate/up accumulators, [M][N] fp32 or (stash_f16) fp16
   int stash_f16 = 0;
 };
 
+#ifdef FASTVLA_AB_SWITCHES
+__device__ int g_g2_krot = 0;
+#endif
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -337,8 +344,16 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   // ksplit 1: A = [hi | lo] bf16, the weight columns are walked twice; 2: nk1 bf16 tiles of A's hi half, then K / 128 fp8 tiles (A's
   // one-byte remainders at byte offset 2K of its rows, W8's rows at the bf16 copy's row stride: the per-lane offsets serve both)
   const int nk1 = p.K / BK, nk = LO8 ? nk1 + p.K / 128 : (p.ksplit ? 2 * nk1 : nk1);
+#ifdef FASTVLA_AB_SWITCHES
+  // tools only (FASTVLA_GEMM_KROT=1): every block starts its K walk at a different K-tile -- does a one-round launch lose time because all
+  // 256 CUs read the same k columns at the same moment?  (plain operands, one K range per tile only)
+  const int krot = (g_g2_krot && !p.ksplit && p.splits == 1) ? (int)((blockIdx.x * 13u) % (unsigned)nk) : 0;
+  auto a_boff = [&](int kt0_) { const int kt = krot ? (kt0_ + krot) % nk : kt0_; return LO8 && kt >= nk1 ? 2 * p.K + (kt - nk1) * 128 : ((kt >= nk1 ? kt - nk1 : kt) * BK + (kt >= nk1 ? p.K : 0)) * 2; };
+  auto w_boff = [&](int kt0_) { const int kt = krot ? (kt0_ + krot) % nk : kt0_; return LO8 && kt >= nk1 ? (kt - nk1) * 128 : (kt >= nk1 ? kt - nk1 : kt) * BK * 2; };
+#else
   auto a_boff = [&](int kt) { return LO8 && kt >= nk1 ? 2 * p.K + (kt - nk1) * 128 : ((kt >= nk1 ? kt - nk1 : kt) * BK + (kt >= nk1 ? p.K : 0)) * 2; };
   auto w_boff = [&](int kt) { return LO8 && kt >= nk1 ? (kt - nk1) * 128 : (kt >= nk1 ? kt - nk1 : kt) * BK * 2; };
+#endif
   const int wslot = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
   // staging: slot s = j * 512 + tid is 16 B of row s >> 3 at LDS position s & 7, filled from k-chunk (s & 7) ^ (row & 7)
@@ -352,6 +367,11 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
     if (p.tiles_m) {
       bn = (logical / p.tiles_m) * BNT;
       bm = (logical % p.tiles_m) * BMT;
+    } else if (p.group_m) {
+      const int gsz = p.group_m * p.tiles_n, g = logical / gsz, r = logical - g * gsz;
+      const int rows = min(p.group_m, p.tiles_mt - g * p.group_m);
+      bm = (g * p.group_m + r % rows) * BMT;
+      bn = (r / rows) * BNT;
     } else {
       bm = (logical / p.tiles_n) * BMT;
       bn = (logical % p.tiles_n) * BNT;
@@ -834,6 +854,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
 
 static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   g_norm_fused = false;
+#ifdef FASTVLA_AB_SWITCHES
+  {
+    static bool done = false;
+    if (!done) { done = true; const int v = fv_ab_env("FASTVLA_GEMM_KROT") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_g2_krot), &v, sizeof(int)); }
+  }
+#endif
   if (!a.A || !a.W || !a.out) return fv_fail(FV_ERR_ARG, "gemm: null operand");
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fv_fail(FV_ERR_ARG, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.K % 8 || a.lda % 8 || a.N % 8) return fv_fail(FV_ERR_ARG, "gemm: K, lda, N must be multiples of 8 (K=%d lda=%d N=%d)", a.K, a.lda, a.N);
@@ -880,6 +906,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   static const bool colmajor_ok = fv_ab_env("FASTVLA_NO_GEMM_COLMAJOR") == nullptr;   // A/B
   constexpr int cm_max = 8;   // (16 measured at the headline shape in round 3: gate/up -3.5 %, split-K down +9 %, step unchanged)
   static const bool no_asym = fv_ab_env("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
+  static const int group_m_default = fv_ab_env("FASTVLA_GEMM_GROUP_M") ? atoi(fv_ab_env("FASTVLA_GEMM_GROUP_M")) : 4;   // A/B (0 = row-major walk)
   const bool asym = !no_asym && a.M <= 8192 && a.M % 256 == 0;   // the asymmetric staging addresses row + 32 from a (clamped) base row: whole row tiles only
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
   static const bool no_splitk = fv_ab_env("FASTVLA_NO_SPLITK") != nullptr, no_g256 = fv_ab_env("FASTVLA_NO_GEMM256") != nullptr;
@@ -906,6 +933,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     if (splits > 1) {
       p.tiles_n = tn;
       p.tiles_m = colmajor_ok && tmr <= cm_max ? tmr : 0;
+      p.tiles_mt = tmr; p.group_m = (!p.tiles_m && tn > 8) ? group_m_default : 0;
       p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
       p.nwg = tiles * splits;
       const dim3 g2(p.nwg < cus ? p.nwg : cus / 8 * 8);
@@ -950,7 +978,9 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     p.tiles_n = (a.N + gt - 1) / gt;
     p.nwg = tmr * p.tiles_n;
     p.tiles_m = colmajor_ok && tmr <= cm_max ? tmr : 0;
-    const int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
+    p.tiles_mt = tmr; p.group_m = (!p.tiles_m && p.tiles_n > 8) ? group_m_default : 0;   // (the 128-tile instance shares the kernel: two blocks per CU, 64 tiles per XCD at a time)
+    int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
+    if (const char* e = fv_ab_env("FASTVLA_GEMM_GRID")) { const int v = atoi(e); if (v >= 8 && gt == 256) slots = v / 8 * 8; }   // tools only
     const int grid = p.nwg < slots ? p.nwg : slots;
     if (gt == 256 && a.ksplit == 2) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, false, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else if (a.ksplit == 2) hipLaunchKernelGGL((gemm256_kernel<4, 2, false, false, true>), dim3(grid), dim3(256), 2 * 256 * 128, s, p);
