@@ -667,7 +667,9 @@ def test_gemm_splitk_few_rows_many_splits(ws_splits):
 
 
 @pytest.mark.parametrize("M,N,K,ksplit,ws", [(8200, 896, 256, 0, False), (10240, 1152, 192, 1, False), (9728, 904, 128, 1, False),
-                                              (896, 4864, 2048, 1, True), (900, 904, 4096, 0, True), (1152, 896, 2048, 1, True)])
+                                              (896, 4864, 2048, 1, True), (900, 904, 4096, 0, True), (1152, 896, 2048, 1, True),
+                                              # 11 x 12 tiles, ragged on both edges: the grouped tile walk (groups of 4 tile rows) with a last group of 3
+                                              (2660, 2920, 128, 0, False), (2660, 2920, 1024, 1, True)])
 def test_gemm_256_tile_ragged_edges_fp32_epilogues(M, N, K, ksplit, ws):
     """Round 4: fp32-epilogue problems whose M or N is not a multiple of 256 (the decoder's N = 896 / 1152 projections at a training
     batch, every dgrad / wgrad of the unfrozen path: M = 896, N = 4864 ...) on the 256-tile LDS-DMA kernel with ragged edge tiles --

@@ -906,6 +906,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   static const bool colmajor_ok = fv_ab_env("FASTVLA_NO_GEMM_COLMAJOR") == nullptr;   // A/B
   constexpr int cm_max = 8;   // (16 measured at the headline shape in round 3: gate/up -3.5 %, split-K down +9 %, step unchanged)
   static const bool no_asym = fv_ab_env("FASTVLA_NO_GEMM_ASYM") != nullptr;   // A/B
+  static const int min_kt_per_range = fv_ab_env("FASTVLA_GEMM_MIN_KT") ? atoi(fv_ab_env("FASTVLA_GEMM_MIN_KT")) : 16;   // A/B
   static const int group_m_default = fv_ab_env("FASTVLA_GEMM_GROUP_M") ? atoi(fv_ab_env("FASTVLA_GEMM_GROUP_M")) : 4;   // A/B (0 = row-major walk)
   const bool asym = !no_asym && a.M <= 8192 && a.M % 256 == 0;   // the asymmetric staging addresses row + 32 from a (clamped) base row: whole row tiles only
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
@@ -924,7 +925,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
       const double part_us = 2.0 * (double)a.M * (tn * 256) * 4.0 / 4.0e6;               // one range's partials written + read at ~4 TB/s
       double best = 1e30;
       for (int sN = 1; sN <= 8; ++sN) {
-        if (sN > 1 && (nkt / sN < 16 || (size_t)sN * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes)) break;
+        if (sN > 1 && (nkt / sN < min_kt_per_range || (size_t)sN * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes)) break;
         const long units = (long)tiles * sN, rounds = (units + cus - 1) / cus;
         const double t = (double)rounds * tile_us / sN + (sN > 1 ? sN * part_us : 0.0);
         if (t < best * 0.97) { best = t; splits = sN; }
