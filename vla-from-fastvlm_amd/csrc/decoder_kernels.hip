@@ -531,7 +531,7 @@ int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int
   static const bool no_mfma = fv_ab_env("FASTVLA_NO_ATTN_F32_MFMA") != nullptr;
   static const bool no_split = fv_ab_env("FASTVLA_NO_ATTN_SPLIT") != nullptr;   // A/B: the fp32-MFMA kernels of round 4's first version
   // training (lse wanted): the split-bf16 kernel -- 5x the fp32 pipe's rate at 16 significant bits per operand (attention_split.hip)
-  if (D >= 64 && lse && !pre && !lo8 && !no_split && split_scratch)
+  if (D >= 64 && (lse || T >= FV_ATTN_SPLIT_MIN_T) && !pre && !lo8 && !no_split && split_scratch)
     return launch_attention_split_fwd(qkv, ld, out_hi, out_lo, ldo, B, T, heads, kv_heads, D, lens, len_add, scale, rope, lse, split_scratch, s);
   if (D >= 64 && (!no_mfma || pre || lse)) {
     const long nb = (long)B * heads * ((T - Np + 63) / 64);

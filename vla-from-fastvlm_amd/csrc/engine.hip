@@ -93,7 +93,7 @@ struct DecLayer {
 struct Decoder { bf16_t* embed = nullptr; std::vector<DecLayer> layers; float* norm = nullptr; };
 
 struct WsPlan {
-  size_t bufA, bufB, bufH, se, tower_out, x, xn, qkv, att, act, xn_lo, att_lo, act_lo, qkvf, guf, splitk, splitk_bytes, head_scr, total;
+  size_t bufA, bufB, bufH, se, tower_out, x, xn, qkv, att, act, xn_lo, att_lo, act_lo, qkvf, guf, splitk, splitk_bytes, head_scr, attn_scr, attn_scr_bytes, total;
 };
 
 // optional per-launch HIP-event timing on the caller's stream (bench.py's roofline numbers); off by default
@@ -391,6 +391,11 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
   p.splitk_bytes = rows % 256 == 0 ? (size_t)(rows <= 2048 ? 8 : 4) * rows * ((std::max((size_t)d.llm_hidden, qkvw) + 255) / 256 * 256) * 4 : 0;
   p.splitk = take(p.splitk_bytes);
   p.head_scr = take(fv::head_bwd_scratch_bytes(h->hd, B));
+  // long sequences (the spliced prefill: 256 image + T text positions) run the split-bf16 attention kernel: its per-layer K / V records
+  const int Tseq = T + (splice ? (int)P : 0);
+  p.attn_scr_bytes = (d.llm_precision != 0 && Tseq >= fv::FV_ATTN_SPLIT_MIN_T && (d.llm_head_dim == 64 || d.llm_head_dim == 128))
+                         ? fv::attention_split_scratch_bytes(B, Tseq, d.llm_kv_heads, d.llm_head_dim) : 0;
+  p.attn_scr = take(p.attn_scr_bytes);
   p.total = o;
   return p;
 }
@@ -655,7 +660,8 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
       // RoPE rides inside the attention kernel (q fragments in registers, K rows on their way into LDS)
       FV_P(FV_FAM_ATTN, 2.0 * B * (double)Tq * Tt * qd + 3.0 * rows * (qd + kd), 4.0 * rows * (qkvw + qd),
            fv::launch_attention_f32(qkvf, qkvw, as, as + qd, 2 * qd, B, Tt, d.llm_heads, d.llm_kv_heads, D, lens, len_add, att_scale, s, h->rope,
-                                    mode == DEC_SUFFIX ? kv + li * kv_layer : nullptr, 2 * kd, mode == DEC_SUFFIX ? Np : 0, nullptr, lo8));
+                                    mode == DEC_SUFFIX ? kv + li * kv_layer : nullptr, 2 * kd, mode == DEC_SUFFIX ? Np : 0, nullptr, lo8,
+                                    wp.attn_scr_bytes && mode != DEC_SUFFIX ? ws + wp.attn_scr : nullptr));
       fv::GemmArgs o1{as, 2 * qd, L.o_w, rows, Hd, qd, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, KS};
       o1.W8 = L.o_w8;
       o1.splitk_ws = q1.splitk_ws;

@@ -920,7 +920,13 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     // (s x M x npad floats written and read back: ~0.5 of a 2048-deep K loop per range at 10 240 x 1024) -- 160 tiles (the unfrozen path's
     // 10 240 x 896 projections) take 3 ranges = 480 units = 1.9 rounds instead of 0.6 of one
     int splits = 1;
-    {
+    static const bool old_rule = fv_ab_env("FASTVLA_SPLITK_OLD") != nullptr;   // A/B: round 3's rule (cus / tiles ranges, only below one round)
+    if (old_rule) {
+      splits = tiles < cus ? cus / tiles : 1;
+      if (splits > 8) splits = 8;
+      while (splits > 1 && nkt / splits < 16) --splits;
+      while (splits > 1 && (size_t)splits * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes) --splits;
+    } else {
       const double tile_us = (double)nkt * 64.0 * 131072.0 / 1.0e6 / 4.0;                 // ~a 256 x 256 x (64 nkt) tile on one CU at ~4 GF/us/CU
       const double part_us = 2.0 * (double)a.M * (tn * 256) * 4.0 / 4.0e6;               // one range's partials written + read at ~4 TB/s
       double best = 1e30;

@@ -109,7 +109,9 @@ int launch_attention_f32(float* qkv, int ld, bf16_t* out_hi, bf16_t* out_lo, int
                          const float* pre = nullptr, int ldp = 0, int Np = 0,    // pre: cached [k | v] rows of positions < Np (8f-1)
                          float* lse = nullptr,    // optional [B][heads][T] row statistics max + log(sum) for the backward pass (head_dim 64 / 128, Np = 0)
                          int lo8 = 0,             // remainders as fp8 bytes (the hi + lo8 operand form of llm_precision = 5)
-                         void* split_scratch = nullptr);   // with lse: attention_split_scratch_bytes() bytes -> the split-bf16 kernel (attention_split.hip)
+                         void* split_scratch = nullptr);   // attention_split_scratch_bytes() bytes -> the split-bf16 kernel (attention_split.hip) when lse is wanted (training)
+                                                           // or the sequence is at least FV_ATTN_SPLIT_MIN_T long (the spliced prefill); never with a cached prefix or lo8
+constexpr int FV_ATTN_SPLIT_MIN_T = 128;
 // table: [>=T][D/2] (cos, sin) pairs built by rope_table_host(); position = row % T
 int launch_rope(bf16_t* qkv, const float2* table, int ld, int rows, int T, int heads, int kv_heads, int D,
                 hipStream_t s);
