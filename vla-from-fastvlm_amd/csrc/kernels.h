@@ -124,14 +124,12 @@ constexpr int RMS_BWD_RPW = 4;      // rows per wave of rmsnorm_bwd_kernel (one 
 constexpr int COLSUM_CHUNKS = 64;   // row ranges of the two-stage deterministic column sum
 int launch_split_rows(const float* in, int ldi, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);
 int launch_lo8_rows(const float* in, int ldi, bf16_t* out, int ldo, long R, int C, hipStream_t s);   // the fp8 remainder bytes of the hi + lo8 operand form
-int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
 int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, int ldo, int lo_off, int R, int Rp, int C, hipStream_t s);
 // the same transpose to fp16 (saturating; clamps counted in *sat): in_kind 0 = fp32, 1 = bf16, 2 = split bf16 (value = in[c] + in[lo_in + c]: both halves summed before rounding)
 int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, int R, int Rp, int C, unsigned* sat, hipStream_t s,
                             bf16_t* rows_out = nullptr, int ldro = 0);   // rows_out: the same values also as fp16 rows [R][ldro]
 int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, long R, int C, unsigned* sat, hipStream_t s);   // row-major fp16 rows (in_kind as above)
-int launch_swiglu_fwd(const float* gu, bf16_t* act, int ldo, int lo_off, long rows, int I, hipStream_t s);
 int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s, bf16_t* out_split = nullptr);   // out_split: [rows][4I] = [hi | lo] bf16 instead of fp32 in place
 // dgu straight into the two fp16 operands of its consumers: rows [rows][2I] and columns [2I][Rp] (zero for rows in [rows, Rp)); clamps counted in *sat
 int launch_swiglu_bwd_f16(const void* gu, int gu_f16, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s,

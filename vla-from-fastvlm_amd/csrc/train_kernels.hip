@@ -67,13 +67,6 @@ __global__ __launch_bounds__(256) void lo8_rows_kernel(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n8) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-    float v[8];
-    load8(in + i * 8, v);
-    reinterpret_cast<uint4*>(out)[i] = pack8(v);
-  }
-}
 __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n8) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
     float v[8];
@@ -246,26 +239,8 @@ __global__ __launch_bounds__(256) void commit_kernel(const CommitDesc* __restric
   }
 }
 
-// SwiGLU on the gate/up accumulators.  gu fp32 [rows][2I], columns in the packed weight's order: 16-column groups [8 gate | 8 up]
-// of the outputs 8j .. 8j+7.  act = silu(gate) * up as split bf16: [rows][ldo] with hi at column i, lo at lo_off + i.
-__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const float* __restrict__ gu, bf16_t* __restrict__ act, int ldo, int lo_off, long rows, int I) {
-  const int j8 = I >> 3;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * j8; i += (long)gridDim.x * 256) {
-    const long r = i / j8;
-    const int j = (int)(i % j8);
-    float g[8], u[8], o[8], h[8], l[8];
-    load8(gu + r * 2 * I + 16 * j, g);
-    load8(gu + r * 2 * I + 16 * j + 8, u);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = silu_f(g[e]) * u[e];
-    const uint4 hv = pack8(o);
-    *reinterpret_cast<uint4*>(act + r * ldo + 8 * j) = hv;
-    unpack8(hv, h);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) l[e] = o[e] - h[e];
-    *reinterpret_cast<uint4*>(act + r * ldo + lo_off + 8 * j) = pack8(l);
-  }
-}
+// (SwiGLU forward: in the gate/up GEMM's epilogue, FV_EPI_SWIGLU_SPLIT + GemmArgs::stash.)  gu [rows][2I] has its columns in the packed weight's
+// order: 16-column groups [8 gate | 8 up] of the outputs 8j .. 8j+7.
 // dgu (same interleaved layout) from dact [rows][I]:  dgate = dact * up * silu'(gate), dup = dact * silu(gate).  out_split == null: fp32,
 // written over gu; else split bf16 [rows][4I] = [hi 2I | lo 2I]: the dgrad GEMM's operand as it is, and (transposed) the wgrad's
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(float* __restrict__ gu, const float* __restrict__ dact, long rows, int I, bf16_t* __restrict__ out_split) {
@@ -872,12 +847,6 @@ int launch_lo8_rows(const float* in, int ldi, bf16_t* out, int ldo, long R, int 
   return FV_OK;
 }
 
-int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
-  if (!in || !out || n == 0 || n % 8 || (((uintptr_t)in | (uintptr_t)out) & 15)) return fv_fail(FV_ERR_ARG, "f32_to_bf16: n %% 8 == 0 and 16-byte aligned pointers");
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for((long)(n / 8))), dim3(256), 0, s, in, out, (long)(n / 8));
-  FV_HIP_CHECK(hipGetLastError());
-  return FV_OK;
-}
 int launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s) {
   if (!in || !out || n == 0 || n % 8 || (((uintptr_t)in | (uintptr_t)out) & 15)) return fv_fail(FV_ERR_ARG, "bf16_to_f32: n %% 8 == 0 and 16-byte aligned pointers");
   hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for((long)(n / 8))), dim3(256), 0, s, in, out, (long)(n / 8));
@@ -923,12 +892,6 @@ int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* 
   return FV_OK;
 }
 
-int launch_swiglu_fwd(const float* gu, bf16_t* act, int ldo, int lo_off, long rows, int I, hipStream_t s) {
-  if (!gu || !act || rows <= 0 || I <= 0 || I % 8 || ldo % 8 || lo_off < I || lo_off % 8 || ldo < lo_off + I) return fv_fail(FV_ERR_ARG, "swiglu_fwd: bad arguments");
-  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (I / 8))), dim3(256), 0, s, gu, act, ldo, lo_off, rows, I);
-  FV_HIP_CHECK(hipGetLastError());
-  return FV_OK;
-}
 int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s, bf16_t* out_split) {
   if (!gu || !dact || rows <= 0 || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_bwd: bad arguments");
   hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (I / 8))), dim3(256), 0, s, gu, dact, rows, I, out_split);
