@@ -245,6 +245,16 @@ def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
     pooled = eng.llm_pooled(ids, mask.sum(1), tok_ref.to(DEV))
     torch.cuda.synchronize()
     assert rel_l2(pooled.cpu(), pooled_ref) <= 3e-4
+    if name == "small":
+        # the one-launch commit also rewrote the dgrad's transposed fp16 weight copies: a backward on them must equal, bit for bit, a backward on
+        # copies rebuilt from the library's weights by the standalone transpose kernels (what a switch of the dgrad form and back does)
+        _, _, g_commit = eng.train_forward_backward(new, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+        eng.train_set_options(grad_split=1)
+        eng.train_set_options()
+        _, _, g_rebuilt = eng.train_forward_backward(new, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+        torch.cuda.synchronize()
+        assert torch.equal(g_commit, g_rebuilt)
+        assert float((g_commit - grads).abs().max()) > 0      # (and the parameters did move)
     eng.close()
 
 
