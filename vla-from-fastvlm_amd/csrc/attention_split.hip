@@ -173,8 +173,8 @@ template <int D> struct ASGeo {
 };
 
 // flat 16-byte copy global -> LDS by the whole block
-__device__ __forceinline__ void copy_flat(char* __restrict__ dst, const char* __restrict__ src, int bytes, int tid) {
-  for (int i = tid * 16; i < bytes; i += 256 * 16) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+__device__ __forceinline__ void copy_flat(char* __restrict__ dst, const char* __restrict__ src, int bytes, int tid, int nthreads = 256) {
+  for (int i = tid * 16; i < bytes; i += nthreads * 16) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
 }
 
 // K (rotated) and V of every (batch, kv head) as split bf16 in both forms, one record per 64-key chunk: what every q head's and every query block's
@@ -209,8 +209,10 @@ __global__ __launch_bounds__(256) void attn_prep_kv_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------------------------------------- forward
 // out = softmax(Q K^T * scale + causal / key-length mask) V as split bf16 (hi | lo), lse = max + log(sum) per (batch, head, query)
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float* __restrict__ qkv, int ld, bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
+// GQ: one block = the q heads of ONE GQA group (a wave per head, 2 <= group <= 8) on one 16 NT-query block -- the group's K / V records go through
+// LDS once for all of its heads (2.6x fewer L2 -> LDS bytes at 14 q / 2 kv heads, T = 320: the staging, not the products, bounds this kernel)
+template <int D, bool GQ>
+__global__ __launch_bounds__(GQ ? 512 : 256, 2) void attn_fwd_split_kernel(const float* __restrict__ qkv, int ld, bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
                                                                  const int32_t* __restrict__ lens, int len_add, int T, int heads, int kv_heads, float scale,
                                                                  const float2* __restrict__ rope, float* __restrict__ lse, const char* __restrict__ rec, int nchunks) {
   using GEO = ASGeo<D>;
@@ -222,18 +224,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float* __r
   bf16_t* sVTl = reinterpret_cast<bf16_t*>(as_smem + 2 * GEO::NATB + GEO::TRB);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int qblocks = (T + RB - 1) / RB;
+  constexpr int QB = GQ ? 16 * NT : RB;   // queries per block (GQ: every wave takes the same queries of its own head)
+  const int qblocks = (T + QB - 1) / QB;
   // the query blocks with the longest causal key range first: the launch is ~1.3 rounds of resident blocks, and its tail should be the short ones
   // (blocks of one GQA group deliberately NOT gathered on one XCD: with xcd_remap the forward takes 68 instead of 58 us and dq 134 instead of 116 --
   // the seven heads' copies of a K / V record are better spread over eight L2s than served by one; AS_ABL(8) in the tools build is that A/B)
   int bid = AS_ABL(8) ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int h = bid % heads; bid /= heads;
-  const int b = bid % (int)(gridDim.x / (heads * qblocks));
-  const int qb = qblocks - 1 - bid / (int)(gridDim.x / (heads * qblocks));
-  const int hk = h / (heads / kv_heads);
+  int h, hk, b, qb;
+  if constexpr (GQ) {
+    const int grp = heads / kv_heads, nb_ = (int)(gridDim.x / (kv_heads * qblocks));
+    hk = bid % kv_heads; bid /= kv_heads;
+    b = bid % nb_; qb = qblocks - 1 - bid / nb_;
+    h = hk * grp + wid;
+  } else {
+    h = bid % heads; bid /= heads;
+    b = bid % (int)(gridDim.x / (heads * qblocks));
+    qb = qblocks - 1 - bid / (int)(gridDim.x / (heads * qblocks));
+    hk = h / (heads / kv_heads);
+  }
   int len = lens ? lens[b] + len_add : T;
   len = max(1, min(len, T));
-  const int q0w = qb * RB + wid * (16 * NT);
+  const int q0w = GQ ? qb * QB : qb * RB + wid * (16 * NT);
+  const int nthr = (int)blockDim.x;
   const float* base = qkv + (size_t)b * T * ld;
 
   bf16x8 Qh[NT][KS], Ql[NT][KS];
@@ -254,10 +266,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float* __r
     for (int dt = 0; dt < DT; ++dt) o[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  const int kend = min(len, qb * RB + RB);   // causal: keys beyond the block's last query are never visible
+  const int kend = min(len, qb * QB + QB);   // causal: keys beyond the block's last query are never visible
   for (int k0 = 0; k0 < kend; k0 += ACH) {
     __syncthreads();
-    copy_flat(as_smem, rec + ((size_t)(b * kv_heads + hk) * nchunks + k0 / ACH) * GEO::REC, GEO::REC_FWD, tid);
+    copy_flat(as_smem, rec + ((size_t)(b * kv_heads + hk) * nchunks + k0 / ACH) * GEO::REC, GEO::REC_FWD, tid, nthr);
     __syncthreads();
 #pragma unroll 1
     for (int kp = 0; kp < ACH / 32; ++kp) {
@@ -337,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const float* __r
 //   P = exp(S * scale - lse),  dP = dO . V^T,  delta_i = sum_d dO_id O_id,  dS = P o (dP - delta) * scale,
 //   dQ = dS . K,  dK = dS^T . Q,  dV = P^T . dO        (Q, K = the ROTATED projections; the gradient is rotated back on the way out)
 // dq kernel: block = RB queries of one (batch, q head); K (natural and transposed) and V chunks through LDS; also writes delta.
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_split_kernel(const float* __restrict__ qkv, int ld, const bf16_t* __restrict__ o_hi, const bf16_t* __restrict__ o_lo,
+template <int D, bool GQ>   // GQ: as attn_fwd_split_kernel -- one block per GQA group and 16 NT-query block, a wave per q head
+__global__ __launch_bounds__(GQ ? 512 : 256, GQ ? 1 : 2) void attn_bwd_dq_split_kernel(const float* __restrict__ qkv, int ld, const bf16_t* __restrict__ o_hi, const bf16_t* __restrict__ o_lo,
                                                                     int ldo, const float* __restrict__ dO, int lddo, const float* __restrict__ lse,
                                                                     float* __restrict__ delta, float* __restrict__ dqkv, const int32_t* __restrict__ lens,
                                                                     int len_add, int T, int heads, int kv_heads, float scale, const float2* __restrict__ rope,
@@ -354,18 +366,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split_kernel(const float* 
   bf16_t* sKTl = reinterpret_cast<bf16_t*>(as_smem + 4 * GEO::NATB + GEO::TRB);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int qblocks = (T + RB - 1) / RB;
-  // the query blocks with the longest causal key range first: the launch is ~1.3 rounds of resident blocks, and its tail should be the short ones
-  // (blocks of one GQA group deliberately NOT gathered on one XCD: with xcd_remap the forward takes 68 instead of 58 us and dq 134 instead of 116 --
-  // the seven heads' copies of a K / V record are better spread over eight L2s than served by one; AS_ABL(8) in the tools build is that A/B)
-  int bid = AS_ABL(8) ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int h = bid % heads; bid /= heads;
-  const int b = bid % (int)(gridDim.x / (heads * qblocks));
-  const int qb = qblocks - 1 - bid / (int)(gridDim.x / (heads * qblocks));
-  const int hk = h / (heads / kv_heads);
+  constexpr int QB = GQ ? 16 * NT : RB;
+  const int qblocks = (T + QB - 1) / QB;
+  int bid = AS_ABL(8) ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // (query blocks with the longest causal range first, as in the forward)
+  int h, hk, b, qb;
+  if constexpr (GQ) {
+    const int grp = heads / kv_heads, nb_ = (int)(gridDim.x / (kv_heads * qblocks));
+    hk = bid % kv_heads; bid /= kv_heads;
+    b = bid % nb_; qb = qblocks - 1 - bid / nb_;
+    h = hk * grp + wid;
+  } else {
+    h = bid % heads; bid /= heads;
+    b = bid % (int)(gridDim.x / (heads * qblocks));
+    qb = qblocks - 1 - bid / (int)(gridDim.x / (heads * qblocks));
+    hk = h / (heads / kv_heads);
+  }
   int len = lens ? lens[b] + len_add : T;
   len = max(1, min(len, T));
-  const int q0w = qb * RB + wid * (16 * NT);
+  const int q0w = GQ ? qb * QB : qb * RB + wid * (16 * NT);
+  const int nthr = (int)blockDim.x;
   const float* base = qkv + (size_t)b * T * ld;
 
   bf16x8 Qh[NT][KS], Ql[NT][KS], Gh[NT][KS], Gl[NT][KS];   // Q (rotated) and dO rows as B operands
@@ -401,13 +420,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split_kernel(const float* 
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int kend = min(len, qb * RB + RB);
+  const int kend = min(len, qb * QB + QB);
   for (int k0 = 0; k0 < kend; k0 += ACH) {
     __syncthreads();
     if (!AS_ABL(1) || k0 == 0) {
       const char* r0 = rec + ((size_t)(b * kv_heads + hk) * nchunks + k0 / ACH) * GEO::REC;
-      copy_flat(as_smem, r0, 2 * GEO::NATB, tid);                                              // K natural
-      copy_flat(as_smem + 2 * GEO::NATB, r0 + GEO::REC_VN, 2 * GEO::NATB + 2 * GEO::TRB, tid);  // V natural, K transposed
+      copy_flat(as_smem, r0, 2 * GEO::NATB, tid, nthr);                                              // K natural
+      copy_flat(as_smem + 2 * GEO::NATB, r0 + GEO::REC_VN, 2 * GEO::NATB + 2 * GEO::TRB, tid, nthr);  // V natural, K transposed
     }
     __syncthreads();
 #pragma unroll 1
@@ -653,22 +672,36 @@ int launch_attention_split_fwd(const float* qkv, int ld, bf16_t* out_hi, bf16_t*
     return fv_fail(FV_ERR_ARG, "attention_split_fwd: bad shape");
   static bool attr = false;
   if (!attr) {
-    FV_TRY_RC(set_lds(attn_fwd_split_kernel<64>, as_fwd_lds<64>()));
-    FV_TRY_RC(set_lds(attn_fwd_split_kernel<128>, as_fwd_lds<128>()));
+    FV_TRY_RC(set_lds(attn_fwd_split_kernel<64, false>, as_fwd_lds<64>()));
+    FV_TRY_RC(set_lds(attn_fwd_split_kernel<128, false>, as_fwd_lds<128>()));
+    FV_TRY_RC(set_lds(attn_fwd_split_kernel<64, true>, as_fwd_lds<64>()));
+    FV_TRY_RC(set_lds(attn_fwd_split_kernel<128, true>, as_fwd_lds<128>()));
     attr = true;
   }
-  char* rec = static_cast<char*>(scratch);
-  const int nch = (T + ACH - 1) / ACH;
 #ifdef FASTVLA_AB_SWITCHES
   as_set_abl();
 #endif
+  char* rec = static_cast<char*>(scratch);
+  const int nch = (T + ACH - 1) / ACH, grp = heads / kv_heads;
   FV_TRY_RC(launch_prep_kv(qkv, ld, B, T, heads, kv_heads, D, rope, rec, s));
+  static const bool no_gq = fv_ab_env("FASTVLA_ATTN_NO_GQ") != nullptr;   // A/B: one block per q head
+  const bool gq = !no_gq && grp >= 2 && grp <= 8;
   if (D == 64) {
-    const long nb = (long)B * heads * ((T + ASGeo<64>::RB - 1) / ASGeo<64>::RB);
-    hipLaunchKernelGGL(attn_fwd_split_kernel<64>, dim3((unsigned)nb), dim3(256), as_fwd_lds<64>(), s, qkv, ld, out_hi, out_lo, ldo, lens, len_add, T, heads, kv_heads, scale, rope, lse, rec, nch);
+    if (gq) {
+      const long nb = (long)B * kv_heads * ((T + 16 * ASGeo<64>::NT - 1) / (16 * ASGeo<64>::NT));
+      hipLaunchKernelGGL((attn_fwd_split_kernel<64, true>), dim3((unsigned)nb), dim3(64 * grp), as_fwd_lds<64>(), s, qkv, ld, out_hi, out_lo, ldo, lens, len_add, T, heads, kv_heads, scale, rope, lse, rec, nch);
+    } else {
+      const long nb = (long)B * heads * ((T + ASGeo<64>::RB - 1) / ASGeo<64>::RB);
+      hipLaunchKernelGGL((attn_fwd_split_kernel<64, false>), dim3((unsigned)nb), dim3(256), as_fwd_lds<64>(), s, qkv, ld, out_hi, out_lo, ldo, lens, len_add, T, heads, kv_heads, scale, rope, lse, rec, nch);
+    }
   } else {
-    const long nb = (long)B * heads * ((T + ASGeo<128>::RB - 1) / ASGeo<128>::RB);
-    hipLaunchKernelGGL(attn_fwd_split_kernel<128>, dim3((unsigned)nb), dim3(256), as_fwd_lds<128>(), s, qkv, ld, out_hi, out_lo, ldo, lens, len_add, T, heads, kv_heads, scale, rope, lse, rec, nch);
+    if (gq) {
+      const long nb = (long)B * kv_heads * ((T + 16 * ASGeo<128>::NT - 1) / (16 * ASGeo<128>::NT));
+      hipLaunchKernelGGL((attn_fwd_split_kernel<128, true>), dim3((unsigned)nb), dim3(64 * grp), as_fwd_lds<128>(), s, qkv, ld, out_hi, out_lo, ldo, lens, len_add, T, heads, kv_heads, scale, rope, lse, rec, nch);
+    } else {
+      const long nb = (long)B * heads * ((T + ASGeo<128>::RB - 1) / ASGeo<128>::RB);
+      hipLaunchKernelGGL((attn_fwd_split_kernel<128, false>), dim3((unsigned)nb), dim3(256), as_fwd_lds<128>(), s, qkv, ld, out_hi, out_lo, ldo, lens, len_add, T, heads, kv_heads, scale, rope, lse, rec, nch);
+    }
   }
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
@@ -690,8 +723,10 @@ int launch_attention_split_bwd(const float* qkv, int ld, const bf16_t* o_hi, con
   FV_TRY_RC(launch_prep_kv(qkv, ld, B, T, heads, kv_heads, D, rope, rec, s));
   static bool attr = false;
   if (!attr) {
-    FV_TRY_RC(set_lds(attn_bwd_dq_split_kernel<64>, as_dq_lds<64>()));
-    FV_TRY_RC(set_lds(attn_bwd_dq_split_kernel<128>, as_dq_lds<128>()));
+    FV_TRY_RC(set_lds(attn_bwd_dq_split_kernel<64, false>, as_dq_lds<64>()));
+    FV_TRY_RC(set_lds(attn_bwd_dq_split_kernel<128, false>, as_dq_lds<128>()));
+    FV_TRY_RC(set_lds(attn_bwd_dq_split_kernel<64, true>, as_dq_lds<64>()));
+    FV_TRY_RC(set_lds(attn_bwd_dq_split_kernel<128, true>, as_dq_lds<128>()));
     FV_TRY_RC(set_lds(attn_bwd_dkv_split_kernel<64, true>, as_dkv_lds<64>()));
     FV_TRY_RC(set_lds(attn_bwd_dkv_split_kernel<64, false>, as_dkv_lds<64>()));
     FV_TRY_RC(set_lds(attn_bwd_dkv_split_kernel<128, true>, as_dkv_lds<128>()));
@@ -700,16 +735,20 @@ int launch_attention_split_bwd(const float* qkv, int ld, const bf16_t* o_hi, con
   }
   const int grp = heads / kv_heads;
   const bool parts = part != nullptr && grp > 1;
+  static const bool no_gq = fv_ab_env("FASTVLA_ATTN_NO_GQ") != nullptr;   // A/B: one block per q head (dq: 118 -> 86 us with the group's heads in one block, forward 58 -> 49)
+  const bool gqm = !no_gq && grp >= 2 && grp <= 8;
   if (D == 64) {
     const int blocks = (T + ASGeo<64>::RB - 1) / ASGeo<64>::RB;
     const dim3 gq(B * heads * blocks), gk(B * kv_heads * blocks * (parts ? grp : 1));
-    hipLaunchKernelGGL(attn_bwd_dq_split_kernel<64>, gq, dim3(256), as_dq_lds<64>(), s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, rec, nch);
+    if (gqm) hipLaunchKernelGGL((attn_bwd_dq_split_kernel<64, true>), dim3(B * kv_heads * ((T + 16 * ASGeo<64>::NT - 1) / (16 * ASGeo<64>::NT))), dim3(64 * grp), as_dq_lds<64>(), s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, rec, nch);
+    else hipLaunchKernelGGL((attn_bwd_dq_split_kernel<64, false>), gq, dim3(256), as_dq_lds<64>(), s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, rec, nch);
     if (parts) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<64, true>), gk, dim3(256), as_dkv_lds<64>(), s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
     else hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<64, false>), gk, dim3(256), as_dkv_lds<64>(), s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
   } else {
     const int blocks = (T + ASGeo<128>::RB - 1) / ASGeo<128>::RB;
     const dim3 gq(B * heads * blocks), gk(B * kv_heads * blocks * (parts ? grp : 1));
-    hipLaunchKernelGGL(attn_bwd_dq_split_kernel<128>, gq, dim3(256), as_dq_lds<128>(), s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, rec, nch);
+    if (gqm) hipLaunchKernelGGL((attn_bwd_dq_split_kernel<128, true>), dim3(B * kv_heads * ((T + 16 * ASGeo<128>::NT - 1) / (16 * ASGeo<128>::NT))), dim3(64 * grp), as_dq_lds<128>(), s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, rec, nch);
+    else hipLaunchKernelGGL((attn_bwd_dq_split_kernel<128, false>), gq, dim3(256), as_dq_lds<128>(), s, qkv, ld, o_hi, o_lo, ldo, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, rec, nch);
     if (parts) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<128, true>), gk, dim3(256), as_dkv_lds<128>(), s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
     else hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<128, false>), gk, dim3(256), as_dkv_lds<128>(), s, qkv, ld, dO, lddo, lse, delta, dqkv, lens, len_add, T, heads, kv_heads, scale, rope, part, pstride);
   }
