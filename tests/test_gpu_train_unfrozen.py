@@ -61,7 +61,9 @@ def _attention_autograd(qkv, B, T, heads, kv, D, lens, theta):
     return (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B * T, qd)
 
 
-@pytest.mark.parametrize("B,T,heads,kv,D", [(2, 52, 4, 2, 64), (3, 96, 14, 2, 64), (2, 70, 6, 2, 128), (1, 320, 14, 2, 64)])
+@pytest.mark.parametrize("B,T,heads,kv,D", [(2, 52, 4, 2, 64), (3, 96, 14, 2, 64), (2, 70, 6, 2, 128), (1, 320, 14, 2, 64),
+                                            # no grouping (one block per head) and a group wider than a block holds (9 q heads per kv head): the per-head kernels
+                                            (2, 200, 2, 2, 64), (1, 130, 9, 1, 64)])
 def test_attention_backward_matches_autograd(B, T, heads, kv, D):
     torch.manual_seed(B * 100 + T)
     qd, kd = heads * D, kv * D
