@@ -150,7 +150,7 @@ struct fv_handle {
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
   bool no_ffn32 = false;      // FASTVLA_NO_FFN32=1: A/B switch back to the 16x16x32 fused ConvFFN
   TrainState train;               // unfrozen-backbone training (train_path.inc): library-owned transposed bf16 weight copies
-  unsigned* f16_flags = nullptr;  // device (64 zeroed words; [16 .. 63] = the one-launch column sums' arrival counters): [0] = activation groups clamped to the fp16 range (fv_llm_fp16_saturations),
+  unsigned* f16_flags = nullptr;  // device: [0] = activation groups clamped to the fp16 range (fv_llm_fp16_saturations),
                                   // [1] = max |scaled weight| bits seen by the loader's in-place fp16 conversion
 };
 

@@ -137,11 +137,9 @@ int launch_swiglu_bwd_f16(const void* gu, int gu_f16, const float* dact, int row
 int launch_gelu_fwd(const float* pre, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);
 int launch_gelu_bwd(float* dh, const float* pre, size_t n, hipStream_t s);
 size_t rmsnorm_bwd_scratch_floats(long rows, int H);
-constexpr int COLSUM_COUNTERS = 48;   // zero-initialised device words a one-launch column sum may use (one per 256-column block; each is left at zero)
-int launch_colsum(const float* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s,   // scratch >= COLSUM_CHUNKS * C floats
-                  unsigned* counters = nullptr);   // COLSUM_COUNTERS zeroed words: the two stages in ONE launch (the last block of a column range folds the chunks, in chunk order)
+int launch_colsum(const float* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s);   // scratch >= COLSUM_CHUNKS * C floats
 int launch_rmsnorm_bwd(const float* x, const float* w, const float* dy, const float* dres, float* dx, float* dw, float* scratch, long rows, int H,
-                       float eps, hipStream_t s, unsigned* counters = nullptr);
+                       float eps, hipStream_t s);
 int launch_pool_rows(float* stream, float* compact, const int32_t* lens, int B, int Tt, int Ni, int H, int scatter, hipStream_t s);
 int launch_image_rows(const float* stream, float* compact, int B, int Tt, int Ni, int H, hipStream_t s);
 int launch_embed_bwd(const int32_t* ids, const int32_t* lens, const float* dx, float* dE, int B, int T, int Ni, int H, int vocab, hipStream_t s);

@@ -453,35 +453,20 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 }
 
 // deterministic column sums of in [R][ld] (C columns): stage 1 = `chunks` row ranges -> part[chunk][C]; stage 2 (chunks == 1) -> out.
-// fold_out != null: ONE launch -- the block of a column range that arrives LAST (a counter per column block, reset by that block) adds the
-// chunks' partial sums in chunk order, so the result does not depend on which block that was
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int ld, long R, int C, float* __restrict__ out, long rows_per_chunk,
-                                                      float* __restrict__ fold_out, unsigned* __restrict__ counters) {
+// (Two launches on purpose.  A one-launch form -- the block of a column range that arrives last folds the chunks -- was built and measured at
+// 36-66 us against 5 + 6: on this chip the device-scope release / acquire it needs writes back and invalidates a whole XCD's L2, the eight L2s not
+// being coherent with each other.)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int ld, long R, int C, float* __restrict__ out, long rows_per_chunk) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < C) {
-    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    long r = r0;
-    for (; r + 3 < r1; r += 4) {
-      s0 += in[r * ld + c]; s1 += in[(r + 1) * ld + c]; s2 += in[(r + 2) * ld + c]; s3 += in[(r + 3) * ld + c];
-    }
-    for (; r < r1; ++r) s0 += in[r * ld + c];
-    out[(size_t)blockIdx.y * C + c] = (s0 + s1) + (s2 + s3);
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += in[r * ld + c]; s1 += in[(r + 1) * ld + c]; s2 += in[(r + 2) * ld + c]; s3 += in[(r + 3) * ld + c];
   }
-  if (!fold_out) return;
-  __shared__ int s_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(&counters[blockIdx.x], 1u) == gridDim.y - 1;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  if (c < C) {
-    float acc = 0.f;
-    for (unsigned y = 0; y < gridDim.y; ++y) acc += __hip_atomic_load(out + (size_t)y * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-scope loads: other CUs wrote these
-    fold_out[c] = acc;
-  }
-  if (threadIdx.x == 0) counters[blockIdx.x] = 0;
+  for (; r < r1; ++r) s0 += in[r * ld + c];
+  out[(size_t)blockIdx.y * C + c] = (s0 + s1) + (s2 + s3);
 }
 
 // rows of the pooled position (last_token: Ni + max(len - 1, 0)) between the [B * Tt][H] stream and a compact [B][H] buffer
@@ -929,26 +914,24 @@ size_t rmsnorm_bwd_scratch_floats(long rows, int H) {   // dw partial rows + one
   const long waves = (rows + RMS_BWD_RPW - 1) / RMS_BWD_RPW;
   return (size_t)((waves + 3) / 4 * 4 + COLSUM_CHUNKS) * H;
 }
-int launch_colsum(const float* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s, unsigned* counters) {
+int launch_colsum(const float* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s) {
   if (!in || !out || !scratch || R <= 0 || C <= 0 || ld < C) return fv_fail(FV_ERR_ARG, "colsum: bad arguments");
   int chunks = R >= 4 * COLSUM_CHUNKS ? COLSUM_CHUNKS : 1;
   const long rpc = (R + chunks - 1) / chunks;
   chunks = (int)((R + rpc - 1) / rpc);
   const dim3 g((C + 255) / 256, chunks);
   if (chunks == 1) {
-    hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, s, in, ld, R, C, out, rpc, (float*)nullptr, (unsigned*)nullptr);
-  } else if (counters && g.x <= (unsigned)COLSUM_COUNTERS) {   // one launch: the last block of each column range folds the chunks
-    hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, s, in, ld, R, C, scratch, rpc, out, counters);
+    hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, s, in, ld, R, C, out, rpc);
   } else {
-    hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, s, in, ld, R, C, scratch, rpc, (float*)nullptr, (unsigned*)nullptr);
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, 1), dim3(256), 0, s, scratch, C, (long)chunks, C, out, (long)chunks, (float*)nullptr, (unsigned*)nullptr);
+    hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, s, in, ld, R, C, scratch, rpc);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, 1), dim3(256), 0, s, scratch, C, (long)chunks, C, out, (long)chunks);
   }
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
 // dx = dres + rmsnorm'(dy) and dw (H floats); scratch >= rmsnorm_bwd_scratch_floats(rows, H).  dx may alias dres or dy.
 int launch_rmsnorm_bwd(const float* x, const float* w, const float* dy, const float* dres, float* dx, float* dw, float* scratch, long rows, int H,
-                       float eps, hipStream_t s, unsigned* counters) {
+                       float eps, hipStream_t s) {
   if (!x || !w || !dy || !dx || !scratch) return fv_fail(FV_ERR_ARG, "rmsnorm_bwd: null pointer");
   if (rows <= 0 || H <= 0 || H % 8 || H > 4096) return fv_fail(FV_ERR_ARG, "rmsnorm_bwd: bad shape rows=%ld H=%d", rows, H);
   const long waves = (rows + RMS_BWD_RPW - 1) / RMS_BWD_RPW;
@@ -960,7 +943,7 @@ int launch_rmsnorm_bwd(const float* x, const float* w, const float* dy, const fl
   else if (H <= 2048) hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, g, dim3(256), 0, s, x, w, dy, dres, dx, part, rows, H, eps, RMS_BWD_RPW);
   else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, g, dim3(256), 0, s, x, w, dy, dres, dx, part, rows, H, eps, RMS_BWD_RPW);
   FV_HIP_CHECK(hipGetLastError());
-  if (dw) return launch_colsum(scratch, H, wpad, H, dw, scratch + wpad * H, s, counters);
+  if (dw) return launch_colsum(scratch, H, wpad, H, dw, scratch + wpad * H, s);
   return FV_OK;
 }
 
