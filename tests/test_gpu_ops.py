@@ -557,7 +557,9 @@ def test_gemm_pointwise_square(M, C):
     check_close(_gemm(A, W, _lib.EPI_BIAS_GELU, bias=b), F.gelu(ref), what=f"pwconv gelu {M}x{C}")
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 2048, 192), (8192, 4096, 448), (4096, 5632, 192), (1024, 9216, 192), (512, 20480, 128)])
+@pytest.mark.parametrize("M,N,K", [(16384, 2048, 192), (8192, 4096, 448), (4096, 5632, 192), (1024, 9216, 192), (512, 20480, 128),
+                                   # ragged edge tiles under the bf16 epilogues: a half-filled last column tile (N = 896), a last row tile of 8 rows
+                                   (8192, 896, 256), (8200, 1024, 192), (32768, 384, 384)])
 def test_gemm_256_tile_variant(M, N, K):
     """Shapes the 256 x 256 LDS-DMA kernel takes (M, N multiples of 256, K of 64, >= 320 tiles; from 128 tiles up when M <= 2048): all
     three of its epilogues, plus the asymmetric-operand check that a swapped row/column map cannot pass.  The third shape has 352 tiles: a

@@ -32,6 +32,7 @@ def main():
         ("stem 1x1", B * 65536, 96, 96, _lib.EPI_BIAS_GELU, 0, False),
         ("patch pw s2", B * 16384, 192, 192, _lib.EPI_BIAS_GELU, 0, False),
         ("patch pw s3", B * 4096, 384, 384, _lib.EPI_BIAS_GELU, 0, False),
+        ("projector 0", B * 256, 896, 3072, _lib.EPI_BIAS_GELU, 0, False),
         ("tower s4 qkv", B * 256, 2304, 768, _lib.EPI_BIAS, 0, False),
         ("tower s4 fc1", B * 256, 3072, 768, _lib.EPI_BIAS_GELU, 0, False),
         ("tower s4 fc2", B * 256, 768, 3072, _lib.EPI_LS_RES, 0, False),

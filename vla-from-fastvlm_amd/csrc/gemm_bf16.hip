@@ -821,7 +821,10 @@ int gemm_glds_tile(const GemmArgs& a) {
   // take RAGGED edge tiles on the 256-tile kernel -- staging clamps rows past M / N, the epilogue drops them -- when the edge waste is
   // small: the register-staged kernel they fell to runs at ~0.45 PF against ~0.9 here
   static const bool no_ragged = fv_ab_env("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
-  if (!no_ragged && ((f32 && a.N % 8 == 0) || (a.epi == FV_EPI_SWIGLU_SPLIT && a.N % 256 == 0))) {   // (SwiGLU: ragged rows only)
+  // (late round 4: the bf16 epilogues too -- bias / bias + GELU / layer-scale + residual share the guarded store loop: the PatchEmbed 1x1 at
+  // 262144 x 384 x 384 and the projector's first Linear, N = 896, were the last two launches on the register-staged kernel)
+  const bool bf16_epi = a.epi == FV_EPI_BIAS || a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES;
+  if (!no_ragged && (((f32 || bf16_epi) && a.N % 8 == 0) || (a.epi == FV_EPI_SWIGLU_SPLIT && a.N % 256 == 0))) {   // (SwiGLU: ragged rows only)
     const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
     const double fill = (double)a.M * a.N / ((double)tm * tn * 65536.0);
     if (tm * tn >= 128 && fill >= 0.75) return 256;
