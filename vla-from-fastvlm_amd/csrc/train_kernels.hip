@@ -496,29 +496,30 @@ __global__ __launch_bounds__(256) void image_rows_kernel(const float* __restrict
 
 // d embed_tokens: dE[id][:] = sum over the valid text positions holding `id` of dx[row][:], in row order (no atomics).  One block
 // per text position; the block of an id's FIRST valid occurrence sums all of them, the others return.  dE is zero-filled by the caller.
+// The (clamped id | -1 for padding) of every position is staged in LDS first: read from global memory inside the two scans, each of the
+// B T-long loops was a chain of dependent L2 round trips (0.57 ms per step at B T = 2048 for a few MB of work).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ lens, const float* __restrict__ dx,
                                                          float* __restrict__ dE, int B, int T, int Ni, int H, int vocab) {
-  __shared__ int s_first;
-  const int pos = blockIdx.x, b = pos / T, t = pos % T;
-  const int len = lens ? min(max(lens[b], 0), T) : T;
-  if (t >= len) return;
-  const int id = min(max(ids[pos], 0), vocab - 1);
-  if (threadIdx.x == 0) s_first = 1;
-  __syncthreads();
-  for (int p = threadIdx.x; p < pos; p += 256) {
-    const int pb = p / T, pt = p % T;
+  extern __shared__ int s_ids[];
+  const int pos = blockIdx.x, n = B * T;
+  for (int p = threadIdx.x; p < n; p += 256) {
+    const int pb = p / T, pt = p - pb * T;
     const int pl = lens ? min(max(lens[pb], 0), T) : T;
-    if (pt < pl && min(max(ids[p], 0), vocab - 1) == id) s_first = 0;   // benign race: every writer stores 0
+    s_ids[p] = pt < pl ? min(max(ids[p], 0), vocab - 1) : -1;
   }
   __syncthreads();
-  if (!s_first) return;
+  const int id = s_ids[pos];
+  if (id < 0) return;
+  int mine = 1;
+  for (int p = threadIdx.x; p < pos; p += 256)
+    if (s_ids[p] == id) mine = 0;
+  if (!__syncthreads_and(mine)) return;
   const int Tt = Ni + T;
   for (int c = threadIdx.x * 4; c < H; c += 1024) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = pos; p < B * T; ++p) {
-      const int pb = p / T, pt = p % T;
-      const int pl = lens ? min(max(lens[pb], 0), T) : T;
-      if (pt >= pl || min(max(ids[p], 0), vocab - 1) != id) continue;
+    for (int p = pos; p < n; ++p) {
+      if (s_ids[p] != id) continue;
+      const int pb = p / T, pt = p - pb * T;
       const float4 v = *reinterpret_cast<const float4*>(dx + ((size_t)pb * Tt + Ni + pt) * H + c);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
@@ -962,7 +963,8 @@ int launch_image_rows(const float* stream, float* compact, int B, int Tt, int Ni
 }
 int launch_embed_bwd(const int32_t* ids, const int32_t* lens, const float* dx, float* dE, int B, int T, int Ni, int H, int vocab, hipStream_t s) {
   if (!ids || !dx || !dE || B <= 0 || T <= 0 || H % 4 || vocab <= 0) return fv_fail(FV_ERR_ARG, "embed_bwd: bad arguments");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * T), dim3(256), 0, s, ids, lens, dx, dE, B, T, Ni, H, vocab);
+  if ((long)B * T > 16384) return fv_fail(FV_ERR_UNSUPPORTED, "embed_bwd: %ld text positions (the id table lives in 64 KB of LDS)", (long)B * T);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * T), dim3(256), (size_t)B * T * sizeof(int), s, ids, lens, dx, dE, B, T, Ni, H, vocab);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
