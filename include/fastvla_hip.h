@@ -261,7 +261,12 @@ int fv_train_commit(fv_handle* h, const float* flat_params, fv_stream s);
  *                 2e-3 gradient bar; an explicit speed knob);
  *              2: ONE fp16 pass -- the loss-scaled gradient rounded once to 11 significant bits against an fp16 copy of the transposed weight (exact:
  *                 bf16 widens into fp16): the same single pass as 0 at 8x its precision.
- *   wgrad_f16  1: every weight gradient in ONE fp16 pass -- the gradient and the activation each rounded once to 11 significant bits;
+ *   wgrad_f16  1: every weight gradient in ONE fp16 pass -- the gradient and the activation each rounded once to 11 significant bits (operands as
+ *                 transposed fp16 copies, made where the data is produced);
+ *              2: (with grad_split 2) the same arithmetic with the contraction running over the ROWS of the two row-major fp16 operands -- the TN
+ *                 instance of the 256-tile GEMM (LDS image in [k/8][n/16] blocks, fragments by ds_read_b64_tr_b16): nothing is transposed and the
+ *                 gradient's rows serve the dgrad and the wgrad alike; same gradients, but its GEMMs run 29 % slower than the NT ones (twice the
+ *                 fragment-read instructions), +1 ms per 0.5B step: an option, not the default;
  *              0: the split-bf16 gradient against the activation's bf16 hi half (two passes; the activation's 8 bits bound the result at ~1.8e-3).
  *   loss_scale_log2: dL/dactions is multiplied by 2^k, so EVERY gradient fv_train_forward_backward writes carries that factor (it keeps the wgrad's
  *              fp16 gradient operand inside binary16's range; saturating casts, clamps counted by fv_llm_fp16_saturations); pass

@@ -281,6 +281,10 @@ def test_backward_arithmetic_options():
     assert eng.train_loss_scale() == 4096.0
     a1, l1, g1 = run()                                     # default: dgrad and wgrad each ONE fp16 pass
     worst_default = _check_grads(eng, g1, ref, tol=1e-3)
+    eng.train_set_options(grad_split=2, wgrad_f16=2)       # the same arithmetic on the TN GEMM instance (row-major operands, nothing transposed)
+    a7, l7, g7 = run()
+    worst_tn = _check_grads(eng, g7, ref, tol=1e-3)
+    assert torch.equal(a7, a1) and torch.equal(l7, l1) and abs(worst_tn[1] - worst_default[1]) <= 1e-4
     eng.train_set_options(grad_split=1, wgrad_f16=True)    # split-bf16 dgrad operands (two passes): the most exact form
     a6, l6, g6 = run()
     worst_split = _check_grads(eng, g6, ref, tol=1e-3)
@@ -296,7 +300,7 @@ def test_backward_arithmetic_options():
     assert eng.train_loss_scale() == 256.0
     worst_ls8 = _check_grads(eng, g4, ref, tol=1e-3)
     print(f"[unfrozen small, backward arithmetic] worst gradient -- default (fp16 dgrad + fp16 wgrad, one pass each): {worst_default[0]} {worst_default[1]:.2e}; "
-          f"split-bf16 dgrad: {worst_split[1]:.2e}; + two-pass split-bf16 wgrad: {worst_legacy[1]:.2e}; plain-bf16 dgrad operands: {worst_plain[1]:.2e}; "
+          f"TN wgrads: {worst_tn[1]:.2e}; split-bf16 dgrad: {worst_split[1]:.2e}; + two-pass split-bf16 wgrad: {worst_legacy[1]:.2e}; plain-bf16 dgrad operands: {worst_plain[1]:.2e}; "
           f"loss scale 2^8: {worst_ls8[1]:.2e}")
     for a, l in ((a2, l2), (a3, l3), (a4, l4)):
         assert torch.equal(a, a1) and torch.equal(l, l1)

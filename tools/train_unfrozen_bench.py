@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--no-tower", action="store_true", help="reuse one tower output (times the trainable part alone)")
     ap.add_argument("--grad-bf16", action="store_true", help="fv_train_set_options(grad_split=0): plain bf16 dgrad operands (speed knob, outside the 2e-3 gradient bar)")
     ap.add_argument("--dgrad-split", action="store_true", help="fv_train_set_options(grad_split=1): split-bf16 dgrad operands (two passes) instead of ONE fp16 pass")
+    ap.add_argument("--wgrad-tn", action="store_true", help="fv_train_set_options(wgrad_f16=2): the fp16 wgrads on the TN GEMM instance (row-major operands, nothing transposed)")
     ap.add_argument("--wgrad-bf16", action="store_true", help="fv_train_set_options(wgrad_f16=0): weight gradients as split-bf16 gradient x bf16 activation (two passes)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -37,7 +38,7 @@ def main():
     else:
         eng.load_weights(weights.init_backbone(model, seed=1234))
     eng.train_begin()
-    eng.train_set_options(grad_split=1 if args.dgrad_split else (0 if args.grad_bf16 else 2), wgrad_f16=not args.wgrad_bf16)
+    eng.train_set_options(grad_split=1 if args.dgrad_split else (0 if args.grad_bf16 else 2), wgrad_f16=0 if args.wgrad_bf16 else (2 if args.wgrad_tn else 1))
     _, total, nb = eng.train_layout()
     flat = torch.zeros(total, device=dev)
     eng.train_export_params(flat)

@@ -83,6 +83,7 @@ struct TrainState {
   bool ready = false; std::vector<TrainLayerT> layers; bf16_t *pj2T = nullptr, *pj2T16 = nullptr;
   fv::CommitDesc* commit_desc = nullptr; int commit_n = 0, commit_tiles = 0;   // fv_train_commit's descriptor table (device)
   int grad_split = 2;   // dgrad's gradient operand: 1 split bf16 (hi + lo, two passes), 0 its bf16 hi half alone, 2 ONE fp16 pass against fp16 transposed weights (fv_train_set_options)
+  int wgrad_tn = 0;     // 1 (fv_train_set_options wgrad_f16 = 2): weight gradients on the TN GEMM instance (row-major operands, no transposed copies) -- same gradients, +1 ms per step: not the default
   int wgrad_f16 = 1;    // 1: the weight gradients in ONE fp16 pass (both operands 11 significant bits, the gradient carrying the loss scale); 0: split-bf16 gradient x bf16 activation
   int loss_scale_log2 = 12;   // every gradient the backward produces is multiplied by 2^this (the optimiser's grad_scale takes it out again): fp16's range for the wgrad operands
 };

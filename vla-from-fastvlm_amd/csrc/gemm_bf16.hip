@@ -31,10 +31,11 @@ struct Params {
   // time).  For few row tiles against many weight columns (the 7B decoder at M = 1024: 4 x 148) the row-major walk makes every XCD
   // stream 32 different 3.7 MB weight tiles per round and each weight tile is fetched by four XCDs: 2.2 GB per launch, 4.3 TB/s.
   int tiles_m = 0;
-  // gemm256 only: group_m > 0 = walk the tiles in groups of group_m tile ROWS, column-major inside a group (tiles_mt = row tiles in all): the 32 CUs
+  // gemm256 only: group_m = 2 / 4 (dividing the row-tile count) = walk the tiles in groups of group_m tile ROWS, column-major inside a group: the 32 CUs
   // of an XCD work on ~32 consecutive tiles of the walk, which row-major are 1 row x 32 columns = 33 operand panels through that XCD's L2 and
   // grouped by 4 are 4 x 8 = 12 (a 4096^3 problem, 16 x 16 tiles, sat at 790 TF whatever the grid: L2 fill, not the K loop)
   int group_m = 0, tiles_mt = 0;
+  int ldw = 0;   // gemm256 TN instance: W's row stride (elements); lda is A's
   const uint8_t* W8 = nullptr;   // ksplit == 2: fp8 copy of W (x 2^6), row stride 2K bytes
   unsigned* sat = nullptr;   // FV_EPI_SWIGLU_F16: device counter of 8-value groups clamped to the fp16 range (0 in a healthy model)
   void* stash = nullptr;     // FV_EPI_SWIGLU_SPLIT: raw gate/up accumulators, [M][N] fp32 or (stash_f16) fp16
@@ -322,6 +323,16 @@ __device__ unsigned long long g_g2_stamps[256 * 8];   // diagnostics (tools/gemm
 #endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((ext_vector_type(4))) short g2_s16x4;
+// TN fragment of k-step ks (32 deep) for the 16-column tile c16 of a region laid out as [k / 8][cols16 blocks of 256 bytes]: the two
+// transposed reads take k-rows 32 ks + 4 fq + (0..3) and 32 ks + 16 + 4 fq + (0..3) (block rows 4 ks + (fq >> 1) and + 2)
+__device__ __forceinline__ bf16x8 g2_tr_frag(const char* region, int cols16, int c16, int ks, uint32_t tr_lane, int fq_hi) {
+  const char* p0 = region + ((((4 * ks + fq_hi) * cols16 + c16) << 8) + tr_lane);
+  const g2_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g2_s16x4 __attribute__((address_space(3)))*)(p0));
+  const g2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g2_s16x4 __attribute__((address_space(3)))*)(p0 + ((2 * cols16) << 8)));
+  const uint2 lu = __builtin_bit_cast(uint2, lo), hu = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(bf16x8, make_uint4(lu.x, lu.y, hu.x, hu.y));
+}
 
 // MI = 16-row tiles per wave along M (the block has 2 waves along M), WN = waves along N (64 columns each):
 // <8, 4> = 256 x 256 with 8 waves (one block per CU), <4, 2> = 128 x 128 with 4 waves (two per CU) for problems with too few
@@ -331,9 +342,15 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 // straight to their fragment reads and MFMAs and run ahead.  Measured (tools/gemm_shapes.py, A/B in one session): +6 % on the decoder's
 // M = 4096 gate/up and split-K down projections, +-2 % on the tower's shapes, -15 % at 8192^3 (the staging waves' 16 pieces become the
 // critical path of a long K loop with many tiles per CU) -- launch_gemm uses it for M <= 8192 only.
-template <int MI, int WN, bool ASYM = false, bool F16 = false, bool LO8 = false>   // LO8: the hi + lo8 instance (p.ksplit == 2)
+// TN (<8, 4, false, F16, false, true>): both operands are row-major over the CONTRACTION index (A [K][M], W [K][N]: a weight gradient's dY and X as
+// they are produced, no transposed copies).  A K-tile's 64 x 256 slab lands in LDS as [k/8][m/16] blocks of 8 k-rows x 16 columns (32 bytes
+// per row: the per-lane source address of the lane-linear LDS-DMA picks the block's bytes), and a fragment is two ds_read_b64_tr_b16 -- the
+// 16 lanes of group fq address 4 k-rows x 16 columns and each receives its column's 4 values -- giving k-slots (fq, e) <-> k = 4 fq + e (e < 4),
+// 16 + 4 fq + e - 4 (e >= 4) of a 32-deep step on BOTH operands (attention32_kernel's V recipe).
+template <int MI, int WN, bool ASYM = false, bool F16 = false, bool LO8 = false, bool TN = false>   // LO8: the hi + lo8 instance (p.ksplit == 2)
 __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Params p) {   // <8,4> 256x256, <4,2> 128x128
   static_assert(!ASYM || WN == 4, "asymmetric staging pairs wave w with wave w + 4");
+  static_assert(!TN || (!ASYM && !LO8 && MI == 8 && WN == 4), "the TN instance is the plain 256 x 256 one");
   constexpr int BMT = 32 * MI, BNT = 64 * WN, NTH = 128 * WN, BUFB = (BMT + BNT) * 128, AB = BMT * 128;
   constexpr int SA = BMT * 8 / NTH, SW = BNT * 8 / NTH;   // 16-byte staging slots per thread: activations / weights
   static_assert(SA * NTH == BMT * 8 && SW * NTH == BNT * 8 && SA <= 4 && SW <= 4, "whole slots per thread");
@@ -348,11 +365,11 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   // tools only (FASTVLA_GEMM_KROT=1): every block starts its K walk at a different K-tile -- does a one-round launch lose time because all
   // 256 CUs read the same k columns at the same moment?  (plain operands, one K range per tile only)
   const int krot = (g_g2_krot && !p.ksplit && p.splits == 1) ? (int)((blockIdx.x * 13u) % (unsigned)nk) : 0;
-  auto a_boff = [&](int kt0_) { const int kt = krot ? (kt0_ + krot) % nk : kt0_; return LO8 && kt >= nk1 ? 2 * p.K + (kt - nk1) * 128 : ((kt >= nk1 ? kt - nk1 : kt) * BK + (kt >= nk1 ? p.K : 0)) * 2; };
-  auto w_boff = [&](int kt0_) { const int kt = krot ? (kt0_ + krot) % nk : kt0_; return LO8 && kt >= nk1 ? (kt - nk1) * 128 : (kt >= nk1 ? kt - nk1 : kt) * BK * 2; };
+  auto a_boff = [&](int kt0_) { const int kt = krot ? (kt0_ + krot) % nk : kt0_; if constexpr (TN) return kt * BK * p.lda * 2; else return LO8 && kt >= nk1 ? 2 * p.K + (kt - nk1) * 128 : ((kt >= nk1 ? kt - nk1 : kt) * BK + (kt >= nk1 ? p.K : 0)) * 2; };
+  auto w_boff = [&](int kt0_) { const int kt = krot ? (kt0_ + krot) % nk : kt0_; if constexpr (TN) return kt * BK * p.ldw * 2; else return LO8 && kt >= nk1 ? (kt - nk1) * 128 : (kt >= nk1 ? kt - nk1 : kt) * BK * 2; };
 #else
-  auto a_boff = [&](int kt) { return LO8 && kt >= nk1 ? 2 * p.K + (kt - nk1) * 128 : ((kt >= nk1 ? kt - nk1 : kt) * BK + (kt >= nk1 ? p.K : 0)) * 2; };
-  auto w_boff = [&](int kt) { return LO8 && kt >= nk1 ? (kt - nk1) * 128 : (kt >= nk1 ? kt - nk1 : kt) * BK * 2; };
+  auto a_boff = [&](int kt) { if constexpr (TN) return kt * BK * p.lda * 2; else return LO8 && kt >= nk1 ? 2 * p.K + (kt - nk1) * 128 : ((kt >= nk1 ? kt - nk1 : kt) * BK + (kt >= nk1 ? p.K : 0)) * 2; };
+  auto w_boff = [&](int kt) { if constexpr (TN) return kt * BK * p.ldw * 2; else return LO8 && kt >= nk1 ? (kt - nk1) * 128 : (kt >= nk1 ? kt - nk1 : kt) * BK * 2; };
 #endif
   const int wslot = __builtin_amdgcn_readfirstlane(wid) * 1024;
 
@@ -367,15 +384,26 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
     if (p.tiles_m) {
       bn = (logical / p.tiles_m) * BNT;
       bm = (logical % p.tiles_m) * BMT;
-    } else if (p.group_m) {
-      const int gsz = p.group_m * p.tiles_n, g = logical / gsz, r = logical - g * gsz;
-      const int rows = min(p.group_m, p.tiles_mt - g * p.group_m);
-      bm = (g * p.group_m + r % rows) * BMT;
-      bn = (r / rows) * BNT;
+    } else if (p.group_m) {   // group_m = 2 or 4 and divides the row-tile count (launch side): one division, as the row-major walk has
+      const int sh = p.group_m >> 1, gsz = p.tiles_n << sh, g = logical / gsz, r = logical - g * gsz;   // (>> 1 of 2 / 4 = its log2)
+      bm = ((g << sh) + (r & (p.group_m - 1))) * BMT;
+      bn = (r >> sh) * BNT;
     } else {
       bm = (logical / p.tiles_n) * BMT;
       bn = (logical % p.tiles_n) * BNT;
     }
+    if constexpr (TN) {
+      // slot sl = 16 bytes = 8 columns of ONE k-row: block sl >> 4 = (k / 8, column / 16), inside it (row k % 8, half) = (sl & 15) >> 1, sl & 1;
+      // columns past the edge repeat the last 8 (the epilogue drops them)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sl = j * NTH + tid, blk = sl >> 4, rr = (sl & 15) >> 1, hh = sl & 1;
+        const int ka = 8 * (blk / (BMT / 16)) + rr, ma = 16 * (blk % (BMT / 16)) + 8 * hh;
+        const int kw = 8 * (blk / (BNT / 16)) + rr, nw = 16 * (blk % (BNT / 16)) + 8 * hh;
+        oa[j] = j < SA ? (uint32_t)(((size_t)ka * p.lda + min(bm + ma, p.M - 8)) * 2) : 0u;
+        ow[j] = j < SW ? (uint32_t)(((size_t)kw * p.ldw + min(bn + nw, p.N - 8)) * 2) : 0u;
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int sl = j * NTH + tid, row = sl >> 3, chunk = (sl & 7) ^ (row & 7);
@@ -415,6 +443,8 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       for (int j = 0; j < SW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(lw + j * (NTH * 16)), 16, ow[j], woff, 0, 0);
     }
   };
+  // TN: the lane's byte offset inside a block's half for ds_read_b64_tr_b16: k-row 4 (fq & 1) + (fr >> 2) of the block, columns 4 (fr & 3) ..
+  const uint32_t tr_lane = (uint32_t)((4 * (fq & 1) + (fr >> 2)) * 32 + (fr & 3) * 8);
   // lane's fragment offsets: row fr of a 16-row tile, swizzled chunk per k-step
   const uint32_t fo0 = (uint32_t)(fr * 128 + (((0 * 4 + fq) ^ (fr & 7)) << 4));
   const uint32_t fo1 = (uint32_t)(fr * 128 + (((1 * 4 + fq) ^ (fr & 7)) << 4));
@@ -491,8 +521,10 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
   #undef G2_RD8
         } else {
           bf16x8 fwA[4], fwB[4], far[3];
-  #define G2_RD_A(T) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + ((T) % MI) * 2048 + ((T) / MI ? fo1 : fo0)))
-  #define G2_RD_W(KS, J) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lw + (J) * 2048 + ((KS) ? fo1 : fo0)))
+  #define G2_RD_A(T) (TN ? g2_tr_frag(g2_smem + cur * BUFB, BMT / 16, wr * MI + (T) % MI, (T) / MI, tr_lane, fq >> 1) \
+                         : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(la + ((T) % MI) * 2048 + ((T) / MI ? fo1 : fo0))))
+  #define G2_RD_W(KS, J) (TN ? g2_tr_frag(g2_smem + cur * BUFB + AB, BNT / 16, wc * 4 + (J), (KS), tr_lane, fq >> 1) \
+                             : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lw + (J) * 2048 + ((KS) ? fo1 : fo0))))
   #pragma unroll
           for (int j = 0; j < 4; ++j) fwA[j] = G2_RD_W(0, j);
           far[0] = G2_RD_A(0);
@@ -855,6 +887,62 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   return FV_OK;
 }
 
+// the grouped tile walk's group height: 4 or 2 tile rows, whichever divides the row-tile count (the kernel then needs one division and no
+// short last group: a general group height cost gemm256_kernel 20 bytes of scratch per lane); 0 = row-major
+static int pick_group_m(int tiles_m_total, int want) {
+  if (want >= 4 && tiles_m_total % 4 == 0) return 4;
+  if (want >= 2 && tiles_m_total % 2 == 0) return 2;
+  return 0;
+}
+
+// TN problems (GemmArgs::tn): always the 256-tile kernel, ragged edges allowed, K ranges per tile from the same cost model as the NT path
+static int launch_gemm_tn(const GemmArgs& a, hipStream_t s) {
+  const bool f32out = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
+  if (!f32out || a.ksplit || a.norm_w || a.stash) return fv_fail(FV_ERR_UNSUPPORTED, "gemm (TN): fp32 epilogues only, no ksplit / fused norm / stash");
+  if (a.K % 64 || a.M % 8 || a.N % 8 || a.lda % 8 || a.ldw % 8 || a.lda < a.M || a.ldw < a.N)
+    return fv_fail(FV_ERR_ARG, "gemm (TN): K %% 64, M %% 8, N %% 8, lda >= M, ldw >= N (M=%d N=%d K=%d lda=%d ldw=%d)", a.M, a.N, a.K, a.lda, a.ldw);
+  if (a.ldo < a.N || a.ldo % 4 || (a.epi == FV_EPI_RES_F32 && (!a.res || a.ldr % 4 || a.ldr < a.N))) return fv_fail(FV_ERR_ARG, "gemm (TN): bad ldo / residual");
+  if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.bias) & 15) return fv_fail(FV_ERR_ARG, "gemm (TN): pointers must be 16-byte aligned");
+  if ((size_t)a.K * a.lda * 2 >= ((size_t)1 << 31) || (size_t)a.K * a.ldw * 2 >= ((size_t)1 << 31)) return fv_fail(FV_ERR_UNSUPPORTED, "gemm (TN): operands of 2 GiB or more");
+  Params p;
+  p.A = a.A; p.W = a.W; p.bias = a.bias; p.scale = nullptr; p.res = a.res; p.out = a.out;
+  p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldw = a.ldw; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi; p.ksplit = 0;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+  }
+  const int tmr = (a.M + 255) / 256, tn = (a.N + 255) / 256, tiles = tmr * tn, nkt = a.K / 64;
+  int splits = 1;
+  if (a.splitk_ws) {
+    const double tile_us = (double)nkt * 64.0 * 131072.0 / 1.0e6 / 4.0, part_us = 2.0 * (double)a.M * (tn * 256) * 4.0 / 4.0e6;
+    double best = 1e30;
+    for (int sN = 1; sN <= 8; ++sN) {
+      if (sN > 1 && (nkt / sN < 16 || (size_t)sN * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes)) break;
+      const long units = (long)tiles * sN, rounds = (units + cus - 1) / cus;
+      const double t = (double)rounds * tile_us / sN + (sN > 1 ? sN * part_us : 0.0);
+      if (t < best * 0.97) { best = t; splits = sN; }
+    }
+  }
+  p.tiles_n = tn; p.tiles_m = tmr <= 8 ? tmr : 0; p.tiles_mt = tmr; p.group_m = (!p.tiles_m && tn > 8) ? pick_group_m(tmr, 4) : 0;
+  p.splits = splits; p.npad = tn * 256; p.part = splits > 1 ? a.splitk_ws : nullptr;
+  p.nwg = tiles * splits;
+  const int slots = cus / 8 * 8;
+  const dim3 g(p.nwg < slots ? p.nwg : slots);
+  if (a.f16) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, true, false, true>), g, dim3(512), 2 * 512 * 128, s, p);
+  else hipLaunchKernelGGL((gemm256_kernel<8, 4, false, false, false, true>), g, dim3(512), 2 * 512 * 128, s, p);
+  if (splits > 1) {
+    const long quads = (long)a.M * (a.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, p.npad, a.bias,
+                       a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo);
+  }
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
 static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   g_norm_fused = false;
 #ifdef FASTVLA_AB_SWITCHES
@@ -865,6 +953,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
 #endif
   if (!a.A || !a.W || !a.out) return fv_fail(FV_ERR_ARG, "gemm: null operand");
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fv_fail(FV_ERR_ARG, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.tn) return launch_gemm_tn(a, s);
   if (a.K % 8 || a.lda % 8 || a.N % 8) return fv_fail(FV_ERR_ARG, "gemm: K, lda, N must be multiples of 8 (K=%d lda=%d N=%d)", a.K, a.lda, a.N);
   if (a.lda < a.K) return fv_fail(FV_ERR_ARG, "gemm: lda < K");
   if (a.epi < FV_EPI_BIAS || (a.epi > FV_EPI_F32 && a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16)) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
@@ -943,7 +1032,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     if (splits > 1) {
       p.tiles_n = tn;
       p.tiles_m = colmajor_ok && tmr <= cm_max ? tmr : 0;
-      p.tiles_mt = tmr; p.group_m = (!p.tiles_m && tn > 8) ? group_m_default : 0;
+      p.tiles_mt = tmr; p.group_m = (!p.tiles_m && tn > 8) ? pick_group_m(tmr, group_m_default) : 0;
       p.splits = splits; p.npad = tn * 256; p.part = a.splitk_ws;
       p.nwg = tiles * splits;
       const dim3 g2(p.nwg < cus ? p.nwg : cus / 8 * 8);
@@ -988,7 +1077,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     p.tiles_n = (a.N + gt - 1) / gt;
     p.nwg = tmr * p.tiles_n;
     p.tiles_m = colmajor_ok && tmr <= cm_max ? tmr : 0;
-    p.tiles_mt = tmr; p.group_m = (!p.tiles_m && p.tiles_n > 8) ? group_m_default : 0;   // (the 128-tile instance shares the kernel: two blocks per CU, 64 tiles per XCD at a time)
+    p.tiles_mt = tmr; p.group_m = (!p.tiles_m && p.tiles_n > 8) ? pick_group_m(tmr, group_m_default) : 0;   // (the 128-tile instance shares the kernel: two blocks per CU, 64 tiles per XCD at a time)
     int slots = (gt == 128 ? 2 * cus : cus) / 8 * 8;   // persistent; a multiple of 8 keeps the XCD remap exact
     if (const char* e = fv_ab_env("FASTVLA_GEMM_GRID")) { const int v = atoi(e); if (v >= 8 && gt == 256) slots = v / 8 * 8; }   // tools only
     const int grid = p.nwg < slots ? p.nwg : slots;

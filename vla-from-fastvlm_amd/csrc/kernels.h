@@ -33,6 +33,10 @@ struct GemmArgs {
   void* stash = nullptr;        // FV_EPI_SWIGLU_SPLIT only: also keep the raw gate/up accumulators [M][N] (row stride N, the packed column order):
                                 // what the SwiGLU backward of the unfrozen training path differentiates; fp32, or
   int stash_f16 = 0;            // 1: fp16 (saturating, clamps counted in *sat): half the bytes of a launch whose epilogue is write-bound
+  // tn = 1 ("TN": the contraction runs over the ROWS of both operands, the wgrad's shape): A is [K][M] with row stride lda >= M, W is [K][N]
+  // with row stride ldw >= N, out[m][n] = sum_k A[k][m] W[k][n].  K % 64 == 0 (rows past the data must be zero), M % 8 == 0, N % 8 == 0, fp32
+  // epilogues, no ksplit; the 256-tile kernel only (LDS image in [k/8][n/16][8][16] blocks, fragments by ds_read_b64_tr_b16)
+  int tn = 0, ldw = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -129,9 +133,12 @@ int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, 
 // the same transpose to fp16 (saturating; clamps counted in *sat): in_kind 0 = fp32, 1 = bf16, 2 = split bf16 (value = in[c] + in[lo_in + c]: both halves summed before rounding)
 int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, int R, int Rp, int C, unsigned* sat, hipStream_t s,
                             bf16_t* rows_out = nullptr, int ldro = 0);   // rows_out: the same values also as fp16 rows [R][ldro]
-int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, long R, int C, unsigned* sat, hipStream_t s);   // row-major fp16 rows (in_kind as above)
+int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, long R, int C, unsigned* sat, hipStream_t s,
+                       long Rp = 0);   // Rp > R: rows [R, Rp) of the output written as zeros (the TN wgrad's K-tile padding)   // row-major fp16 rows (in_kind as above)
 int launch_swiglu_bwd(float* gu, const float* dact, long rows, int I, hipStream_t s, bf16_t* out_split = nullptr);   // out_split: [rows][4I] = [hi | lo] bf16 instead of fp32 in place
 // dgu straight into the two fp16 operands of its consumers: rows [rows][2I] and columns [2I][Rp] (zero for rows in [rows, Rp)); clamps counted in *sat
+// d gate/up and act as fp16 ROWS only, rows [rows, Rp) zero: the operands of the TN wgrads (and d gate/up's rows of the dgrad)
+int launch_swiglu_bwd_rows(const void* gu, int gu_f16, const float* dact, long rows, long Rp, int I, bf16_t* dgu_rows, bf16_t* act_rows, unsigned* sat, hipStream_t s);
 int launch_swiglu_bwd_f16(const void* gu, int gu_f16, const float* dact, int rows, int Rp, int I, bf16_t* out_rows, bf16_t* outT, unsigned* sat, hipStream_t s,
                           bf16_t* actT = nullptr);   // gu_f16: the kept accumulators are fp16 (GemmArgs::stash_f16)   // actT: also silu(gate) * up as fp16 columns [I][Rp] (the down projection's wgrad operand)
 int launch_gelu_fwd(const float* pre, bf16_t* out, int ldo, int lo_off, long R, int C, hipStream_t s);

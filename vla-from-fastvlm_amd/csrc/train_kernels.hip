@@ -156,27 +156,30 @@ __global__ __launch_bounds__(256) void transpose_f16_kernel(const void* __restri
   }
 }
 
-// rows -> fp16 rows (the dgrad's gradient operand in its one-pass fp16 form): KIND as transpose_f16_kernel; saturating, clamps counted
+// rows -> fp16 rows (the gradient operand of the one-pass fp16 dgrad -- and, rows [R, Rp) written as zeros, either operand of the TN wgrad, whose
+// contraction runs over whole 64-row K-tiles): KIND as transpose_f16_kernel; saturating, clamps counted
 template <int KIND>
-__global__ __launch_bounds__(256) void rows_f16_kernel(const void* __restrict__ in_v, int ldi, int lo_in, bf16_t* __restrict__ out, int ldo, long R, int C,
+__global__ __launch_bounds__(256) void rows_f16_kernel(const void* __restrict__ in_v, int ldi, int lo_in, bf16_t* __restrict__ out, int ldo, long R, long Rp, int C,
                                                         unsigned* __restrict__ sat) {
   const int c8 = C >> 3;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < R * c8; i += (long)gridDim.x * 256) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Rp * c8; i += (long)gridDim.x * 256) {
     const long r = i / c8;
     const int c = (int)(i % c8) * 8;
-    float v[8];
-    if constexpr (KIND == 0) load8(static_cast<const float*>(in_v) + r * ldi + c, v);
-    else {
-      const bf16_t* p = static_cast<const bf16_t*>(in_v) + r * ldi + c;
-      unpack8(*reinterpret_cast<const uint4*>(p), v);
-      if constexpr (KIND == 2) {
-        float l[8];
-        unpack8(*reinterpret_cast<const uint4*>(p + lo_in), l);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      if constexpr (KIND == 0) load8(static_cast<const float*>(in_v) + r * ldi + c, v);
+      else {
+        const bf16_t* p = static_cast<const bf16_t*>(in_v) + r * ldi + c;
+        unpack8(*reinterpret_cast<const uint4*>(p), v);
+        if constexpr (KIND == 2) {
+          float l[8];
+          unpack8(*reinterpret_cast<const uint4*>(p + lo_in), l);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += l[e];
+          for (int e = 0; e < 8; ++e) v[e] += l[e];
+        }
       }
+      count_f16_sat8(v, sat);
     }
-    count_f16_sat8(v, sat);
     *reinterpret_cast<uint4*>(out + r * ldo + c) = pack8_h(v);
   }
 }
@@ -350,6 +353,48 @@ __global__ __launch_bounds__(256) void swiglu_bwd_f16_kernel(const void* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[r + e][c];
     *reinterpret_cast<uint4*>(outT + (size_t)(c0 + c) * Rp + r0 + r) = pack8_h(v);
+  }
+}
+
+// The form the TN wgrad wants: d gate/up AND act = silu(gate) * up as fp16 ROWS only ([Rp][2I] / [Rp][I], rows [rows, Rp) zero -- the TN
+// contraction walks whole 64-row K-tiles): no LDS, no transposed outputs; one thread = one 8-output group of one row
+template <bool G16>
+__global__ __launch_bounds__(256) void swiglu_bwd_rows_kernel(const void* __restrict__ gu_v, const float* __restrict__ dact, long rows, long Rp, int I,
+                                                               bf16_t* __restrict__ dgu_rows, bf16_t* __restrict__ act_rows, unsigned* __restrict__ sat) {
+  const int j8 = I >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Rp * j8; i += (long)gridDim.x * 256) {
+    const long r = i / j8;
+    const int j = (int)(i % j8);
+    float dg[8], du[8], av[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dg[e] = du[e] = av[e] = 0.f;
+    if (r < rows) {
+      float g[8], u[8], d[8];
+      if constexpr (G16) {
+        const bf16_t* gp = static_cast<const bf16_t*>(gu_v) + r * 2 * I + 16 * j;
+        unpack8_h(*reinterpret_cast<const uint4*>(gp), g);
+        unpack8_h(*reinterpret_cast<const uint4*>(gp + 8), u);
+      } else {
+        const float* gp = static_cast<const float*>(gu_v) + r * 2 * I + 16 * j;
+        load8(gp, g);
+        load8(gp + 8, u);
+      }
+      load8(dact + r * I + 8 * j, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sg = 1.0f / (1.0f + __expf(-g[e]));
+        dg[e] = d[e] * u[e] * sg * (1.0f + g[e] * (1.0f - sg));
+        du[e] = d[e] * g[e] * sg;
+        av[e] = silu_f(g[e]) * u[e];
+      }
+      count_f16_sat8(dg, sat);
+      count_f16_sat8(du, sat);
+      count_f16_sat8(av, sat);
+    }
+    bf16_t* op = dgu_rows + r * 2 * I + 16 * j;
+    *reinterpret_cast<uint4*>(op) = pack8_h(dg);
+    *reinterpret_cast<uint4*>(op + 8) = pack8_h(du);
+    *reinterpret_cast<uint4*>(act_rows + r * I + 8 * j) = pack8_h(av);
   }
 }
 
@@ -867,13 +912,14 @@ int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf1
   return FV_OK;
 }
 
-int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, long R, int C, unsigned* sat, hipStream_t s) {
-  if (!in || !out || R <= 0 || C <= 0 || C % 8 || ldi < C || ldi % (in_kind ? 8 : 4) || ldo % 8 || ldo < C || in_kind < 0 || in_kind > 2 || (in_kind == 2 && (lo_in % 8 || lo_in < C)))
+int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, long R, int C, unsigned* sat, hipStream_t s, long Rp) {
+  if (!in || !out || R <= 0 || C <= 0 || C % 8 || ldi < C || ldi % (in_kind ? 8 : 4) || ldo % 8 || ldo < C || in_kind < 0 || in_kind > 2 || (in_kind == 2 && (lo_in % 8 || lo_in < C)) || (Rp && Rp < R))
     return fv_fail(FV_ERR_ARG, "rows_to_f16: bad arguments");
-  const dim3 g(grid_for(R * (C / 8)));
-  if (in_kind == 0) hipLaunchKernelGGL(rows_f16_kernel<0>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, C, sat);
-  else if (in_kind == 1) hipLaunchKernelGGL(rows_f16_kernel<1>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, C, sat);
-  else hipLaunchKernelGGL(rows_f16_kernel<2>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, C, sat);
+  if (!Rp) Rp = R;
+  const dim3 g(grid_for(Rp * (C / 8)));
+  if (in_kind == 0) hipLaunchKernelGGL(rows_f16_kernel<0>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
+  else if (in_kind == 1) hipLaunchKernelGGL(rows_f16_kernel<1>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
+  else hipLaunchKernelGGL(rows_f16_kernel<2>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -895,6 +941,14 @@ int launch_swiglu_bwd_f16(const void* gu, int gu_f16, const float* dact, int row
   const dim3 g((Rp + TP - 1) / TP, (2 * I + TP - 1) / TP);
   if (gu_f16) hipLaunchKernelGGL(swiglu_bwd_f16_kernel<true>, g, dim3(256), 0, s, gu, dact, rows, Rp, I, out_rows, outT, sat, actT);
   else hipLaunchKernelGGL(swiglu_bwd_f16_kernel<false>, g, dim3(256), 0, s, gu, dact, rows, Rp, I, out_rows, outT, sat, actT);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+int launch_swiglu_bwd_rows(const void* gu, int gu_f16, const float* dact, long rows, long Rp, int I, bf16_t* dgu_rows, bf16_t* act_rows, unsigned* sat, hipStream_t s) {
+  if (!gu || !dact || !dgu_rows || !act_rows || !sat || rows <= 0 || Rp < rows || I <= 0 || I % 8) return fv_fail(FV_ERR_ARG, "swiglu_bwd_rows: bad arguments");
+  const dim3 g(grid_for(Rp * (I / 8)));
+  if (gu_f16) hipLaunchKernelGGL(swiglu_bwd_rows_kernel<true>, g, dim3(256), 0, s, gu, dact, rows, Rp, I, dgu_rows, act_rows, sat);
+  else hipLaunchKernelGGL(swiglu_bwd_rows_kernel<false>, g, dim3(256), 0, s, gu, dact, rows, Rp, I, dgu_rows, act_rows, sat);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

@@ -480,7 +480,7 @@ class FastVLAEngine:
         for k, v in (("grad_split", grad_split), ("wgrad_f16", wgrad_f16), ("loss_scale_log2", loss_scale_log2)):
             if v is not None:
                 opts[k] = v
-        _lib.check(self.lib.fv_train_set_options(self.h, int(opts["grad_split"]), int(bool(opts["wgrad_f16"])), int(opts["loss_scale_log2"])),
+        _lib.check(self.lib.fv_train_set_options(self.h, int(opts["grad_split"]), int(opts["wgrad_f16"]), int(opts["loss_scale_log2"])),   # wgrad_f16: False / True or 0 / 1 / 2 (2 = fp16 on transposed copies)
                    "fv_train_set_options", self.h)
         self._train_options = opts
 
