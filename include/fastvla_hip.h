@@ -333,6 +333,10 @@ int fv_op_gemm_ksplit(const void* A, int lda, const void* W, int M, int N, int K
 /* fv_op_gemm_ksplit (ksplit != 0) or fv_op_gemm with a caller-owned scratch buffer for split-K partial sums: fp32 epilogues
  * (FV_EPI_RES_F32 / FV_EPI_F32) of problems with few output tiles and a long K are cut along K, one unit per CU, and
  * summed by a second kernel.  ws may be NULL (then exactly fv_op_gemm / fv_op_gemm_ksplit). */
+/* out f32[M,N] = sum_k A[k][m] W[k][n] (+ bias[n]): both operands row-major over the CONTRACTION index (A [K][M] row stride lda, W [K][N] row stride
+ * ldw; bf16, or fp16 bits with f16 != 0), K % 64 == 0, M % 8 == 0, N % 8 == 0 -- the weight-gradient shape (fv_train_set_options wgrad_f16 = 2) */
+int fv_op_gemm_tn(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int f16, const float* bias, void* out, int ldo, void* ws,
+                  size_t ws_bytes, fv_stream s);
 int fv_op_gemm_splitk(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const void* res, int ldr,
                       void* out, int ldo, int epilogue, int ksplit, void* ws, size_t ws_bytes, fv_stream s);
 /* depthwise / channel-multiplier grouped conv, NHWC bf16: x (B,H,W,C) -> y (B,Ho,Wo,C*mult); w f32 [k*k][C*mult] */

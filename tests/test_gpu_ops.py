@@ -705,6 +705,30 @@ def test_gemm_256_tile_ragged_edges_fp32_epilogues(M, N, K, ksplit, ws):
     assert torch.isnan(o[M:]).all() and torch.isnan(o[:, N:]).all(), "wrote past the edge"
 
 
+@pytest.mark.parametrize("M,N,K,f16,ws", [(896, 4864, 1024, 1, True), (2304, 904, 512, 0, False), (9728, 896, 2048, 1, True), (520, 264, 192, 1, False)])
+def test_gemm_tn_row_major_operands(M, N, K, f16, ws):
+    """Round 4: the TN instance of the 256-tile kernel -- out[m][n] = sum_k A[k][m] W[k][n] with both operands row-major over the contraction
+    (a weight gradient's dY and X as they are produced; LDS image in [k/8][n/16] blocks, fragments by ds_read_b64_tr_b16) -- against fp64, bf16
+    and fp16 operands, ragged edges, with and without K ranges; embedded in NaN guards, operands with padded row strides."""
+    torch.manual_seed(M + N + K + f16)
+    lda, ldw = M + 8, N + 16
+    A, W, b = torch.randn(K, M) * 0.5, torch.randn(K, N) / math.sqrt(K), torch.randn(N)
+    cast = (lambda t: t.half()) if f16 else (lambda t: t.bfloat16())
+    Ad, Wd = torch.zeros(K, lda, dtype=torch.float16 if f16 else torch.bfloat16, device=DEV), torch.zeros(K, ldw, dtype=torch.float16 if f16 else torch.bfloat16, device=DEV)
+    Ad[:, :M], Wd[:, :N] = cast(A).to(DEV), cast(W).to(DEV)
+    ref = (cast(A).double().t() @ cast(W).double() + b.double()).float()
+    bd = dev_f32(b)
+    wsb = torch.empty(8 * 1024 * 1024, dtype=torch.float32, device=DEV) if ws else None
+    guard = 8
+    out = torch.full((M + guard, N + guard), float("nan"), dtype=torch.float32, device=DEV)
+    call(lib().fv_op_gemm_tn(Ad.data_ptr(), lda, Wd.data_ptr(), ldw, M, N, K, f16, bd.data_ptr(), out.data_ptr(), N + guard,
+                             wsb.data_ptr() if ws else None, wsb.numel() * 4 if ws else 0, stream()), "fv_op_gemm_tn")
+    torch.cuda.synchronize()
+    o = out.cpu()
+    check_close(o[:M, :N], ref, rel=2e-5, amax=2e-4, what=f"TN gemm {M}x{N}x{K} f16={f16}")
+    assert torch.isnan(o[M:]).all() and torch.isnan(o[:, N:]).all(), "wrote past the edge"
+
+
 # ------------------------------------------------------------------------------------------------ round 4: "hi + lo8" operands
 def _e4m3(t):
     return t.to(torch.float8_e4m3fn).float()

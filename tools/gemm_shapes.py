@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--tn", action="store_true", help="also: the weight-gradient problems on the NT kernel and on the TN instance")
     a = ap.parse_args()
     L = _lib.load()
     dev = torch.device("cuda:0")
@@ -98,5 +99,32 @@ def main():
         print(f"{name:14s} M={M:6d} N={N:5d} K={K:5d}{' x2' if ks else '   '}  {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF executed", flush=True)
 
 
+def tn_vs_nt(L, dev, s, iters=20):
+    """the weight-gradient problems of the unfrozen step (fp16 operands, K = 10 240 rows) on the NT kernel (transposed operand copies) and on the TN
+    instance (row-major operands), plus a multi-round square"""
+    ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    for name, M, N, K in (("wgrad down", 896, 4864, 10240), ("wgrad gate/up", 9728, 896, 10240), ("wgrad qkv", 1152, 896, 10240), ("square", 8192, 4096, 4096)):
+        At = torch.randn(K, M, device=dev).half(); Wt = (torch.randn(K, N, device=dev) / K ** 0.5).half()
+        An, Wn = At.t().contiguous(), Wt.t().contiguous()
+        out = torch.empty(M, N, device=dev)
+        def nt():
+            rc = L.fv_op_gemm_f16(An.data_ptr(), K, Wn.data_ptr(), M, N, K, None, None, 0, out.data_ptr(), N, _lib.EPI_F32, ws.data_ptr(), ws.numel() * 4, s) if hasattr(L, "fv_op_gemm_f16") else -1
+            return rc
+        def tn():
+            return L.fv_op_gemm_tn(At.data_ptr(), M, Wt.data_ptr(), N, M, N, K, 1, None, out.data_ptr(), N, ws.data_ptr(), ws.numel() * 4, s)
+        for label, f in (("NT", nt), ("TN", tn)):
+            if f() != 0:
+                print(f"{name:14s} {label}: not available"); continue
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters): f()
+            e1.record(); e1.synchronize()
+            us = e0.elapsed_time(e1) / iters * 1e3
+            print(f"{name:14s} {label}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF")
+
+
 if __name__ == "__main__":
     main()
+    if "--tn" in sys.argv:
+        tn_vs_nt(_lib.load(), torch.device("cuda:0"), torch.cuda.current_stream().cuda_stream)

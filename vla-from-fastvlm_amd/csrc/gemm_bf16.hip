@@ -324,12 +324,14 @@ __device__ unsigned long long g_g2_stamps[256 * 8];   // diagnostics (tools/gemm
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((ext_vector_type(4))) short g2_s16x4;
-// TN fragment of k-step ks (32 deep) for the 16-column tile c16 of a region laid out as [k / 8][cols16 blocks of 256 bytes]: the two
-// transposed reads take k-rows 32 ks + 4 fq + (0..3) and 32 ks + 16 + 4 fq + (0..3) (block rows 4 ks + (fq >> 1) and + 2)
+// TN fragment of k-step ks (32 deep) for the 16-column tile c16 of a region laid out in 1 KB pieces [k / 8][cols / 64], a piece = [column-block
+// pair][k-row][64 bytes]: the two transposed reads take k-rows 32 ks + 4 fq + (0..3) and 32 ks + 16 + 4 fq + (0..3) (piece rows 4 ks + (fq >> 1)
+// and + 2).  (64-byte source runs per lane quad: the first layout, 32-byte blocks, was conflict-free in LDS and 24 % slower than the NT kernel --
+// half-line requests on the L2 -> LDS path; here the two 16-lane groups of a half share banks, 2 extra LDS cycles per read.)
 __device__ __forceinline__ bf16x8 g2_tr_frag(const char* region, int cols16, int c16, int ks, uint32_t tr_lane, int fq_hi) {
-  const char* p0 = region + ((((4 * ks + fq_hi) * cols16 + c16) << 8) + tr_lane);
+  const char* p0 = region + ((((4 * ks + fq_hi) * (cols16 >> 2) + (c16 >> 2)) << 10) + (((c16 >> 1) & 1) << 9) + ((c16 & 1) << 5) + tr_lane);
   const g2_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g2_s16x4 __attribute__((address_space(3)))*)(p0));
-  const g2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g2_s16x4 __attribute__((address_space(3)))*)(p0 + ((2 * cols16) << 8)));
+  const g2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((g2_s16x4 __attribute__((address_space(3)))*)(p0 + ((2 * (cols16 >> 2)) << 10)));
   const uint2 lu = __builtin_bit_cast(uint2, lo), hu = __builtin_bit_cast(uint2, hi);
   return __builtin_bit_cast(bf16x8, make_uint4(lu.x, lu.y, hu.x, hu.y));
 }
@@ -393,13 +395,15 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
       bn = (logical % p.tiles_n) * BNT;
     }
     if constexpr (TN) {
-      // slot sl = 16 bytes = 8 columns of ONE k-row: block sl >> 4 = (k / 8, column / 16), inside it (row k % 8, half) = (sl & 15) >> 1, sl & 1;
-      // columns past the edge repeat the last 8 (the epilogue drops them)
+      // slot sl = 16 bytes = 8 columns of ONE k-row.  A 1 KB piece (one wave-instruction of the LDS-DMA) = 8 k-rows x 64 columns; its quad t = (sl & 63) >> 2
+      // (four consecutive lanes: 64 contiguous source bytes, one request) holds row t & 7, column-block pair t >> 3; columns past the edge repeat
+      // the last 8 (the epilogue drops them)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int sl = j * NTH + tid, blk = sl >> 4, rr = (sl & 15) >> 1, hh = sl & 1;
-        const int ka = 8 * (blk / (BMT / 16)) + rr, ma = 16 * (blk % (BMT / 16)) + 8 * hh;
-        const int kw = 8 * (blk / (BNT / 16)) + rr, nw = 16 * (blk % (BNT / 16)) + 8 * hh;
+        const int sl = j * NTH + tid, piece = sl >> 6, t = (sl & 63) >> 2, w8 = sl & 3;
+        const int rr = t & 7, cpair = t >> 3;
+        const int ka = 8 * (piece / (BMT / 64)) + rr, ma = 64 * (piece % (BMT / 64)) + 32 * cpair + 8 * w8;
+        const int kw = 8 * (piece / (BNT / 64)) + rr, nw = 64 * (piece % (BNT / 64)) + 32 * cpair + 8 * w8;
         oa[j] = j < SA ? (uint32_t)(((size_t)ka * p.lda + min(bm + ma, p.M - 8)) * 2) : 0u;
         ow[j] = j < SW ? (uint32_t)(((size_t)kw * p.ldw + min(bn + nw, p.N - 8)) * 2) : 0u;
       }
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
     }
   };
   // TN: the lane's byte offset inside a block's half for ds_read_b64_tr_b16: k-row 4 (fq & 1) + (fr >> 2) of the block, columns 4 (fr & 3) ..
-  const uint32_t tr_lane = (uint32_t)((4 * (fq & 1) + (fr >> 2)) * 32 + (fr & 3) * 8);
+  const uint32_t tr_lane = (uint32_t)((4 * (fq & 1) + (fr >> 2)) * 64 + (fr & 3) * 8);
   // lane's fragment offsets: row fr of a 16-row tile, swizzled chunk per k-step
   const uint32_t fo0 = (uint32_t)(fr * 128 + (((0 * 4 + fq) ^ (fr & 7)) << 4));
   const uint32_t fo1 = (uint32_t)(fr * 128 + (((1 * 4 + fq) ^ (fr & 7)) << 4));

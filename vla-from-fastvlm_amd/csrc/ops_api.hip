@@ -27,6 +27,15 @@ int fv_op_gemm_splitk(const void* A, int lda, const void* W, int M, int N, int K
   return fv::launch_gemm(g, static_cast<hipStream_t>(s));
 }
 
+int fv_op_gemm_tn(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int f16, const float* bias, void* out, int ldo, void* ws,
+                  size_t ws_bytes, fv_stream s) {
+  fv::GemmArgs g{static_cast<const bf16_t*>(A), lda, static_cast<const bf16_t*>(W), M, N, K, bias, nullptr, nullptr, 0, out, ldo, FV_EPI_F32};
+  g.tn = 1; g.ldw = ldw; g.f16 = f16 != 0;
+  g.splitk_ws = static_cast<float*>(ws);
+  g.splitk_bytes = ws_bytes;
+  return fv::launch_gemm(g, static_cast<hipStream_t>(s));
+}
+
 int fv_op_gemm_lo8(const void* A, int lda, const void* W, const void* W8, int M, int N, int K, const float* bias, const void* res, int ldr, void* out,
                    int ldo, int epilogue, void* ws, size_t ws_bytes, fv_stream s) {
   fv::GemmArgs g{static_cast<const bf16_t*>(A), lda, static_cast<const bf16_t*>(W), M, N, K, bias, nullptr, res, ldr, out, ldo, epilogue};

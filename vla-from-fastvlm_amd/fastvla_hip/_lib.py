@@ -124,6 +124,7 @@ SIGNATURES = {
     "fv_op_gemm_lo8": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _vp]),
     "fv_op_lo8_pack": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "fv_op_gemm_ksplit": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "fv_op_gemm_tn": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
     "fv_op_gemm_splitk": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, C.c_size_t, _vp]),
     "fv_op_dwconv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fv_op_stem_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
