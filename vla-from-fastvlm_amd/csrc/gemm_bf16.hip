@@ -533,6 +533,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
           for (int j = 0; j < 4; ++j) fwA[j] = G2_RD_W(0, j);
           far[0] = G2_RD_A(0);
           far[1] = G2_RD_A(1);
+          // (s_setprio(1) around the product steps, the guide's T5: measured +-0.5 % on every shape of tools/gemm_shapes.py -- not kept)
   #pragma unroll
           for (int t = 0; t < 2 * MI; ++t) {
             if (t + 2 < 2 * MI) far[(t + 2) % 3] = G2_RD_A(t + 2);
