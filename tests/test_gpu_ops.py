@@ -383,7 +383,9 @@ def _toeplitz(w, k):
 
 
 @pytest.mark.parametrize("k,C,H,W,gelu", [(7, 32, 8, 32, 0), (7, 96, 40, 64, 0), (3, 64, 33, 47, 0), (7, 64, 19, 33, 1),
-                                          (3, 192, 16, 32, 0), (7, 384, 24, 40, 0)])
+                                          (3, 192, 16, 32, 0), (7, 384, 24, 40, 0),
+                                          # maps narrower than a 32-column strip (the last stage's 16 x 16, and a ragged 20): half-masked strips
+                                          (7, 1536, 16, 16, 0), (7, 64, 16, 20, 1), (3, 96, 12, 16, 0)])
 def test_dwconv_mfma(k, C, H, W, gelu):
     torch.manual_seed(k * 1000 + C + W)
     B = 2

@@ -1721,7 +1721,7 @@ int launch_dwconv_s2_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias
 }
 
 bool dwconv_mfma_supported(int W, int C, int k, int stride, int mult) {
-  return stride == 1 && mult == 1 && (k == 3 || k == 7) && W >= 32 && C % 32 == 0;
+  return stride == 1 && mult == 1 && (k == 3 || k == 7) && W >= 16 && C % 32 == 0;   // (W = 16, the last stage's maps: half of a 32-column strip is masked, and it still beats the VALU kernel)
 }
 
 int launch_dwconv_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, bf16_t* y, int B, int H, int W, int C, int k,
