@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-train-unfrozen", action="store_true", help="skip the unfrozen decoder + projector training leg (SURVEY.md 8f-4)")
+    ap.add_argument("--no-train-tower", action="store_true", help="skip the everything-trainable leg (tower backward too)")
     ap.add_argument("--train-unfrozen-dp", action="store_true", help="N > 1: run the unfrozen training leg too (per-bucket all-reduce under the backward pass); off by default at N > 1 so that "
                                                                     "a failure of ONE rank inside this secondary leg can never hang the collectives of a scaling run before its JSON line is out")
     ap.add_argument("--unfrozen-batch", type=int, default=int(os.environ.get("FASTVLA_UNFROZEN_BATCH", "32")), help="per-GPU batch of the unfrozen training leg (C3's rank shape)")
@@ -530,6 +531,65 @@ def main():
             train_unfrozen = {"error": f"{type(exc).__name__}: {exc}"}
         torch.cuda.empty_cache()
 
+    # ---- EVERYTHING trainable: the FastViT-HD tower too (the tower half; fv_train_tower_*).  One step = letterbox + tower forward with every
+    # unit's tensors kept + the unfrozen step above + the tower's backward (recomputed ConvFFN hidden, fp16 dgrad / TN wgrad GEMMs, depthwise / attention / norm
+    # backward kernels) + clip + AdamW over 494 M + 125 M parameters + refresh of every packed operand image.  Algorithmic flops: 3 x (tower + projector + decoder
+    # GEMMs) + attention fwd/bwd (the recomputed fc1 of every ConvFFN is executed, not counted).
+    train_unfrozen_tower = None
+    if train_unfrozen is not None and "error" not in train_unfrozen and not args.no_train_tower:
+        try:
+            eng.train_tower_begin()
+            tensors_t, total_t, nb_t = eng.train_layout()
+            flat_t = torch.zeros(total_t, dtype=torch.float32, device=dev)
+            eng.train_export_params(flat_t)
+            flat_t[: flat.numel()].copy_(flat)
+            flat_t0 = flat_t.clone()
+            g_t, m_t, v_t = torch.zeros_like(flat_t), torch.zeros_like(flat_t), torch.zeros_like(flat_t)
+            ws_t, tws_t = eng.train_workspace(Bu, T), eng.train_tower_workspace(Bu)
+            dto_t = torch.zeros(Bu, model.tower.num_tokens, model.tower.out_dim, dtype=torch.float16, device=dev)
+            eng.train_set_tower_grad(dto_t)
+            bex_t = BucketedGradExchange(dev, min_numel=1 << 22)
+            tst = {"step": 0}
+
+            def step_tower():
+                tst["step"] += 1
+                pix_t = eng.preprocess(images[:Bu])
+                tower_out_t = eng.train_tower_forward(pix_t, tws_t)
+                bex_t.begin(g_t)
+                eng.train_forward_backward(flat_t, tower_out_t, ids[:Bu], lens[:Bu], states[:Bu], targets[:Bu], ws_t, training=True, dropout_p=0.1,
+                                           seed=args.seed + rank, offset=tst["step"], flat_grads=g_t, bucket_cb=bex_t.bucket_ready)
+                eng.train_tower_backward(pix_t, dto_t, tws_t, g_t, bucket_cb=bex_t.bucket_ready)
+                scale = bex_t.finish(dev)
+                eng.adamw_step(flat_t, g_t, m_t, v_t, tst["step"], lr=1e-5, weight_decay=1e-4, max_grad_norm=1.0, grad_scale=scale / eng.train_loss_scale())
+                eng.train_commit(flat_t)
+
+            nstw = max(2, args.steps // 4)
+            eltw = timed(step_tower, nstw, 2)
+            sat_t = eng.fp16_saturations()
+            # where the step goes: one more step under the per-launch event profiler
+            eng.profile(True)
+            step_tower()
+            fams_t, _ = eng.profile_read()
+            eng.profile(False)
+            step_fl_t = 3.0 * tower_fl + 3.0 * (dec_fl + proj_fl) + 3.5 * attn_fl
+            train_unfrozen_tower = {"value": round(world * nstw / eltw, 3), "unit": "train steps/s (whole job)", "ms_per_step": round(1e3 * eltw / nstw, 3),
+                                    "batch_per_gpu": Bu, "global_batch": Bu * world, "trainable_params": int(total_t), "tower_params": int(total_t - total_u),
+                                    "grad_bytes": int(total_t * 4), "buckets": nb_t, "collectives_per_step": len(bex_t.launched), "parallelism": f"dp{world}",
+                                    "algorithmic_tflop_per_step": round(step_fl_t / 1e12, 2),
+                                    "roofline": {"bound": "mfma", "achieved": round(step_fl_t / (eltw / nstw) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                 "frac": round(step_fl_t / (eltw / nstw) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                                 "note": "whole step; forward + backward of tower, projector, decoder, head; every ConvFFN's fc1 is executed twice (recomputed in the backward)"},
+                                    "workspace_gb": round((ws_t.numel() + tws_t.numel()) / 2 ** 30, 2), "fp16_saturations": int(sat_t),
+                                    "profiled_step_ms_by_family": {k: round(v["ms"], 3) for k, v in fams_t.items() if v["launches"]},
+                                    "backward_arithmetic": "fp16 gradient stream (x 2^12), fp16 dgrad / TN wgrad GEMMs with fp32 accumulation, fp32 tap / norm / layer-scale gradients by fixed-order partial sums"}
+            eng.train_set_tower_grad(None)
+            eng.train_commit(flat_t0)
+            torch.cuda.synchronize()
+            del ws_t, tws_t, g_t, m_t, v_t, flat_t, flat_t0, dto_t
+        except Exception as exc:  # the leg must never take the headline line down with it
+            train_unfrozen_tower = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.empty_cache()
+
     # ---- the same step through the reference's plugin surface (reference lerobot_fastvla/modeling_fastvla.py:109-133):
     # FastVLAPolicy.select_action(batch) / .forward(batch) with a LeRobot batch dict and B task strings through the tokenizer;
     # Python glue, tokenisation, the action deque and forward()'s `.item()` are inside these numbers.  The policy drives the SAME
@@ -763,7 +823,7 @@ def main():
                                          4: "split-bf16 qkv/o/gate/up, fp16 down (one pass), fp32 attention",
                                          5: "bf16 hi + fp8 lo operands (lo product on the scaled fp8 MFMA, 1.5 passes), fp32 attention"}[args.llm_precision]},
             "samples_per_s": round(value * B, 2),
-            "roofline": roofline, "power": power_info, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "train_unfrozen": train_unfrozen, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
+            "roofline": roofline, "power": power_info, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "train_unfrozen": train_unfrozen, "train_unfrozen_tower": train_unfrozen_tower, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
             "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
         }
         print(json.dumps(out))

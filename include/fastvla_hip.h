@@ -291,6 +291,26 @@ int fv_train_forward_backward(fv_handle* h, const float* flat_params, const void
                               uint64_t offset, void* ws, size_t ws_bytes, float* actions, float* loss, float* flat_grads, fv_bucket_cb cb,
                               void* user, fv_stream s);
 
+/* ---- the TOWER half of the slice (FastViT-HD trainable too; csrc/tower_train.inc).  After fv_train_begin:
+ * fv_train_tower_begin appends the tower's tensors (inference form: folded RepMixer / ConvFFN convolutions, fc1 / fc2, layer scales, attention, PatchEmbed,
+ * stem, conv_exp + SE) to the flat master -- fv_train_layout then lists them after "model.norm.weight" (packing 3 = depthwise weights tap-major [k*k][C],
+ * 4 = the stem's dense 3x3 as [27][C0] with row (ky*3+kx)*3+ci; new gradient buckets 3 + L + 1 ...: stem, then per stage [blocks (+RepCPE)] [PatchEmbed],
+ * last conv_exp + SE) -- and fv_train_export_params / fv_train_commit cover them (commit refreshes every packed operand image the kernels read).
+ * One step: fv_train_tower_forward (pixels -> tower_out, every unit's tensors kept in tws) -> fv_train_forward_backward with fv_train_set_tower_grad's buffer
+ * bound (it then also leaves dL/d(tower_out) there, fp16 [B][tokens][tower_out_dim], loss-scaled) -> fv_train_tower_backward (tower gradients into the same
+ * flat_grads, cb per tower bucket in backward order).  pix must stay alive between the two tower calls. */
+int fv_train_tower_begin(fv_handle* h);
+int fv_train_tower_workspace_bytes(fv_handle* h, int B, size_t* out_bytes);
+int fv_train_tower_forward(fv_handle* h, const void* pix, int B, void* tws, size_t tws_bytes, void* tower_out, fv_stream s);
+int fv_train_set_tower_grad(fv_handle* h, void* d_tower_out_f16);
+int fv_train_tower_backward(fv_handle* h, const void* pix, const void* d_tower_out_f16, int B, void* tws, size_t tws_bytes, float* flat_grads, fv_bucket_cb cb,
+                            void* user, fv_stream s);
+/* ONE tower unit, teacher-forced (parity tests): forward of unit `unit` (fv_vision_unit_info's index; the unit count itself = conv_exp + SE) on x_in (bf16 NHWC;
+ * the stem: fv_preprocess pixels), then its backward from g_out (fp32 NHWC, dL/d(output)) x gscale.  y_out (bf16, optional) = the unit's output, g_in (fp32,
+ * optional; ignored for the stem) = dL/d(input), the unit's weight gradients x gscale at their fv_train_layout offsets in flat_grads. */
+int fv_train_tower_unit(fv_handle* h, int unit, const void* x_in, const float* g_out, float gscale, int B, void* tws, size_t tws_bytes, void* y_out, float* g_in,
+                        float* flat_grads, fv_stream s);
+
 /* ---- optional per-kernel-family HIP-event timing (bench.py roofline numbers) ------------------------------------- */
 enum fv_family { FV_FAM_GEMM = 0, FV_FAM_DWCONV, FV_FAM_STEM, FV_FAM_ATTN, FV_FAM_NORM, FV_FAM_ELT, FV_FAM_HEAD, FV_FAM_COUNT };
 typedef struct fv_profile_entry { double ms, flops, bytes; int64_t launches; } fv_profile_entry;
@@ -310,8 +330,12 @@ enum fv_gemm_epilogue {
   FV_EPI_SWIGLU = 4,      /* out bf16[M,N/2] = silu(gate) * up, W rows 8-interleaved */
   FV_EPI_F32 = 5,         /* out f32  = acc + bias                                  */
   FV_EPI_SWIGLU_SPLIT = 7,/* out bf16[M,N] = [hi | lo] of silu(gate)*up (split-bf16 operand), W rows 8-interleaved */
-  FV_EPI_SWIGLU_F16 = 8   /* out f16[M,N/2] = silu(gate)*up / 16 (the fp16 operand of the down projection, whose fp16 weights carry the
+  FV_EPI_SWIGLU_F16 = 8,  /* out f16[M,N/2] = silu(gate)*up / 16 (the fp16 operand of the down projection, whose fp16 weights carry the
                            * 16: the power of two keeps SwiGLU outputs up to 1e6 inside fp16's range), W rows 8-interleaved */
+  /* the tower backward's three (all 2-byte outputs are fp16, saturating, whatever the operand type) */
+  FV_EPI_GELU_GRAD = 9,   /* a = acc + bias: out f16 = gelu(a) (exact erf form, rounded to a bf16 value first; out may be NULL), stash f16 = gelu'(a), both [M][ldo] */
+  FV_EPI_MUL_AUX = 10,    /* out f16 = acc * aux_f16[m][n] (aux = res, row stride ldr; out may alias aux)                              */
+  FV_EPI_F16 = 11         /* out f16 = acc + bias                                                                                      */
 };
 /* out[M,N] = A[M,K] (bf16, row stride lda) x W[N,K]^T (bf16) with fp32 accumulation on MFMA */
 int fv_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const float* scale,

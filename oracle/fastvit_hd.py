@@ -59,6 +59,9 @@ def _conv(x, p, name, stride=1, padding=0, groups=1):
 
 def _convffn(x, p, pre, cfg: TowerCfg):
     c = x.shape[1]
+    if pre + "conv.folded.weight" in p:   # the TRAINABLE inference form (oracle/train_tower.py fold_tower): BatchNorm already inside the 7x7
+        y = F.conv2d(x, p[pre + "conv.folded.weight"], p[pre + "conv.folded.bias"], padding=3, groups=c)
+        return _conv(gelu(_conv(y, p, pre + "fc1")), p, pre + "fc2")
     y = F.conv2d(x, p[pre + "conv.conv.weight"], None, padding=3, groups=c)
     y = F.batch_norm(y, p[pre + "conv.bn.running_mean"], p[pre + "conv.bn.running_var"],
                      p[pre + "conv.bn.weight"], p[pre + "conv.bn.bias"], training=False, eps=cfg.bn_eps)
@@ -95,14 +98,27 @@ def _mhsa(x, p, pre, cfg: TowerCfg):
 # restates the SAME graph with a round-to-bf16 at exactly the points where the product's kernels round
 # (csrc/engine.hip tower_pass; one `_r` per tensor that reaches HBM or an MFMA operand), so the comparison isolates the
 # kernels' arithmetic from the precision policy.  Everything else (fp32 accumulation, exact-erf GELU, softmax) stays as is.
+class _RoundBF16(torch.autograd.Function):
+    """round-to-bf16 with a STRAIGHT-THROUGH gradient.  (Plain `x.to(bfloat16).to(float32)` is differentiable too, but its backward casts the incoming
+    gradient to bf16 on the way: oracle/train_tower.py differentiates this graph, and the gradient must stay fp32.)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def _r(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+    return _RoundBF16.apply(x) if x.requires_grad else x.to(torch.bfloat16).to(torch.float32)
 
 
 def _dw_mfma(map_w: int, c: int) -> bool:
     """stride-1 depthwise layers the product runs on MFMA with bf16 Toeplitz tables (csrc/tower_kernels.hip
     dwconv_mfma_supported): their weights are rounded to bf16; smaller maps use the fp32-weight VALU kernel."""
-    return map_w >= 32 and c % 32 == 0
+    return map_w >= 16 and c % 32 == 0   # (W >= 16 since round 4: the last stage's 16 x 16 maps run on the MFMA kernels too)
 
 
 def _convffn_bf16(x, p, pre, cfg: TowerCfg):
@@ -110,9 +126,12 @@ def _convffn_bf16(x, p, pre, cfg: TowerCfg):
     folded weights rounded to bf16 where the MFMA depthwise kernel serves the layer; t, the GELU'd hidden and nothing else
     rounded (the second product's fp32 accumulator goes straight into the layer-scale + residual epilogue)."""
     c, w = x.shape[1], x.shape[-1]
-    sc = p[pre + "conv.bn.weight"] / torch.sqrt(p[pre + "conv.bn.running_var"] + cfg.bn_eps)
-    wf = p[pre + "conv.conv.weight"] * sc.view(-1, 1, 1, 1)
-    bf = p[pre + "conv.bn.bias"] - p[pre + "conv.bn.running_mean"] * sc
+    if pre + "conv.folded.weight" in p:   # the trainable inference form (oracle/train_tower.py fold_tower)
+        wf, bf = p[pre + "conv.folded.weight"], p[pre + "conv.folded.bias"]
+    else:
+        sc = p[pre + "conv.bn.weight"] / torch.sqrt(p[pre + "conv.bn.running_var"] + cfg.bn_eps)
+        wf = p[pre + "conv.conv.weight"] * sc.view(-1, 1, 1, 1)
+        bf = p[pre + "conv.bn.bias"] - p[pre + "conv.bn.running_mean"] * sc
     t = _r(F.conv2d(x, _r(wf) if _dw_mfma(w, c) else wf, bf, padding=3, groups=c))
     h = _r(gelu(_conv(t, p, pre + "fc1")))
     return _conv(h, p, pre + "fc2")

@@ -164,14 +164,23 @@ def test_bench_launcher_starts_its_own_ranks_and_reports_failures():
 
 
 # ------------------------------------------------------------------------------------------------ unfrozen backbone
-def _bucket_layout(L=5):
-    """the flat buffer of fv_train_layout in miniature: [head | projector | embedding | layer 0 .. L-1 | final norm] and the order in which
-    fv_train_forward_backward reports the buckets complete (head, final norm, layers last to first, embedding, projector)"""
-    sizes = [52, 40, 96] + [64] * L + [8]
+def _bucket_layout(L=5, S=5):
+    """the flat buffer of fv_train_layout in miniature: [head | projector | embedding | layer 0 .. L-1 | final norm | TOWER: stem, stage 0, PatchEmbed 0, ...,
+    stage S-1, conv_exp + SE] and the order in which the buckets are reported complete: fv_train_forward_backward's (head, final norm, layers last to first,
+    embedding, projector), then fv_train_tower_backward's (conv_exp + SE, then stage / PatchEmbed from the last stage down, the stem last)"""
+    sizes = [52, 40, 96] + [64] * L + [8] + [24] + [s for i in range(S) for s in ([120 + 16 * i] + ([48] if i + 1 < S else []))] + [36]
     offs = [0]
     for n in sizes:
         offs.append(offs[-1] + n)
     order = [0, 3 + L] + [3 + l for l in range(L - 1, -1, -1)] + [2, 1]
+    base = 3 + L + 1
+    order.append(base + 2 * S)
+    for i in range(S - 1, -1, -1):
+        order.append(base + 1 + 2 * i)
+        if i > 0:
+            order.append(base + 2 + 2 * (i - 1))
+    order.append(base)
+    assert sorted(order) == list(range(len(sizes)))
     return sizes, offs, order
 
 

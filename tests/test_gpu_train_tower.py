@@ -1,0 +1,263 @@
+"""-m gpu: the TOWER half of the unfrozen-backbone training slice (fv_train_tower_* in include/fastvla_hip.h).
+
+The reference would run this if model/fastvlm_adapter.py:501 were not an unconditional no_grad (`freeze_backbone`, fastvla/configuration_fastvla.py:23,
+applied at model/fastvlm_adapter.py:170-173; step body training/trainer.py:171-182).  Oracle = torch.autograd over the fp32 inference-form graph of
+oracle/fastvit_hd.py with the ConvFFN BatchNorms folded (oracle/train_tower.py), on the same seeded weights and inputs:
+  * every tower unit TEACHER-FORCED (the engine's own unit input + a seeded upstream gradient -> the oracle unit's backward): input gradient and every weight
+    gradient <= 4e-3, on the `small` preset (ragged attention, VALU fallbacks) and on FastVLM-0.5B's tower at 1024^2 (all 51 units + conv_exp/SE);
+  * the whole `small` policy with EVERYTHING trainable (tower + projector + decoder + head): loss, actions, every tensor's gradient <= 2e-3, bucket order and
+    coverage, bit-identical repeats, one clip + AdamW step over all tensors, and every packed operand image following the master (fv_train_commit).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, rel_l2  # noqa: E402
+from fastvla_hip import FastVLAEngine, arch, weights  # noqa: E402
+from oracle import fastvit_hd, head, qwen2, train_tower, train_unfrozen  # noqa: E402
+
+UNIT_TOL = 4e-3     # against autograd over the forward the engine computes (oracle/fastvit_hd.py's bf16-faithful graph: same rounding points, fp32 arithmetic)
+FP32_TOL = 1.2e-2   # against autograd over the all-fp32 graph: one unit's share of the bf16 precision policy (tests/precision_budget_tower.py), recorded
+GRAD_TOL = 2e-3
+VT = fastvit_hd.VT
+
+
+def _tcfg(model):
+    t = model.tower
+    return fastvit_hd.TowerCfg(layers=t.layers, dims=t.dims, mlp_ratio=t.mlp_ratio, head_dim=t.head_dim, attn_stages=t.attn_stages, se_ratio=t.se_ratio,
+                               cls_ratio=t.cls_ratio, ln_eps=t.ln_eps, bn_eps=t.bn_eps)
+
+
+def _lcfg(model):
+    l = model.llm
+    return qwen2.Qwen2Cfg(hidden=l.hidden, layers=l.layers, heads=l.heads, kv_heads=l.kv_heads, head_dim=l.head_dim, inter=l.inter, vocab=l.vocab,
+                          rope_theta=l.rope_theta, rms_eps=l.rms_eps)
+
+
+def _engine(model, B, T, hd=64, seed=51):
+    w = weights.init_backbone(model, seed=seed)
+    eng = FastVLAEngine(model, state_dim=14, action_dim=14, hidden_dim=hd, fusion_dim=hd, max_batch=B, max_text_tokens=T, llm_precision=1)
+    eng.load_weights(w)
+    eng.train_begin()
+    eng.train_tower_begin()
+    return w, eng
+
+
+def _unit_sweep(model, w, eng, B, seed, label):
+    tc = _tcfg(model)
+    tensors, total, nb = eng.train_layout()
+    by_name = {t["name"]: t for t in tensors}
+    pf = train_tower.fold_tower(w, tc)
+    qf = fastvit_hd.strip_prefix(pf)
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 3, 336, 336, generator=g)
+    pix = eng.preprocess(img.to(DEV))
+    _, tout, taps = eng.vision_forward_unit_taps(pix)
+    torch.cuda.synchronize()
+    units = fastvit_hd.tower_units(tc) + [("head", len(tc.layers) - 1, None, None)]
+    tws = eng.train_tower_workspace(B)
+    grads = torch.zeros(total, dtype=torch.float32, device=DEV)
+    gscale = 1024.0
+    worst_in, worst_w, worst32 = (0.0, None), (0.0, None), (0.0, None)
+    fails = []
+    for n, unit in enumerate(units):
+        x_in = pix if n == 0 else taps[n - 1]
+        x_ref = (pix.float().cpu()[..., :3] if n == 0 else x_in.float().cpu()).permute(0, 3, 1, 2).contiguous()
+        with torch.no_grad():
+            y_shape = (fastvit_hd.tower_head_forward(qf, x_ref, tc) if unit[0] == "head" else fastvit_hd.unit_forward(qf, x_ref, unit, tc)).shape
+        g_ref = torch.randn(y_shape, generator=g) * 1e-2        # NCHW (head: (B, tokens, C))
+        g_nhwc = g_ref if unit[0] == "head" else g_ref.permute(0, 2, 3, 1).contiguous()
+        grads.zero_()
+        y, g_in = eng.train_tower_unit(n, x_in, g_nhwc.contiguous(), tws, grads, gscale)
+        torch.cuda.synchronize()
+        # the oracle differentiates the forward the engine computes (bf16 rounding points included); the all-fp32 graph's distance is recorded beside it
+        y_ref, gx_ref, gw_ref = train_tower.unit_backward(qf, x_ref, unit, g_ref, tc, emulate_bf16=True)
+        _, gx32, gw32 = train_tower.unit_backward(qf, x_ref, unit, g_ref, tc, emulate_bf16=False)
+        got_y = y.float().cpu().reshape(y_ref.shape if unit[0] == "head" else y.shape)
+        ry = rel_l2(got_y, y_ref if unit[0] == "head" else y_ref.permute(0, 2, 3, 1))
+        if not ry <= 1.5 * UNIT_TOL:      # (the forward's own parity bar lives in tests/test_gpu_fullsize.py; the stem is three layers)
+            fails.append(f"{label} unit {n} {unit}: forward rel_l2 {ry:.3e}")
+        if n > 0:
+            r = rel_l2(g_in.cpu(), gx_ref.permute(0, 2, 3, 1))
+            worst_in = max(worst_in, (r, (n, unit)))
+            worst32 = max(worst32, (rel_l2(g_in.cpu(), gx32.permute(0, 2, 3, 1)), (n, unit)))
+            if not worst32[0] <= FP32_TOL:
+                fails.append(f"{label} unit {n} {unit}: input gradient {worst32[0]:.3e} from the all-fp32 graph")
+            if not r <= UNIT_TOL:
+                fails.append(f"{label} unit {n} {unit}: input gradient rel_l2 {r:.3e}")
+        named = eng.train_named_tensors(grads / gscale)
+        pre = train_tower.unit_prefix(unit)
+        assert gw_ref, (n, unit)
+        for k, ref in gw_ref.items():
+            got = named[VT + k].cpu()
+            assert got.shape == ref.shape or got.numel() == ref.numel(), (k, got.shape, ref.shape)
+            r = rel_l2(got.reshape(ref.shape), ref)
+            worst_w = max(worst_w, (r, k))
+            r32 = rel_l2(got.reshape(ref.shape), gw32[k])
+            worst32 = max(worst32, (r32, k))
+            if not r32 <= FP32_TOL:
+                fails.append(f"{label} unit {n} {unit}: gradient of {k} {r32:.3e} from the all-fp32 graph")
+            if not r <= UNIT_TOL:
+                fails.append(f"{label} unit {n} {unit}: gradient of {k} rel_l2 {r:.3e}")
+        # nothing outside this unit's tensors was touched
+        own = {VT + k for k in gw_ref}
+        for t in tensors:
+            if t["name"].startswith(VT + pre) or t["name"] in own:
+                continue
+            if t["name"].startswith(VT):
+                if float(grads[t["offset"]: t["offset"] + t["numel"]].abs().max()) != 0.0:
+                    fails.append(f"{label} unit {n} {unit}: wrote into {t['name']}")
+    print(f"[{label}] {len(units)} units teacher-forced: worst input gradient {worst_in[0]:.2e} at {worst_in[1]}; worst weight gradient {worst_w[0]:.2e} ({worst_w[1]}); "
+          f"worst distance from the all-fp32 graph's gradient {worst32[0]:.2e} ({worst32[1]})")
+    assert not fails, "\n".join(fails)
+    assert by_name
+
+
+def test_small_tower_every_unit_backward_teacher_forced():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    model = arch.preset("small")
+    w, eng = _engine(model, 2, 16)
+    _unit_sweep(model, w, eng, 2, 7, "small 384^2 B=2")
+    eng.close()
+
+
+def test_full_size_tower_every_unit_backward_teacher_forced():
+    model = arch.preset("fastvlm-0.5b")
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    small_llm = arch.ModelConfig("tower-full", arch.LLMConfig(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=64, inter=640, vocab=1024), model.tower)
+    w, eng = _engine(small_llm, 1, 16)
+    _unit_sweep(small_llm, w, eng, 1, 9, "fastvlm-0.5b tower 1024^2 B=1")
+    eng.close()
+
+
+def _policy_inputs(model, B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 3, 336, 336, generator=g)
+    ids = torch.randint(0, model.llm.vocab, (B, T), generator=g)
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, T // 2 + 1:] = 0
+    states, targets = torch.randn(B, 14, generator=g), torch.randn(B, 14, generator=g)
+    return img, ids, mask, states, targets
+
+
+def test_small_policy_everything_trainable_matches_autograd():
+    model = arch.preset("small")
+    tc, lc = _tcfg(model), _lcfg(model)
+    B, T, hd = 2, 16, 64
+    w, eng = _engine(model, B, T, hd)
+    tensors, total, nb = eng.train_layout()
+    L = model.llm.layers
+    assert nb == 3 + L + 1 + 2 * len(model.tower.layers) + 1
+    flat = torch.zeros(total, dtype=torch.float32, device=DEV)
+    eng.train_export_params(flat)
+    shapes = head.head_shapes(lc.hidden, 14, 14, hd, hd)
+    g = torch.Generator().manual_seed(52)
+    hp = {k: (torch.randn(*s, generator=g) / (s[-1] ** 0.5 if len(s) > 1 else 10.0)) + (1.0 if k in ("state_projection.0.weight", "fusion.1.weight") else 0.0)
+          for k, s in shapes.items()}
+    for k, v in eng.head_views(flat).items():
+        v.copy_(hp[k])
+    pf = train_tower.fold_tower(w, tc)
+    # the exported master equals the folded inference-form weights (bf16 matrices widen exactly; the 7x7 fold is the loader's own arithmetic)
+    named = eng.train_named_tensors(flat)
+    for k in train_tower.tower_keys(pf):
+        a, b = named[k].cpu(), pf[k].reshape(named[k].shape).float()
+        assert rel_l2(a, b) <= 1e-6, k
+    img, ids, mask, states, targets = _policy_inputs(model, B, T, 53)
+    pix = eng.preprocess(img.to(DEV))
+    ws, tws = eng.train_workspace(B, T), eng.train_tower_workspace(B)
+    dto = torch.zeros(B, model.tower.num_tokens, model.tower.out_dim, dtype=torch.float16, device=DEV)
+    eng.train_set_tower_grad(dto)
+
+    def step(flat_, order=None):
+        grads = torch.zeros_like(flat_)
+        tower_out = eng.train_tower_forward(pix, tws)
+        cb = (lambda b, off, n: order.append((b, off, n))) if order is not None else None
+        act, loss, _ = eng.train_forward_backward(flat_, tower_out, ids, mask.sum(1), states, targets, ws, training=False, flat_grads=grads, bucket_cb=cb)
+        eng.train_tower_backward(pix, dto, tws, grads, bucket_cb=cb)
+        torch.cuda.synchronize()
+        return act, loss, grads, tower_out
+
+    order = []
+    act, loss, grads, tower_out = step(flat, order)
+    x = pix.float().cpu()[..., :3].permute(0, 3, 1, 2).contiguous()
+    # oracle: autograd over the bf16-faithful tower graph + fp32 projector / decoder / head, the tower's OUTPUT VALUE taken from the engine (the gradient still
+    # flows through the oracle's tower): what is compared is the backward chain, not how far two bf16 forwards drift apart before the loss differentiates them
+    ref = train_tower.forward_backward(pf, hp, x, ids, mask, states, targets, tc, lc, emulate_bf16=True, tower_out_value=tower_out.float().cpu())
+    free = train_tower.forward_backward(pf, hp, x, ids, mask, states, targets, tc, lc, emulate_bf16=True)
+    ra, rl = rel_l2(act.cpu(), ref["pred"]), abs(float(loss) - float(ref["loss"])) / float(ref["loss"])
+    rt = rel_l2(tower_out.float().cpu(), free["tower_out"])
+    rfree = max(rel_l2(gk_.cpu().reshape(free["grads"][k_].shape), free["grads"][k_]) for k_, gk_ in eng.train_named_tensors(grads / eng.train_loss_scale()).items())
+    got = eng.train_named_tensors(grads / eng.train_loss_scale())
+    assert set(got) == set(ref["grads"]), sorted(set(got) ^ set(ref["grads"]))[:8]
+    worst = ("", 0.0)
+    for k, gk in got.items():
+        r = ref["grads"][k]
+        e = rel_l2(gk.cpu().reshape(r.shape), r)
+        if e > worst[1]:
+            worst = (k, e)
+    print(f"[everything trainable, small] B={B} T={T} tower_out rel_l2={rt:.2e} actions rel_l2={ra:.2e} loss rel={rl:.2e} worst gradient: {worst[0]} {worst[1]:.2e} "
+          f"({len(got)} tensors, {eng.fp16_saturations()} fp16 saturations); without the value teacher-forcing at tower_out the worst gradient sits {rfree:.2e} from the oracle's")
+    # the forward runs the bf16 tower (parity bound of the spliced mode: tests/test_gpu_fullsize.py); gradients are held to the per-tensor bar
+    for k, gk in got.items():
+        r = ref["grads"][k]
+        e = rel_l2(gk.cpu().reshape(r.shape), r)
+        assert e <= (GRAD_TOL if not k.startswith(VT) else 2.5 * GRAD_TOL), f"gradient of {k}: rel_l2 {e:.3e}"
+    # buckets: the decoder's order, then the tower's: conv_exp + SE, then stage / PatchEmbed pairs from the last stage down, the stem last; they tile the buffer once
+    base = 3 + L + 1
+    ns = len(model.tower.layers)
+    tower_order = [base + 2 * ns]
+    for i in range(ns - 1, -1, -1):
+        tower_order.append(base + 1 + 2 * i)
+        if i > 0:
+            tower_order.append(base + 2 + 2 * (i - 1))
+    tower_order.append(base)
+    assert [b for b, _, _ in order] == [0, 3 + L] + [3 + l for l in range(L - 1, -1, -1)] + [2, 1] + tower_order
+    spans = sorted((off, off + n) for _, off, n in order)
+    assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    # bit-identical repeat
+    act2, loss2, grads2, _ = step(flat)
+    assert torch.equal(grads, grads2) and torch.equal(act, act2)
+    # one clip + AdamW step over ALL tensors, then every operand image follows the master: the committed engine == a FRESH engine loaded with the new weights
+    m, v, norm = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros(1, device=DEV)
+    new = flat.clone()
+    eng.adamw_step(new, grads, m, v, 1, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0, grad_norm_out=norm, grad_scale=1.0 / eng.train_loss_scale())
+    params = {k: pf[k].float() for k in pf if k.startswith("model.")}
+    params.update({"head." + k: t for k, t in hp.items()})
+    _, ref_norm = train_unfrozen.adamw_clip_step(params, ref["grads"], lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0)
+    assert abs(float(norm) - float(ref_norm)) <= 3e-3 * float(ref_norm), (float(norm), float(ref_norm))
+    eng.train_commit(new)
+    torch.cuda.synchronize()
+    assert float((new - flat).abs().max()) > 0
+    tok_c, tout_c = eng.vision_forward(pix, return_tower_out=True)
+    tower_out_train = eng.train_tower_forward(pix, tws)
+    torch.cuda.synchronize()
+    assert torch.equal(tout_c, tower_out_train)        # the inference path (fused stem) and the training forward read the same refreshed operand images ...
+    got_new = eng.train_named_tensors(new)
+    w2 = {}
+    for k, t in got_new.items():
+        if k.startswith("head."):
+            continue
+        w2[k] = t.cpu()
+    # ... and they are the images a fresh load of the new weights builds (BatchNorm identity: the folded 7x7 IS the weight)
+    for k in list(w2):
+        if k.endswith("convffn.conv.folded.weight"):
+            pre = k[: -len("folded.weight")]
+            c = w2[k].shape[0]
+            w2[pre + "conv.weight"] = w2.pop(k)
+            w2[pre + "bn.weight"] = torch.ones(c)
+            w2[pre + "bn.bias"] = w2.pop(pre + "folded.bias")
+            w2[pre + "bn.running_mean"] = torch.zeros(c)
+            w2[pre + "bn.running_var"] = torch.full((c,), 1.0 - tc.bn_eps)
+    for k, t in w.items():
+        if k not in w2 and not k.startswith(VT):
+            w2[k] = t
+    fresh = FastVLAEngine(model, state_dim=14, action_dim=14, hidden_dim=hd, fusion_dim=hd, max_batch=B, max_text_tokens=T, llm_precision=1)
+    fresh.load_weights({k: (t.reshape(w[k].shape) if k in w else t) for k, t in w2.items()})
+    tok_f, tout_f = fresh.vision_forward(pix, return_tower_out=True)
+    torch.cuda.synchronize()
+    assert rel_l2(tout_c.float().cpu(), tout_f.float().cpu()) <= 2e-3, rel_l2(tout_c.float().cpu(), tout_f.float().cpu())
+    fresh.close()
+    eng.train_set_tower_grad(None)
+    eng.close()

@@ -368,7 +368,7 @@ def test_policy_level_unfrozen_training_overfits_one_batch_and_exports_the_train
     k0 = "model.backbone.model.model.layers.0.mlp.down_proj.weight"
     assert torch.equal(sd[k0], after["model.layers.0.mlp.down_proj.weight"].cpu()) and not torch.equal(sd[k0], before["model.layers.0.mlp.down_proj.weight"].cpu())
     again = load_policy_from_checkpoint(str(out_dir)).to(DEV)
-    again.model.backbone.splice_image_tokens = True
+    assert again.model.backbone.splice_image_tokens is True and "model.backbone.splice_image_tokens" in sd   # the mode the decoder was trained in travels with the file
     with torch.no_grad():
         a2 = again(batch["images"], batch["states"], batch["tasks"])
     torch.cuda.synchronize()
@@ -432,3 +432,55 @@ def test_two_rank_unfrozen_step_equals_the_full_batch_step(tmp_path):
     assert e <= 2e-3 and abs(r0["grad_norm"] - full["grad_norm"]) <= 2e-3 * full["grad_norm"]
     # the half-batch losses average to the full-batch loss
     assert abs(0.5 * (r0["loss"] + r1["loss"]) - full["loss"]) <= 1e-4 * abs(full["loss"])
+
+
+@pytest.mark.parametrize("tower", [False, True])
+def test_trainer_fit_with_the_backbone_unfrozen_saves_and_resumes(tmp_path, tower):
+    """the documented route -- `Trainer.fit()` (reference training/trainer.py:145-206) over a loader with several batches while the backbone is
+    unfrozen.  The loop's one batch of look-ahead (`next_batch=`) must not break the unfrozen step; its checkpoints must carry the TRAINED VLM, the splice mode
+    and the whole-master AdamW moments; a resumed run must continue bit for bit where the uninterrupted one is.  tower=True: FastViT-HD trainable as well."""
+    from vla_fastvlm.fastvla import FastVLAConfig, FastVLAPolicy
+    from vla_fastvlm.training import Trainer, TrainingConfig
+    g = torch.Generator().manual_seed(8)
+
+    def mk(B):
+        return {"images": torch.rand(B, 3, 96, 128, generator=g), "states": torch.randn(B, 14, generator=g), "actions": torch.randn(B, 14, generator=g),
+                "tasks": ["pick up the red cube", "open the drawer", "push"][:B]}
+
+    data = [mk(3), mk(3), mk(3), mk(3)]
+    cfg = FastVLAConfig(vlm_model_name="synthetic:small:43", hidden_dim=64, fusion_dim=64, dropout=0.0, freeze_backbone=False)
+    tkw = dict(num_epochs=1, learning_rate=1e-3, warmup_ratio=0.5, logging_steps=1000, eval_steps=1000, seed=1)
+
+    def fresh():
+        torch.manual_seed(7)
+        p = FastVLAPolicy(cfg).to(DEV)
+        p.enable_backbone_training(tower=tower)
+        return p
+
+    a = fresh()
+    Trainer(a, data, None, TrainingConfig(output_dir=str(tmp_path / "a"), save_steps=1000, max_steps=4, **tkw)).fit()
+    b = fresh()
+    tb = Trainer(b, data[:3], None, TrainingConfig(output_dir=str(tmp_path / "b"), save_steps=3, max_steps=4, **tkw))
+    tb.num_training_steps = 4
+    tb.fit()
+    ck = tmp_path / "b" / "checkpoints" / "step-3"
+    sd = torch.load(ck / "policy_state_dict.pt", map_location="cpu")
+    opt = torch.load(ck / "optimizer.pt", map_location="cpu")
+    assert any(k.startswith("model.backbone.model.model.layers.") for k in sd) and "model.backbone.splice_image_tokens" in sd    # the trained VLM travels by default
+    assert opt["m"].numel() == b._unfrozen.flat.numel() and int(opt["step"]) == 3
+    if tower:
+        assert any(".vision_tower." in k and k.endswith("convffn.conv.bn.running_var") for k in sd)
+    c = fresh()
+    tc = Trainer(c, data[3:], None, TrainingConfig(output_dir=str(tmp_path / "c"), save_steps=1000, max_steps=4, resume_from=str(ck), **tkw))
+    tc.num_training_steps = 4
+    tc.fit()
+    torch.cuda.synchronize()
+    assert tc.global_step == 4 and c._unfrozen.step_count == 4
+    fa, fc = a._unfrozen.flat, c._unfrozen.flat
+    # the checkpoint holds the fp32 master of the decoder / projector / head exactly; a trained tower goes through its checkpoint form (folded conv + identity
+    # BatchNorm: one fp32 rounding of the fold) -- so the resumed run equals the uninterrupted one to fp32 rounding, not bit for bit
+    e = rel_l2(fc.cpu(), fa.cpu())
+    print(f"[Trainer.fit unfrozen, tower={tower}] resumed vs uninterrupted master after 4 steps: rel_l2 {e:.2e}")
+    assert e <= (1e-6 if not tower else 1e-5)
+    for p_ in (a, b, c):
+        p_.model.backbone.engine().close()

@@ -226,6 +226,14 @@ __device__ __forceinline__ f32x2 gelu2_f(f32x2 x) {
   gelu2_n<1>(v);
   return v[0];
 }
+// exact (erf) GELU and its derivative, for the tower backward's recomputed hidden (FV_EPI_GELU_GRAD, gelu_grad_mul_kernel):
+// Phi(x) = (1 + erf(x / sqrt 2)) / 2, gelu = x Phi, gelu' = Phi + x phi
+__device__ __forceinline__ void gelu_and_grad(float x, float& g, float& dg) {
+  const float Phi = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float phi = 0.3989422804014327f * __expf(-0.5f * x * x);
+  g = x * Phi;
+  dg = Phi + x * phi;
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 

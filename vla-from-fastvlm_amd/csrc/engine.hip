@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -79,8 +80,15 @@ struct TrainLayerT {   // transposed weight copies (dgrad operands): bf16, and f
   bf16_t *qkvT = nullptr, *oT = nullptr, *guT = nullptr, *downT = nullptr;
   bf16_t *qkvT16 = nullptr, *oT16 = nullptr, *guT16 = nullptr, *downT16 = nullptr;
 };
+struct GTab { int* idx = nullptr; float* coef = nullptr; size_t n = 0; };   // gather table of one packed operand image (tower_train.inc make_gtab), device arrays
+struct TowerTrainUnit { bf16_t *fc1T16 = nullptr, *fc2sT16 = nullptr, *qkvT16 = nullptr, *projsT16 = nullptr, *pwT16 = nullptr; };   // transposed fp16 dgrad operands of one tower unit
 struct TrainState {
   bool ready = false; std::vector<TrainLayerT> layers; bf16_t *pj2T = nullptr, *pj2T16 = nullptr;
+  // the tower half (tower_train.inc): its tensors join the flat master when `tower` is set
+  bool tower = false; std::vector<TowerTrainUnit> tunits; std::map<std::string, GTab> gtabs;
+  fv::TowerCommitOp* tower_ops = nullptr; int tower_nops = 0, tower_blocks = 0;
+  bf16_t *pj0T = nullptr, *pj0T16 = nullptr;   // the projector's first Linear, transposed (its input gradient feeds the tower)
+  void* d_tower_out = nullptr;                 // fv_train_set_tower_grad: where fv_train_forward_backward leaves dL/d(tower_out) as fp16 rows
   fv::CommitDesc* commit_desc = nullptr; int commit_n = 0, commit_tiles = 0;   // fv_train_commit's descriptor table (device)
   int grad_split = 2;   // dgrad's gradient operand: 1 split bf16 (hi + lo, two passes), 0 its bf16 hi half alone, 2 ONE fp16 pass against fp16 transposed weights (fv_train_set_options)
   int wgrad_tn = 0;     // 1 (fv_train_set_options wgrad_f16 = 2): weight gradients on the TN GEMM instance (row-major operands, no transposed copies) -- same gradients, +1 ms per step: not the default
@@ -1375,3 +1383,4 @@ int fv_allreduce_grads(fv_handle* h, void* comm, float* flat_grads, int64_t n, f
 }  // extern "C"
 
 #include "train_path.inc"
+#include "tower_train.inc"

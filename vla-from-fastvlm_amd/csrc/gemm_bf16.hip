@@ -272,6 +272,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
       const float4 hi = *reinterpret_cast<const float4*>(p.bias + gn + 4);
       v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
     }
+    if (epi == FV_EPI_GELU_GRAD || epi == FV_EPI_MUL_AUX || epi == FV_EPI_F16) {   // the tower backward's fp16 outputs
+      if (epi == FV_EPI_GELU_GRAD) {
+        float g8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gelu_and_grad(v[e], v[e], g8[e]); v[e] = bf2f(f2bf(v[e])); }   // the forward's hidden is a bf16 MFMA operand: the same value here
+        *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.stash) + (size_t)gm * p.ldo + gn) = pack8_h(g8);
+        if (!p.out) continue;
+      } else if (epi == FV_EPI_MUL_AUX) {
+        float a8[8];
+        unpack8_h(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), a8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= a8[e];
+      }
+      count_f16_sat8(v, p.sat);
+      *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8_h(v);
+      continue;
+    }
     if (epi == FV_EPI_BIAS_GELU) {  // packed, transcendental-free form (common.h): half the VALU issues of gelu_f
       f32x2 g[4] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}};
       gelu2_n<4>(g);
@@ -661,6 +678,23 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
         const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
         const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
         float v[8] = {y0.x + bs[0], y0.y + bs[1], y0.z + bs[2], y0.w + bs[3], y1.x + bs[4], y1.y + bs[5], y1.z + bs[6], y1.w + bs[7]};
+        if (p.epi == FV_EPI_GELU_GRAD || p.epi == FV_EPI_MUL_AUX || p.epi == FV_EPI_F16) {   // the tower backward's fp16 outputs
+          if (p.epi == FV_EPI_GELU_GRAD) {
+            float g8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gelu_and_grad(v[e], v[e], g8[e]); v[e] = bf2f(f2bf(v[e])); }   // the forward's hidden is a bf16 MFMA operand: the same value here
+            *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.stash) + (size_t)gm * p.ldo + gn) = pack8_h(g8);
+            if (!p.out) continue;
+          } else if (p.epi == FV_EPI_MUL_AUX) {
+            float a8[8];
+            unpack8_h(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), a8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= a8[e];
+          }
+          count_f16_sat8(v, p.sat);
+          *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8_h(v);
+          continue;
+        }
         if (p.epi == FV_EPI_BIAS_GELU) {
           f32x2 g[4] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}};
           gelu2_n<4>(g);
@@ -846,7 +880,8 @@ int gemm_glds_tile(const GemmArgs& a) {
   // 4 GiB or more go to the register-staged kernel, which addresses with size_t
   if ((size_t)a.M * a.lda * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return 0;
   const bool f32 = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
-  if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16 && !f32) return 0;
+  const bool f16_epi = a.epi == FV_EPI_GELU_GRAD || a.epi == FV_EPI_MUL_AUX || a.epi == FV_EPI_F16;   // the tower backward's (2-byte fp16 outputs: the bf16 epilogues' store loop)
+  if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16 && !f32 && !f16_epi) return 0;
   if ((a.epi == FV_EPI_SWIGLU_SPLIT || a.epi == FV_EPI_SWIGLU_F16) && a.bias) return 0;
   // (a 128 x 256 variant for shapes whose last round of 256-tiles is mostly idle -- the decoder's gate/up, 608 tiles = 2.4
   // rounds -- was measured slower, 184 vs 150 us: 64 x 64 per wave reads a third more LDS per MFMA)
@@ -860,7 +895,7 @@ int gemm_glds_tile(const GemmArgs& a) {
   static const bool no_ragged = fv_ab_env("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
   // (late round 4: the bf16 epilogues too -- bias / bias + GELU / layer-scale + residual share the guarded store loop: the PatchEmbed 1x1 at
   // 262144 x 384 x 384 and the projector's first Linear, N = 896, were the last two launches on the register-staged kernel)
-  const bool bf16_epi = a.epi == FV_EPI_BIAS || a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES;
+  const bool bf16_epi = a.epi == FV_EPI_BIAS || a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES || f16_epi;
   if (!no_ragged && (((f32 || bf16_epi) && a.N % 8 == 0) || (a.epi == FV_EPI_SWIGLU_SPLIT && a.N % 256 == 0))) {   // (SwiGLU: ragged rows only)
     const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
     const double fill = (double)a.M * a.N / ((double)tm * tn * 65536.0);
@@ -925,7 +960,7 @@ static int launch_gemm_tn(const GemmArgs& a, hipStream_t s) {
   if (a.splitk_ws) {
     const double tile_us = (double)nkt * 64.0 * 131072.0 / 1.0e6 / 4.0, part_us = 2.0 * (double)a.M * (tn * 256) * 4.0 / 4.0e6;
     double best = 1e30;
-    for (int sN = 1; sN <= 8; ++sN) {
+    for (int sN = 1; sN <= 32; ++sN) {   // (up to 32 ranges: the tower's weight gradients are 1 .. 12 tiles over a contraction of 10^5 .. 10^6 pixels)
       if (sN > 1 && (nkt / sN < 16 || (size_t)sN * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes)) break;
       const long units = (long)tiles * sN, rounds = (units + cus - 1) / cus;
       const double t = (double)rounds * tile_us / sN + (sN > 1 ? sN * part_us : 0.0);
@@ -956,12 +991,15 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     if (!done) { done = true; const int v = fv_ab_env("FASTVLA_GEMM_KROT") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_g2_krot), &v, sizeof(int)); }
   }
 #endif
-  if (!a.A || !a.W || !a.out) return fv_fail(FV_ERR_ARG, "gemm: null operand");
+  if (!a.A || !a.W || (!a.out && a.epi != FV_EPI_GELU_GRAD)) return fv_fail(FV_ERR_ARG, "gemm: null operand");
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fv_fail(FV_ERR_ARG, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.tn) return launch_gemm_tn(a, s);
   if (a.K % 8 || a.lda % 8 || a.N % 8) return fv_fail(FV_ERR_ARG, "gemm: K, lda, N must be multiples of 8 (K=%d lda=%d N=%d)", a.K, a.lda, a.N);
   if (a.lda < a.K) return fv_fail(FV_ERR_ARG, "gemm: lda < K");
-  if (a.epi < FV_EPI_BIAS || (a.epi > FV_EPI_F32 && a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16)) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
+  if (a.epi < FV_EPI_BIAS || a.epi > FV_EPI_F16 || a.epi == 6) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
+  if ((a.epi == FV_EPI_GELU_GRAD || a.epi == FV_EPI_MUL_AUX || a.epi == FV_EPI_F16) && a.ksplit) return fv_fail(FV_ERR_ARG, "gemm: the fp16-output epilogues take no ksplit");
+  if (a.epi == FV_EPI_GELU_GRAD && (!a.stash || ((uintptr_t)a.stash & 15))) return fv_fail(FV_ERR_ARG, "gemm: GELU_GRAD needs a 16-byte aligned stash (gelu' output)");
+  if (a.epi == FV_EPI_MUL_AUX && (!a.res || a.ldr % 8 || a.ldr < a.N)) return fv_fail(FV_ERR_ARG, "gemm: MUL_AUX needs the fp16 factor in res");
   if (a.f16 && a.ksplit) return fv_fail(FV_ERR_ARG, "gemm: fp16 operands are a single pass (no ksplit)");
   if (a.f16 && (a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES || a.epi == FV_EPI_SWIGLU))
     return fv_fail(FV_ERR_UNSUPPORTED, "gemm: fp16 operands go with the BIAS / F32 / RES_F32 / SWIGLU_SPLIT / SWIGLU_F16 epilogues");
@@ -980,7 +1018,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   p.ksplit = a.ksplit == 2 ? 2 : (a.ksplit ? 1 : 0);
   p.sat = a.sat;
   p.stash = a.stash; p.stash_f16 = a.stash_f16;
-  if (a.stash && (a.epi != FV_EPI_SWIGLU_SPLIT || ((uintptr_t)a.stash & 15) || (a.stash_f16 && !a.sat)))
+  if (a.stash && a.epi != FV_EPI_GELU_GRAD && (a.epi != FV_EPI_SWIGLU_SPLIT || ((uintptr_t)a.stash & 15) || (a.stash_f16 && !a.sat)))
     return fv_fail(FV_ERR_ARG, "gemm: stash goes with FV_EPI_SWIGLU_SPLIT (16-byte aligned; the fp16 form with a saturation counter)");
   p.W8 = static_cast<const uint8_t*>(a.W8);
   if (a.ksplit == 2) {

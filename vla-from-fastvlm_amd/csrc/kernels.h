@@ -170,6 +170,41 @@ struct CommitDesc {
 };
 int launch_commit(const CommitDesc* desc_dev, int ndesc, int ntiles, const float* flat, int f16_transposes, unsigned* sat, hipStream_t s);
 
+// ---- tower backward (tower_bwd_kernels.hip; SURVEY.md 8f-4, second slice) ---------------------------------------------------------
+// gradients NHWC fp16 (loss-scaled), activations NHWC bf16, weight gradients fp32 by fixed-order partial sums (no atomics)
+size_t dw_bwd_scratch_floats(int B, int Ho, int Wo, int Co, int k);
+int launch_dw_dgrad(const bf16_t* dy, const float* w, const bf16_t* res, bf16_t* dx, int B, int Hi, int Wi, int Ci, int k, int stride, int mult, unsigned* sat,
+                    hipStream_t s, int round_w = 0);   // round_w: taps rounded to bf16 first (the forward ran on a bf16 Toeplitz table)
+int launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, float* db, float* scratch, int B, int Hi, int Wi, int Ci, int k, int stride, int mult,
+                    hipStream_t s);
+int launch_colsum16(const bf16_t* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s);   // scratch >= COLSUM_CHUNKS * C floats
+int launch_mul16(const bf16_t* a, const bf16_t* b, bf16_t* out, size_t n, unsigned* sat, hipStream_t s);
+int launch_gelu_grad_mul(const bf16_t* dh, const bf16_t* pre, bf16_t* out, size_t n, unsigned* sat, hipStream_t s);   // out f16 = dh f16 * gelu'(pre bf16)
+int launch_f16_to_f32(const bf16_t* in, float* out, size_t n, float scale, hipStream_t s);
+int launch_scale_to_f16(const float* in, bf16_t* out, size_t n, float scale, unsigned* sat, hipStream_t s);   // out f16 = in * scale (saturating)
+int launch_ls_grads(const float* dWraw, const float* dbraw, const bf16_t* W, const float* bias, const float* ls, float* dW, float* db, float* dls, int C, int Kd,
+                    hipStream_t s);
+size_t ln_bwd_scratch_floats(long rows, int C);
+int launch_ln_bwd(const bf16_t* x, const bf16_t* dy, const float* w, const bf16_t* res, bf16_t* dx, float* dw, float* db, float* scratch, long rows, int C,
+                  float eps, unsigned* sat, hipStream_t s);
+int launch_tower_attn_bwd(const bf16_t* qkv, int ld, const bf16_t* o, int ldo, const bf16_t* dO, int lddo, bf16_t* dqkv, int ldd, float* stats, int B, int T,
+                          int heads, float scale, hipStream_t s);   // stats: 2 * B * heads * T floats
+int launch_se_bwd(const bf16_t* e, const bf16_t* dout, const float* se, const float* w1, const float* w2, bf16_t* de, float* dW1, float* db1, float* dW2,
+                  float* db2, float* tmp, int B, int P, int C, int R, unsigned* sat, hipStream_t s);   // tmp >= B * (2 C + 2 R) floats
+size_t stem0_wgrad_scratch_floats(int B, int S, int C0);
+int launch_stem0_wgrad(const bf16_t* pix, const float* w, const float* bias, const bf16_t* dh0, float* dw, float* db, float* scratch, int B, int S, int C0,
+                       hipStream_t s, int round_w = 0);
+// fv_train_commit's tower part: one launch over a table of operations (device array, sorted by blk0; a block = 1024 destination elements)
+//   kind 0: dst f32[i] = src[i]      1: dst bf16[i] = src[i]      2: dst bf16[i] = idx[i] >= 0 ? coef[i] * src[idx[i]] : 0   (the packed operand images)
+//   kind 3: dst f16 [cols][rows] = src[rows][cols]^T              4: the same with row r scaled by flat[src2_off + r]         (dgrad operands)
+struct TowerCommitOp {
+  long long src_off, src2_off, n;
+  void* dst;
+  const int* idx; const float* coef;
+  int kind, rows, cols, blk0;
+};
+int launch_tower_commit(const TowerCommitOp* ops_dev, int nops, int nblocks, const float* flat, unsigned* sat, hipStream_t s);
+
 // attention_split.hip: the same forward (training: with lse) and backward on the bf16 matrix core with split (hi + lo) operands, three passes per product
 // scratch: attention_split_scratch_bytes(B, T, kv_heads, D) bytes -- K (rotated) and V of every kv head as split bf16 in both operand forms, written once
 // per call by a small pre-pass and copied flat into LDS by every q head's / query block's thread block

@@ -1,0 +1,970 @@
+// tower_bwd_kernels.hip -- backward kernels of the FastViT-HD tower (second slice: the tower trainable).
+//
+// The reference never differentiates the tower (model/fastvlm_adapter.py:501 is an unconditional no_grad; the knob it nominally has is
+// fastvla/configuration_fastvla.py:23 `freeze_backbone`, applied at model/fastvlm_adapter.py:170-173): the arithmetic here is torch autograd's
+// over the inference-form graph oracle/fastvit_hd.py restates (every gradient checked against it, tests/test_gpu_train_tower.py).
+//
+// Conventions.  Activations NHWC bf16 as the forward leaves them; every gradient tensor NHWC fp16 carrying the loss scale of
+// fv_train_set_options (saturating casts); weight gradients fp32, summed in a FIXED order (per-block partial sums + one reduce pass, no
+// atomics: bit-repeatable).  The dense contractions (1x1 convs) run on the GEMM kernels of gemm_bf16.hip (FV_EPI_GELU_GRAD / MUL_AUX / F16
+// epilogues, TN instance for the weight gradients); this file holds what is left:
+//   dw_dgrad_kernel / dw_wgrad_kernel   depthwise k x k (stride 1 / 2, channel multiplier 1 / 2): input gradient (+ residual), tap + bias gradients
+//   ln_bwd_kernel                       LayerNormChannel (rows of C)
+//   tattn_dq_kernel / tattn_dkv_kernel  non-causal head_dim-32 attention on v_mfma_f32_16x16x32_f16 (row statistics recomputed: any token count)
+//   se_*                                conv_exp's squeeze-excite + GELU
+//   stem0_wgrad_kernel                  the dense 3x3 stride-2 stem conv (pre-activation recomputed from the pixels)
+//   colsum16 / partial_reduce / ls_grads / mul / gelu_grad_mul / tower_commit  HBM-bound glue
+#include "kernels.h"
+
+namespace fv {
+namespace {
+
+__device__ __forceinline__ float h2f_lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+__device__ __forceinline__ float h2f_hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+
+// ------------------------------------------------------------------------------------------------ depthwise: input gradient
+// dx[b][yi][xi][ci] = (res) + sum_{q < MULT} sum_{ky, kx} w[ky K + kx][ci MULT + q] dy[b][yo][xo][ci MULT + q],  yo S = yi + PAD - ky, xo S = xi + PAD - kx
+// block = one slab of CS input channels (weights of the slab in LDS) x a run of pixels; thread = 8 input channels of one pixel
+template <int K, int S, int MULT>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ w, const bf16_t* __restrict__ res,
+                                                        bf16_t* __restrict__ dx, int Hi, int Wi, int Ci, int Ho, int Wo, int CS, int nslabs, long npix,
+                                                        int iters, unsigned* sat, int round_w) {
+  constexpr int PAD = K / 2;
+  extern __shared__ __attribute__((aligned(16))) float sw_dg[];   // [K*K][CS * MULT]
+  const int slab = blockIdx.x % nslabs;
+  const long pblock = blockIdx.x / nslabs;
+  const int Co = Ci * MULT, cw = CS * MULT;
+  // round_w: the forward ran this layer on the MFMA depthwise kernels, whose Toeplitz tables hold the taps rounded to bf16 -- the backward differentiates THAT function
+  for (int i = threadIdx.x; i < K * K * cw; i += 256) {
+    const float wv = w[(size_t)(i / cw) * Co + slab * cw + (i % cw)];
+    sw_dg[i] = round_w ? bf2f(f2bf(wv)) : wv;
+  }
+  __syncthreads();
+  const int G = CS >> 3, ppb = 256 / G;
+  const int g = threadIdx.x % G, pl = threadIdx.x / G;
+  if (pl >= ppb) return;
+  const int ci0 = slab * CS + g * 8;
+  for (int it = 0; it < iters; ++it) {
+    const long p = (pblock * iters + it) * ppb + pl;
+    if (p >= npix) return;
+    const int xi = (int)(p % Wi);
+    const long t = p / Wi;
+    const int yi = (int)(t % Hi);
+    const long b = t / Hi;
+    float acc[8];
+    if (res) {
+      unpack8_h(*reinterpret_cast<const uint4*>(res + p * Ci + ci0), acc);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    }
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+      const int yy = yi + PAD - ky;
+      if (S == 2 && (yy & 1)) continue;
+      const int yo = S == 2 ? (yy >> 1) : yy;
+      if (yo < 0 || yo >= Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int xx = xi + PAD - kx;
+        if (S == 2 && (xx & 1)) continue;
+        const int xo = S == 2 ? (xx >> 1) : xx;
+        if (xo < 0 || xo >= Wo) continue;
+        const bf16_t* dp = dy + ((b * Ho + yo) * Wo + xo) * (long)Co + (long)ci0 * MULT;
+        const float* wp = sw_dg + (ky * K + kx) * cw + g * 8 * MULT;
+        if (MULT == 1) {
+          float v[8];
+          unpack8_h(*reinterpret_cast<const uint4*>(dp), v);
+          const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+          acc[0] += w0.x * v[0]; acc[1] += w0.y * v[1]; acc[2] += w0.z * v[2]; acc[3] += w0.w * v[3];
+          acc[4] += w1.x * v[4]; acc[5] += w1.y * v[5]; acc[6] += w1.z * v[6]; acc[7] += w1.w * v[7];
+        } else {
+          float v[16];
+          unpack8_h(*reinterpret_cast<const uint4*>(dp), v);
+          unpack8_h(*reinterpret_cast<const uint4*>(dp + 8), v + 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += wp[2 * e] * v[2 * e] + wp[2 * e + 1] * v[2 * e + 1];
+        }
+      }
+    }
+    count_f16_sat8(acc, sat);
+    *reinterpret_cast<uint4*>(dx + p * Ci + ci0) = pack8_h(acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise: tap + bias gradients
+// part[pb][t][co] = sum over the block's output pixels of dy[pix][co] x[pix S - PAD + tap t][co / MULT]  (t = K*K: the bias gradient, x = 1)
+// thread = one output-channel PAIR x a slice of the block's pixels; K*K + 1 accumulator pairs in registers; slices folded through LDS in a fixed order
+template <int K, int S, int MULT>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int Hi, int Wi,
+                                                        int Ci, int Ho, int Wo, int CS, int nslabs, long npix, long ppb) {
+  constexpr int PAD = K / 2, NT = K * K + 1, RT = 10;   // RT taps per LDS fold round
+  extern __shared__ __attribute__((aligned(16))) float sr_wg[];   // [RT][NPS][CS]
+  const int slab = blockIdx.x % nslabs;
+  const long pb = blockIdx.x / nslabs;
+  const int Co = Ci * MULT, hp = CS >> 1, NPS = 256 / hp;
+  const int cp = threadIdx.x % hp, ps = threadIdx.x / hp;
+  const int co = slab * CS + 2 * cp;
+  float a0[NT], a1[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
+  if (ps < NPS) {
+    const long p1 = pb * ppb + ppb < npix ? pb * ppb + ppb : npix;
+    for (long p = pb * ppb + ps; p < p1; p += NPS) {
+      const int xo = (int)(p % Wo);
+      const long t2 = p / Wo;
+      const int yo = (int)(t2 % Ho);
+      const long b = t2 / Ho;
+      const uint32_t du = *reinterpret_cast<const uint32_t*>(dy + p * Co + co);
+      const float d0 = h2f_lo(du), d1 = h2f_hi(du);
+      a0[K * K] += d0; a1[K * K] += d1;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = yo * S - PAD + ky;
+        if (iy < 0 || iy >= Hi) continue;
+        const bf16_t* rowp = x + ((b * Hi + iy) * (long)Wi) * Ci + (MULT == 1 ? co : (co >> 1));
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int ix = xo * S - PAD + kx;
+          if (ix < 0 || ix >= Wi) continue;
+          if (MULT == 1) {
+            const uint32_t xu = *reinterpret_cast<const uint32_t*>(rowp + (long)ix * Ci);
+            a0[ky * K + kx] += d0 * bf_lo(xu);
+            a1[ky * K + kx] += d1 * bf_hi(xu);
+          } else {
+            const float xv = bf2f(rowp[(long)ix * Ci]);
+            a0[ky * K + kx] += d0 * xv;
+            a1[ky * K + kx] += d1 * xv;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r0 = 0; r0 < NT; r0 += RT) {
+    if (ps < NPS) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+        if (r0 + t < NT) {
+          sr_wg[(t * NPS + ps) * CS + 2 * cp] = a0[r0 + t];
+          sr_wg[(t * NPS + ps) * CS + 2 * cp + 1] = a1[r0 + t];
+        }
+    }
+    __syncthreads();
+    const int nt = NT - r0 < RT ? NT - r0 : RT;
+    for (int i = threadIdx.x; i < nt * CS; i += 256) {
+      const int t = i / CS, c = i % CS;
+      float s = 0.f;
+      for (int q = 0; q < NPS; ++q) s += sr_wg[(t * NPS + q) * CS + c];
+      part[((size_t)pb * NT + r0 + t) * Co + slab * CS + c] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// out[i] = sum_p part[p * stride + i] (fixed order), i < n; the first n1 results go to out1, the rest to out2 (taps | bias, dw | db ...)
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, long nparts, long stride, long n, long n1, float* __restrict__ out1,
+                                                              float* __restrict__ out2, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (long p = 0; p < nparts; ++p) s += part[p * stride + i];
+  s *= scale;
+  if (i < n1) out1[i] = s;
+  else out2[i - n1] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ column sums of fp16 rows
+// part[chunk][c] = sum of rows [chunk * rpc, ...) of in (fp16 [R][ld]); grid (ceil(C / 256), nchunks)
+__global__ __launch_bounds__(256) void colsum16_kernel(const bf16_t* __restrict__ in, int ld, long R, int C, float* __restrict__ part, long rpc) {
+  __shared__ float sr[8][256];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + tx * 8;
+  const long r0 = (long)blockIdx.y * rpc, r1 = r0 + rpc < R ? r0 + rpc : R;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < C) {
+    for (long r = r0 + ty; r < r1; r += 8) {
+      float v[8];
+      unpack8_h(*reinterpret_cast<const uint4*>(in + r * ld + c0), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sr[ty][tx * 8 + e] = a[e];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += sr[q][threadIdx.x];
+    part[(size_t)blockIdx.y * C + c] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+__global__ __launch_bounds__(256) void mul16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, long n8, unsigned* sat) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float x[8], y[8];
+  unpack8_h(*reinterpret_cast<const uint4*>(a + i * 8), x);
+  unpack8_h(*reinterpret_cast<const uint4*>(b + i * 8), y);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] *= y[e];
+  count_f16_sat8(x, sat);
+  *reinterpret_cast<uint4*>(out + i * 8) = pack8_h(x);
+}
+// out f16 = dh f16 * gelu'(a bf16)
+__global__ __launch_bounds__(256) void gelu_grad_mul_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ pre, bf16_t* __restrict__ out, long n8, unsigned* sat) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float x[8], a[8];
+  unpack8_h(*reinterpret_cast<const uint4*>(dh + i * 8), x);
+  unpack8(*reinterpret_cast<const uint4*>(pre + i * 8), a);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { float g, dg; gelu_and_grad(a[e], g, dg); x[e] *= dg; }
+  count_f16_sat8(x, sat);
+  *reinterpret_cast<uint4*>(out + i * 8) = pack8_h(x);
+}
+__global__ __launch_bounds__(256) void f16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n8, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float x[8];
+  unpack8_h(*reinterpret_cast<const uint4*>(in + i * 8), x);
+  *reinterpret_cast<float4*>(out + i * 8) = make_float4(x[0] * scale, x[1] * scale, x[2] * scale, x[3] * scale);
+  *reinterpret_cast<float4*>(out + i * 8 + 4) = make_float4(x[4] * scale, x[5] * scale, x[6] * scale, x[7] * scale);
+}
+
+__global__ __launch_bounds__(256) void scale_to_f16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n8, float scale, unsigned* sat) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = *reinterpret_cast<const float4*>(in + i * 8), b = *reinterpret_cast<const float4*>(in + i * 8 + 4);
+  float x[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
+  count_f16_sat8(x, sat);
+  *reinterpret_cast<uint4*>(out + i * 8) = pack8_h(x);
+}
+
+// layer-scaled 1x1 conv out = res + ls (.) (W h + b): from the UN-scaled products dWraw[c][j] = sum_m dout[m][c] h[m][j], dbraw[c] = sum_m dout[m][c]
+//   dW[c][j] = ls[c] dWraw[c][j];  db[c] = ls[c] dbraw[c];  dls[c] = sum_j W[c][j] dWraw[c][j] + b[c] dbraw[c]      (one wave per output channel c)
+__global__ __launch_bounds__(256) void ls_grads_kernel(const float* __restrict__ dWraw, const float* __restrict__ dbraw, const bf16_t* __restrict__ W,
+                                                        const float* __restrict__ bias, const float* __restrict__ ls, float* __restrict__ dW,
+                                                        float* __restrict__ db, float* __restrict__ dls, int C, int Kd) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  const float l = ls[c];
+  float s = 0.f;
+  for (int j = lane; j < Kd; j += 64) {
+    const float r = dWraw[(size_t)c * Kd + j];
+    s += bf2f(W[(size_t)c * Kd + j]) * r;
+    dW[(size_t)c * Kd + j] = l * r;
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float br = dbraw[c];
+    db[c] = l * br;
+    dls[c] = s + bias[c] * br;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNormChannel backward
+// y = w xhat + b, xhat = (x - mean) rstd over the C channels of a row.  dx (+ res) as fp16; per-block partial sums of dw = sum dy xhat, db = sum dy
+// one wave per row, RPB rows per block (strided over its 4 waves); part[blk][2][C]
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ w,
+                                                      const bf16_t* __restrict__ res, bf16_t* __restrict__ dx, float* __restrict__ part, long rows, int C,
+                                                      float eps, int rpb, unsigned* sat) {
+  __shared__ float sred[4][2048];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  float aw[4][8], ab[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ab[i][e] = 0.f; }
+  const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
+  for (long row = r0 + wv; row < r1; row += 4) {
+    float v[4][8], g[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        unpack8(*reinterpret_cast<const uint4*>(x + row * C + ch * 8), v[i]);
+        unpack8_h(*reinterpret_cast<const uint4*>(dy + row * C + ch * 8), g[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+      }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (v[i][e] - mean) * rstd;
+          const float dyv = g[i][e];
+          aw[i][e] += dyv * xh;
+          ab[i][e] += dyv;
+          const float gw = dyv * w[ch * 8 + e];
+          v[i][e] = xh;
+          g[i][e] = gw;
+          s1 += gw;
+          s2 += gw * xh;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[8];
+        if (res) unpack8_h(*reinterpret_cast<const uint4*>(res + row * C + ch * 8), o);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += rstd * (g[i][e] - s1 - v[i][e] * s2);
+        count_f16_sat8(o, sat);
+        *reinterpret_cast<uint4*>(dx + row * C + ch * 8) = pack8_h(o);
+      }
+    }
+  }
+  // fold the four waves (fixed order), dw then db
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sred[wv][ch * 8 + e] = pass == 0 ? aw[i][e] : ab[i][e];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) part[((size_t)blockIdx.x * 2 + pass) * C + c] = sred[0][c] + sred[1][c] + sred[2][c] + sred[3][c];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ tower attention backward (non-causal, head_dim 32)
+// qkv bf16 [B*T][ld] = q | k | v (each C = heads * 32 wide, head h at column h * 32), o bf16 [B*T][C], dO fp16 [B*T][C] -> dqkv fp16 [B*T][ldd] in the
+// same column order.  S = scale Q K^T, P = softmax(S), dV = P^T dO, dP = dO V^T, dS = P (dP - delta) scale, dQ = dS K, dK = dS^T Q.
+// Both kernels keep the lane = query (dq) / key (dkv) layout of attention32_kernel: the score tile of a product over head_dim (its C/D registers) is the B
+// operand of the following product over keys / queries, whose A operand (K^T, dO^T, Q^T) comes from the row-major LDS tile by ds_read_b64_tr_b16.
+// Operands are converted to fp16 on the way into LDS / registers (bf16 widens exactly inside fp16's range); row statistics are recomputed here (log2
+// domain), so neither forward kernel has to keep them and any token count works (keys / queries past T masked).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+constexpr int TA_LD = 48;   // LDS row stride (halves) of a 32-wide tile: 96 B, 16-byte aligned rows for both the natural and the transposing reads
+
+__device__ __forceinline__ uint4 bf8_to_h8(const uint4& u) {
+  float f[8];
+  unpack8(u, f);
+  return pack8_h(f);
+}
+__device__ __forceinline__ f16x8 ta_tr_frag(const bf16_t* tile, int krow0, int dt, int fr) {
+  // rows krow0 .. krow0 + 3 and 16 rows further, columns dt * 16 + 4 (fr & 3) .. + 3, through the transposing read: lane fr ends up with column
+  // dt * 16 + fr of the eight rows {krow0 + j, krow0 + 16 + j}
+  const bf16_t* vr = tile + (krow0 + (fr >> 2)) * TA_LD + dt * 16 + 4 * (fr & 3);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vr));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vr + 16 * TA_LD));
+  const uint2 lu = __builtin_bit_cast(uint2, lo), hu = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(f16x8, make_uint4(lu.x, lu.y, hu.x, hu.y));
+}
+__device__ __forceinline__ f16x8 ta_pack(const f32x4& a, const f32x4& b) {
+  uint4 u;
+  u.x = pack_h2(a[0], a[1]); u.y = pack_h2(a[2], a[3]); u.z = pack_h2(b[0], b[1]); u.w = pack_h2(b[2], b[3]);
+  return __builtin_bit_cast(f16x8, u);
+}
+__device__ __forceinline__ float xor_sum_32_16(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float xor_max_32_16b(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+
+struct TAttnParams {
+  const bf16_t* qkv; const bf16_t* o; const bf16_t* dO; bf16_t* dqkv; float* lse2; float* delta;
+  int ld, ldo, lddo, ldd, B, T, heads, C; float scale;
+};
+
+// dQ (and the row statistics lse2 = log2 sum exp, delta = sum_d dO O): block = 64 queries of one (batch, head), lane = query
+__global__ __launch_bounds__(256) void tattn_dq_kernel(TAttnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * TA_LD], sV[64 * TA_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int qblocks = (p.T + 63) >> 6;
+  int bid = blockIdx.x;
+  const int qb = bid % qblocks; bid /= qblocks;
+  const int h = bid % p.heads;
+  const int b = bid / p.heads;
+  const int q = qb * 64 + wid * 16 + fr;
+  const bool qok = q < p.T;
+  const size_t qrow = (size_t)b * p.T + (qok ? q : 0);
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const f16x8 fq = __builtin_bit_cast(f16x8, qok ? bf8_to_h8(*reinterpret_cast<const uint4*>(p.qkv + qrow * p.ld + h * 32 + fg * 8)) : zero4);
+  const uint4 dou = qok ? *reinterpret_cast<const uint4*>(p.dO + qrow * p.lddo + h * 32 + fg * 8) : zero4;
+  const f16x8 fdo = __builtin_bit_cast(f16x8, dou);
+  float delta;
+  {
+    float a[8], c[8];
+    unpack8_h(dou, a);
+    unpack8(qok ? *reinterpret_cast<const uint4*>(p.o + qrow * p.ldo + h * 32 + fg * 8) : zero4, c);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += a[e] * c[e];
+    delta = xor_sum_32_16(s);
+  }
+  const float c2 = p.scale * 1.4426950408889634f;
+  const int nkb = (p.T + 63) >> 6;
+  const int skey = tid >> 2, sch = tid & 3;
+  const bf16_t* kbase = p.qkv + (size_t)b * p.T * p.ld + p.C + h * 32 + sch * 8;
+  auto stage = [&](int kb, bool with_v) {
+    const int key = kb * 64 + skey;
+    const bool ok = key < p.T;
+    const bf16_t* kp = kbase + (size_t)(ok ? key : 0) * p.ld;
+    *reinterpret_cast<uint4*>(sK + skey * TA_LD + sch * 8) = ok ? bf8_to_h8(*reinterpret_cast<const uint4*>(kp)) : zero4;
+    if (with_v) *reinterpret_cast<uint4*>(sV + skey * TA_LD + sch * 8) = ok ? bf8_to_h8(*reinterpret_cast<const uint4*>(kp + p.C)) : zero4;
+  };
+  // pass 1: running max / sum of the scaled scores (log2 domain)
+  float m_run = -1e30f, l_run = 0.f;
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    stage(kb, false);
+    __syncthreads();
+    f32x4 sacc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const f16x8 fk = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * TA_LD + fg * 8));
+      sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fk, fq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    float mloc = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool kok = kb * 64 + kt * 16 + 4 * fg + r < p.T;
+        sacc[kt][r] = kok ? sacc[kt][r] * c2 : -1e30f;
+        mloc = fmaxf(mloc, sacc[kt][r]);
+      }
+    mloc = xor_max_32_16b(mloc);
+    const float m_new = fmaxf(m_run, mloc);
+    float ls = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ls += __builtin_amdgcn_exp2f(sacc[kt][r] - m_new);
+    ls = xor_sum_32_16(ls);
+    l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ls;
+    m_run = m_new;
+  }
+  const float lse2 = m_run + __builtin_amdgcn_logf(l_run);   // v_log_f32 is log2
+  if (qok && fg == 0) {
+    p.lse2[((size_t)b * p.heads + h) * p.T + q] = lse2;
+    p.delta[((size_t)b * p.heads + h) * p.T + q] = delta;
+  }
+  // pass 2: dQ^T += K^T dS^T
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    stage(kb, true);
+    __syncthreads();
+    f32x4 sacc[4], dacc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const f16x8 fk = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * TA_LD + fg * 8));
+      const f16x8 fv = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sV + (kt * 16 + fr) * TA_LD + fg * 8));
+      sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fk, fq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      dacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, fdo, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool kok = kb * 64 + kt * 16 + 4 * fg + r < p.T;
+        const float pr = kok ? __builtin_amdgcn_exp2f(sacc[kt][r] * c2 - lse2) : 0.f;
+        sacc[kt][r] = pr * (dacc[kt][r] - delta) * p.scale;
+      }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const f16x8 fp = ta_pack(sacc[2 * ks2], sacc[2 * ks2 + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta_tr_frag(sK, (2 * ks2) * 16 + 4 * fg, dt, fr), fp, acc[dt], 0, 0, 0);
+    }
+  }
+  if (qok) {
+    bf16_t* op = p.dqkv + qrow * p.ldd + h * 32;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      uint2 u;
+      u.x = pack_h2(acc[dt][0], acc[dt][1]);
+      u.y = pack_h2(acc[dt][2], acc[dt][3]);
+      *reinterpret_cast<uint2*>(op + dt * 16 + fg * 4) = u;
+    }
+  }
+}
+
+// dK, dV: block = 64 keys of one (batch, head), lane = key; Q and dO tiles (64 queries) row-major in LDS with their statistics
+__global__ __launch_bounds__(256) void tattn_dkv_kernel(TAttnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[64 * TA_LD], sD[64 * TA_LD];
+  __shared__ float sL[64], sDl[64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int kblocks = (p.T + 63) >> 6;
+  int bid = blockIdx.x;
+  const int kb = bid % kblocks; bid /= kblocks;
+  const int h = bid % p.heads;
+  const int b = bid / p.heads;
+  const int key = kb * 64 + wid * 16 + fr;
+  const bool kok = key < p.T;
+  const size_t krow = (size_t)b * p.T + (kok ? key : 0);
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const f16x8 fk = __builtin_bit_cast(f16x8, kok ? bf8_to_h8(*reinterpret_cast<const uint4*>(p.qkv + krow * p.ld + p.C + h * 32 + fg * 8)) : zero4);
+  const f16x8 fv = __builtin_bit_cast(f16x8, kok ? bf8_to_h8(*reinterpret_cast<const uint4*>(p.qkv + krow * p.ld + 2 * p.C + h * 32 + fg * 8)) : zero4);
+  const float c2 = p.scale * 1.4426950408889634f;
+  const int nqb = (p.T + 63) >> 6;
+  const int srow = tid >> 2, sch = tid & 3;
+  f32x4 ak[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, av[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  for (int qb = 0; qb < nqb; ++qb) {
+    __syncthreads();
+    {
+      const int q = qb * 64 + srow;
+      const bool ok = q < p.T;
+      const size_t row = (size_t)b * p.T + (ok ? q : 0);
+      *reinterpret_cast<uint4*>(sQ + srow * TA_LD + sch * 8) = ok ? bf8_to_h8(*reinterpret_cast<const uint4*>(p.qkv + row * p.ld + h * 32 + sch * 8)) : zero4;
+      *reinterpret_cast<uint4*>(sD + srow * TA_LD + sch * 8) = ok ? *reinterpret_cast<const uint4*>(p.dO + row * p.lddo + h * 32 + sch * 8) : zero4;
+      if (tid < 64) {
+        const int q2 = qb * 64 + tid;
+        const bool ok2 = q2 < p.T;
+        sL[tid] = ok2 ? p.lse2[((size_t)b * p.heads + h) * p.T + q2] : 1e30f;   // exp2(s - 1e30) = 0: queries past T contribute nothing
+        sDl[tid] = ok2 ? p.delta[((size_t)b * p.heads + h) * p.T + q2] : 0.f;
+      }
+    }
+    __syncthreads();
+    f32x4 sacc[4], dacc[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const f16x8 fq = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sQ + (qt * 16 + fr) * TA_LD + fg * 8));
+      const f16x8 fd = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sD + (qt * 16 + fr) * TA_LD + fg * 8));
+      sacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fq, fk, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);    // rows = queries qt * 16 + 4 fg + r, column = this lane's key
+      dacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fd, fv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    f32x4 pacc[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qt * 16 + 4 * fg + r;
+        const float pr = __builtin_amdgcn_exp2f(sacc[qt][r] * c2 - sL[qi]);
+        pacc[qt][r] = pr;
+        sacc[qt][r] = pr * (dacc[qt][r] - sDl[qi]) * p.scale;
+      }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const f16x8 fp = ta_pack(pacc[2 * ks2], pacc[2 * ks2 + 1]);
+      const f16x8 fs = ta_pack(sacc[2 * ks2], sacc[2 * ks2 + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta_tr_frag(sD, (2 * ks2) * 16 + 4 * fg, dt, fr), fp, av[dt], 0, 0, 0);
+        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta_tr_frag(sQ, (2 * ks2) * 16 + 4 * fg, dt, fr), fs, ak[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (kok) {
+    bf16_t* kp = p.dqkv + krow * p.ldd + p.C + h * 32;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      uint2 u;
+      u.x = pack_h2(ak[dt][0], ak[dt][1]); u.y = pack_h2(ak[dt][2], ak[dt][3]);
+      *reinterpret_cast<uint2*>(kp + dt * 16 + fg * 4) = u;
+      u.x = pack_h2(av[dt][0], av[dt][1]); u.y = pack_h2(av[dt][2], av[dt][3]);
+      *reinterpret_cast<uint2*>(kp + p.C + dt * 16 + fg * 4) = u;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ conv_exp's SE + GELU, backward
+// forward: s = mean_p e, r = relu(W1 s + b1), g = sigmoid(W2 r + b2), out = gelu(e g).   (e bf16 [B][P][C]; s, r, g kept by the forward)
+// du = dout gelu'(e g) (fp16, written to `du`), dz2[b][c] = (sum_p du e) g (1 - g)
+__global__ __launch_bounds__(256) void se_bwd_du_kernel(const bf16_t* __restrict__ e, const bf16_t* __restrict__ dout, const float* __restrict__ g,
+                                                         bf16_t* __restrict__ du, float* __restrict__ dz2, int P, int C, unsigned* sat) {
+  const int ch = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (ch >= (C >> 3)) return;
+  float gv[8], a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gv[k] = g[(size_t)b * C + ch * 8 + k];
+  for (int p = 0; p < P; ++p) {
+    const size_t off = ((size_t)b * P + p) * C + ch * 8;
+    float ev[8], d[8];
+    unpack8(*reinterpret_cast<const uint4*>(e + off), ev);
+    unpack8_h(*reinterpret_cast<const uint4*>(dout + off), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float gl, dg;
+      gelu_and_grad(ev[k] * gv[k], gl, dg);
+      d[k] *= dg;
+      a[k] += d[k] * ev[k];
+    }
+    count_f16_sat8(d, sat);
+    *reinterpret_cast<uint4*>(du + off) = pack8_h(d);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dz2[(size_t)b * C + ch * 8 + k] = a[k] * gv[k] * (1.0f - gv[k]);
+}
+// y[b][n] = sum_k x[b][k] W[k * ldw + n], optionally masked by (gate[b][n] > 0); one thread per (b, n) (tiny)
+__global__ __launch_bounds__(256) void matvec_t_kernel(const float* __restrict__ x, const float* __restrict__ W, int ldw, const float* __restrict__ gate,
+                                                        float* __restrict__ y, int N, int K) {
+  const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += x[(size_t)b * K + k] * W[(size_t)k * ldw + n];
+  if (gate && !(gate[(size_t)b * N + n] > 0.f)) s = 0.f;
+  y[(size_t)b * N + n] = s;
+}
+// out[n][k] = sum_b a[b][n] v[b][k] (k < K), bias[n] = sum_b a[b][n]; thread per (n, k), k == K computes the bias
+__global__ __launch_bounds__(256) void outer_sum_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ out, float* __restrict__ bias,
+                                                         int B, int N, int K) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)N * (K + 1)) return;
+  const int n = (int)(i / (K + 1)), k = (int)(i % (K + 1));
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += a[(size_t)b * N + n] * (k < K ? v[(size_t)b * K + k] : 1.0f);
+  if (k < K) out[(size_t)n * K + k] = s;
+  else bias[n] = s;
+}
+// de = du g + ds / P, in place over du (fp16)
+__global__ __launch_bounds__(256) void se_bwd_de_kernel(bf16_t* __restrict__ du, const float* __restrict__ g, const float* __restrict__ ds, int P, int C,
+                                                         long total_chunks, unsigned* sat) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total_chunks) return;
+  const int nch = C >> 3;
+  const int ch = (int)(i % nch);
+  const long b = i / ((long)nch * P);
+  float v[8];
+  unpack8_h(*reinterpret_cast<const uint4*>(du + i * 8), v);
+  const float invp = 1.0f / (float)P;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = v[k] * g[b * C + ch * 8 + k] + ds[b * C + ch * 8 + k] * invp;
+  count_f16_sat8(v, sat);
+  *reinterpret_cast<uint4*>(du + i * 8) = pack8_h(v);
+}
+
+// ------------------------------------------------------------------------------------------------ stem conv 3x3 s2 (3 -> C0) + GELU, weight gradient
+// a0 = b + sum_k w[k][co] patch[k] is recomputed from the pixels (B,S,S,4) bf16; da0 = dh0 gelu'(a0); dW[k][co] += da0 patch[k], db[co] += da0.
+// thread = one output channel x a slice of the block's output pixels (the 27 patch values are a broadcast load); part[blk][28][C0]
+__global__ __launch_bounds__(384) void stem0_wgrad_kernel(const bf16_t* __restrict__ pix, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const bf16_t* __restrict__ dh0, float* __restrict__ part, int S, int C0, long npix, long ppb, int round_w) {
+  extern __shared__ __attribute__((aligned(16))) float sr_st[];   // [NPS][28][C0]
+  const int NPS = 384 / C0;
+  const int co = threadIdx.x % C0, ps = threadIdx.x / C0;
+  const int So = S >> 1;
+  float wr[27], acc[28];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) { const float wv = w[(size_t)k * C0 + co]; wr[k] = round_w ? bf2f(f2bf(wv)) : wv; }   // round_w: the forward's implicit-GEMM stem holds bf16 weights
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.f;
+  const float bv = bias[co];
+  if (ps < NPS) {
+    const long p0 = (long)blockIdx.x * ppb, p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    for (long p = p0 + ps; p < p1; p += NPS) {
+      const int ox = (int)(p % So);
+      const long t = p / So;
+      const int oy = (int)(t % So);
+      const long b = t / So;
+      float pt[27];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ox * 2 - 1 + kx;
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+          if (iy >= 0 && iy < S && ix >= 0 && ix < S) {
+            const uint2 u = *reinterpret_cast<const uint2*>(pix + ((b * S + iy) * S + ix) * 4);
+            c0 = bf_lo(u.x); c1 = bf_hi(u.x); c2 = bf_lo(u.y);
+          }
+          pt[(ky * 3 + kx) * 3 + 0] = c0; pt[(ky * 3 + kx) * 3 + 1] = c1; pt[(ky * 3 + kx) * 3 + 2] = c2;
+        }
+      }
+      float a0 = bv;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) a0 += wr[k] * pt[k];
+      float gl, dg;
+      gelu_and_grad(a0, gl, dg);
+      const _Float16 hv = __builtin_bit_cast(_Float16, dh0[p * C0 + co]);
+      const float d = (float)hv * dg;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc[k] += d * pt[k];
+      acc[27] += d;
+    }
+  }
+  if (ps < NPS) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) sr_st[(ps * 28 + k) * C0 + co] = acc[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 28 * C0; i += 384) {
+    float s = 0.f;
+    for (int q = 0; q < NPS; ++q) s += sr_st[(size_t)q * 28 * C0 + i];
+    part[(size_t)blockIdx.x * 28 * C0 + i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fv_train_commit, tower part
+// one launch over a table of operations; a block takes 1024 consecutive destination elements of one operation
+__global__ __launch_bounds__(256) void tower_commit_kernel(const TowerCommitOp* __restrict__ ops, int nops, const float* __restrict__ flat, unsigned* sat) {
+  int lo = 0, hi = nops - 1;
+  const int blk = blockIdx.x;
+  while (lo < hi) {   // last op whose blk0 <= blk
+    const int mid = (lo + hi + 1) >> 1;
+    if (ops[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+  }
+  const TowerCommitOp op = ops[lo];
+  const long base = (long)(blk - op.blk0) * 1024;
+  const float* src = flat + op.src_off;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i = base + u * 256 + threadIdx.x;
+    if (i >= op.n) return;
+    switch (op.kind) {
+      case 0: static_cast<float*>(op.dst)[i] = src[i]; break;
+      case 1: static_cast<bf16_t*>(op.dst)[i] = f2bf(src[i]); break;
+      case 2: {
+        const int j = op.idx[i];
+        static_cast<bf16_t*>(op.dst)[i] = j >= 0 ? f2bf(op.coef[i] * src[j]) : (bf16_t)0;
+        break;
+      }
+      default: {   // 3: dst f16 [cols][rows] = src[rows][cols]^T; 4: the same with row r of src scaled by flat[src2_off + r]
+        const long j = i / op.rows, r = i % op.rows;
+        float v = src[r * op.cols + j];
+        if (op.kind == 4) v *= flat[op.src2_off + r];
+        if (sat && !(fabsf(v) <= FV_F16_MAX)) atomicAdd(sat, 1u);
+        v = __builtin_amdgcn_fmed3f(v, -FV_F16_MAX, FV_F16_MAX);
+        static_cast<bf16_t*>(op.dst)[i] = __builtin_bit_cast(bf16_t, (_Float16)v);
+      }
+    }
+  }
+}
+
+inline unsigned grid1(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+// ================================================================================================ launchers
+static int pick_slab(int C, int cap) {   // largest multiple of 8 that divides C and is <= cap
+  int best = 8;
+  for (int d = 8; d <= cap && d <= C; d += 8)
+    if (C % d == 0) best = d;
+  return best;
+}
+
+size_t dw_bwd_scratch_floats(int B, int Ho, int Wo, int Co, int k) {
+  const long npix = (long)B * Ho * Wo;
+  long npb = (npix + 255) / 256;
+  if (npb > 512) npb = 512;
+  return (size_t)npb * (k * k + 1) * Co;
+}
+
+// input gradient of a depthwise / channel-multiplier conv: dy fp16 (B,Ho,Wo,Ci*mult) -> dx fp16 (B,Hi,Wi,Ci) (+ res fp16); w fp32 tap-major [k*k][Ci*mult]
+int launch_dw_dgrad(const bf16_t* dy, const float* w, const bf16_t* res, bf16_t* dx, int B, int Hi, int Wi, int Ci, int k, int stride, int mult, unsigned* sat,
+                    hipStream_t s, int round_w) {
+  if (!dy || !w || !dx) return fv_fail(FV_ERR_ARG, "dw_dgrad: null pointer");
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Ci % 8) return fv_fail(FV_ERR_ARG, "dw_dgrad: bad shape C=%d", Ci);
+  const int pad = k / 2;
+  const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+  const int CS = pick_slab(Ci, mult == 1 ? 128 : 64);
+  const int nslabs = Ci / CS, G = CS / 8, ppb = 256 / G, iters = 8;
+  const long npix = (long)B * Hi * Wi;
+  const long pblocks = (npix + (long)ppb * iters - 1) / ((long)ppb * iters);
+  if (pblocks * nslabs > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dw_dgrad: grid too large");
+  const dim3 grid((unsigned)(pblocks * nslabs));
+  const size_t lds = (size_t)k * k * CS * mult * 4;
+#define FV_DG(K_, S_, M_)                                                                                                              \
+  if (k == K_ && stride == S_ && mult == M_) {                                                                                         \
+    hipLaunchKernelGGL((dw_dgrad_kernel<K_, S_, M_>), grid, dim3(256), lds, s, dy, w, res, dx, Hi, Wi, Ci, Ho, Wo, CS, nslabs, npix, iters, sat, round_w); \
+    FV_HIP_CHECK(hipGetLastError());                                                                                                   \
+    return FV_OK;                                                                                                                      \
+  }
+  FV_DG(3, 1, 1) FV_DG(7, 1, 1) FV_DG(3, 2, 1) FV_DG(7, 2, 2) FV_DG(3, 1, 2)
+#undef FV_DG
+  return fv_fail(FV_ERR_UNSUPPORTED, "dw_dgrad: unsupported k=%d stride=%d mult=%d", k, stride, mult);
+}
+
+// tap + bias gradients: x bf16 (B,Hi,Wi,Ci), dy fp16 (B,Ho,Wo,Ci*mult) -> dw fp32 tap-major [k*k][Ci*mult], db [Ci*mult]; scratch >= dw_bwd_scratch_floats
+int launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, float* db, float* scratch, int B, int Hi, int Wi, int Ci, int k, int stride, int mult,
+                    hipStream_t s) {
+  if (!x || !dy || !dw || !db || !scratch) return fv_fail(FV_ERR_ARG, "dw_wgrad: null pointer");
+  const int Co = Ci * mult;
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Co % 8) return fv_fail(FV_ERR_ARG, "dw_wgrad: bad shape C=%d", Ci);
+  const int pad = k / 2;
+  const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+  const int CS = pick_slab(Co, 128);
+  const int nslabs = Co / CS, NPS = 256 / (CS / 2), NT = k * k + 1;
+  const long npix = (long)B * Ho * Wo;
+  long npb = (npix + 255) / 256;
+  if (npb > 512) npb = 512;
+  const long ppb = (npix + npb - 1) / npb;
+  npb = (npix + ppb - 1) / ppb;
+  const dim3 grid((unsigned)(npb * nslabs));
+  const size_t lds = (size_t)10 * NPS * CS * 4;
+#define FV_WG(K_, S_, M_)                                                                                                          \
+  if (k == K_ && stride == S_ && mult == M_) {                                                                                     \
+    hipLaunchKernelGGL((dw_wgrad_kernel<K_, S_, M_>), grid, dim3(256), lds, s, x, dy, scratch, Hi, Wi, Ci, Ho, Wo, CS, nslabs, npix, ppb); \
+    const long n = (long)NT * Co;                                                                                                   \
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(grid1(n)), dim3(256), 0, s, scratch, npb, n, n, (long)k * k * Co, dw, db, 1.0f); \
+    FV_HIP_CHECK(hipGetLastError());                                                                                               \
+    return FV_OK;                                                                                                                  \
+  }
+  FV_WG(3, 1, 1) FV_WG(7, 1, 1) FV_WG(3, 2, 1) FV_WG(7, 2, 2) FV_WG(3, 1, 2)
+#undef FV_WG
+  return fv_fail(FV_ERR_UNSUPPORTED, "dw_wgrad: unsupported k=%d stride=%d mult=%d", k, stride, mult);
+}
+
+// out[c] = sum_r in[r][c] over fp16 rows; scratch >= COLSUM_CHUNKS * C floats
+int launch_colsum16(const bf16_t* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s) {
+  if (!in || !out || !scratch || R <= 0 || C <= 0 || C % 8 || ld % 8) return fv_fail(FV_ERR_ARG, "colsum16: bad argument");
+  long nch = (R + 63) / 64;
+  if (nch > COLSUM_CHUNKS) nch = COLSUM_CHUNKS;
+  const long rpc = (R + nch - 1) / nch;
+  nch = (R + rpc - 1) / rpc;
+  hipLaunchKernelGGL(colsum16_kernel, dim3((C + 255) / 256, (unsigned)nch), dim3(256), 0, s, in, ld, R, C, scratch, rpc);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(grid1(C)), dim3(256), 0, s, scratch, nch, (long)C, (long)C, (long)C, out, out, 1.0f);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_mul16(const bf16_t* a, const bf16_t* b, bf16_t* out, size_t n, unsigned* sat, hipStream_t s) {
+  if (!a || !b || !out || n % 8) return fv_fail(FV_ERR_ARG, "mul16: bad argument");
+  hipLaunchKernelGGL(mul16_kernel, dim3(grid1((long)(n / 8))), dim3(256), 0, s, a, b, out, (long)(n / 8), sat);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+int launch_gelu_grad_mul(const bf16_t* dh, const bf16_t* pre, bf16_t* out, size_t n, unsigned* sat, hipStream_t s) {
+  if (!dh || !pre || !out || n % 8) return fv_fail(FV_ERR_ARG, "gelu_grad_mul: bad argument");
+  hipLaunchKernelGGL(gelu_grad_mul_kernel, dim3(grid1((long)(n / 8))), dim3(256), 0, s, dh, pre, out, (long)(n / 8), sat);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+int launch_f16_to_f32(const bf16_t* in, float* out, size_t n, float scale, hipStream_t s) {
+  if (!in || !out || n % 8) return fv_fail(FV_ERR_ARG, "f16_to_f32: bad argument");
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(grid1((long)(n / 8))), dim3(256), 0, s, in, out, (long)(n / 8), scale);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+int launch_scale_to_f16(const float* in, bf16_t* out, size_t n, float scale, unsigned* sat, hipStream_t s) {
+  if (!in || !out || n % 8) return fv_fail(FV_ERR_ARG, "scale_to_f16: bad argument");
+  hipLaunchKernelGGL(scale_to_f16_kernel, dim3(grid1((long)(n / 8))), dim3(256), 0, s, in, out, (long)(n / 8), scale, sat);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+int launch_ls_grads(const float* dWraw, const float* dbraw, const bf16_t* W, const float* bias, const float* ls, float* dW, float* db, float* dls, int C, int Kd,
+                    hipStream_t s) {
+  if (!dWraw || !dbraw || !W || !bias || !ls || !dW || !db || !dls) return fv_fail(FV_ERR_ARG, "ls_grads: null pointer");
+  hipLaunchKernelGGL(ls_grads_kernel, dim3((C + 3) / 4), dim3(256), 0, s, dWraw, dbraw, W, bias, ls, dW, db, dls, C, Kd);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+size_t ln_bwd_scratch_floats(long rows, int C) {
+  long nb = (rows + 15) / 16;
+  if (nb > 512) nb = 512;
+  return (size_t)nb * 2 * C;
+}
+int launch_ln_bwd(const bf16_t* x, const bf16_t* dy, const float* w, const bf16_t* res, bf16_t* dx, float* dw, float* db, float* scratch, long rows, int C,
+                  float eps, unsigned* sat, hipStream_t s) {
+  if (!x || !dy || !w || !dx || !dw || !db || !scratch) return fv_fail(FV_ERR_ARG, "ln_bwd: null pointer");
+  if (rows <= 0 || C % 8 || C > 2048) return fv_fail(FV_ERR_ARG, "ln_bwd: bad shape rows=%ld C=%d", rows, C);
+  long nb = (rows + 15) / 16;
+  if (nb > 512) nb = 512;
+  const int rpb = (int)((rows + nb - 1) / nb);
+  nb = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, dy, w, res, dx, scratch, rows, C, eps, rpb, sat);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(grid1(2L * C)), dim3(256), 0, s, scratch, nb, 2L * C, 2L * C, (long)C, dw, db, 1.0f);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+// stats: 2 * B * heads * T floats (lse2 | delta)
+int launch_tower_attn_bwd(const bf16_t* qkv, int ld, const bf16_t* o, int ldo, const bf16_t* dO, int lddo, bf16_t* dqkv, int ldd, float* stats, int B, int T,
+                          int heads, float scale, hipStream_t s) {
+  if (!qkv || !o || !dO || !dqkv || !stats) return fv_fail(FV_ERR_ARG, "tower_attn_bwd: null pointer");
+  const int C = heads * 32;
+  if (B <= 0 || T <= 0 || heads <= 0 || ld < 3 * C || ldo < C || lddo < C || ldd < 3 * C || (ld | ldo | lddo | ldd) % 8)
+    return fv_fail(FV_ERR_ARG, "tower_attn_bwd: bad shape / strides");
+  if (((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dqkv) & 15) return fv_fail(FV_ERR_ARG, "tower_attn_bwd: misaligned pointer");
+  TAttnParams p{qkv, o, dO, dqkv, stats, stats + (size_t)B * heads * T, ld, ldo, lddo, ldd, B, T, heads, C, scale};
+  const long blocks = (long)B * heads * ((T + 63) / 64);
+  if (blocks > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "tower_attn_bwd: grid too large");
+  hipLaunchKernelGGL(tattn_dq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(tattn_dkv_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+// conv_exp's SE + GELU backward.  e bf16 [B][P][C] (the depthwise conv's output), dout fp16 [B][P][C], se = the forward's scratch (s [B][C] | r [B][R] | g [B][C]);
+// de fp16 [B][P][C] (the gradient the depthwise conv's backward continues from); dW1 [R][C], db1 [R], dW2 [C][R], db2 [C];
+// tmp >= B * (2 C + 2 R) floats
+int launch_se_bwd(const bf16_t* e, const bf16_t* dout, const float* se, const float* w1, const float* w2, bf16_t* de, float* dW1, float* db1, float* dW2,
+                  float* db2, float* tmp, int B, int P, int C, int R, unsigned* sat, hipStream_t s) {
+  if (!e || !dout || !se || !w1 || !w2 || !de || !dW1 || !db1 || !dW2 || !db2 || !tmp) return fv_fail(FV_ERR_ARG, "se_bwd: null pointer");
+  if (B <= 0 || P <= 0 || C % 8 || R <= 0) return fv_fail(FV_ERR_ARG, "se_bwd: bad shape");
+  const float* sp = se;
+  const float* r = se + (size_t)B * C;
+  const float* g = r + (size_t)B * R;
+  float* dz2 = tmp;                       // [B][C]
+  float* dz1 = dz2 + (size_t)B * C;       // [B][R]
+  float* ds = dz1 + (size_t)B * R;        // [B][C]
+  hipLaunchKernelGGL(se_bwd_du_kernel, dim3((C / 8 + 255) / 256, B), dim3(256), 0, s, e, dout, g, de, dz2, P, C, sat);
+  // dr = W2^T dz2 (W2 [C][R]), masked by relu: dz1
+  hipLaunchKernelGGL(matvec_t_kernel, dim3((R + 255) / 256, B), dim3(256), 0, s, dz2, w2, R, r, dz1, R, C);
+  // ds = W1^T dz1 (W1 [R][C])
+  hipLaunchKernelGGL(matvec_t_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, dz1, w1, C, static_cast<const float*>(nullptr), ds, C, R);
+  hipLaunchKernelGGL(outer_sum_kernel, dim3(grid1((long)C * (R + 1))), dim3(256), 0, s, dz2, r, dW2, db2, B, C, R);
+  hipLaunchKernelGGL(outer_sum_kernel, dim3(grid1((long)R * (C + 1))), dim3(256), 0, s, dz1, sp, dW1, db1, B, R, C);
+  const long chunks = (long)B * P * (C / 8);
+  hipLaunchKernelGGL(se_bwd_de_kernel, dim3(grid1(chunks)), dim3(256), 0, s, de, g, ds, P, C, chunks, sat);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+size_t stem0_wgrad_scratch_floats(int B, int S, int C0) {
+  const long npix = (long)B * (S / 2) * (S / 2);
+  long nb = (npix + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  return (size_t)nb * 28 * C0;
+}
+// pix bf16 (B,S,S,4), w fp32 [27][C0], dh0 fp16 (B,S/2,S/2,C0) = dL/d(gelu output) -> dw [27][C0], db [C0]
+int launch_stem0_wgrad(const bf16_t* pix, const float* w, const float* bias, const bf16_t* dh0, float* dw, float* db, float* scratch, int B, int S, int C0,
+                       hipStream_t s, int round_w) {
+  if (!pix || !w || !bias || !dh0 || !dw || !db || !scratch) return fv_fail(FV_ERR_ARG, "stem0_wgrad: null pointer");
+  if (B <= 0 || S < 2 || (S & 1) || C0 < 8 || C0 > 384) return fv_fail(FV_ERR_UNSUPPORTED, "stem0_wgrad: bad shape S=%d C0=%d", S, C0);
+  const long npix = (long)B * (S / 2) * (S / 2);
+  long nb = (npix + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  const long ppb = (npix + nb - 1) / nb;
+  nb = (npix + ppb - 1) / ppb;
+  const int NPS = 384 / C0;
+  hipLaunchKernelGGL(stem0_wgrad_kernel, dim3((unsigned)nb), dim3(384), (size_t)NPS * 28 * C0 * 4, s, pix, w, bias, dh0, scratch, S, C0, npix, ppb, round_w);
+  const long n = 28L * C0;
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(grid1(n)), dim3(256), 0, s, scratch, nb, n, n, 27L * C0, dw, db, 1.0f);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_tower_commit(const TowerCommitOp* ops_dev, int nops, int nblocks, const float* flat, unsigned* sat, hipStream_t s) {
+  if (!ops_dev || !flat || nops <= 0 || nblocks <= 0) return fv_fail(FV_ERR_ARG, "tower_commit: bad argument");
+  hipLaunchKernelGGL(tower_commit_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, ops_dev, nops, flat, sat);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+}  // namespace fv

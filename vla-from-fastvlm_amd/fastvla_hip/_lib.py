@@ -116,6 +116,12 @@ SIGNATURES = {
     "fv_train_loss_scale": (_i, [_vp, C.POINTER(_f)]),
     "fv_train_workspace_bytes": (_i, [_vp, _i, _i, C.POINTER(C.c_size_t)]),
     "fv_train_forward_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64, _vp, C.c_size_t, _vp, _vp, _vp, BUCKET_CB, _vp, _vp]),
+    "fv_train_tower_begin": (_i, [_vp]),
+    "fv_train_tower_workspace_bytes": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
+    "fv_train_tower_forward": (_i, [_vp, _vp, _i, _vp, C.c_size_t, _vp, _vp]),
+    "fv_train_set_tower_grad": (_i, [_vp, _vp]),
+    "fv_train_tower_backward": (_i, [_vp, _vp, _vp, _i, _vp, C.c_size_t, _vp, BUCKET_CB, _vp, _vp]),
+    "fv_train_tower_unit": (_i, [_vp, _i, _vp, _vp, _f, _i, _vp, C.c_size_t, _vp, _vp, _vp, _vp]),
     "fv_profile": (_i, [_vp, _i]),
     "fv_profile_read": (_i, [_vp, C.POINTER(ProfileEntry), C.POINTER(GemmProfile), _i, C.POINTER(_i)]),
     "fv_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(AdamWHParams), _i64, _vp, _vp]),

@@ -536,6 +536,11 @@ class FastVLAEngine:
                 g = v.view(l.inter // 8, 2, 8, l.hidden)
                 out[base + ".gate_proj.weight"] = g[:, 0].reshape(l.inter, l.hidden).clone()
                 out[base + ".up_proj.weight"] = g[:, 1].reshape(l.inter, l.hidden).clone()
+            elif t["packing"] == 3:      # depthwise weight, tap-major [k*k][C] -> [C, 1, k, k]
+                k = int(round(t["rows"] ** 0.5))
+                out[name] = v.t().reshape(t["cols"], 1, k, k).clone()
+            elif t["packing"] == 4:      # the stem's dense 3x3, [27][C0] with row (ky*3+kx)*3+ci -> [C0, 3, 3, 3]
+                out[name] = v.view(3, 3, 3, t["cols"]).permute(3, 2, 0, 1).contiguous()
             else:
                 out[name] = v.clone()
         return out
@@ -577,6 +582,76 @@ class FastVLAEngine:
             raise err["exc"]
         _lib.check(rc, "fv_train_forward_backward", self.h)
         return actions, loss, flat_grads
+
+    # ---------------------------------------------------------------- the tower half of the slice (fv_train_tower_*; csrc/tower_train.inc)
+    def train_tower_begin(self) -> None:
+        """After train_begin(): the FastViT-HD tower's tensors (inference form) join the flat master -- train_layout() then lists them behind
+        "model.norm.weight" (packing 3 = depthwise weights tap-major [k*k][C], 4 = the stem's [27][C0]) with their own gradient buckets."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fv_train_tower_begin(self.h), "fv_train_tower_begin", self.h)
+        self._tower_training = True
+
+    def train_tower_workspace(self, B: int) -> torch.Tensor:
+        n = C.c_size_t()
+        _lib.check(self.lib.fv_train_tower_workspace_bytes(self.h, B, C.byref(n)), "fv_train_tower_workspace_bytes", self.h)
+        return torch.empty(n.value + 256, dtype=torch.uint8, device=self.device)
+
+    @staticmethod
+    def _aligned(ws: torch.Tensor):
+        base = ws.data_ptr()
+        pad = (-base) % 256
+        return base + pad, ws.numel() - pad
+
+    def train_tower_forward(self, pix: torch.Tensor, tws: torch.Tensor) -> torch.Tensor:
+        """pixels (B, S, S, 4) bf16 (preprocess()) -> tower_out (B, tokens, tower_out_dim) bf16; every unit's tensors stay in tws for train_tower_backward."""
+        B = pix.shape[0]
+        t = self.model.tower
+        tower_out = torch.empty(B, t.num_tokens, t.out_dim, dtype=torch.bfloat16, device=self.device)
+        p, n = self._aligned(tws)
+        _lib.check(self.lib.fv_train_tower_forward(self.h, pix.data_ptr(), B, p, n, tower_out.data_ptr(), _stream()), "fv_train_tower_forward", self.h)
+        return tower_out
+
+    def train_set_tower_grad(self, buf: Optional[torch.Tensor]) -> None:
+        """bind (or, with None, unbind) the fp16 (B, tokens, tower_out_dim) buffer train_forward_backward leaves dL/d(tower_out) in"""
+        _lib.check(self.lib.fv_train_set_tower_grad(self.h, _ptr(buf)), "fv_train_set_tower_grad", self.h)
+
+    def train_tower_backward(self, pix: torch.Tensor, d_tower_out: torch.Tensor, tws: torch.Tensor, flat_grads: torch.Tensor, bucket_cb=None) -> None:
+        """the tower's backward from dL/d(tower_out) (fp16, loss-scaled): its gradients into flat_grads at their train_layout() offsets"""
+        B = pix.shape[0]
+        err = {}
+
+        def _cb(_user, bucket, off, numel):
+            if bucket_cb is not None:
+                try:
+                    bucket_cb(int(bucket), int(off), int(numel))
+                except Exception as exc:  # must not unwind through the C frames
+                    err.setdefault("exc", exc)
+
+        fn = _lib.BUCKET_CB(_cb)
+        p, n = self._aligned(tws)
+        rc = self.lib.fv_train_tower_backward(self.h, pix.data_ptr(), d_tower_out.data_ptr(), B, p, n, flat_grads.data_ptr(), fn, None, _stream())
+        if "exc" in err:
+            raise err["exc"]
+        _lib.check(rc, "fv_train_tower_backward", self.h)
+
+    def train_tower_unit(self, unit: int, x_in: torch.Tensor, g_out: torch.Tensor, tws: torch.Tensor, flat_grads: torch.Tensor, gscale: float = 1.0):
+        """ONE tower unit, teacher-forced (parity tests): x_in bf16 NHWC (stem: pixels), g_out fp32 NHWC = dL/d(output).
+        -> (y bf16 NHWC, g_in fp32 NHWC or None for the stem); the unit's weight gradients x gscale land in flat_grads."""
+        B = x_in.shape[0]
+        units = self.tower_units()
+        t = self.model.tower
+        if unit == len(units):
+            side, ch = t.tokens_side, t.out_dim
+        else:
+            side, ch = units[unit][2], units[unit][3]
+        y = torch.empty(B, side, side, ch, dtype=torch.bfloat16, device=self.device)
+        g_in = None if unit == 0 else torch.empty(tuple(x_in.shape), dtype=torch.float32, device=self.device)
+        g_out = g_out.to(device=self.device, dtype=torch.float32).contiguous()
+        assert g_out.numel() == y.numel(), (tuple(g_out.shape), tuple(y.shape))
+        p, n = self._aligned(tws)
+        _lib.check(self.lib.fv_train_tower_unit(self.h, unit, x_in.contiguous().data_ptr(), g_out.data_ptr(), float(gscale), B, p, n, y.data_ptr(), _ptr(g_in),
+                                                flat_grads.data_ptr(), _stream()), "fv_train_tower_unit", self.h)
+        return y, g_in
 
     # ---------------------------------------------------------------- RCCL without torch in between (fv_comm_*)
     def comm_unique_id(self) -> bytes:

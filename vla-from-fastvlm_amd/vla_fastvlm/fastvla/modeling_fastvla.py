@@ -27,13 +27,18 @@ class FastVLAPolicy(nn.Module):
         self._opt_state = None
         self._unfrozen = None   # training/unfrozen.py UnfrozenState once enable_backbone_training() ran
 
-    def enable_backbone_training(self, bucket_min_numel: int = 1 << 22):
+    def enable_backbone_training(self, bucket_min_numel: int = 1 << 22, tower: Optional[bool] = None):
         """Extension of this build: fine-tune the Qwen2 decoder + mm_projector together with the action expert
-        (vision tower frozen, image tokens spliced).  Explicit on purpose: the reference's `freeze_backbone=False` trains nothing but the
-        head either (model/fastvlm_adapter.py:501), so the config flag alone must not change what a step computes."""
+        (image tokens spliced); tower=True (or FASTVLA_TRAIN_TOWER=1) trains the FastViT-HD tower too, in its inference form, otherwise it stays
+        frozen.  Explicit on purpose: the reference's `freeze_backbone=False` trains nothing but the head either (model/fastvlm_adapter.py:501),
+        so the config flag alone must not change what a step computes."""
+        if tower is None:
+            tower = os.environ.get("FASTVLA_TRAIN_TOWER", "0") == "1"
+        if self._unfrozen is not None and bool(tower) and not self._unfrozen.train_tower:
+            raise RuntimeError("backbone training is already running with the tower frozen: ask for tower=True on the first call")
         if self._unfrozen is None:
             from ..training.unfrozen import UnfrozenState
-            self._unfrozen = UnfrozenState(self, bucket_min_numel=bucket_min_numel)
+            self._unfrozen = UnfrozenState(self, bucket_min_numel=bucket_min_numel, train_tower=bool(tower))
         return self._unfrozen
 
     def forward(self, images: torch.Tensor, states: torch.Tensor, tasks: List[str] | str,
@@ -105,6 +110,19 @@ class FastVLAPolicy(nn.Module):
     def load_optimizer_state(self, m: torch.Tensor, v: torch.Tensor, step: int) -> None:
         """Restore AdamW moments and the bias-correction step (Trainer._load_checkpoint; reference trainer.py:257-262
         restores them through accelerator.load_state)."""
+        head_numel = sum(p.numel() for p in self.model.head_parameters())
+        if self._unfrozen is None and m.numel() > 2 * head_numel:
+            # moments of a whole-backbone run (training/unfrozen.py writes one flat m / v over every trainable tensor): the run resumes unfrozen
+            self.enable_backbone_training()
+        if self._unfrozen is not None:
+            u = self._unfrozen
+            if m.numel() != u.m.numel():
+                raise ValueError(f"optimizer state has {m.numel()} elements, the trainable tensors of this run {u.m.numel()} (tower trained in one run and frozen in the other?)")
+            u.m.copy_(m.to(u.m.device))
+            u.v.copy_(v.to(u.v.device))
+            u.step_count = int(step)
+            self._opt_state["step"] = int(step)
+            return
         flat = self.model._flat
         if flat is None:
             self._opt_state = {"resume": {"m": m, "v": v, "step": int(step)}}
@@ -132,10 +150,13 @@ class FastVLAPolicy(nn.Module):
         if self._unfrozen is None and not self.config.freeze_backbone and os.environ.get("FASTVLA_TRAIN_BACKBONE", "0") == "1":
             self.enable_backbone_training()
         if self._unfrozen is not None:
+            out = self._unfrozen.step(batch, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
+                                      process_group=process_group, prepared=prepared, grad_accum_steps=grad_accum_steps, force_sync=force_sync)
             if next_batch is not None:
-                raise ValueError("the look-ahead pipeline (next_batch) belongs to the frozen-backbone step: an unfrozen forward depends on the update")
-            return self._unfrozen.step(batch, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
-                                       process_group=process_group, prepared=prepared, grad_accum_steps=grad_accum_steps, force_sync=force_sync)
+                # Trainer's one batch of look-ahead (training/trainer.py _train_one_epoch): an unfrozen forward depends on the update, so only the
+                # parameter-INDEPENDENT half of the next batch is prepared here, AFTER the commit (image prep, tokenisation, the tower while it is frozen)
+                out["next"] = self._unfrozen.prepare(next_batch)
+            return out
         m = self.model
         prep = prepared if prepared is not None else self.prepare_batch(batch)
         dev = prep["pooled"].device

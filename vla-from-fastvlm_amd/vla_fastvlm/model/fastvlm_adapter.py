@@ -372,8 +372,13 @@ class FastVLMBackbone(nn.Module):
         if self._io_norm is not None:
             for k in self._IO_KEYS:
                 destination[prefix + "io_norm." + k] = torch.as_tensor(self._io_norm[k], dtype=torch.float32).detach().cpu().clone().reshape(-1)
+        if self.splice_image_tokens:
+            # the decoder of an unfrozen run was trained on [image tokens | text] (training/unfrozen.py): a reload must run the same graph
+            destination[prefix + "splice_image_tokens"] = torch.ones(1)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if prefix + "splice_image_tokens" in state_dict:
+            self.splice_image_tokens = bool(float(state_dict.pop(prefix + "splice_image_tokens").reshape(-1)[0]) != 0.0)
         found = {k: state_dict.pop(prefix + "io_norm." + k) for k in self._IO_KEYS if prefix + "io_norm." + k in state_dict}
         if found and len(found) != len(self._IO_KEYS):
             error_msgs.append(f"incomplete folded normalisation statistics under '{prefix}io_norm.': have {sorted(found)}")

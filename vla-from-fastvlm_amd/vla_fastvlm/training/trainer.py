@@ -130,6 +130,9 @@ class Trainer:
         if self._resume_opt is not None and hasattr(self.model, "load_optimizer_state"):
             self.model.load_optimizer_state(self._resume_opt["m"], self._resume_opt["v"], int(self._resume_opt["step"]))
             self._resume_opt = None
+        un = getattr(self.model, "_unfrozen", None)
+        if un is not None:
+            flat = un.flat        # an unfrozen run: the replicas share the WHOLE master (head + projector + decoder [+ tower]), not the head alone
         if self.world > 1:
             broadcast_flat(flat)
             st = getattr(self.model, "_opt_state", None)
@@ -205,8 +208,9 @@ class Trainer:
         if not self.is_main_process:
             return
         from ..utils.checkpoint import save_policy_checkpoint
+        # an unfrozen run's checkpoint without the VLM would lose what was trained: the backbone always travels then
         d = save_policy_checkpoint(self.model, Path(self.config.output_dir) / "checkpoints" / suffix,
-                                   include_backbone=self.save_backbone_weights)
+                                   include_backbone=self.save_backbone_weights or getattr(self.model, "_unfrozen", None) is not None)
         st = getattr(self.model, "_opt_state", None)
         if st is not None:
             torch.save({"m": st["m"].cpu(), "v": st["v"].cpu(), "step": st["step"], "global_step": self.global_step,
@@ -217,10 +221,20 @@ class Trainer:
         if not p.exists():
             raise FileNotFoundError(f"Checkpoint path {path} does not exist.")
         state = torch.load(p / "policy_state_dict.pt", map_location="cpu")
+        from ..utils.checkpoint import BACKBONE_PREFIX, EXTRA_STATE_MARKS
+        vlm = {k[len(BACKBONE_PREFIX):]: v for k, v in state.items() if k.startswith(BACKBONE_PREFIX)}
+        if vlm:
+            # the VLM the checkpoint carries (always, for an unfrozen run) replaces the one `vlm_model_name` resolves to; a running unfrozen state
+            # mirrors the OLD weights in its master, so it is rebuilt from the restored ones
+            un = getattr(self.model, "_unfrozen", None)
+            self.model._unfrozen = None
+            self.model.model.backbone.load_backbone_state(vlm)
+            if un is not None:
+                self.model.enable_backbone_training(tower=un.train_tower)
         own = self.model.state_dict()
-        # `.io_norm.` keys: folded dataset statistics exist in state_dict() only while the folding is on, so a freshly built model does
-        # not list them -- let them through (FastVLMBackbone._load_from_state_dict re-applies them)
-        self.model.load_state_dict({k: v for k, v in state.items() if k in own or ".io_norm." in k}, strict=False)
+        # `.io_norm.` / splice-mode keys exist in state_dict() only while they are on, so a freshly built model does not list them -- let them
+        # through (FastVLMBackbone._load_from_state_dict re-applies them)
+        self.model.load_state_dict({k: v for k, v in state.items() if k in own or any(m in k for m in EXTRA_STATE_MARKS)}, strict=False)
         if (p / "optimizer.pt").is_file():
             self._resume_opt = torch.load(p / "optimizer.pt", map_location="cpu")  # applied by _sync_replicas()
             self.global_step = int(self._resume_opt.get("global_step", 0))

@@ -24,7 +24,7 @@ from .dp import BucketedGradExchange, GradExchange
 
 
 class UnfrozenState:
-    def __init__(self, policy, bucket_min_numel: int = 1 << 22):
+    def __init__(self, policy, bucket_min_numel: int = 1 << 22, train_tower: bool = False):
         m = policy.model
         bb = m.backbone
         self.policy = policy
@@ -33,6 +33,11 @@ class UnfrozenState:
             raise RuntimeError("backbone training needs the split-bf16 decoder policy (llm_precision=1): its bf16 weight copies are refreshed "
                                f"from the fp32 master after every step; this engine runs llm_precision={eng.llm_precision}")
         eng.train_begin()
+        self.train_tower = bool(train_tower)
+        if self.train_tower:
+            eng.train_tower_begin()        # the FastViT-HD tower's inference-form tensors join the flat master (fv_train_tower_*)
+        self._tws: Dict[int, torch.Tensor] = {}
+        self._dto: Dict[int, torch.Tensor] = {}
         self.eng = eng
         self.tensors, self.total, self.n_buckets = eng.train_layout()
         dev = eng.device
@@ -60,12 +65,32 @@ class UnfrozenState:
         self._ws: Dict[tuple, torch.Tensor] = {}
         bb.splice_image_tokens = True          # the model being trained IS the spliced one: inference must run the same graph
         bb._trained_tensors = self.named_backbone_tensors   # checkpoint export reads the master, not the original weight source
+        pending = policy._opt_state if isinstance(policy._opt_state, dict) and "resume" in policy._opt_state else None
         policy._opt_state = {"m": self.m, "v": self.v, "step": 0, "flat": self.flat, "norm": self.norm}
+        if pending is not None and pending["resume"]["m"].numel() == self.m.numel():   # load_optimizer_state() ran before this state existed
+            r = pending["resume"]
+            self.m.copy_(r["m"].to(dev))
+            self.v.copy_(r["v"].to(dev))
+            self.step_count = int(r["step"])
+            policy._opt_state["step"] = self.step_count
 
     # ------------------------------------------------------------------ views / export
     def named_backbone_tensors(self) -> Dict[str, torch.Tensor]:
         """canonical checkpoint key -> fp32 copy of every trained decoder / projector tensor (q / k / v and gate / up unpacked)"""
-        return {k: v for k, v in self.eng.train_named_tensors(self.flat).items() if not k.startswith("head.")}
+        out = {k: v for k, v in self.eng.train_named_tensors(self.flat).items() if not k.startswith("head.")}
+        # a trained tower lives in the master in its inference form (every ConvFFN's BatchNorm folded into its 7x7): written back under the
+        # checkpoint's own keys as that conv + an identity BatchNorm, which is what a loader (this build's or the reference's) folds to the same tensor
+        bn_eps = float(self.eng.model.tower.bn_eps)
+        for k in [k for k in out if k.endswith(".convffn.conv.folded.weight")]:
+            pre = k[: -len("folded.weight")]
+            w = out.pop(k)
+            c = w.shape[0]
+            out[pre + "conv.weight"] = w
+            out[pre + "bn.weight"] = torch.ones(c, device=w.device)
+            out[pre + "bn.bias"] = out.pop(pre + "folded.bias")
+            out[pre + "bn.running_mean"] = torch.zeros(c, device=w.device)
+            out[pre + "bn.running_var"] = torch.full((c,), 1.0 - bn_eps, device=w.device)
+        return out
 
     def _workspace(self, B: int, T: int) -> torch.Tensor:
         key = (B, T)
@@ -86,8 +111,10 @@ class UnfrozenState:
         if targets.ndim == 3:
             targets = targets[:, 0]
         pix = bb._prepare_images_tensor(images, dev)
-        with torch.no_grad():
-            _, tower_out = eng.vision_forward(pix, return_tower_out=True)
+        tower_out = None
+        if not self.train_tower:           # a trainable tower's forward depends on the parameters: it belongs to step()
+            with torch.no_grad():
+                _, tower_out = eng.vision_forward(pix, return_tower_out=True)
         text = bb._prep_text(tasks, dev)
         ids, mask = text["input_ids"], text["attention_mask"]
         T = ids.shape[1]
@@ -95,7 +122,8 @@ class UnfrozenState:
         if Tp != T:
             ids = torch.nn.functional.pad(ids, (0, Tp - T))
             mask = torch.nn.functional.pad(mask, (0, Tp - T))
-        return {"tower_out": tower_out, "ids": ids, "lens": mask.to(torch.int32).sum(1).to(torch.int32), "states": states, "targets": targets.contiguous()}
+        return {"tower_out": tower_out, "pix": pix if self.train_tower else None, "ids": ids, "lens": mask.to(torch.int32).sum(1).to(torch.int32), "states": states,
+                "targets": targets.contiguous()}
 
     def step(self, batch: Optional[Dict] = None, *, lr: float, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-4,
              max_grad_norm: Optional[float] = 1.0, process_group=None, prepared: Optional[Dict] = None, grad_accum_steps: int = 1,
@@ -114,9 +142,21 @@ class UnfrozenState:
         if overlap:
             self.bucketed.group = process_group
             self.bucketed.begin(self.g)
-        actions, loss, _ = eng.train_forward_backward(self.flat, prep["tower_out"], prep["ids"], prep["lens"], prep["states"], prep["targets"], ws,
+        tower_out, tws, dto = prep["tower_out"], None, None
+        if self.train_tower:
+            if B not in self._tws:
+                self._tws.clear(); self._dto.clear()
+                self._tws[B] = eng.train_tower_workspace(B)
+                t = eng.model.tower
+                self._dto[B] = torch.zeros(B, t.num_tokens, t.out_dim, dtype=torch.float16, device=eng.device)
+            tws, dto = self._tws[B], self._dto[B]
+            eng.train_set_tower_grad(dto)
+            tower_out = eng.train_tower_forward(prep["pix"], tws)
+        actions, loss, _ = eng.train_forward_backward(self.flat, tower_out, prep["ids"], prep["lens"], prep["states"], prep["targets"], ws,
                                                       training=pol.training, dropout_p=p, seed=m._drop_seed, offset=m._drop_calls, flat_grads=self.g,
                                                       bucket_cb=self.bucketed.bucket_ready if overlap else None)
+        if self.train_tower:
+            eng.train_tower_backward(prep["pix"], dto, tws, self.g, bucket_cb=self.bucketed.bucket_ready if overlap else None)
         total = self.g
         if k > 1:
             if self.acc is None:
@@ -140,6 +180,9 @@ class UnfrozenState:
             eng.adamw_step(self.flat, total, self.m, self.v, self.step_count, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                            max_grad_norm=max_grad_norm or 0.0, grad_scale=scale, grad_norm_out=self.norm)
             eng.train_commit(self.flat)       # bf16 operand copies (and their transposes) follow the master
+            bb = pol.model.backbone
+            bb.clear_prefix_cache()           # per-image decoder prefixes / per-prompt features computed with the OLD weights must not serve an eval between steps
+            bb.clear_prompt_cache()
             pol._opt_state["step"] = self.step_count
             if self.step_count % self.saturation_check_every == 0:
                 # the backward's fp16 operands carry the gradient x 2^loss_scale: a clamp means the scale is too large for this model / loss

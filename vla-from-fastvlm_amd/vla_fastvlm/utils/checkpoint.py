@@ -22,6 +22,9 @@ import torch
 from ..fastvla import FastVLAConfig, FastVLAPolicy
 
 BACKBONE_PREFIX = "model.backbone.model."
+# state-dict keys of this build that exist only while their feature is on (so a default policy keeps exactly the reference's keys): folded
+# dataset statistics, and the spliced-sequence mode an unfrozen run trains the decoder in (FastVLMBackbone._save_to_state_dict)
+EXTRA_STATE_MARKS = (".io_norm.", ".splice_image_tokens")
 
 
 def load_policy_from_checkpoint(checkpoint_dir: str, device: torch.device | None = None) -> FastVLAPolicy:
@@ -37,11 +40,11 @@ def load_policy_from_checkpoint(checkpoint_dir: str, device: torch.device | None
     vlm = {k[len(BACKBONE_PREFIX):]: v for k, v in state.items() if k.startswith(BACKBONE_PREFIX)}
     if vlm:
         policy.model.backbone.load_backbone_state(vlm)
-    own = policy.state_dict()
+    own = [k for k in policy.state_dict() if not any(m in k for m in EXTRA_STATE_MARKS)]
     missing = [k for k in own if k not in state]
     if missing:
         raise KeyError(f"checkpoint lacks head tensors: {missing}")
-    extra = {k: v for k, v in state.items() if ".io_norm." in k}   # folded dataset statistics travel with the state dict
+    extra = {k: v for k, v in state.items() if any(m in k for m in EXTRA_STATE_MARKS)}   # folded dataset statistics / the splice mode travel with the state dict
     policy.load_state_dict({**{k: state[k] for k in own}, **extra})
     policy.eval()
     return policy
