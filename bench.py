@@ -43,6 +43,23 @@ MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
+
+def _usable_cpus() -> int:
+    """Threads of the CPU baseline legs: EVERY host CPU this process may run on (set_num_threads(os.cpu_count())) -- the scheduler
+    affinity set, cut to the cgroup's CPU quota where the box grants a share of its cores (more runnable threads than granted CPUs only makes the baseline
+    slower).  FASTVLA_CPU_THREADS overrides it.  The count used is printed in the line ("cores")."""
+    if os.environ.get("FASTVLA_CPU_THREADS"):
+        return max(1, int(os.environ["FASTVLA_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -700,8 +717,7 @@ def main():
         tc = fastvit_hd.TowerCfg(layers=model.tower.layers, dims=model.tower.dims)
         hp = {k: v.detach().cpu().clone() for k, v in eng.head_views(flat).items()}
         # the box exposes every host core but grants a 16-CPU share per GPU: size the pool to the share
-        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        torch.set_num_threads(max(1, min(share, int(os.environ.get("FASTVLA_CPU_THREADS", "16")))))
+        torch.set_num_threads(_usable_cpus())
         ci, cids = images[:n].cpu(), ids[:n].cpu().long()
         cmask = torch.ones(n, T, dtype=torch.long)
         t = time.perf_counter()
@@ -731,8 +747,7 @@ def main():
         lc = qwen2.Qwen2Cfg(hidden=model.llm.hidden, layers=model.llm.layers, heads=model.llm.heads, kv_heads=model.llm.kv_heads,
                             head_dim=model.llm.head_dim, inter=model.llm.inter, vocab=model.llm.vocab)
         tc = fastvit_hd.TowerCfg(layers=model.tower.layers, dims=model.tower.dims)
-        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        torch.set_num_threads(max(1, min(share, int(os.environ.get("FASTVLA_CPU_THREADS", "16")))))
+        torch.set_num_threads(_usable_cpus())
         hp = {k: v.detach().cpu().clone() for k, v in eng.head_views(flat).items()}
         mo = {k: torch.zeros_like(v) for k, v in hp.items()}
         vo = {k: torch.zeros_like(v) for k, v in hp.items()}

@@ -308,6 +308,8 @@ int fv_train_tower_backward(fv_handle* h, const void* pix, const void* d_tower_o
 /* ONE tower unit, teacher-forced (parity tests): forward of unit `unit` (fv_vision_unit_info's index; the unit count itself = conv_exp + SE) on x_in (bf16 NHWC;
  * the stem: fv_preprocess pixels), then its backward from g_out (fp32 NHWC, dL/d(output)) x gscale.  y_out (bf16, optional) = the unit's output, g_in (fp32,
  * optional; ignored for the stem) = dL/d(input), the unit's weight gradients x gscale at their fv_train_layout offsets in flat_grads. */
+/* unit `unit`'s output (bf16 NHWC) as the last fv_train_tower_forward left it in tws */
+int fv_train_tower_read_unit(fv_handle* h, int unit, int B, const void* tws, size_t tws_bytes, void* out, fv_stream s);
 int fv_train_tower_unit(fv_handle* h, int unit, const void* x_in, const float* g_out, float gscale, int B, void* tws, size_t tws_bytes, void* y_out, float* g_in,
                         float* flat_grads, fv_stream s);
 

@@ -71,13 +71,22 @@ def unit_backward(qf: Dict[str, torch.Tensor], x: torch.Tensor, unit, g_out: tor
 
 def forward_backward(pf: Dict[str, torch.Tensor], head_p: Dict[str, torch.Tensor], pixels: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor,
                      states: torch.Tensor, targets: torch.Tensor, tcfg: TowerCfg, lcfg: qwen2.Qwen2Cfg, drop_mask: Optional[torch.Tensor] = None, drop_p: float = 0.0,
-                     emulate_bf16: bool = False, tower_out_value: Optional[torch.Tensor] = None):
+                     emulate_bf16: bool = False, tower_out_value: Optional[torch.Tensor] = None, unit_values=None):
     """The whole spliced policy with EVERYTHING trainable: pixels (B, 3, S, S) fp32 (already letterboxed) -> tower -> projector -> decoder -> head -> MSE.
     pf = fold_tower(checkpoint).  -> dict(loss, pred, tower_out, grads={key -> gradient} for every model.* tensor and `head.<key>`)."""
     keys = [k for k in pf if k.startswith("model.")]
     q = {k: (v.detach().clone().float().requires_grad_(True) if k in keys else v) for k, v in pf.items()}
     hp = {k: v.detach().clone().float().requires_grad_(True) for k, v in head_p.items()}
-    emb = fastvit_hd.tower_forward(q, pixels.float(), tcfg, emulate_bf16=emulate_bf16)   # (the bf16-faithful tower: see unit_backward; projector / decoder / head stay fp32)
+    # (the bf16-faithful tower: see unit_backward; projector / decoder / head stay fp32)
+    # unit_values (the engine's own unit outputs, NCHW): VALUE teacher-forcing at every unit boundary -- each unit's forward value is replaced by the engine's while
+    # the gradient flows through this graph, so two bf16 executions cannot drift apart (free-running they sit ~1e-2 apart after 17 units) before being differentiated
+    qs = fastvit_hd.strip_prefix(q)
+    xx = pixels.float()
+    for n, unit in enumerate(fastvit_hd.tower_units(tcfg)):
+        xx = fastvit_hd.unit_forward(qs, xx, unit, tcfg, emulate_bf16)
+        if unit_values is not None:
+            xx = xx + (unit_values[n].float() - xx).detach()
+    emb = fastvit_hd.tower_head_forward(qs, xx, tcfg, emulate_bf16)
     if tower_out_value is not None:
         # VALUE teacher-forcing at the tower's output: everything downstream sees the embeddings the engine computed (so dL/dpred = 2 (pred - target) / n does not
         # amplify the bf16 tower's forward noise by |pred| / |pred - target|), while the gradient still flows through THIS graph's tower

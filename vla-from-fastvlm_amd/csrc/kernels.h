@@ -187,8 +187,8 @@ int launch_ls_grads(const float* dWraw, const float* dbraw, const bf16_t* W, con
 size_t ln_bwd_scratch_floats(long rows, int C);
 int launch_ln_bwd(const bf16_t* x, const bf16_t* dy, const float* w, const bf16_t* res, bf16_t* dx, float* dw, float* db, float* scratch, long rows, int C,
                   float eps, unsigned* sat, hipStream_t s);
-int launch_tower_attn_bwd(const bf16_t* qkv, int ld, const bf16_t* o, int ldo, const bf16_t* dO, int lddo, bf16_t* dqkv, int ldd, float* stats, int B, int T,
-                          int heads, float scale, hipStream_t s);   // stats: 2 * B * heads * T floats
+int launch_tower_attn_bwd(const bf16_t* qkv, int ld, const bf16_t* dO, int lddo, bf16_t* dqkv, int ldd, float* stats, int B, int T, int heads, float scale,
+                          hipStream_t s);   // stats: 2 * B * heads * T floats
 int launch_se_bwd(const bf16_t* e, const bf16_t* dout, const float* se, const float* w1, const float* w2, bf16_t* de, float* dW1, float* db1, float* dW2,
                   float* db2, float* tmp, int B, int P, int C, int R, unsigned* sat, hipStream_t s);   // tmp >= B * (2 C + 2 R) floats
 size_t stem0_wgrad_scratch_floats(int B, int S, int C0);

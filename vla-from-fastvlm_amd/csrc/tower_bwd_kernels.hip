@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ tower attention backward (non-causal, head_dim 32)
-// qkv bf16 [B*T][ld] = q | k | v (each C = heads * 32 wide, head h at column h * 32), o bf16 [B*T][C], dO fp16 [B*T][C] -> dqkv fp16 [B*T][ldd] in the
+// qkv bf16 [B*T][ld] = q | k | v (each C = heads * 32 wide, head h at column h * 32), dO fp16 [B*T][C] -> dqkv fp16 [B*T][ldd] in the
 // same column order.  S = scale Q K^T, P = softmax(S), dV = P^T dO, dP = dO V^T, dS = P (dP - delta) scale, dQ = dS K, dK = dS^T Q.
 // Both kernels keep the lane = query (dq) / key (dkv) layout of attention32_kernel: the score tile of a product over head_dim (its C/D registers) is the B
 // operand of the following product over keys / queries, whose A operand (K^T, dO^T, Q^T) comes from the row-major LDS tile by ds_read_b64_tr_b16.
@@ -392,8 +392,8 @@ __device__ __forceinline__ float xor_sum_32_16(float v) { v += __shfl_xor(v, 16,
 __device__ __forceinline__ float xor_max_32_16b(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
 
 struct TAttnParams {
-  const bf16_t* qkv; const bf16_t* o; const bf16_t* dO; bf16_t* dqkv; float* lse2; float* delta;
-  int ld, ldo, lddo, ldd, B, T, heads, C; float scale;
+  const bf16_t* qkv; const bf16_t* dO; bf16_t* dqkv; float* lse2; float* delta;
+  int ld, lddo, ldd, B, T, heads, C; float scale;
 };
 
 // dQ (and the row statistics lse2 = log2 sum exp, delta = sum_d dO O): block = 64 queries of one (batch, head), lane = query
@@ -413,16 +413,6 @@ __global__ __launch_bounds__(256) void tattn_dq_kernel(TAttnParams p) {
   const f16x8 fq = __builtin_bit_cast(f16x8, qok ? bf8_to_h8(*reinterpret_cast<const uint4*>(p.qkv + qrow * p.ld + h * 32 + fg * 8)) : zero4);
   const uint4 dou = qok ? *reinterpret_cast<const uint4*>(p.dO + qrow * p.lddo + h * 32 + fg * 8) : zero4;
   const f16x8 fdo = __builtin_bit_cast(f16x8, dou);
-  float delta;
-  {
-    float a[8], c[8];
-    unpack8_h(dou, a);
-    unpack8(qok ? *reinterpret_cast<const uint4*>(p.o + qrow * p.ldo + h * 32 + fg * 8) : zero4, c);
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += a[e] * c[e];
-    delta = xor_sum_32_16(s);
-  }
   const float c2 = p.scale * 1.4426950408889634f;
   const int nkb = (p.T + 63) >> 6;
   const int skey = tid >> 2, sch = tid & 3;
@@ -434,17 +424,20 @@ __global__ __launch_bounds__(256) void tattn_dq_kernel(TAttnParams p) {
     *reinterpret_cast<uint4*>(sK + skey * TA_LD + sch * 8) = ok ? bf8_to_h8(*reinterpret_cast<const uint4*>(kp)) : zero4;
     if (with_v) *reinterpret_cast<uint4*>(sV + skey * TA_LD + sch * 8) = ok ? bf8_to_h8(*reinterpret_cast<const uint4*>(kp + p.C)) : zero4;
   };
-  // pass 1: running max / sum of the scaled scores (log2 domain)
-  float m_run = -1e30f, l_run = 0.f;
+  // pass 1: running max / sum of the scaled scores (log2 domain) and delta = sum_j P_ij dP_ij from the SAME exponentials.  (The textbook shortcut
+  // delta = sum_d dO O reads the forward's bf16-ROUNDED output: where the softmax is peaked, dP_ij - delta cancels and that 2^-9 shows up as 3e-3 in dQ / dK.)
+  float m_run = -1e30f, l_run = 0.f, d_run = 0.f;
   for (int kb = 0; kb < nkb; ++kb) {
     __syncthreads();
-    stage(kb, false);
+    stage(kb, true);
     __syncthreads();
-    f32x4 sacc[4];
+    f32x4 sacc[4], dacc[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const f16x8 fk = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * TA_LD + fg * 8));
+      const f16x8 fv = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sV + (kt * 16 + fr) * TA_LD + fg * 8));
       sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fk, fq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      dacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, fdo, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
     float mloc = -1e30f;
 #pragma unroll
@@ -457,16 +450,24 @@ __global__ __launch_bounds__(256) void tattn_dq_kernel(TAttnParams p) {
       }
     mloc = xor_max_32_16b(mloc);
     const float m_new = fmaxf(m_run, mloc);
-    float ls = 0.f;
+    float ls = 0.f, ds = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ls += __builtin_amdgcn_exp2f(sacc[kt][r] - m_new);
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - m_new);
+        ls += e;
+        ds += e * dacc[kt][r];
+      }
     ls = xor_sum_32_16(ls);
-    l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ls;
+    ds = xor_sum_32_16(ds);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run = l_run * alpha + ls;
+    d_run = d_run * alpha + ds;
     m_run = m_new;
   }
   const float lse2 = m_run + __builtin_amdgcn_logf(l_run);   // v_log_f32 is log2
+  const float delta = d_run / l_run;
   if (qok && fg == 0) {
     p.lse2[((size_t)b * p.heads + h) * p.T + q] = lse2;
     p.delta[((size_t)b * p.heads + h) * p.T + q] = delta;
@@ -894,14 +895,13 @@ int launch_ln_bwd(const bf16_t* x, const bf16_t* dy, const float* w, const bf16_
 }
 
 // stats: 2 * B * heads * T floats (lse2 | delta)
-int launch_tower_attn_bwd(const bf16_t* qkv, int ld, const bf16_t* o, int ldo, const bf16_t* dO, int lddo, bf16_t* dqkv, int ldd, float* stats, int B, int T,
-                          int heads, float scale, hipStream_t s) {
-  if (!qkv || !o || !dO || !dqkv || !stats) return fv_fail(FV_ERR_ARG, "tower_attn_bwd: null pointer");
+int launch_tower_attn_bwd(const bf16_t* qkv, int ld, const bf16_t* dO, int lddo, bf16_t* dqkv, int ldd, float* stats, int B, int T, int heads, float scale,
+                          hipStream_t s) {
+  if (!qkv || !dO || !dqkv || !stats) return fv_fail(FV_ERR_ARG, "tower_attn_bwd: null pointer");
   const int C = heads * 32;
-  if (B <= 0 || T <= 0 || heads <= 0 || ld < 3 * C || ldo < C || lddo < C || ldd < 3 * C || (ld | ldo | lddo | ldd) % 8)
-    return fv_fail(FV_ERR_ARG, "tower_attn_bwd: bad shape / strides");
-  if (((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dqkv) & 15) return fv_fail(FV_ERR_ARG, "tower_attn_bwd: misaligned pointer");
-  TAttnParams p{qkv, o, dO, dqkv, stats, stats + (size_t)B * heads * T, ld, ldo, lddo, ldd, B, T, heads, C, scale};
+  if (B <= 0 || T <= 0 || heads <= 0 || ld < 3 * C || lddo < C || ldd < 3 * C || (ld | lddo | ldd) % 8) return fv_fail(FV_ERR_ARG, "tower_attn_bwd: bad shape / strides");
+  if (((uintptr_t)qkv | (uintptr_t)dO | (uintptr_t)dqkv) & 15) return fv_fail(FV_ERR_ARG, "tower_attn_bwd: misaligned pointer");
+  TAttnParams p{qkv, dO, dqkv, stats, stats + (size_t)B * heads * T, ld, lddo, ldd, B, T, heads, C, scale};
   const long blocks = (long)B * heads * ((T + 63) / 64);
   if (blocks > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "tower_attn_bwd: grid too large");
   hipLaunchKernelGGL(tattn_dq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "fv_train_tower_forward": (_i, [_vp, _vp, _i, _vp, C.c_size_t, _vp, _vp]),
     "fv_train_set_tower_grad": (_i, [_vp, _vp]),
     "fv_train_tower_backward": (_i, [_vp, _vp, _vp, _i, _vp, C.c_size_t, _vp, BUCKET_CB, _vp, _vp]),
+    "fv_train_tower_read_unit": (_i, [_vp, _i, _i, _vp, C.c_size_t, _vp, _vp]),
     "fv_train_tower_unit": (_i, [_vp, _i, _vp, _vp, _f, _i, _vp, C.c_size_t, _vp, _vp, _vp, _vp]),
     "fv_profile": (_i, [_vp, _i]),
     "fv_profile_read": (_i, [_vp, C.POINTER(ProfileEntry), C.POINTER(GemmProfile), _i, C.POINTER(_i)]),

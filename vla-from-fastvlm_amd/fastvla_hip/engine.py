@@ -611,6 +611,16 @@ class FastVLAEngine:
         _lib.check(self.lib.fv_train_tower_forward(self.h, pix.data_ptr(), B, p, n, tower_out.data_ptr(), _stream()), "fv_train_tower_forward", self.h)
         return tower_out
 
+    def train_tower_unit_outputs(self, B: int, tws: torch.Tensor):
+        """-> [output of unit 0, 1, ...] (bf16 NHWC) as the last train_tower_forward left them in tws"""
+        p, n = self._aligned(tws)
+        outs = []
+        for u, (_, _, sd, ch) in enumerate(self.tower_units()):
+            t = torch.empty(B, sd, sd, ch, dtype=torch.bfloat16, device=self.device)
+            _lib.check(self.lib.fv_train_tower_read_unit(self.h, u, B, p, n, t.data_ptr(), _stream()), "fv_train_tower_read_unit", self.h)
+            outs.append(t)
+        return outs
+
     def train_set_tower_grad(self, buf: Optional[torch.Tensor]) -> None:
         """bind (or, with None, unbind) the fp16 (B, tokens, tower_out_dim) buffer train_forward_backward leaves dL/d(tower_out) in"""
         _lib.check(self.lib.fv_train_set_tower_grad(self.h, _ptr(buf)), "fv_train_set_tower_grad", self.h)
