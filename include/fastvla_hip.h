@@ -256,18 +256,15 @@ int fv_train_export_params(fv_handle* h, float* flat_params, fv_stream s);
 int fv_train_commit(fv_handle* h, const float* flat_params, fv_stream s);
 /* Arithmetic of the backward's contractions (defaults 2, 1, 12: every dgrad and wgrad ONE fp16 pass -- worst per-tensor gradient 8.4e-4 from fp32 autograd
  * through the whole 24-layer 0.5B decoder, 6.7e-4 at the 7B width; in this mode the gate/up accumulators are kept as fp16 for the backward):
- *   grad_split 1: the gradient operand of every dgrad GEMM is split bf16 (hi + lo, 16 significant bits) against the exact-bf16 transposed weights;
- *              0: its bf16 hi half alone (the usual mixed-precision recipe: half the dgrad work, gradients ~3e-3 from fp32 -- outside this repo's
- *                 2e-3 gradient bar; an explicit speed knob);
- *              2: ONE fp16 pass -- the loss-scaled gradient rounded once to 11 significant bits against an fp16 copy of the transposed weight (exact:
- *                 bf16 widens into fp16): the same single pass as 0 at 8x its precision.
+ *   grad_split 2: ONE fp16 pass -- the loss-scaled gradient rounded once to 11 significant bits against an fp16 copy of the transposed weight (exact:
+ *                 bf16 widens into fp16);
+ *              1: the gradient operand of every dgrad GEMM is split bf16 (hi + lo, 16 significant bits) against the exact-bf16 transposed weights
+ *                 (two passes; the most exact form: 3.3e-4 through all 24 layers).
  *   wgrad_f16  1: every weight gradient in ONE fp16 pass -- the gradient and the activation each rounded once to 11 significant bits (operands as
  *                 transposed fp16 copies, made where the data is produced);
- *              2: (with grad_split 2) the same arithmetic with the contraction running over the ROWS of the two row-major fp16 operands -- the TN
- *                 instance of the 256-tile GEMM (LDS image in [k/8][n/16] blocks, fragments by ds_read_b64_tr_b16): nothing is transposed and the
- *                 gradient's rows serve the dgrad and the wgrad alike; same gradients, but its GEMMs run 29 % slower than the NT ones (twice the
- *                 fragment-read instructions), +1 ms per 0.5B step: an option, not the default;
  *              0: the split-bf16 gradient against the activation's bf16 hi half (two passes; the activation's 8 bits bound the result at ~1.8e-3).
+ *   (Round 5 removed grad_split 0 -- plain-bf16 gradient operands, 3.7e-3: outside the 2e-3 bar -- and wgrad_f16 2 -- the decoder's wgrads on the TN GEMM
+ *   instance: same gradients, 1 ms per step slower.  The TN instance lives on in the tower's weight gradients, whose contraction runs over 10^5 .. 10^6 pixel rows.)
  *   loss_scale_log2: dL/dactions is multiplied by 2^k, so EVERY gradient fv_train_forward_backward writes carries that factor (it keeps the wgrad's
  *              fp16 gradient operand inside binary16's range; saturating casts, clamps counted by fv_llm_fp16_saturations); pass
  *              grad_scale = 2^-k / world to fv_adamw_clip_step (fv_train_loss_scale returns 2^k).  The loss itself is not scaled. */
@@ -335,7 +332,7 @@ enum fv_gemm_epilogue {
   FV_EPI_SWIGLU_F16 = 8,  /* out f16[M,N/2] = silu(gate)*up / 16 (the fp16 operand of the down projection, whose fp16 weights carry the
                            * 16: the power of two keeps SwiGLU outputs up to 1e6 inside fp16's range), W rows 8-interleaved */
   /* the tower backward's three (all 2-byte outputs are fp16, saturating, whatever the operand type) */
-  FV_EPI_GELU_GRAD = 9,   /* a = acc + bias: out f16 = gelu(a) (exact erf form, rounded to a bf16 value first; out may be NULL), stash f16 = gelu'(a), both [M][ldo] */
+  FV_EPI_GELU_GRAD = 9,   /* a = acc + bias: out f16 = gelu(a) (the 5e-5 minimax Phi of the forward kernels, rounded to a bf16 value first; out may be NULL), stash f16 = gelu'(a), both [M][ldo] */
   FV_EPI_MUL_AUX = 10,    /* out f16 = acc * aux_f16[m][n] (aux = res, row stride ldr; out may alias aux)                              */
   FV_EPI_F16 = 11         /* out f16 = acc + bias                                                                                      */
 };

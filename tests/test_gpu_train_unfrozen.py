@@ -189,6 +189,11 @@ def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
         torch.cuda.synchronize()
         w1s = _check_grads(eng, g1s, ref, tol=GRAD_TOL)
         print(f"[unfrozen {name}] split-bf16 dgrad operands: worst gradient {w1s[0]} {w1s[1]:.2e}")
+        eng.train_set_options(grad_split=1, wgrad_f16=False)      # ... and the other shipped option at full width: two-pass split-bf16 weight gradients
+        _, _, g2p = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+        torch.cuda.synchronize()
+        w2p = _check_grads(eng, g2p, ref, tol=2.5e-3)              # (the activation operand's 8 bits: 1.8e-3 on `small`; why it is not the default)
+        print(f"[unfrozen {name}] + two-pass split-bf16 wgrad: worst gradient {w2p[0]} {w2p[1]:.2e}")
         eng.train_set_options()
     assert ra <= 1e-3 and rl <= 1e-3
     # buckets: head first, then final norm, layers last to first, embedding, projector; together they tile the flat buffer exactly once
@@ -281,10 +286,10 @@ def test_backward_arithmetic_options():
     assert eng.train_loss_scale() == 4096.0
     a1, l1, g1 = run()                                     # default: dgrad and wgrad each ONE fp16 pass
     worst_default = _check_grads(eng, g1, ref, tol=1e-3)
-    eng.train_set_options(grad_split=2, wgrad_f16=2)       # the same arithmetic on the TN GEMM instance (row-major operands, nothing transposed)
-    a7, l7, g7 = run()
-    worst_tn = _check_grads(eng, g7, ref, tol=1e-3)
-    assert torch.equal(a7, a1) and torch.equal(l7, l1) and abs(worst_tn[1] - worst_default[1]) <= 1e-4
+    from fastvla_hip import FastVLAHipError
+    for gone in (dict(grad_split=0), dict(wgrad_f16=2)):   # round 5: the two options outside the bar / slower than the default are no longer in the product
+        with pytest.raises(FastVLAHipError):
+            eng.train_set_options(**gone)
     eng.train_set_options(grad_split=1, wgrad_f16=True)    # split-bf16 dgrad operands (two passes): the most exact form
     a6, l6, g6 = run()
     worst_split = _check_grads(eng, g6, ref, tol=1e-3)
@@ -292,17 +297,14 @@ def test_backward_arithmetic_options():
     eng.train_set_options(grad_split=1, wgrad_f16=False)   # round 4's first form: split-bf16 gradient x bf16 activation for the weight gradients
     a2, l2, g2 = run()
     worst_legacy = _check_grads(eng, g2, ref, tol=GRAD_TOL)
-    eng.train_set_options(grad_split=0, wgrad_f16=True)    # plain-bf16 dgrad operands: one pass at 8 bits
-    a3, l3, g3 = run()
-    worst_plain = _check_grads(eng, g3, ref, tol=8e-3)
     eng.train_set_options(loss_scale_log2=8)
     a4, l4, g4 = run()
     assert eng.train_loss_scale() == 256.0
     worst_ls8 = _check_grads(eng, g4, ref, tol=1e-3)
     print(f"[unfrozen small, backward arithmetic] worst gradient -- default (fp16 dgrad + fp16 wgrad, one pass each): {worst_default[0]} {worst_default[1]:.2e}; "
-          f"TN wgrads: {worst_tn[1]:.2e}; split-bf16 dgrad: {worst_split[1]:.2e}; + two-pass split-bf16 wgrad: {worst_legacy[1]:.2e}; plain-bf16 dgrad operands: {worst_plain[1]:.2e}; "
+          f"split-bf16 dgrad: {worst_split[1]:.2e}; + two-pass split-bf16 wgrad: {worst_legacy[1]:.2e}; "
           f"loss scale 2^8: {worst_ls8[1]:.2e}")
-    for a, l in ((a2, l2), (a3, l3), (a4, l4)):
+    for a, l in ((a2, l2), (a4, l4)):
         assert torch.equal(a, a1) and torch.equal(l, l1)
     assert eng.fp16_saturations() == 0
     eng.train_set_options()

@@ -1,4 +1,4 @@
-"""tools/prec_sweep.py [model] [B] -- decoder precision policies (fv_model_desc.llm_precision 1..4) on one seeded synthetic model: the
+"""tools/prec_sweep.py [model] [B] -- (needs the TOOLS build: make AB=1, FASTVLA_HIP_LIB=tools/bin/libfastvla_hip_ab.so: policies 3 / 4 are not in the product library) -- decoder precision policies (fv_model_desc.llm_precision 1..4) on one seeded synthetic model: the
 pooled feature of each policy against policy 1 (split-bf16 everywhere, 1e-5 of the fp32 oracle at 0.5B), its batch-invariance
 (rows 3 and 5 alone against the same rows of the batch) and the time of the decoder call.  GPU box only; prints a table."""
 import sys

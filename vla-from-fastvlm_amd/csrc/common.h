@@ -234,6 +234,36 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& g, float& dg) {
   g = x * Phi;
   dg = Phi + x * phi;
 }
+// The same pair for the tower backward's hot places (the recompute GEMM's epilogue touches 12 G hidden activations per B = 32 step): Phi from gelu2_n's packed
+// minimax polynomial (max |error| 5e-5, both tails exact through the clamp), phi from ONE v_exp_f32 -- ~14 VALU issues per element instead of ~60 for erff + expf.
+__device__ __forceinline__ void gelu_and_grad2(const f32x2 x, f32x2& g, f32x2& dg) {
+  const float R = 4.625f;
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -R, R), __builtin_amdgcn_fmed3f(x.y, -R, R)};
+  const f32x2 x2 = xc * xc;
+  f32x2 p = __builtin_elementwise_fma(x2, (f32x2){FV_GELU_C8, FV_GELU_C8}, (f32x2){FV_GELU_C7, FV_GELU_C7});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){FV_GELU_C6, FV_GELU_C6});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){FV_GELU_C5, FV_GELU_C5});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){FV_GELU_C4, FV_GELU_C4});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){FV_GELU_C3, FV_GELU_C3});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){FV_GELU_C2, FV_GELU_C2});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){FV_GELU_C1, FV_GELU_C1});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){FV_GELU_C0, FV_GELU_C0});
+  f32x2 Phi = __builtin_elementwise_fma(xc, p, (f32x2){0.5f, 0.5f});
+  Phi.x = __builtin_amdgcn_fmed3f(Phi.x, 0.f, 1.f);
+  Phi.y = __builtin_amdgcn_fmed3f(Phi.y, 0.f, 1.f);
+  const f32x2 xx = x * x;
+  const f32x2 phi = {0.3989422804014327f * __builtin_amdgcn_exp2f(-0.7213475204444817f * xx.x), 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.7213475204444817f * xx.y)};
+  g = x * Phi;
+  dg = __builtin_elementwise_fma(x, phi, Phi);
+}
+__device__ __forceinline__ void gelu_and_grad8(float* v, float* d) {   // v[8] -> gelu in place, d[8] = gelu'
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    f32x2 g, dg;
+    gelu_and_grad2((f32x2){v[e], v[e + 1]}, g, dg);
+    v[e] = g.x; v[e + 1] = g.y; d[e] = dg.x; d[e + 1] = dg.y;
+  }
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 

@@ -81,7 +81,11 @@ struct TrainLayerT {   // transposed weight copies (dgrad operands): bf16, and f
   bf16_t *qkvT16 = nullptr, *oT16 = nullptr, *guT16 = nullptr, *downT16 = nullptr;
 };
 struct GTab { int* idx = nullptr; float* coef = nullptr; size_t n = 0; };   // gather table of one packed operand image (tower_train.inc make_gtab), device arrays
-struct TowerTrainUnit { bf16_t *fc1T16 = nullptr, *fc2sT16 = nullptr, *qkvT16 = nullptr, *projsT16 = nullptr, *pwT16 = nullptr; };   // transposed fp16 dgrad operands of one tower unit
+struct TowerTrainUnit {   // the backward's own operand images of one tower unit: transposed fp16 dgrad operands of the dense layers ...
+  bf16_t *fc1T16 = nullptr, *fc2sT16 = nullptr, *qkvT16 = nullptr, *projsT16 = nullptr, *pwT16 = nullptr;
+  bf16_t* stem0_w32 = nullptr;                  // (stem) the first conv as fp16 [C0][32]: taps (bf16-rounded, as the forward's MFMA image holds them) in columns 0 .. 26, zeros behind
+  bf16_t *mixF16 = nullptr, *dwF16 = nullptr;   // ... and fp16 Toeplitz tables of the FLIPPED depthwise taps (3x3 mixer / RepCPE 7x7 in mixF16, the ConvFFN's 7x7 in dwF16): dgrad on the marching MFMA kernel
+};
 struct TrainState {
   bool ready = false; std::vector<TrainLayerT> layers; bf16_t *pj2T = nullptr, *pj2T16 = nullptr;
   // the tower half (tower_train.inc): its tensors join the flat master when `tower` is set
@@ -90,8 +94,7 @@ struct TrainState {
   bf16_t *pj0T = nullptr, *pj0T16 = nullptr;   // the projector's first Linear, transposed (its input gradient feeds the tower)
   void* d_tower_out = nullptr;                 // fv_train_set_tower_grad: where fv_train_forward_backward leaves dL/d(tower_out) as fp16 rows
   fv::CommitDesc* commit_desc = nullptr; int commit_n = 0, commit_tiles = 0;   // fv_train_commit's descriptor table (device)
-  int grad_split = 2;   // dgrad's gradient operand: 1 split bf16 (hi + lo, two passes), 0 its bf16 hi half alone, 2 ONE fp16 pass against fp16 transposed weights (fv_train_set_options)
-  int wgrad_tn = 0;     // 1 (fv_train_set_options wgrad_f16 = 2): weight gradients on the TN GEMM instance (row-major operands, no transposed copies) -- same gradients, +1 ms per step: not the default
+  int grad_split = 2;   // dgrad's gradient operand: 2 ONE fp16 pass against fp16 transposed weights, 1 split bf16 (hi + lo, two passes) (fv_train_set_options)
   int wgrad_f16 = 1;    // 1: the weight gradients in ONE fp16 pass (both operands 11 significant bits, the gradient carrying the loss scale); 0: split-bf16 gradient x bf16 activation
   int loss_scale_log2 = 12;   // every gradient the backward produces is multiplied by 2^this (the optimiser's grad_scale takes it out again): fp16's range for the wgrad operands
 };
@@ -741,7 +744,12 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
   if (d.llm_hidden % 8 || d.llm_inter % 8 || d.llm_heads % d.llm_kv_heads) return fv_fail(FV_ERR_ARG, "llm dims must be multiples of 8 and heads %% kv_heads == 0");
   if (d.tower_out_dim != 2 * d.tower_dims[d.tower_stages - 1] && d.tower_out_dim != d.tower_dims[d.tower_stages - 1]) return fv_fail(FV_ERR_UNSUPPORTED, "tower_out_dim must be 1x or 2x the last stage dim");
   if (d.llm_precision < 0 || d.llm_precision > 5)
-    return fv_fail(FV_ERR_ARG, "llm_precision must be 0 (bf16), 1 (split-bf16), 2 (split-bf16 qkv/o + fp16 gate/up/down), 3 (fp16 gate/up only), 4 (fp16 down only) or 5 (bf16 hi + fp8 lo)");
+    return fv_fail(FV_ERR_ARG, "llm_precision must be 0 (bf16), 1 (split-bf16), 2 (split-bf16 qkv/o + fp16 gate/up/down) or 5 (bf16 hi + fp8 lo)");
+#ifndef FASTVLA_AB_SWITCHES
+  // 3 (fp16 gate/up only) and 4 (fp16 down only) exist for tools/prec_sweep.py's per-family error budget: the tools build (make AB=1) only
+  if (d.llm_precision == 3 || d.llm_precision == 4)
+    return fv_fail(FV_ERR_UNSUPPORTED, "llm_precision = %d is a measurement mode of the tools build (make AB=1); the product ships 0, 1, 2 and 5", d.llm_precision);
+#endif
   if (d.llm_precision == 5 && (d.llm_hidden % 128 || d.llm_inter % 128 || (d.llm_heads * d.llm_head_dim) % 128))
     return fv_fail(FV_ERR_UNSUPPORTED, "llm_precision = 5 (hi + lo8 operands) needs hidden, inter and heads * head_dim to be multiples of 128");
   if (d.state_dim <= 0 || d.action_dim <= 0 || d.hidden_dim <= 0 || d.fusion_dim <= 0) return fv_fail(FV_ERR_ARG, "head dims must be positive");

@@ -275,8 +275,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
     if (epi == FV_EPI_GELU_GRAD || epi == FV_EPI_MUL_AUX || epi == FV_EPI_F16) {   // the tower backward's fp16 outputs
       if (epi == FV_EPI_GELU_GRAD) {
         float g8[8];
+        gelu_and_grad8(v, g8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gelu_and_grad(v[e], v[e], g8[e]); v[e] = bf2f(f2bf(v[e])); }   // the forward's hidden is a bf16 MFMA operand: the same value here
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));   // the forward's hidden is a bf16 MFMA operand: the same value here
         *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.stash) + (size_t)gm * p.ldo + gn) = pack8_h(g8);
         if (!p.out) continue;
       } else if (epi == FV_EPI_MUL_AUX) {
@@ -681,8 +682,9 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
         if (p.epi == FV_EPI_GELU_GRAD || p.epi == FV_EPI_MUL_AUX || p.epi == FV_EPI_F16) {   // the tower backward's fp16 outputs
           if (p.epi == FV_EPI_GELU_GRAD) {
             float g8[8];
+            gelu_and_grad8(v, g8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { gelu_and_grad(v[e], v[e], g8[e]); v[e] = bf2f(f2bf(v[e])); }   // the forward's hidden is a bf16 MFMA operand: the same value here
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));   // the forward's hidden is a bf16 MFMA operand: the same value here
             *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.stash) + (size_t)gm * p.ldo + gn) = pack8_h(g8);
             if (!p.out) continue;
           } else if (p.epi == FV_EPI_MUL_AUX) {
@@ -960,7 +962,7 @@ static int launch_gemm_tn(const GemmArgs& a, hipStream_t s) {
   if (a.splitk_ws) {
     const double tile_us = (double)nkt * 64.0 * 131072.0 / 1.0e6 / 4.0, part_us = 2.0 * (double)a.M * (tn * 256) * 4.0 / 4.0e6;
     double best = 1e30;
-    for (int sN = 1; sN <= 32; ++sN) {   // (up to 32 ranges: the tower's weight gradients are 1 .. 12 tiles over a contraction of 10^5 .. 10^6 pixels)
+    for (int sN = 1; sN <= 128; ++sN) {   // (up to 128 ranges: the tower's weight gradients are 1 .. 12 tiles over a contraction of 10^5 .. 10^6 pixels)
       if (sN > 1 && (nkt / sN < 16 || (size_t)sN * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes)) break;
       const long units = (long)tiles * sN, rounds = (units + cus - 1) / cus;
       const double t = (double)rounds * tile_us / sN + (sN > 1 ? sN * part_us : 0.0);

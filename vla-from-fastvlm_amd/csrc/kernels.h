@@ -175,13 +175,18 @@ int launch_commit(const CommitDesc* desc_dev, int ndesc, int ntiles, const float
 size_t dw_bwd_scratch_floats(int B, int Ho, int Wo, int Co, int k);
 int launch_dw_dgrad(const bf16_t* dy, const float* w, const bf16_t* res, bf16_t* dx, int B, int Hi, int Wi, int Ci, int k, int stride, int mult, unsigned* sat,
                     hipStream_t s, int round_w = 0);   // round_w: taps rounded to bf16 first (the forward ran on a bf16 Toeplitz table)
+// the same input gradient on the marching MFMA depthwise kernel (stride 1, W >= 16, H >= 16, C % 32 == 0): ttab16 = fp16 Toeplitz table of the flipped taps
+bool dw_dgrad_mfma_supported(int H, int W, int C, int k);
+int launch_dw_dgrad_mfma(const bf16_t* dy, const bf16_t* ttab16, const bf16_t* res, bf16_t* dx, int B, int H, int W, int C, int k, hipStream_t s);
 int launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, float* db, float* scratch, int B, int Hi, int Wi, int Ci, int k, int stride, int mult,
                     hipStream_t s);
-int launch_colsum16(const bf16_t* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s);   // scratch >= COLSUM_CHUNKS * C floats
+constexpr int TOWER_COLSUM_CHUNKS = 512;   // row ranges of the tower backward's column sums (10^5 .. 10^6 rows of 96 .. 1536 columns: the grid must fill the chip)
+int launch_colsum16(const bf16_t* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s);   // scratch >= TOWER_COLSUM_CHUNKS * C floats
 int launch_mul16(const bf16_t* a, const bf16_t* b, bf16_t* out, size_t n, unsigned* sat, hipStream_t s);
 int launch_gelu_grad_mul(const bf16_t* dh, const bf16_t* pre, bf16_t* out, size_t n, unsigned* sat, hipStream_t s);   // out f16 = dh f16 * gelu'(pre bf16)
 int launch_f16_to_f32(const bf16_t* in, float* out, size_t n, float scale, hipStream_t s);
 int launch_scale_to_f16(const float* in, bf16_t* out, size_t n, float scale, unsigned* sat, hipStream_t s);   // out f16 = in * scale (saturating)
+int launch_ones_col(bf16_t* out, int ld, int C, long R, hipStream_t s);   // fp16 rows [R][ld]: columns [C, C + 8) <- {1, 0, ..., 0}
 int launch_ls_grads(const float* dWraw, const float* dbraw, const bf16_t* W, const float* bias, const float* ls, float* dW, float* db, float* dls, int C, int Kd,
                     hipStream_t s);
 size_t ln_bwd_scratch_floats(long rows, int C);
@@ -194,9 +199,12 @@ int launch_se_bwd(const bf16_t* e, const bf16_t* dout, const float* se, const fl
 size_t stem0_wgrad_scratch_floats(int B, int S, int C0);
 int launch_stem0_wgrad(const bf16_t* pix, const float* w, const float* bias, const bf16_t* dh0, float* dw, float* db, float* scratch, int B, int S, int C0,
                        hipStream_t s, int round_w = 0);
+// fp16 patch rows of the stem's dense 3x3 s2 conv: P [B (S/2)^2][32], column (ky*3+kx)*3+ci, column 27 = 1 (the bias tap), 28 .. 31 = 0
+int launch_stem_im2col16(const bf16_t* pix, bf16_t* P, int B, int S, hipStream_t s);
 // fv_train_commit's tower part: one launch over a table of operations (device array, sorted by blk0; a block = 1024 destination elements)
 //   kind 0: dst f32[i] = src[i]      1: dst bf16[i] = src[i]      2: dst bf16[i] = idx[i] >= 0 ? coef[i] * src[idx[i]] : 0   (the packed operand images)
 //   kind 3: dst f16 [cols][rows] = src[rows][cols]^T              4: the same with row r scaled by flat[src2_off + r]         (dgrad operands)
+//   kind 5: as 2 with the value rounded to bf16 first and stored as fp16 (the flipped-tap Toeplitz tables of the depthwise input gradients)
 struct TowerCommitOp {
   long long src_off, src2_off, n;
   void* dst;

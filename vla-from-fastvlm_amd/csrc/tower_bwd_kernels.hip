@@ -14,6 +14,8 @@
 //   se_*                                conv_exp's squeeze-excite + GELU
 //   stem0_wgrad_kernel                  the dense 3x3 stride-2 stem conv (pre-activation recomputed from the pixels)
 //   colsum16 / partial_reduce / ls_grads / mul / gelu_grad_mul / tower_commit  HBM-bound glue
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace fv {
@@ -162,16 +164,209 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const bf16_t* __restrict_
   }
 }
 
+// The stride-1, multiplier-1 form (every RepMixer 3x3, ConvFFN / RepCPE 7x7: 99 % of the tap-gradient work), register-blocked: a thread owns one channel
+// PAIR and walks whole output rows in chunks of 8 pixels -- for each kernel row ky it loads the 8 + K - 1 input values and the 8 gradient values once and does
+// 8 K packed FMAs on them (no per-tap address arithmetic, no integer division in the loop).  part[rb][t][c] as dw_wgrad_kernel.
+template <int K, int S = 1, int MULT = 1>   // H, W: the INPUT map; C: OUTPUT channels (input channel of output channel co: co / MULT); nrows = B * Ho output rows
+__global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int H, int W,
+                                                             int C, int CS, int nslabs, int nrows, int rpb, int Ho, int Wo) {
+  constexpr int PAD = K / 2, NT = K * K + 1, RT = 10, R = 8, NX = (R - 1) * S + K;
+  extern __shared__ __attribute__((aligned(16))) float sr_wr[];   // [RT][NPS][CS]
+  const int slab = blockIdx.x % nslabs;
+  const int rb = blockIdx.x / nslabs;
+  const int hp = CS >> 1, NPS = 256 / hp;
+  const int cp = threadIdx.x % hp, ps = threadIdx.x / hp;
+  const int co = slab * CS + 2 * cp;
+  f32x2 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x2{0.f, 0.f};
+  if (ps < NPS) {
+    const int r1 = (rb + 1) * rpb < nrows ? (rb + 1) * rpb : nrows;
+    const int Ci = C / MULT, ci = co / MULT;
+    for (int row = rb * rpb + ps; row < r1; row += NPS) {
+      const int yo = row % Ho, b = row / Ho;
+      const bf16_t* dyrow = dy + ((size_t)row * Wo) * C + co;
+      for (int x0 = 0; x0 < Wo; x0 += R) {
+        f32x2 d[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t u = x0 + r < Wo ? *reinterpret_cast<const uint32_t*>(dyrow + (size_t)(x0 + r) * C) : 0u;
+          d[r] = f32x2{h2f_lo(u), h2f_hi(u)};
+          acc[K * K] += d[r];
+        }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const int iy = yo * S + ky - PAD;
+          if (iy < 0 || iy >= H) continue;
+          const bf16_t* xrow = x + (((size_t)b * H + iy) * W) * Ci + ci;
+          f32x2 xv[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            const int ix = x0 * S - PAD + i;
+            const bool ok = ix >= 0 && ix < W;
+            if (MULT == 1) {
+              const uint32_t u = ok ? *reinterpret_cast<const uint32_t*>(xrow + (size_t)ix * Ci) : 0u;
+              xv[i] = f32x2{bf_lo(u), bf_hi(u)};
+            } else {   // both outputs of the pair read the same input channel
+              const float v = ok ? bf2f(xrow[(size_t)ix * Ci]) : 0.f;
+              xv[i] = f32x2{v, v};
+            }
+          }
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[ky * K + kx] = __builtin_elementwise_fma(d[r], xv[r * S + kx], acc[ky * K + kx]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r0 = 0; r0 < NT; r0 += RT) {
+    if (ps < NPS) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+        if (r0 + t < NT) *reinterpret_cast<f32x2*>(&sr_wr[(t * NPS + ps) * CS + 2 * cp]) = acc[r0 + t];
+    }
+    __syncthreads();
+    const int nt = NT - r0 < RT ? NT - r0 : RT;
+    for (int i = threadIdx.x; i < nt * CS; i += 256) {
+      const int t = i / CS, c = i % CS;
+      float sm = 0.f;
+      for (int q = 0; q < NPS; ++q) sm += sr_wr[(t * NPS + q) * CS + c];
+      part[((size_t)rb * NT + r0 + t) * C + slab * CS + c] = sm;
+    }
+    __syncthreads();
+  }
+}
+
 // out[i] = sum_p part[p * stride + i] (fixed order), i < n; the first n1 results go to out1, the rest to out2 (taps | bias, dw | db ...)
+// The same stride-1 form with the INPUT tile staged through LDS (round 5; the default): the register-blocked kernel above reads every input row K times from
+// global memory with two waves per SIMD to hide it behind -- it ran at 1/12 of its packed-FMA time.  Here a block = CS channels x NPS consecutive output rows of
+// one image; per 8-column chunk the (NPS + K - 1) x (8 + K - 1) input pixels of the slab go global -> registers -> LDS once (the next chunk's loads in flight
+// under the current chunk's FMAs), every thread reads its K x (8 + K - 1) window as conflict-free dwords, out-of-map pixels are stored as zeros (no bounds
+// checks in the FMA loop).  part[block][t][c] as above.
+template <int K>
+__global__ __launch_bounds__(256, 2) void dw_wgrad_lds_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int H, int W,
+                                                               int C, int CS, int nslabs, int ngroups, int gpb, int gpi, unsigned xbytes) {
+  constexpr int PAD = K / 2, NT = K * K + 1, RT = 10, R = 8, NC = R + K - 1;
+  constexpr int MAXP = 10;                              // 16-byte pieces per thread: NR * NC * CS / 8 / 256 <= (4 + 6) * 14 * 16 / 256 = 8.75
+  extern __shared__ __attribute__((aligned(16))) char sm_wl[];   // two input tiles [NR][NC][CS] bf16 (MAXP * 4 KB each), reused at the end as the fold scratch [RT][NPS][CS] f32
+  float* sR = reinterpret_cast<float*>(sm_wl);
+  const int slab = blockIdx.x % nslabs;
+  const int gb = blockIdx.x / nslabs;
+  const int hp = CS >> 1, NPS = 256 / hp, NR = NPS + K - 1;
+  const int cp = threadIdx.x % hp, ps = threadIdx.x / hp;
+  const int co = slab * CS + 2 * cp;
+  const int c8n = CS >> 3, nchunk16 = NR * NC * c8n;   // 16-byte pieces of a tile
+  const int wv = threadIdx.x >> 6;
+  f32x2 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x2{0.f, 0.f};
+  const int g1 = (gb + 1) * gpb < ngroups ? (gb + 1) * gpb : ngroups;
+  const int ncx = (W + R - 1) / R;
+  // the tile goes global -> LDS by LDS-DMA (no staging registers next to the 100 accumulators): piece idx = (pixel slot, 8-channel group) lands at byte 16 idx;
+  // pixels outside the map read past the descriptor's range and arrive as zeros
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, xbytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  auto issue = [&](int g, int cx, int buf) {
+    const int b = g / gpi, yb = (g % gpi) * NPS, x0 = cx * R;
+    char* base = sm_wl + buf * (MAXP * 4096);
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) {
+      if (q * 256 + wv * 64 < nchunk16) {   // wave-uniform
+        const int idx = threadIdx.x + 256 * q;
+        const int c8 = idx % c8n, slot = idx / c8n;
+        const int col = slot % NC, row = slot / NC;
+        const int iy = yb - PAD + row, ix = x0 - PAD + col;
+        const bool ok = idx < nchunk16 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const uint32_t off = ok ? (uint32_t)(((((size_t)b * H + iy) * W + ix) * C + slab * CS + c8 * 8) * 2) : 0xfffffff0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(base + (q * 256 + wv * 64) * 16), 16, off, 0, 0, 0);
+      }
+    }
+  };
+  auto load_d = [&](int g, int cx, uint32_t (&dn)[R]) {
+    const int b = g / gpi, yo = (g % gpi) * NPS + ps, x0 = cx * R;
+    const bool rowok = ps < NPS && yo < H;
+    const bf16_t* dyrow = dy + (((size_t)b * H + (rowok ? yo : 0)) * W) * C + co;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dn[r] = (rowok && x0 + r < W) ? *reinterpret_cast<const uint32_t*>(dyrow + (size_t)(x0 + r) * C) : 0u;
+  };
+  int g = gb * gpb, cx = 0, buf = 0;
+  uint32_t dcur[R], dnext[R];
+  if (g < g1) { issue(g, 0, 0); load_d(g, 0, dcur); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  while (g < g1) {
+    int gn = g, cxn = cx + 1;
+    if (cxn == ncx) { cxn = 0; gn = g + 1; }
+    const bool more = gn < g1;
+    if (more) { issue(gn, cxn, buf ^ 1); load_d(gn, cxn, dnext); }
+    {
+      const bf16_t* sX = reinterpret_cast<const bf16_t*>(sm_wl + buf * (MAXP * 4096));
+      if (ps < NPS) {
+        f32x2 d[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          d[r] = f32x2{h2f_lo(dcur[r]), h2f_hi(dcur[r])};
+          acc[K * K] += d[r];
+        }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          f32x2 xv[NC];
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            const uint32_t u = *reinterpret_cast<const uint32_t*>(sX + ((size_t)((ps + ky) * NC + i)) * CS + 2 * cp);
+            xv[i] = f32x2{bf_lo(u), bf_hi(u)};
+          }
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[ky * K + kx] = __builtin_elementwise_fma(d[r], xv[r + kx], acc[ky * K + kx]);
+          __builtin_amdgcn_sched_barrier(0);   // one kernel row's window at a time (hoisting the next rows' LDS reads over these FMAs spills)
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile (and the next gradient values) have landed ...
+    __syncthreads();                                     // ... for everybody, and nobody still reads this one
+#pragma unroll
+    for (int r = 0; r < R; ++r) dcur[r] = dnext[r];
+    g = gn; cx = cxn; buf ^= 1;
+  }
+#pragma unroll
+  for (int r0 = 0; r0 < NT; r0 += RT) {
+    if (ps < NPS) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+        if (r0 + t < NT) *reinterpret_cast<f32x2*>(&sR[(t * NPS + ps) * CS + 2 * cp]) = acc[r0 + t];
+    }
+    __syncthreads();
+    const int nt = NT - r0 < RT ? NT - r0 : RT;
+    for (int i = threadIdx.x; i < nt * CS; i += 256) {
+      const int t = i / CS, c = i % CS;
+      float sm = 0.f;
+      for (int q = 0; q < NPS; ++q) sm += sR[(t * NPS + q) * CS + c];
+      part[((size_t)gb * NT + r0 + t) * C + slab * CS + c] = sm;
+    }
+    __syncthreads();
+  }
+}
+
+// (a block = 64 outputs x 4 part lanes: each lane sums every fourth partial in order, the four are folded in order -- a fixed association)
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, long nparts, long stride, long n, long n1, float* __restrict__ out1,
                                                               float* __restrict__ out2, float scale) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float sp[4][64];
+  const int li = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + li;
   float s = 0.f;
-  for (long p = 0; p < nparts; ++p) s += part[p * stride + i];
-  s *= scale;
-  if (i < n1) out1[i] = s;
-  else out2[i - n1] = s;
+  if (i < n)
+    for (long p = pl; p < nparts; p += 4) s += part[p * stride + i];
+  sp[pl][li] = s;
+  __syncthreads();
+  if (pl == 0 && i < n) {
+    s = ((sp[0][li] + sp[1][li]) + (sp[2][li] + sp[3][li])) * scale;
+    if (i < n1) out1[i] = s;
+    else out2[i - n1] = s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ column sums of fp16 rows
@@ -221,8 +416,10 @@ __global__ __launch_bounds__(256) void gelu_grad_mul_kernel(const bf16_t* __rest
   float x[8], a[8];
   unpack8_h(*reinterpret_cast<const uint4*>(dh + i * 8), x);
   unpack8(*reinterpret_cast<const uint4*>(pre + i * 8), a);
+  float dg8[8];
+  gelu_and_grad8(a, dg8);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { float g, dg; gelu_and_grad(a[e], g, dg); x[e] *= dg; }
+  for (int e = 0; e < 8; ++e) x[e] *= dg8[e];
   count_f16_sat8(x, sat);
   *reinterpret_cast<uint4*>(out + i * 8) = pack8_h(x);
 }
@@ -235,6 +432,12 @@ __global__ __launch_bounds__(256) void f16_to_f32_kernel(const bf16_t* __restric
   *reinterpret_cast<float4*>(out + i * 8 + 4) = make_float4(x[4] * scale, x[5] * scale, x[6] * scale, x[7] * scale);
 }
 
+// columns [C, C + 8) of fp16 rows [R][ld] <- {1, 0, ..., 0}: the ones column that makes a TN weight gradient deliver its bias gradient too
+__global__ __launch_bounds__(256) void ones_col_kernel(bf16_t* __restrict__ out, int ld, int C, long R) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  *reinterpret_cast<uint4*>(out + r * ld + C) = make_uint4(0x00003c00u, 0u, 0u, 0u);   // fp16 1.0 = 0x3c00
+}
 __global__ __launch_bounds__(256) void scale_to_f16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n8, float scale, unsigned* sat) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;
@@ -675,12 +878,13 @@ __global__ __launch_bounds__(384) void stem0_wgrad_kernel(const bf16_t* __restri
   for (int k = 0; k < 28; ++k) acc[k] = 0.f;
   const float bv = bias[co];
   if (ps < NPS) {
-    const long p0 = (long)blockIdx.x * ppb, p1 = p0 + ppb < npix ? p0 + ppb : npix;
-    for (long p = p0 + ps; p < p1; p += NPS) {
-      const int ox = (int)(p % So);
-      const long t = p / So;
-      const int oy = (int)(t % So);
-      const long b = t / So;
+    // (ppb = rows per block here: the block walks whole output rows, its slices interleaved along a row -- no division per pixel)
+    const long rows = npix / So, r0 = (long)blockIdx.x * ppb, r1 = r0 + ppb < rows ? r0 + ppb : rows;
+    for (long row = r0; row < r1; ++row) {
+      const int oy = (int)(row % So);
+      const long b = row / So;
+      for (int ox = ps; ox < So; ox += NPS) {
+      const long p = row * So + ox;
       float pt[27];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
@@ -699,13 +903,14 @@ __global__ __launch_bounds__(384) void stem0_wgrad_kernel(const bf16_t* __restri
       float a0 = bv;
 #pragma unroll
       for (int k = 0; k < 27; ++k) a0 += wr[k] * pt[k];
-      float gl, dg;
-      gelu_and_grad(a0, gl, dg);
+      f32x2 gl, dg2;
+      gelu_and_grad2((f32x2){a0, 0.f}, gl, dg2);
       const _Float16 hv = __builtin_bit_cast(_Float16, dh0[p * C0 + co]);
-      const float d = (float)hv * dg;
+      const float d = (float)hv * dg2.x;
 #pragma unroll
       for (int k = 0; k < 27; ++k) acc[k] += d * pt[k];
       acc[27] += d;
+      }
     }
   }
   if (ps < NPS) {
@@ -718,6 +923,37 @@ __global__ __launch_bounds__(384) void stem0_wgrad_kernel(const bf16_t* __restri
     for (int q = 0; q < NPS; ++q) s += sr_st[(size_t)q * 28 * C0 + i];
     part[(size_t)blockIdx.x * 28 * C0 + i] = s;
   }
+}
+
+// The MFMA route to the same gradients (round 5, default where the GEMM kernels take the shapes): the 27-tap patches of every output pixel as fp16 rows
+// P [B (S/2)^2][32] (column 27 = 1: the bias tap; 28 .. 31 = 0), so that a0 = P . [w | b]^T is an NT GEMM (FV_EPI_GELU_GRAD leaves gelu'(a0)) and
+// [dW | db] = P^T . (dh0 gelu'(a0)) a TN GEMM over the pixels.  thread = one output pixel (64 bytes written)
+__global__ __launch_bounds__(256) void stem_im2col16_kernel(const bf16_t* __restrict__ pix, bf16_t* __restrict__ P, int S, long npix) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  const int So = S >> 1;
+  const int ox = (int)(p % So);
+  const long t = p / So;
+  const int oy = (int)(t % So);
+  const long b = t / So;
+  float v[32];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - 1 + kx;
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      if (iy >= 0 && iy < S && ix >= 0 && ix < S) {
+        const uint2 u = *reinterpret_cast<const uint2*>(pix + ((b * S + iy) * S + ix) * 4);
+        c0 = bf_lo(u.x); c1 = bf_hi(u.x); c2 = bf_lo(u.y);
+      }
+      v[(ky * 3 + kx) * 3 + 0] = c0; v[(ky * 3 + kx) * 3 + 1] = c1; v[(ky * 3 + kx) * 3 + 2] = c2;
+    }
+  }
+  v[27] = 1.0f; v[28] = v[29] = v[30] = v[31] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(P + p * 32 + q * 8) = pack8_h(v + q * 8);
 }
 
 // ------------------------------------------------------------------------------------------------ fv_train_commit, tower part
@@ -744,6 +980,13 @@ __global__ __launch_bounds__(256) void tower_commit_kernel(const TowerCommitOp* 
         static_cast<bf16_t*>(op.dst)[i] = j >= 0 ? f2bf(op.coef[i] * src[j]) : (bf16_t)0;
         break;
       }
+      case 5: case 6: {   // packed image as fp16; 5: of the taps at the precision the forward holds them (bf16)
+        const int j = op.idx[i];
+        float v = j >= 0 ? op.coef[i] * src[j] : 0.f;
+        if (op.kind == 5) v = bf2f(f2bf(v));
+        static_cast<bf16_t*>(op.dst)[i] = __builtin_bit_cast(bf16_t, (_Float16)__builtin_amdgcn_fmed3f(v, -FV_F16_MAX, FV_F16_MAX));
+        break;
+      }
       default: {   // 3: dst f16 [cols][rows] = src[rows][cols]^T; 4: the same with row r of src scaled by flat[src2_off + r]
         const long j = i / op.rows, r = i % op.rows;
         float v = src[r * op.cols + j];
@@ -757,6 +1000,7 @@ __global__ __launch_bounds__(256) void tower_commit_kernel(const TowerCommitOp* 
 }
 
 inline unsigned grid1(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+inline unsigned gridr(long n) { return grid1(n, 64); }   // partial_reduce_kernel: 64 outputs per block
 
 }  // namespace
 
@@ -768,11 +1012,21 @@ static int pick_slab(int C, int cap) {   // largest multiple of 8 that divides C
   return best;
 }
 
+// row blocks of dw_wgrad_rows_kernel: enough blocks to fill the chip several times over (a block is 256 threads of ~170 registers: 2 .. 3 per CU), at least one
+// output row per slice of a block
+static int dw_wgrad_row_blocks(int nrows, int NPS, int nslabs) {
+  int nrb = nrows / NPS;
+  const int cap = 3072 / nslabs;
+  if (nrb > cap) nrb = cap;
+  return nrb < 1 ? 1 : nrb;
+}
 size_t dw_bwd_scratch_floats(int B, int Ho, int Wo, int Co, int k) {
   const long npix = (long)B * Ho * Wo;
   long npb = (npix + 255) / 256;
   if (npb > 512) npb = 512;
-  return (size_t)npb * (k * k + 1) * Co;
+  const int CS = pick_slab(Co, 128);
+  const long nrb = dw_wgrad_row_blocks(B * Ho, 256 / (CS / 2), Co / CS) + 1;
+  return (size_t)std::max(npb, nrb) * (k * k + 1) * Co;
 }
 
 // input gradient of a depthwise / channel-multiplier conv: dy fp16 (B,Ho,Wo,Ci*mult) -> dx fp16 (B,Hi,Wi,Ci) (+ res fp16); w fp32 tap-major [k*k][Ci*mult]
@@ -810,6 +1064,53 @@ int launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, float* db, flo
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
   const int CS = pick_slab(Co, 128);
   const int nslabs = Co / CS, NPS = 256 / (CS / 2), NT = k * k + 1;
+  if ((k == 3 || k == 7) && stride == 1 && mult == 1 && Wi >= 8 && CS >= 32) {   // the LDS-staged form (dw_wgrad_lds_kernel)
+    const int NPSl = 256 / (CS / 2);
+    const int gpi = (Hi + NPSl - 1) / NPSl, ngroups = B * gpi;
+    // two blocks are resident per CU (190 registers, 80 KB of LDS each): 512 blocks are ONE round of a 256-CU chip, and every block more is another partial-sum
+    // row for the reduce pass to read
+    int nb = 512 / nslabs;
+    if (nb < 1) nb = 1;
+    if (nb > ngroups) nb = ngroups;
+    const int gpb = (ngroups + nb - 1) / nb;
+    nb = (ngroups + gpb - 1) / gpb;
+    const int NR = NPSl + k - 1, NCc = 8 + k - 1;
+    const size_t xb = (size_t)B * Hi * Wi * Ci * 2;
+    if ((long)NR * NCc * (CS / 8) <= 256L * 10 && xb < 0xfffffff0ull) {
+      const size_t lds = 2 * 10 * 4096;   // two tiles of up to 10 x 256 16-byte pieces (>= the fold scratch: 10 x 256 x 2 floats)
+      static bool attr = false;
+      if (!attr) {
+        FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_lds_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_lds_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+      }
+      const dim3 grid((unsigned)(nb * nslabs));
+      if (k == 7) hipLaunchKernelGGL((dw_wgrad_lds_kernel<7>), grid, dim3(256), lds, s, x, dy, scratch, Hi, Wi, Ci, CS, nslabs, ngroups, gpb, gpi, (unsigned)xb);
+      else hipLaunchKernelGGL((dw_wgrad_lds_kernel<3>), grid, dim3(256), lds, s, x, dy, scratch, Hi, Wi, Ci, CS, nslabs, ngroups, gpb, gpi, (unsigned)xb);
+      const long n = (long)NT * Co;
+      hipLaunchKernelGGL(partial_reduce_kernel, dim3(gridr(n)), dim3(256), 0, s, scratch, (long)nb, n, n, (long)k * k * Co, dw, db, 1.0f);
+      FV_HIP_CHECK(hipGetLastError());
+      return FV_OK;
+    }
+  }
+  if ((k == 3 || k == 7) && Wo >= 8) {   // whole rows per thread (dw_wgrad_rows_kernel)
+    const int nrows = B * Ho;
+    const int nrb0 = dw_wgrad_row_blocks(nrows, NPS, nslabs);
+    const int rpb = (nrows + nrb0 - 1) / nrb0;
+    const int nrb = (nrows + rpb - 1) / rpb;
+    const size_t lds = (size_t)10 * NPS * CS * 4;
+    const dim3 grid((unsigned)(nrb * nslabs));
+#define FV_WR(K_, S_, M_)                                                                                                                                  \
+  if (k == K_ && stride == S_ && mult == M_) {                                                                                                             \
+    hipLaunchKernelGGL((dw_wgrad_rows_kernel<K_, S_, M_>), grid, dim3(256), lds, s, x, dy, scratch, Hi, Wi, Co, CS, nslabs, nrows, rpb, Ho, Wo);           \
+    const long n = (long)NT * Co;                                                                                                                          \
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(gridr(n)), dim3(256), 0, s, scratch, (long)nrb, n, n, (long)k * k * Co, dw, db, 1.0f);                 \
+    FV_HIP_CHECK(hipGetLastError());                                                                                                                       \
+    return FV_OK;                                                                                                                                          \
+  }
+    FV_WR(3, 1, 1) FV_WR(7, 1, 1) FV_WR(3, 2, 1) FV_WR(7, 2, 2) FV_WR(3, 1, 2)
+#undef FV_WR
+  }
   const long npix = (long)B * Ho * Wo;
   long npb = (npix + 255) / 256;
   if (npb > 512) npb = 512;
@@ -821,7 +1122,7 @@ int launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, float* db, flo
   if (k == K_ && stride == S_ && mult == M_) {                                                                                     \
     hipLaunchKernelGGL((dw_wgrad_kernel<K_, S_, M_>), grid, dim3(256), lds, s, x, dy, scratch, Hi, Wi, Ci, Ho, Wo, CS, nslabs, npix, ppb); \
     const long n = (long)NT * Co;                                                                                                   \
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(grid1(n)), dim3(256), 0, s, scratch, npb, n, n, (long)k * k * Co, dw, db, 1.0f); \
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(gridr(n)), dim3(256), 0, s, scratch, npb, n, n, (long)k * k * Co, dw, db, 1.0f); \
     FV_HIP_CHECK(hipGetLastError());                                                                                               \
     return FV_OK;                                                                                                                  \
   }
@@ -830,15 +1131,15 @@ int launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, float* db, flo
   return fv_fail(FV_ERR_UNSUPPORTED, "dw_wgrad: unsupported k=%d stride=%d mult=%d", k, stride, mult);
 }
 
-// out[c] = sum_r in[r][c] over fp16 rows; scratch >= COLSUM_CHUNKS * C floats
+// out[c] = sum_r in[r][c] over fp16 rows; scratch >= TOWER_COLSUM_CHUNKS * C floats
 int launch_colsum16(const bf16_t* in, int ld, long R, int C, float* out, float* scratch, hipStream_t s) {
   if (!in || !out || !scratch || R <= 0 || C <= 0 || C % 8 || ld % 8) return fv_fail(FV_ERR_ARG, "colsum16: bad argument");
   long nch = (R + 63) / 64;
-  if (nch > COLSUM_CHUNKS) nch = COLSUM_CHUNKS;
+  if (nch > TOWER_COLSUM_CHUNKS) nch = TOWER_COLSUM_CHUNKS;
   const long rpc = (R + nch - 1) / nch;
   nch = (R + rpc - 1) / rpc;
   hipLaunchKernelGGL(colsum16_kernel, dim3((C + 255) / 256, (unsigned)nch), dim3(256), 0, s, in, ld, R, C, scratch, rpc);
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3(grid1(C)), dim3(256), 0, s, scratch, nch, (long)C, (long)C, (long)C, out, out, 1.0f);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(gridr(C)), dim3(256), 0, s, scratch, nch, (long)C, (long)C, (long)C, out, out, 1.0f);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -867,6 +1168,12 @@ int launch_scale_to_f16(const float* in, bf16_t* out, size_t n, float scale, uns
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
+int launch_ones_col(bf16_t* out, int ld, int C, long R, hipStream_t s) {
+  if (!out || ld < C + 8 || ld % 8 || C % 8 || R <= 0) return fv_fail(FV_ERR_ARG, "ones_col: bad argument");
+  hipLaunchKernelGGL(ones_col_kernel, dim3(grid1(R)), dim3(256), 0, s, out, ld, C, R);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
 int launch_ls_grads(const float* dWraw, const float* dbraw, const bf16_t* W, const float* bias, const float* ls, float* dW, float* db, float* dls, int C, int Kd,
                     hipStream_t s) {
   if (!dWraw || !dbraw || !W || !bias || !ls || !dW || !db || !dls) return fv_fail(FV_ERR_ARG, "ls_grads: null pointer");
@@ -889,7 +1196,7 @@ int launch_ln_bwd(const bf16_t* x, const bf16_t* dy, const float* w, const bf16_
   const int rpb = (int)((rows + nb - 1) / nb);
   nb = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, dy, w, res, dx, scratch, rows, C, eps, rpb, sat);
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3(grid1(2L * C)), dim3(256), 0, s, scratch, nb, 2L * C, 2L * C, (long)C, dw, db, 1.0f);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(gridr(2L * C)), dim3(256), 0, s, scratch, nb, 2L * C, 2L * C, (long)C, dw, db, 1.0f);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -937,8 +1244,7 @@ int launch_se_bwd(const bf16_t* e, const bf16_t* dout, const float* se, const fl
 }
 
 size_t stem0_wgrad_scratch_floats(int B, int S, int C0) {
-  const long npix = (long)B * (S / 2) * (S / 2);
-  long nb = (npix + 255) / 256;
+  long nb = (long)B * (S / 2);
   if (nb > 1024) nb = 1024;
   return (size_t)nb * 28 * C0;
 }
@@ -947,15 +1253,23 @@ int launch_stem0_wgrad(const bf16_t* pix, const float* w, const float* bias, con
                        hipStream_t s, int round_w) {
   if (!pix || !w || !bias || !dh0 || !dw || !db || !scratch) return fv_fail(FV_ERR_ARG, "stem0_wgrad: null pointer");
   if (B <= 0 || S < 2 || (S & 1) || C0 < 8 || C0 > 384) return fv_fail(FV_ERR_UNSUPPORTED, "stem0_wgrad: bad shape S=%d C0=%d", S, C0);
-  const long npix = (long)B * (S / 2) * (S / 2);
-  long nb = (npix + 255) / 256;
+  const long npix = (long)B * (S / 2) * (S / 2), rows = (long)B * (S / 2);
+  long nb = rows;
   if (nb > 1024) nb = 1024;
-  const long ppb = (npix + nb - 1) / nb;
-  nb = (npix + ppb - 1) / ppb;
+  const long ppb = (rows + nb - 1) / nb;   // rows per block
+  nb = (rows + ppb - 1) / ppb;
   const int NPS = 384 / C0;
   hipLaunchKernelGGL(stem0_wgrad_kernel, dim3((unsigned)nb), dim3(384), (size_t)NPS * 28 * C0 * 4, s, pix, w, bias, dh0, scratch, S, C0, npix, ppb, round_w);
   const long n = 28L * C0;
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3(grid1(n)), dim3(256), 0, s, scratch, nb, n, n, 27L * C0, dw, db, 1.0f);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(gridr(n)), dim3(256), 0, s, scratch, nb, n, n, 27L * C0, dw, db, 1.0f);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+int launch_stem_im2col16(const bf16_t* pix, bf16_t* P, int B, int S, hipStream_t s) {
+  if (!pix || !P || B <= 0 || S < 2 || (S & 1)) return fv_fail(FV_ERR_ARG, "stem_im2col16: bad argument");
+  const long npix = (long)B * (S / 2) * (S / 2);
+  hipLaunchKernelGGL(stem_im2col16_kernel, dim3(grid1(npix)), dim3(256), 0, s, pix, P, S, npix);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

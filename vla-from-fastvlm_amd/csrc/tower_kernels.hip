@@ -917,10 +917,14 @@ __global__ __launch_bounds__(256, 2) void dwconv_s2_mfma_kernel(const bf16_t* __
 #ifndef DW_MARCH_OCC
 #define DW_MARCH_OCC 2
 #endif
-template <int K>
+// GRAD (round 5, the tower's backward): the same march as the INPUT-GRADIENT of a stride-1 depthwise conv -- x = dL/dy as fp16, ttab = the Toeplitz table of the
+// FLIPPED taps as fp16 (correlation = convolution with the mirrored kernel under "same" padding), products on v_mfma_f32_4x4x4_16b_f16, no bias / GELU, the
+// result (+ the fp16 residual `res`: dL/dx' = G + dw7^T(dL/dt)) written as fp16.  Everything between the loads and the stores moves 16-bit cells and does not care.
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+template <int K, bool GRAD = false>
 __global__ __launch_bounds__(256, DW_MARCH_OCC) void dwconv_march_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ttab,
                                                                const float* __restrict__ bias, bf16_t* __restrict__ y,
-                                                               int H, int W, int C, int gelu, int tiles_x, int nslices) {
+                                                               int H, int W, int C, int gelu, int tiles_x, int nslices, const bf16_t* __restrict__ res = nullptr) {
   constexpr int TW = 32, PAD = K / 2, IW = TW + K - 1;
   constexpr int NQ = (IW + 3) / 4, NM = (K + 3 + 3) / 4;
   constexpr int RS = NQ * 256 + 64, RSO = 8 * 256 + 64;        // ring / output-tile row strides (== 64 mod 256)
@@ -950,7 +954,7 @@ __global__ __launch_bounds__(256, DW_MARCH_OCC) void dwconv_march_kernel(const b
 #pragma unroll
       for (int m = 0; m < NM; ++m) afr[ky][m] = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(tsrc + (ky * NM + m) * 512));
   }
-  const float bv = bias[c0 + gg * 16 + bch];
+  const float bv = GRAD ? 0.f : bias[c0 + gg * 16 + bch];
 
   // one unit = 8 rows x NQ quads x 4 channel groups of (4 pixels x 8 channels) tasks
   constexpr int NTASK = 8 * NQ * 4, TPT = (NTASK + 255) / 256;
@@ -1020,7 +1024,10 @@ __global__ __launch_bounds__(256, DW_MARCH_OCC) void dwconv_march_kernel(const b
       for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          if (q + m < NQ) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[q + m], acc[q], 0, 0, 0);
+          if (q + m < NQ) {
+            if constexpr (GRAD) acc[q] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4_t, afr[ky][m]), __builtin_bit_cast(f16x4_t, xq[q + m]), acc[q], 0, 0, 0);
+            else acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(afr[ky][m], xq[q + m], acc[q], 0, 0, 0);
+          }
     }
     __syncthreads();   // every wave is done with unit g - 1: its ring rows take unit g + 1
 #if DW_MARCH_OCC >= 3
@@ -1042,8 +1049,8 @@ __global__ __launch_bounds__(256, DW_MARCH_OCC) void dwconv_march_kernel(const b
           if (gelu) v[i] = gelu_f(v[i]);
         }
         uint2 u;
-        u.x = pack_bf2(v[0], v[1]);
-        u.y = pack_bf2(v[2], v[3]);
+        if constexpr (GRAD) { u.x = pack_h2(v[0], v[1]); u.y = pack_h2(v[2], v[3]); }
+        else { u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); }
         *reinterpret_cast<uint2*>(orow + sw[q & 3] + q * 256) = u;
       }
     }
@@ -1065,6 +1072,16 @@ __global__ __launch_bounds__(256, DW_MARCH_OCC) void dwconv_march_kernel(const b
 #define FV_PX(A, B) __builtin_amdgcn_perm((j & 2) ? r[B].y : r[B].x, (j & 2) ? r[A].y : r[A].x, sel)
             o.x = FV_PX(0, 1); o.y = FV_PX(2, 3); o.z = FV_PX(4, 5); o.w = FV_PX(6, 7);
 #undef FV_PX
+            if constexpr (GRAD) {
+              if (res) {   // + the residual branch's gradient (a second fp16 rounding of the sum: 2^-12)
+                float a8[8], r8[8];
+                unpack8_h(o, a8);
+                unpack8_h(*reinterpret_cast<const uint4*>(res + (((size_t)b * H + oy) * W + ox0 + j) * C + c0 + cg * 8), r8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] += r8[e];
+                o = pack8_h(a8);
+              }
+            }
             *reinterpret_cast<uint4*>(yp + (size_t)j * C) = o;
           }
         }
@@ -1756,6 +1773,21 @@ int launch_dwconv_mfma(const bf16_t* x, const bf16_t* ttab, const float* bias, b
   if (k == 7 && th == 16) hipLaunchKernelGGL((dwconv_mfma_kernel<7, 16>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
   else if (k == 7) hipLaunchKernelGGL((dwconv_mfma_kernel<7, 8>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
   else hipLaunchKernelGGL((dwconv_mfma_kernel<3, 8>), dim3((unsigned)nblk), dim3(256), 0, s, x, ttab, bias, y, H, W, C, gelu, tiles_x, tiles_y, nsl);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+// input gradient of a stride-1 depthwise k x k conv on the marching MFMA kernel: dy fp16 (B,H,W,C), ttab16 = fp16 Toeplitz table of the FLIPPED taps
+// (dwconv_toeplitz_pack of w[k-1-ky][k-1-kx]), res = optional fp16 residual added to the result; dx fp16
+bool dw_dgrad_mfma_supported(int H, int W, int C, int k) { return dwconv_mfma_supported(W, C, k, 1, 1) && H >= 16; }
+int launch_dw_dgrad_mfma(const bf16_t* dy, const bf16_t* ttab16, const bf16_t* res, bf16_t* dx, int B, int H, int W, int C, int k, hipStream_t s) {
+  if (!dy || !ttab16 || !dx) return fv_fail(FV_ERR_ARG, "dw_dgrad_mfma: null pointer");
+  if (B <= 0 || !dw_dgrad_mfma_supported(H, W, C, k)) return fv_fail(FV_ERR_UNSUPPORTED, "dw_dgrad_mfma: unsupported shape H=%d W=%d C=%d k=%d", H, W, C, k);
+  const int tiles_x = (W + 31) / 32, nsl = C / 32;
+  const long nstrips = (long)B * tiles_x * nsl;
+  if (nstrips > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dw_dgrad_mfma: grid too large");
+  if (k == 7) hipLaunchKernelGGL((dwconv_march_kernel<7, true>), dim3((unsigned)nstrips), dim3(256), 0, s, dy, ttab16, static_cast<const float*>(nullptr), dx, H, W, C, 0, tiles_x, nsl, res);
+  else hipLaunchKernelGGL((dwconv_march_kernel<3, true>), dim3((unsigned)nstrips), dim3(256), 0, s, dy, ttab16, static_cast<const float*>(nullptr), dx, H, W, C, 0, tiles_x, nsl, res);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

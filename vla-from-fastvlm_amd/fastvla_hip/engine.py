@@ -471,7 +471,7 @@ class FastVLAEngine:
     def train_set_options(self, grad_split: Optional[int] = None, wgrad_f16: Optional[bool] = None, loss_scale_log2: Optional[int] = None,
                           keep: bool = False) -> None:
         """Arithmetic of the backward's contractions (fv_train_set_options).  grad_split: dgrad's gradient operand -- 2 (default) ONE fp16 pass against
-        fp16 transposed weights, 1 split bf16 (two passes, the most exact), 0 plain bf16 (one pass at 8 bits: ~3e-3 gradients, outside the bar);
+        fp16 transposed weights, 1 split bf16 (two passes, the most exact);
         wgrad_f16=False: weight gradients as split-bf16 gradient x bf16 activation (two passes) instead of ONE fp16 pass;
         loss_scale_log2: every gradient of train_forward_backward carries 2^k (train_loss_scale()): divide it out in the optimiser's grad_scale.
         An argument left None takes its default -- or, with keep=True, the value of the previous call (to change one knob only)."""
@@ -480,7 +480,7 @@ class FastVLAEngine:
         for k, v in (("grad_split", grad_split), ("wgrad_f16", wgrad_f16), ("loss_scale_log2", loss_scale_log2)):
             if v is not None:
                 opts[k] = v
-        _lib.check(self.lib.fv_train_set_options(self.h, int(opts["grad_split"]), int(opts["wgrad_f16"]), int(opts["loss_scale_log2"])),   # wgrad_f16: False / True or 0 / 1 / 2 (2 = fp16 on transposed copies)
+        _lib.check(self.lib.fv_train_set_options(self.h, int(opts["grad_split"]), int(opts["wgrad_f16"]), int(opts["loss_scale_log2"])),   # wgrad_f16: False / True
                    "fv_train_set_options", self.h)
         self._train_options = opts
 
