@@ -270,6 +270,12 @@ int fv_train_commit(fv_handle* h, const float* flat_params, fv_stream s);
  *              grad_scale = 2^-k / world to fv_adamw_clip_step (fv_train_loss_scale returns 2^k).  The loss itself is not scaled. */
 int fv_train_set_options(fv_handle* h, int grad_split, int wgrad_f16, int loss_scale_log2);
 int fv_train_loss_scale(fv_handle* h, float* scale_out);
+/* on != 0: the TRAINING forward's four projections per layer in ONE fp16 pass (normed rows / attention output / SwiGLU output rounded once to 11 significant bits
+ * against exact fp16 copies of the bf16 weights; down's copy carries 2^4) instead of the split-bf16 form's two -- half the forward's MFMA work; everything the
+ * backward differentiates is kept as before.  The inference entry points do not change.  Needs the default fp16 backward.
+ * OPT-IN, outside the 1e-3 bar: through all 24 layers of the 0.5B decoder actions sit 1.0e-3 and gradients up to 2.1e-3 from fp32 autograd (default forward:
+ * 1.2e-5 / 8.4e-4; tests/test_gpu_train_unfrozen.py). */
+int fv_train_set_forward_f16(fv_handle* h, int on);
 int fv_train_workspace_bytes(fv_handle* h, int B, int T, size_t* out_bytes);
 /* called from inside fv_train_forward_backward, on the calling thread, right after the LAST kernel that writes bucket `bucket`'s gradient
  * has been enqueued on the stream: flat_grads[offset, offset + numel) is final once the stream reaches this point (record an event here and

@@ -196,6 +196,24 @@ def test_unfrozen_step_matches_autograd(name, llm, tower, B, T, hd):
         print(f"[unfrozen {name}] + two-pass split-bf16 wgrad: worst gradient {w2p[0]} {w2p[1]:.2e}")
         eng.train_set_options()
     assert ra <= 1e-3 and rl <= 1e-3
+    # the one-pass fp16 TRAINING forward (fv_train_set_forward_f16: half the forward's MFMA work): loss, actions and every gradient against the same fp32 oracle.
+    # MEASURED OUTSIDE the 1e-3 bar at full depth (actions 1.0e-3, 231 of 306 gradients between 1e-3 and 2.1e-3): an opt-in speed knob, never the default;
+    # what is asserted is its own envelope (actions 2e-3, gradients 2.5e-3)
+    eng.train_set_forward_f16(True)
+    act16, loss16, g16 = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+    torch.cuda.synchronize()
+    ra16, rl16 = rel_l2(act16.cpu(), ref["pred"]), abs(float(loss16) - float(ref["loss"])) / float(ref["loss"])
+    got16 = eng.train_named_tensors(g16 / eng.train_loss_scale())
+    e16 = sorted(((rel_l2(v.cpu(), ref["grads"][k]), k) for k, v in got16.items() if float(ref["grads"][k].norm()) > 1e-12), reverse=True)
+    print(f"[unfrozen {name}] fp16 training forward: actions rel_l2={ra16:.2e} loss rel={rl16:.2e}; worst gradients: " + "; ".join(f"{k} {e:.2e}" for e, k in e16[:5])
+          + f"; tensors above 1e-3: {sum(1 for e, _ in e16 if e > 1e-3)} of {len(e16)} ({eng.fp16_saturations()} saturations)")
+    assert ra16 <= 2e-3 and rl16 <= 1e-3
+    for e, k in e16:
+        assert e <= 2.5e-3, f"fp16 training forward: gradient of {k}: rel_l2 {e:.3e}"
+    eng.train_set_forward_f16(False)
+    act1b, loss1b, g1b = eng.train_forward_backward(flat, tower_out.to(DEV), ids, mask.sum(1), states, targets, ws, training=False, flat_grads=torch.zeros_like(flat))
+    torch.cuda.synchronize()
+    assert torch.equal(g1b, grads) and torch.equal(act1b, act)      # switching back restores the split-bf16 forward bit for bit
     # buckets: head first, then final norm, layers last to first, embedding, projector; together they tile the flat buffer exactly once
     L = model.llm.layers
     assert [b for b, _, _ in order] == [0, 3 + L] + [3 + l for l in range(L - 1, -1, -1)] + [2, 1]
@@ -479,10 +497,10 @@ def test_trainer_fit_with_the_backbone_unfrozen_saves_and_resumes(tmp_path, towe
     torch.cuda.synchronize()
     assert tc.global_step == 4 and c._unfrozen.step_count == 4
     fa, fc = a._unfrozen.flat, c._unfrozen.flat
-    # the checkpoint holds the fp32 master of the decoder / projector / head exactly; a trained tower goes through its checkpoint form (folded conv + identity
-    # BatchNorm: one fp32 rounding of the fold) -- so the resumed run equals the uninterrupted one to fp32 rounding, not bit for bit
+    # optimizer.pt carries the fp32 master itself beside m / v (the VLM tensors of policy_state_dict.pt go through the engine's bf16 operand copies: a master rebuilt
+    # from THEM would lose the residue that the next updates, 1e-3 of a bf16 ulp each, live in): the resumed run IS the uninterrupted one
     e = rel_l2(fc.cpu(), fa.cpu())
     print(f"[Trainer.fit unfrozen, tower={tower}] resumed vs uninterrupted master after 4 steps: rel_l2 {e:.2e}")
-    assert e <= (1e-6 if not tower else 1e-5)
+    assert "flat" in opt and torch.equal(fc, fa)
     for p_ in (a, b, c):
         p_.model.backbone.engine().close()

@@ -79,6 +79,7 @@ struct Tower {
 struct TrainLayerT {   // transposed weight copies (dgrad operands): bf16, and fp16 for the one-pass fp16 dgrad
   bf16_t *qkvT = nullptr, *oT = nullptr, *guT = nullptr, *downT = nullptr;
   bf16_t *qkvT16 = nullptr, *oT16 = nullptr, *guT16 = nullptr, *downT16 = nullptr;
+  bf16_t *qkv16 = nullptr, *o16 = nullptr, *gu16 = nullptr, *down16 = nullptr;   // fp16 ROW copies (down x 2^4): the weight operands of the one-pass fp16 training forward (fv_train_set_forward_f16)
 };
 struct GTab { int* idx = nullptr; float* coef = nullptr; size_t n = 0; };   // gather table of one packed operand image (tower_train.inc make_gtab), device arrays
 struct TowerTrainUnit {   // the backward's own operand images of one tower unit: transposed fp16 dgrad operands of the dense layers ...
@@ -88,6 +89,7 @@ struct TowerTrainUnit {   // the backward's own operand images of one tower unit
 };
 struct TrainState {
   bool ready = false; std::vector<TrainLayerT> layers; bf16_t *pj2T = nullptr, *pj2T16 = nullptr;
+  bool fwd_f16 = false;   // fv_train_set_forward_f16: the TRAINING forward's projections in ONE fp16 pass (half the MFMA work of the split-bf16 form)
   // the tower half (tower_train.inc): its tensors join the flat master when `tower` is set
   bool tower = false; std::vector<TowerTrainUnit> tunits; std::map<std::string, GTab> gtabs;
   fv::TowerCommitOp* tower_ops = nullptr; int tower_nops = 0, tower_blocks = 0;

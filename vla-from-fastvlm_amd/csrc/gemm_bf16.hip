@@ -1020,8 +1020,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   p.ksplit = a.ksplit == 2 ? 2 : (a.ksplit ? 1 : 0);
   p.sat = a.sat;
   p.stash = a.stash; p.stash_f16 = a.stash_f16;
-  if (a.stash && a.epi != FV_EPI_GELU_GRAD && (a.epi != FV_EPI_SWIGLU_SPLIT || ((uintptr_t)a.stash & 15) || (a.stash_f16 && !a.sat)))
-    return fv_fail(FV_ERR_ARG, "gemm: stash goes with FV_EPI_SWIGLU_SPLIT (16-byte aligned; the fp16 form with a saturation counter)");
+  if (a.stash && a.epi != FV_EPI_GELU_GRAD && ((a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16) || ((uintptr_t)a.stash & 15) || (a.stash_f16 && !a.sat)))
+    return fv_fail(FV_ERR_ARG, "gemm: stash goes with FV_EPI_SWIGLU_SPLIT / FV_EPI_SWIGLU_F16 (16-byte aligned; the fp16 form with a saturation counter)");
   p.W8 = static_cast<const uint8_t*>(a.W8);
   if (a.ksplit == 2) {
     if (!a.W8 || a.K % 128 || a.lda * 2 < 3 * a.K || ((uintptr_t)a.W8 & 15)) return fv_fail(FV_ERR_ARG, "gemm: the hi + lo8 form needs W8, K %% 128 == 0 and lda >= 1.5 K");

@@ -130,7 +130,7 @@ int launch_split_rows(const float* in, int ldi, bf16_t* out, int ldo, int lo_off
 int launch_lo8_rows(const float* in, int ldi, bf16_t* out, int ldo, long R, int C, hipStream_t s);   // the fp8 remainder bytes of the hi + lo8 operand form
 int launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
 int launch_transpose_to_bf16(const void* in, int in_bf16, int ldi, bf16_t* out, int ldo, int lo_off, int R, int Rp, int C, hipStream_t s);
-// the same transpose to fp16 (saturating; clamps counted in *sat): in_kind 0 = fp32, 1 = bf16, 2 = split bf16 (value = in[c] + in[lo_in + c]: both halves summed before rounding)
+// the same transpose to fp16 (saturating; clamps counted in *sat): in_kind 0 = fp32, 1 = bf16, 2 = split bf16 (value = in[c] + in[lo_in + c]: both halves summed before rounding), 3 = fp16
 int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, int R, int Rp, int C, unsigned* sat, hipStream_t s,
                             bf16_t* rows_out = nullptr, int ldro = 0);   // rows_out: the same values also as fp16 rows [R][ldro]
 int launch_rows_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf16_t* out, int ldo, long R, int C, unsigned* sat, hipStream_t s,
@@ -167,6 +167,8 @@ struct CommitDesc {
   int rows, cols;        // vector: rows = 1, cols = numel
   int is_mat;
   int tile0;             // first tile of this tensor in the launch's tile numbering
+  void* dst16;           // fp16 [rows][cols] copy x scale16 or null (the one-pass fp16 training forward's weight operand)
+  float scale16;
 };
 int launch_commit(const CommitDesc* desc_dev, int ndesc, int ntiles, const float* flat, int f16_transposes, unsigned* sat, hipStream_t s);
 

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void transpose_f16_kernel(const void* __restri
       if constexpr (KIND == 0) load8(static_cast<const float*>(in_v) + (size_t)(r0 + r) * ldi + c0 + c, v);
       else {
         const bf16_t* p = static_cast<const bf16_t*>(in_v) + (size_t)(r0 + r) * ldi + c0 + c;
-        unpack8(*reinterpret_cast<const uint4*>(p), v);
+        if constexpr (KIND == 3) unpack8_h(*reinterpret_cast<const uint4*>(p), v);   // fp16 rows (the one-pass fp16 training forward's normed operands)
+        else unpack8(*reinterpret_cast<const uint4*>(p), v);
         if constexpr (KIND == 2) {
           float l[8];
           unpack8(*reinterpret_cast<const uint4*>(p + lo_in), l);
@@ -218,6 +219,13 @@ __global__ __launch_bounds__(256) void commit_kernel(const CommitDesc* __restric
       const uint4 hv = pack8(v);
       *reinterpret_cast<uint4*>(dst + (size_t)(r0 + r) * d.cols + c0 + c) = hv;
       unpack8(hv, v);   // the transposed copy holds the ROUNDED weight (what the forward multiplies by)
+      if (d.dst16) {    // ... and so does the fp16 row copy of the one-pass fp16 training forward (down carries 2^4: FV_EPI_SWIGLU_F16 gives it up)
+        float w16[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w16[e] = v[e] * d.scale16;
+        count_f16_sat8(w16, sat);
+        *reinterpret_cast<uint4*>(static_cast<bf16_t*>(d.dst16) + (size_t)(r0 + r) * d.cols + c0 + c) = pack8_h(w16);
+      }
     }
     if (tr) {
 #pragma unroll
@@ -902,11 +910,12 @@ int launch_transpose_to_f16(const void* in, int in_kind, int ldi, int lo_in, bf1
                             bf16_t* rows_out, int ldro) {
   if (!in || !out) return fv_fail(FV_ERR_ARG, "transpose_f16: null pointer");
   if (rows_out && (ldro < C || ldro % 8)) return fv_fail(FV_ERR_ARG, "transpose_f16: bad row output stride %d", ldro);
-  if (R <= 0 || C <= 0 || C % 8 || Rp < R || Rp % 8 || ldi < C || ldi % (in_kind ? 8 : 4) || ldo % 8 || ldo < Rp || in_kind < 0 || in_kind > 2 || (in_kind == 2 && (lo_in % 8 || lo_in < C)))
+  if (R <= 0 || C <= 0 || C % 8 || Rp < R || Rp % 8 || ldi < C || ldi % (in_kind ? 8 : 4) || ldo % 8 || ldo < Rp || in_kind < 0 || in_kind > 3 || (in_kind == 2 && (lo_in % 8 || lo_in < C)))
     return fv_fail(FV_ERR_ARG, "transpose_f16: bad shape R=%d Rp=%d C=%d ldi=%d ldo=%d kind=%d", R, Rp, C, ldi, ldo, in_kind);
   const dim3 g((Rp + TP - 1) / TP, (C + TP - 1) / TP);
   if (in_kind == 0) hipLaunchKernelGGL(transpose_f16_kernel<0>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat, rows_out, ldro);
   else if (in_kind == 1) hipLaunchKernelGGL(transpose_f16_kernel<1>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat, rows_out, ldro);
+  else if (in_kind == 3) hipLaunchKernelGGL(transpose_f16_kernel<3>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat, rows_out, ldro);
   else hipLaunchKernelGGL(transpose_f16_kernel<2>, g, dim3(256), 0, s, in, ldi, lo_in, out, ldo, R, Rp, C, sat, rows_out, ldro);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;

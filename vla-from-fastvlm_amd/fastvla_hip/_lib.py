@@ -114,6 +114,7 @@ SIGNATURES = {
     "fv_train_commit": (_i, [_vp, _vp, _vp]),
     "fv_train_set_options": (_i, [_vp, _i, _i, _i]),
     "fv_train_loss_scale": (_i, [_vp, C.POINTER(_f)]),
+    "fv_train_set_forward_f16": (_i, [_vp, _i]),
     "fv_train_workspace_bytes": (_i, [_vp, _i, _i, C.POINTER(C.c_size_t)]),
     "fv_train_forward_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64, _vp, C.c_size_t, _vp, _vp, _vp, BUCKET_CB, _vp, _vp]),
     "fv_train_tower_begin": (_i, [_vp]),

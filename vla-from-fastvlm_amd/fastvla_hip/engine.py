@@ -484,6 +484,11 @@ class FastVLAEngine:
                    "fv_train_set_options", self.h)
         self._train_options = opts
 
+    def train_set_forward_f16(self, on: bool = True) -> None:
+        """The TRAINING forward's projections in ONE fp16 pass instead of the split-bf16 form's two (fv_train_set_forward_f16); inference is untouched."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fv_train_set_forward_f16(self.h, int(on)), "fv_train_set_forward_f16", self.h)
+
     def train_loss_scale(self) -> float:
         v = C.c_float()
         _lib.check(self.lib.fv_train_loss_scale(self.h, C.byref(v)), "fv_train_loss_scale", self.h)

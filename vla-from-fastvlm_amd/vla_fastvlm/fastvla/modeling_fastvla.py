@@ -107,7 +107,7 @@ class FastVLAPolicy(nn.Module):
             self._opt_state = st
         return st
 
-    def load_optimizer_state(self, m: torch.Tensor, v: torch.Tensor, step: int) -> None:
+    def load_optimizer_state(self, m: torch.Tensor, v: torch.Tensor, step: int, flat: Optional[torch.Tensor] = None) -> None:
         """Restore AdamW moments and the bias-correction step (Trainer._load_checkpoint; reference trainer.py:257-262
         restores them through accelerator.load_state)."""
         head_numel = sum(p.numel() for p in self.model.head_parameters())
@@ -122,6 +122,14 @@ class FastVLAPolicy(nn.Module):
             u.v.copy_(v.to(u.v.device))
             u.step_count = int(step)
             self._opt_state["step"] = int(step)
+            if flat is not None:      # the fp32 master of the run being resumed (Trainer._save_checkpoint): parameters continue bit for bit
+                if flat.numel() != u.flat.numel():
+                    raise ValueError(f"checkpointed master has {flat.numel()} elements, this run's {u.flat.numel()}")
+                u.flat.copy_(flat.to(u.flat.device))
+                u.eng.train_commit(u.flat)
+                bb = self.model.backbone
+                bb.clear_prefix_cache()
+                bb.clear_prompt_cache()
             return
         flat = self.model._flat
         if flat is None:

@@ -128,7 +128,7 @@ class Trainer:
             return
         flat = core.materialize(self.device)
         if self._resume_opt is not None and hasattr(self.model, "load_optimizer_state"):
-            self.model.load_optimizer_state(self._resume_opt["m"], self._resume_opt["v"], int(self._resume_opt["step"]))
+            self.model.load_optimizer_state(self._resume_opt["m"], self._resume_opt["v"], int(self._resume_opt["step"]), flat=self._resume_opt.get("flat"))
             self._resume_opt = None
         un = getattr(self.model, "_unfrozen", None)
         if un is not None:
@@ -213,8 +213,13 @@ class Trainer:
                                    include_backbone=self.save_backbone_weights or getattr(self.model, "_unfrozen", None) is not None)
         st = getattr(self.model, "_opt_state", None)
         if st is not None:
-            torch.save({"m": st["m"].cpu(), "v": st["v"].cpu(), "step": st["step"], "global_step": self.global_step,
-                        "update_step": self.update_step}, d / "optimizer.pt")
+            rec = {"m": st["m"].cpu(), "v": st["v"].cpu(), "step": st["step"], "global_step": self.global_step, "update_step": self.update_step}
+            un = getattr(self.model, "_unfrozen", None)
+            if un is not None:
+                # the fp32 MASTER of an unfrozen run: the VLM tensors of policy_state_dict.pt come back through the engine's bf16 operand copies, and a master
+                # rebuilt from those has lost the low bits every later update (~1e-3 of a bf16 ulp) lives in
+                rec["flat"] = un.flat.cpu()
+            torch.save(rec, d / "optimizer.pt")
 
     def _load_checkpoint(self, path: str) -> None:
         p = Path(path)
