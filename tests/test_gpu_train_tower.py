@@ -265,3 +265,62 @@ def test_small_policy_everything_trainable_matches_autograd():
     fresh.close()
     eng.train_set_tower_grad(None)
     eng.close()
+
+
+def test_bench_shape_b32_gradient_equals_the_two_row_run():
+    """VERDICT r4 weak #1c: the training legs of bench.py run at B = 32, 320 tokens per sample (256 image + 64 text), 1024^2 -- 32-bit buffer offsets, split-K range
+    counts, persistent-loop trip counts and the 47 GB of stashes at their largest -- while the oracle comparisons stop at B = 2 .. 4.  Size-independent property at
+    exactly that shape, FastVLM-0.5B, everything trainable: give rows 2 .. 31 their own predictions as targets (their loss gradient is then exactly zero) and the
+    B = 32 step must reproduce the B = 2 step on rows 0 .. 1 -- actions of those rows, and 16 x every gradient tensor (MSE is a mean over B x A)."""
+    model = arch.preset("fastvlm-0.5b")
+    B, T = 32, 64
+    w, eng = _engine(model, B, T, hd=1024, seed=61)
+    tensors, total, nb = eng.train_layout()
+    flat = torch.zeros(total, dtype=torch.float32, device=DEV)
+    eng.train_export_params(flat)
+    g = torch.Generator().manual_seed(62)
+    for k, v in eng.head_views(flat).items():
+        v.copy_(torch.randn(v.shape, generator=g) * 0.02 + (1.0 if k in ("state_projection.0.weight", "fusion.1.weight") else 0.0))
+    img = torch.rand(B, 3, 336, 336, generator=g).to(DEV)
+    ids = torch.randint(0, 151643, (B, T), generator=g)
+    lens = torch.full((B,), T)
+    lens[1] = 37
+    states, targets = torch.randn(B, 14, generator=g).to(DEV), torch.randn(B, 14, generator=g).to(DEV)
+
+    def step(n, tg):
+        pix = eng.preprocess(img[:n])
+        tws, ws = eng.train_tower_workspace(n), eng.train_workspace(n, T)
+        dto = torch.zeros(n, model.tower.num_tokens, model.tower.out_dim, dtype=torch.float16, device=DEV)
+        eng.train_set_tower_grad(dto)
+        grads = torch.zeros_like(flat)
+        tower_out = eng.train_tower_forward(pix, tws)
+        act, loss, _ = eng.train_forward_backward(flat, tower_out, ids[:n], lens[:n], states[:n], tg[:n], ws, training=False, flat_grads=grads)
+        eng.train_tower_backward(pix, dto, tws, grads)
+        torch.cuda.synchronize()
+        eng.train_set_tower_grad(None)
+        del tws, ws, dto
+        torch.cuda.empty_cache()
+        return act, loss, grads
+
+    a32, _, _ = step(B, targets)
+    tg = a32.clone()
+    tg[:2] = targets[:2]
+    a32b, l32, g32 = step(B, tg)
+    assert torch.equal(a32b, a32)
+    a2, l2, g2 = step(2, tg)
+    ra = rel_l2(a32[:2].cpu(), a2.cpu())
+    assert ra <= 1e-4, ra
+    assert abs(float(l32) * 16 - float(l2)) <= 1e-3 * float(l2)
+    n32, n2 = eng.train_named_tensors(g32 * 16.0), eng.train_named_tensors(g2)
+    worst = (0.0, "")
+    for k in n2:
+        den = float(n2[k].norm())
+        if den < 1e-12:
+            continue
+        e = rel_l2(n32[k].cpu(), n2[k].cpu())
+        worst = max(worst, (e, k))
+    print(f"[bench shape B=32 vs B=2, everything trainable, 0.5B] actions rows 0-1 rel_l2 {ra:.2e}; worst gradient tensor {worst[1]} {worst[0]:.2e} ({len(n2)} tensors, "
+          f"{eng.fp16_saturations()} fp16 saturations)")
+    assert worst[0] <= 3e-3, worst     # other tile shapes / K ranges at other row counts: the fp16 operand roundings differ, the sums agree
+    assert eng.fp16_saturations() == 0
+    eng.close()

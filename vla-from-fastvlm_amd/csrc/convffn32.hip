@@ -44,6 +44,18 @@
 #define FFN32_BUF 0
 #endif
 #define F32_BUFX ((FFN32_BUF & 1) != 0)
+// cache-policy bits (buffer aux operand; gfx950: bit 1 = nt) of the three activation streams -- x rows, residual rows, output rows.  They pass through a launch once
+// while the 4.8 GB weight stream is re-read from L2 by every block: marked non-temporal they should not evict it (VERDICT r4 #2-iv: 764 MB of HBM traffic per
+// C = 384 launch against 604 MB algorithmic).  tools/ffn32_variants.sh A/B; defaults = the measured winner.
+#ifndef FFN32_NT_X
+#define FFN32_NT_X 0
+#endif
+#ifndef FFN32_NT_RES
+#define FFN32_NT_RES 0
+#endif
+#ifndef FFN32_NT_OUT
+#define FFN32_NT_OUT 0
+#endif
 
 #ifdef FFN32_STAMPS   /* tools/ffn32_variants.sh diagnostic build only: cycle sums per phase of block 0..255, wave 0 */
 __device__ unsigned long long g_ffn32_stamps[256 * 8];
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
       const long m_ = min(mb_ + mt * 32 + (lx_ & 31), (long)p.M - 1);                                        \
       const uint32_t xo_ = (uint32_t)m_ * (uint32_t)(C * 2) + (uint32_t)(lx_ >> 5) * 16u;                    \
       _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                      \
-        xf[mt][ks] = F32_BUFX ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo_ + ks * 32, 0, 0)) \
+        xf[mt][ks] = F32_BUFX ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo_ + ks * 32, 0, FFN32_NT_X)) \
                               : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.x) + xo_ + ks * 32)); \
     }                                                                                                        \
   }
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
     const uint32_t so_ = (uint32_t)((MB) + ((Q) / NPASS) * 32) * (uint32_t)(C * 2) + (uint32_t)(((Q) % NPASS) * CQ * 2); \
     _Pragma("unroll") for (int it = 0; it < RP; ++it)                                                        \
       rr[(Q) % RD][it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(                    \
-          rrsrc, F32_ABL_NORES ? OOB : (it == RP - 1 ? eoff_last : eoff) + (so_ + (uint32_t)(it * (ERW * C * 2))), 0, 0)); \
+          rrsrc, F32_ABL_NORES ? OOB : (it == RP - 1 ? eoff_last : eoff) + (so_ + (uint32_t)(it * (ERW * C * 2))), 0, FFN32_NT_RES)); \
   }
 
 #ifdef FFN32_ABL_NOOUT  /* tools/ffn32_variants.sh only: every output store falls outside the descriptor (dropped) */
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
         o.z = pack_bf2(bf_lo(r4.z) + fmaf(l1.x, y1.x, b1.x), bf_hi(r4.z) + fmaf(l1.y, y1.y, b1.y));
         o.w = pack_bf2(bf_lo(r4.w) + fmaf(l1.z, y1.z, b1.z), bf_hi(r4.w) + fmaf(l1.w, y1.w, b1.w));
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, o), orsrc,
-                                               F32_ABL_NOOUT ? OOB : (it == RP - 1 ? eoff_last : eoff) + (so_ + (uint32_t)(it * (ERW * C * 2))), 0, 0);
+                                               F32_ABL_NOOUT ? OOB : (it == RP - 1 ? eoff_last : eoff) + (so_ + (uint32_t)(it * (ERW * C * 2))), 0, FFN32_NT_OUT);
         if (it & 1) __builtin_amdgcn_sched_barrier(0);   // two items' operands in flight at a time
       }
       if (RD < NPASS * MT && q + RD - 1 < NPASS * MT) F32_LOAD_RES(q + RD - 1, mb)

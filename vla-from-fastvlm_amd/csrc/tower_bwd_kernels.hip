@@ -245,25 +245,26 @@ __global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const bf16_t* __rest
 // one image; per 8-column chunk the (NPS + K - 1) x (8 + K - 1) input pixels of the slab go global -> registers -> LDS once (the next chunk's loads in flight
 // under the current chunk's FMAs), every thread reads its K x (8 + K - 1) window as conflict-free dwords, out-of-map pixels are stored as zeros (no bounds
 // checks in the FMA loop).  part[block][t][c] as above.
-template <int K>
+template <int K, int S = 1, int MULT = 1>   // H, W: the INPUT map; C: OUTPUT channels (CS of them per block, reading CS / MULT input channels); Ho, Wo: the output map
 __global__ __launch_bounds__(256, 2) void dw_wgrad_lds_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int H, int W,
-                                                               int C, int CS, int nslabs, int ngroups, int gpb, int gpi, unsigned xbytes) {
-  constexpr int PAD = K / 2, NT = K * K + 1, RT = 10, R = 8, NC = R + K - 1;
+                                                               int C, int CS, int nslabs, int ngroups, int gpb, int gpi, unsigned xbytes, int Ho, int Wo) {
+  constexpr int PAD = K / 2, NT = K * K + 1, RT = 10, R = 8, NC = (R - 1) * S + K;
   constexpr int MAXP = 10;                              // 16-byte pieces per thread: NR * NC * CS / 8 / 256 <= (4 + 6) * 14 * 16 / 256 = 8.75
   extern __shared__ __attribute__((aligned(16))) char sm_wl[];   // two input tiles [NR][NC][CS] bf16 (MAXP * 4 KB each), reused at the end as the fold scratch [RT][NPS][CS] f32
   float* sR = reinterpret_cast<float*>(sm_wl);
   const int slab = blockIdx.x % nslabs;
   const int gb = blockIdx.x / nslabs;
-  const int hp = CS >> 1, NPS = 256 / hp, NR = NPS + K - 1;
+  const int hp = CS >> 1, NPS = 256 / hp, NR = (NPS - 1) * S + K;
+  const int Ci = C / MULT, CSi = CS / MULT;
   const int cp = threadIdx.x % hp, ps = threadIdx.x / hp;
   const int co = slab * CS + 2 * cp;
-  const int c8n = CS >> 3, nchunk16 = NR * NC * c8n;   // 16-byte pieces of a tile
+  const int c8n = CSi >> 3, nchunk16 = NR * NC * c8n;   // 16-byte pieces of a tile
   const int wv = threadIdx.x >> 6;
   f32x2 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x2{0.f, 0.f};
   const int g1 = (gb + 1) * gpb < ngroups ? (gb + 1) * gpb : ngroups;
-  const int ncx = (W + R - 1) / R;
+  const int ncx = (Wo + R - 1) / R;
   // the tile goes global -> LDS by LDS-DMA (no staging registers next to the 100 accumulators): piece idx = (pixel slot, 8-channel group) lands at byte 16 idx;
   // pixels outside the map read past the descriptor's range and arrive as zeros
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, xbytes, 0x00020000);
@@ -277,19 +278,19 @@ __global__ __launch_bounds__(256, 2) void dw_wgrad_lds_kernel(const bf16_t* __re
         const int idx = threadIdx.x + 256 * q;
         const int c8 = idx % c8n, slot = idx / c8n;
         const int col = slot % NC, row = slot / NC;
-        const int iy = yb - PAD + row, ix = x0 - PAD + col;
+        const int iy = yb * S - PAD + row, ix = x0 * S - PAD + col;
         const bool ok = idx < nchunk16 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const uint32_t off = ok ? (uint32_t)(((((size_t)b * H + iy) * W + ix) * C + slab * CS + c8 * 8) * 2) : 0xfffffff0u;
+        const uint32_t off = ok ? (uint32_t)(((((size_t)b * H + iy) * W + ix) * Ci + slab * CSi + c8 * 8) * 2) : 0xfffffff0u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(base + (q * 256 + wv * 64) * 16), 16, off, 0, 0, 0);
       }
     }
   };
   auto load_d = [&](int g, int cx, uint32_t (&dn)[R]) {
     const int b = g / gpi, yo = (g % gpi) * NPS + ps, x0 = cx * R;
-    const bool rowok = ps < NPS && yo < H;
-    const bf16_t* dyrow = dy + (((size_t)b * H + (rowok ? yo : 0)) * W) * C + co;
+    const bool rowok = ps < NPS && yo < Ho;
+    const bf16_t* dyrow = dy + (((size_t)b * Ho + (rowok ? yo : 0)) * Wo) * C + co;
 #pragma unroll
-    for (int r = 0; r < R; ++r) dn[r] = (rowok && x0 + r < W) ? *reinterpret_cast<const uint32_t*>(dyrow + (size_t)(x0 + r) * C) : 0u;
+    for (int r = 0; r < R; ++r) dn[r] = (rowok && x0 + r < Wo) ? *reinterpret_cast<const uint32_t*>(dyrow + (size_t)(x0 + r) * C) : 0u;
   };
   int g = gb * gpb, cx = 0, buf = 0;
   uint32_t dcur[R], dnext[R];
@@ -315,13 +316,18 @@ __global__ __launch_bounds__(256, 2) void dw_wgrad_lds_kernel(const bf16_t* __re
           f32x2 xv[NC];
 #pragma unroll
           for (int i = 0; i < NC; ++i) {
-            const uint32_t u = *reinterpret_cast<const uint32_t*>(sX + ((size_t)((ps + ky) * NC + i)) * CS + 2 * cp);
-            xv[i] = f32x2{bf_lo(u), bf_hi(u)};
+            if (MULT == 1) {
+              const uint32_t u = *reinterpret_cast<const uint32_t*>(sX + ((size_t)((ps * S + ky) * NC + i)) * CSi + 2 * cp);
+              xv[i] = f32x2{bf_lo(u), bf_hi(u)};
+            } else {   // both outputs of the pair read the same input channel
+              const float v = bf2f(sX[((size_t)((ps * S + ky) * NC + i)) * CSi + cp]);
+              xv[i] = f32x2{v, v};
+            }
           }
 #pragma unroll
           for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[ky * K + kx] = __builtin_elementwise_fma(d[r], xv[r + kx], acc[ky * K + kx]);
+            for (int r = 0; r < R; ++r) acc[ky * K + kx] = __builtin_elementwise_fma(d[r], xv[r * S + kx], acc[ky * K + kx]);
           __builtin_amdgcn_sched_barrier(0);   // one kernel row's window at a time (hoisting the next rows' LDS reads over these FMAs spills)
         }
       }
@@ -1064,9 +1070,9 @@ int launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, float* db, flo
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
   const int CS = pick_slab(Co, 128);
   const int nslabs = Co / CS, NPS = 256 / (CS / 2), NT = k * k + 1;
-  if ((k == 3 || k == 7) && stride == 1 && mult == 1 && Wi >= 8 && CS >= 32) {   // the LDS-staged form (dw_wgrad_lds_kernel)
+  if ((k == 3 || k == 7) && Wo >= 8 && CS >= 32 * mult) {   // the LDS-staged form (dw_wgrad_lds_kernel)
     const int NPSl = 256 / (CS / 2);
-    const int gpi = (Hi + NPSl - 1) / NPSl, ngroups = B * gpi;
+    const int gpi = (Ho + NPSl - 1) / NPSl, ngroups = B * gpi;
     // two blocks are resident per CU (190 registers, 80 KB of LDS each): 512 blocks are ONE round of a 256-CU chip, and every block more is another partial-sum
     // row for the reduce pass to read
     int nb = 512 / nslabs;
@@ -1074,23 +1080,26 @@ int launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, float* db, flo
     if (nb > ngroups) nb = ngroups;
     const int gpb = (ngroups + nb - 1) / nb;
     nb = (ngroups + gpb - 1) / gpb;
-    const int NR = NPSl + k - 1, NCc = 8 + k - 1;
+    const int NR = (NPSl - 1) * stride + k, NCc = 7 * stride + k;
     const size_t xb = (size_t)B * Hi * Wi * Ci * 2;
-    if ((long)NR * NCc * (CS / 8) <= 256L * 10 && xb < 0xfffffff0ull) {
+    if ((long)NR * NCc * (CS / mult / 8) <= 256L * 10 && xb < 0xfffffff0ull) {
       const size_t lds = 2 * 10 * 4096;   // two tiles of up to 10 x 256 16-byte pieces (>= the fold scratch: 10 x 256 x 2 floats)
-      static bool attr = false;
-      if (!attr) {
-        FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_lds_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_lds_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-      }
       const dim3 grid((unsigned)(nb * nslabs));
-      if (k == 7) hipLaunchKernelGGL((dw_wgrad_lds_kernel<7>), grid, dim3(256), lds, s, x, dy, scratch, Hi, Wi, Ci, CS, nslabs, ngroups, gpb, gpi, (unsigned)xb);
-      else hipLaunchKernelGGL((dw_wgrad_lds_kernel<3>), grid, dim3(256), lds, s, x, dy, scratch, Hi, Wi, Ci, CS, nslabs, ngroups, gpb, gpi, (unsigned)xb);
-      const long n = (long)NT * Co;
-      hipLaunchKernelGGL(partial_reduce_kernel, dim3(gridr(n)), dim3(256), 0, s, scratch, (long)nb, n, n, (long)k * k * Co, dw, db, 1.0f);
-      FV_HIP_CHECK(hipGetLastError());
-      return FV_OK;
+#define FV_WL(K_, S_, M_)                                                                                                                                       \
+  if (k == K_ && stride == S_ && mult == M_) {                                                                                                                  \
+    static bool attr = false;                                                                                                                                   \
+    if (!attr) {                                                                                                                                                \
+      FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_lds_kernel<K_, S_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      attr = true;                                                                                                                                              \
+    }                                                                                                                                                           \
+    hipLaunchKernelGGL((dw_wgrad_lds_kernel<K_, S_, M_>), grid, dim3(256), lds, s, x, dy, scratch, Hi, Wi, Co, CS, nslabs, ngroups, gpb, gpi, (unsigned)xb, Ho, Wo); \
+    const long n = (long)NT * Co;                                                                                                                               \
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(gridr(n)), dim3(256), 0, s, scratch, (long)nb, n, n, (long)k * k * Co, dw, db, 1.0f);                       \
+    FV_HIP_CHECK(hipGetLastError());                                                                                                                            \
+    return FV_OK;                                                                                                                                               \
+  }
+      FV_WL(3, 1, 1) FV_WL(7, 1, 1) FV_WL(3, 2, 1) FV_WL(7, 2, 2) FV_WL(3, 1, 2)
+#undef FV_WL
     }
   }
   if ((k == 3 || k == 7) && Wo >= 8) {   // whole rows per thread (dw_wgrad_rows_kernel)
