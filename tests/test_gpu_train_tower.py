@@ -298,6 +298,8 @@ def test_bench_shape_b32_gradient_equals_the_two_row_run():
         eng.train_tower_backward(pix, dto, tws, grads)
         torch.cuda.synchronize()
         eng.train_set_tower_grad(None)
+        a = dto.float().abs()
+        print(f"   [B={n}] dL/d tower_out (fp16, x loss scale): max {float(a.max()):.3e}, median of non-zeros {float(a[a > 0].median()):.3e}, fp16-subnormal share {float(((a > 0) & (a < 6.1e-5)).float().mean()):.3f}, zeros {float((a == 0).float().mean()):.3f}")
         del tws, ws, dto
         torch.cuda.empty_cache()
         return act, loss, grads
@@ -319,6 +321,8 @@ def test_bench_shape_b32_gradient_equals_the_two_row_run():
             continue
         e = rel_l2(n32[k].cpu(), n2[k].cpu())
         worst = max(worst, (e, k))
+    errs = sorted(((rel_l2(n32[k].cpu(), n2[k].cpu()), k) for k in n2 if float(n2[k].norm()) > 1e-12), reverse=True)
+    print("   worst ten:", "; ".join(f"{k.replace(VT, 'VT.')} {e:.2e}" for e, k in errs[:10]), "| tensors above 3e-3:", sum(1 for e, _ in errs if e > 3e-3))
     print(f"[bench shape B=32 vs B=2, everything trainable, 0.5B] actions rows 0-1 rel_l2 {ra:.2e}; worst gradient tensor {worst[1]} {worst[0]:.2e} ({len(n2)} tensors, "
           f"{eng.fp16_saturations()} fp16 saturations)")
     assert worst[0] <= 3e-3, worst     # other tile shapes / K ranges at other row counts: the fp16 operand roundings differ, the sums agree

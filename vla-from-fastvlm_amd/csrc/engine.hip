@@ -94,6 +94,7 @@ struct TrainState {
   bool tower = false; std::vector<TowerTrainUnit> tunits; std::map<std::string, GTab> gtabs;
   fv::TowerCommitOp* tower_ops = nullptr; int tower_nops = 0, tower_blocks = 0;
   bf16_t *pj0T = nullptr, *pj0T16 = nullptr;   // the projector's first Linear, transposed (its input gradient feeds the tower)
+  float* tscale = nullptr;                     // device: [0] = the tower gradient stream's own power-of-two scale (chosen per step from dL/d(tower_out)), [1] = its inverse; [2] = amax scratch bits
   void* d_tower_out = nullptr;                 // fv_train_set_tower_grad: where fv_train_forward_backward leaves dL/d(tower_out) as fp16 rows
   fv::CommitDesc* commit_desc = nullptr; int commit_n = 0, commit_tiles = 0;   // fv_train_commit's descriptor table (device)
   int grad_split = 2;   // dgrad's gradient operand: 2 ONE fp16 pass against fp16 transposed weights, 1 split bf16 (hi + lo, two passes) (fv_train_set_options)

@@ -188,6 +188,8 @@ int launch_mul16(const bf16_t* a, const bf16_t* b, bf16_t* out, size_t n, unsign
 int launch_gelu_grad_mul(const bf16_t* dh, const bf16_t* pre, bf16_t* out, size_t n, unsigned* sat, hipStream_t s);   // out f16 = dh f16 * gelu'(pre bf16)
 int launch_f16_to_f32(const bf16_t* in, float* out, size_t n, float scale, hipStream_t s);
 int launch_scale_to_f16(const float* in, bf16_t* out, size_t n, float scale, unsigned* sat, hipStream_t s);   // out f16 = in * scale (saturating)
+int launch_rescale_to_f16(const float* in, bf16_t* out, size_t n, float target, unsigned* bits, float* sc, unsigned* sat, hipStream_t s);   // the tower's own gradient scale (device-chosen power of two)
+int launch_unscale_dev(float* p, size_t n, const float* sc, hipStream_t s);
 int launch_ones_col(bf16_t* out, int ld, int C, long R, hipStream_t s);   // fp16 rows [R][ld]: columns [C, C + 8) <- {1, 0, ..., 0}
 int launch_ls_grads(const float* dWraw, const float* dbraw, const bf16_t* W, const float* bias, const float* ls, float* dW, float* db, float* dls, int C, int Kd,
                     hipStream_t s);

@@ -453,6 +453,49 @@ __global__ __launch_bounds__(256) void scale_to_f16_kernel(const float* __restri
   *reinterpret_cast<uint4*>(out + i * 8) = pack8_h(x);
 }
 
+// ---- the tower's own gradient scale.  dL/d(tower_out) of a B = 32 step has a median of 1e-3 x the loss scale and 4 % fp16 subnormals, and the gradient thins out
+// further on its way to the 256 x 256 maps (the attention blocks' dS = P (dP - delta) is another 1e-3): the stream is re-scaled ONCE at the tower's output to
+// put its largest element at ~2^13 (a power of two chosen on the device from the fp32 tensor: bit-repeatable), and every tower bucket is scaled back before it is
+// reported.  amax_kernel: *bits = max |x| as float bits (atomicMax on non-negative floats' bit patterns is exact and order-independent).
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ in, long n4, unsigned* __restrict__ bits) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = *reinterpret_cast<const float4*>(in + i * 4);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m <= 3.0e38f) atomicMax(bits, __float_as_uint(m));
+}
+// sc[0] = 2^k, sc[1] = 2^-k with k = clamp(floor(log2(target / amax)), 0, 24); bits is cleared for the next step
+__global__ void pick_scale_kernel(unsigned* __restrict__ bits, float* __restrict__ sc, float target) {
+  const float amax = __uint_as_float(*bits);
+  int k = 0;
+  if (amax > 0.f) {
+    k = (int)floorf(log2f(target / amax));
+    k = k < 0 ? 0 : (k > 24 ? 24 : k);
+  }
+  sc[0] = ldexpf(1.0f, k);
+  sc[1] = ldexpf(1.0f, -k);
+  *bits = 0u;
+}
+__global__ __launch_bounds__(256) void scale_to_f16_dev_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n8, const float* __restrict__ sc, unsigned* sat) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const float scale = sc[0];
+  const float4 a = *reinterpret_cast<const float4*>(in + i * 8), b = *reinterpret_cast<const float4*>(in + i * 8 + 4);
+  float x[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
+  count_f16_sat8(x, sat);
+  *reinterpret_cast<uint4*>(out + i * 8) = pack8_h(x);
+}
+__global__ __launch_bounds__(256) void scale_inplace_dev_kernel(float* __restrict__ p, long n4, const float* __restrict__ sc) {
+  const float f = sc[1];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 v = *reinterpret_cast<float4*>(p + i * 4);
+    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+    *reinterpret_cast<float4*>(p + i * 4) = v;
+  }
+}
+
 // layer-scaled 1x1 conv out = res + ls (.) (W h + b): from the UN-scaled products dWraw[c][j] = sum_m dout[m][c] h[m][j], dbraw[c] = sum_m dout[m][c]
 //   dW[c][j] = ls[c] dWraw[c][j];  db[c] = ls[c] dbraw[c];  dls[c] = sum_j W[c][j] dWraw[c][j] + b[c] dbraw[c]      (one wave per output channel c)
 __global__ __launch_bounds__(256) void ls_grads_kernel(const float* __restrict__ dWraw, const float* __restrict__ dbraw, const bf16_t* __restrict__ W,
@@ -1174,6 +1217,24 @@ int launch_f16_to_f32(const bf16_t* in, float* out, size_t n, float scale, hipSt
 int launch_scale_to_f16(const float* in, bf16_t* out, size_t n, float scale, unsigned* sat, hipStream_t s) {
   if (!in || !out || n % 8) return fv_fail(FV_ERR_ARG, "scale_to_f16: bad argument");
   hipLaunchKernelGGL(scale_to_f16_kernel, dim3(grid1((long)(n / 8))), dim3(256), 0, s, in, out, (long)(n / 8), scale, sat);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+// out f16 = in * 2^k with 2^k picked on the device so that max |in| 2^k ~ target (sc[0] = 2^k, sc[1] = 2^-k; bits: a zeroed device word of scratch)
+int launch_rescale_to_f16(const float* in, bf16_t* out, size_t n, float target, unsigned* bits, float* sc, unsigned* sat, hipStream_t s) {
+  if (!in || !out || !bits || !sc || n % 8) return fv_fail(FV_ERR_ARG, "rescale_to_f16: bad argument");
+  const long n4 = (long)(n / 4);
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048)), dim3(256), 0, s, in, n4, bits);
+  hipLaunchKernelGGL(pick_scale_kernel, dim3(1), dim3(1), 0, s, bits, sc, target);
+  hipLaunchKernelGGL(scale_to_f16_dev_kernel, dim3(grid1((long)(n / 8))), dim3(256), 0, s, in, out, (long)(n / 8), sc, sat);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+// p[0, n) *= sc[1] (n % 4 == 0, p 16-byte aligned)
+int launch_unscale_dev(float* p, size_t n, const float* sc, hipStream_t s) {
+  if (!p || !sc || n % 4 || ((uintptr_t)p & 15)) return fv_fail(FV_ERR_ARG, "unscale_dev: bad argument");
+  const long n4 = (long)(n / 4);
+  hipLaunchKernelGGL(scale_inplace_dev_kernel, dim3((unsigned)(n4 / 256 + 1 < 4096 ? n4 / 256 + 1 : 4096)), dim3(256), 0, s, p, n4, sc);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
