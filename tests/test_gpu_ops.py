@@ -546,6 +546,33 @@ def test_dwconv_pair_tower_shape_repeats(C, H):
             assert torch.equal(y1, first[0]) and torch.equal(y2, first[1]), f"launch {rep} differs from launch 0"
 
 
+@pytest.mark.parametrize("C,H,W", [(192, 128, 128), (384, 64, 64), (96, 256, 256), (64, 19, 37), (192, 40, 96)])
+def test_dwconv_pair_row_segments_equal_the_uncut_march(C, H, W):
+    """One observation gives the pair 24 strips for 256 CUs, so the launcher cuts the march into row segments (nstrips < 256); a batch of 24 is
+    walked uncut.  The same image must come out bit for bit the same either way (every output row is computed by the same arithmetic in exactly
+    one block), at the tower's three shapes and at ragged ones."""
+    torch.manual_seed(7 * C + H)
+    Bbig = max(2, -(-256 // (-(-W // 16) * max(C // 64, 1))) + 1) if C % 64 == 0 else max(2, -(-256 // (-(-W // 32) * (C // 32))) + 1)
+    x1 = bf(torch.randn(1, C, H, W))
+    xb = torch.cat([x1, bf(torch.randn(Bbig - 1, C, H, W))], 0)
+    w3, w7 = bf(torch.randn(C, 1, 3, 3) / 3), bf(torch.randn(C, 1, 7, 7) / 7)
+    t3, t7 = dev_bf16(_toeplitz(w3, 3)), dev_bf16(_toeplitz(w7, 7))
+    b3d, b7d = dev_f32(torch.randn(C) * 0.1), dev_f32(torch.randn(C) * 0.1)
+    outs = []
+    for x in (x1, xb):
+        B = x.shape[0]
+        xd = dev_bf16(x.permute(0, 2, 3, 1))
+        y1 = torch.full((B, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        y2 = torch.full((B, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        call(lib().fv_op_dwconv_pair(xd.data_ptr(), t3.data_ptr(), b3d.data_ptr(), t7.data_ptr(), b7d.data_ptr(), y1.data_ptr(), y2.data_ptr(),
+                                     B, H, W, C, stream()), "fv_op_dwconv_pair")
+        torch.cuda.synchronize()
+        outs.append((y1[0].clone(), y2[0].clone()))
+    assert not torch.isnan(outs[0][0].float()).any() and not torch.isnan(outs[0][1].float()).any()
+    assert torch.equal(outs[0][0], outs[1][0]), "x' of the segmented march differs from the uncut one"
+    assert torch.equal(outs[0][1], outs[1][1]), "t of the segmented march differs from the uncut one"
+
+
 @pytest.mark.parametrize("M,C", [(128 * 3, 192), (128 * 800, 96), (128 * 300, 192)])
 def test_gemm_pointwise_square(M, C):
     """K = N = C in {96, 192}, M % 128 == 0, contiguous rows: the persistent pointwise-conv kernel (weight resident in LDS,

@@ -88,7 +88,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
-  const int logical = xcd_remap(blockIdx.x, p.nwg);
+  // p.splits > 1 (few-row problems: the control loop's M = 64 ... 128 decoder, the tower's last stages at B <= 4): blocks = tiles x K ranges, a block
+  // leaves the raw fp32 sums of its range in p.part[range][M][npad] and splitk_reduce_* finishes the epilogue -- 7 blocks walking 152 K-tiles each
+  // (the decoder's down projection at M = 64: 108 us of exposed load latency) become 266 blocks of 4
+  const int unit = xcd_remap(blockIdx.x, p.nwg);
+  const int tiles = p.nwg / p.splits, krange = unit / tiles, logical = unit - krange * tiles;
   const int tn = logical % p.tiles_n, tm = logical / p.tiles_n;
   const int bm = tm * BM, bn = tn * BN;
 
@@ -150,16 +154,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
   // needs it (stored at the end of the same iteration, as before, it had only the MFMAs of its own tile: 512 clk against
   // >1000 of memory latency).  Still one barrier per K-tile: it publishes tile kt and retires the reads of tile kt - 1,
   // whose buffer the store then overwrites.
-  load_tile(0);
+  const int kt0 = p.splits > 1 ? krange * nk / p.splits : 0, kt1 = p.splits > 1 ? (krange + 1) * nk / p.splits : nk;
+  load_tile(kt0);
   store_tile(0);
-  if (nk > 1) load_tile(1);
+  if (kt0 + 1 < kt1) load_tile(kt0 + 1);
 
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
     __syncthreads();
-    if (kt + 1 < nk) store_tile(cur ^ 1);
-    if (kt + 2 < nk) load_tile(kt + 2);
+    if (kt + 1 < kt1) store_tile(cur ^ 1);
+    if (kt + 2 < kt1) load_tile(kt + 2);
     const bf16_t* a_base = sA + cur * A_ELEMS;
     const bf16_t* b_base = sB + cur * B_ELEMS;
     if (LO8 && kt >= nk1) {   // fp8 tile: both 16-byte pieces of a row (k-chunks fq and 4 + fq) form one 32-byte operand
@@ -203,6 +208,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
         sC[(wr * (BM / 2) + i * 16 + fq * 4 + r) * LDC + wc * 64 + j * 16 + fr] = acc[i][j][r];
   __syncthreads();
 
+  if (p.splits > 1) {   // raw partial sums of this K range
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 4, cc = c & 15;
+      const int gm = bm + row, gn = bn + cc * 8;
+      if (gm >= p.M || gn >= p.N) continue;
+      float* pp = p.part + ((size_t)krange * p.M + gm) * p.npad + gn;
+      *reinterpret_cast<float4*>(pp) = *reinterpret_cast<const float4*>(sC + row * LDC + cc * 8);
+      *reinterpret_cast<float4*>(pp + 4) = *reinterpret_cast<const float4*>(sC + row * LDC + cc * 8 + 4);
+    }
+    return;
+  }
   const int epi = p.epi;
   if (epi == FV_EPI_SWIGLU || epi == FV_EPI_SWIGLU_SPLIT || epi == FV_EPI_SWIGLU_F16) {
     // W rows are interleaved [8 gate | 8 up]: 16 accumulator columns -> 8 outputs.  SPLIT also writes the bf16
@@ -790,6 +808,62 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
   }
 }
 
+// The same for few rows and many K ranges (the control loop's M = 64: 38 ranges of the down projection): one BLOCK per row, a thread owns four columns
+// (+ 1024 j), the ranges' loads are independent and issued eight at a time (the one-wave-per-row form above walks 38 dependent iterations: 47 us per
+// launch at M = 64); sums in range order, sum of squares by a fixed tree: bit-repeatable
+__global__ __launch_bounds__(256) void splitk_reduce_norm_row_kernel(const float* __restrict__ part, int splits, int M, int N, int npad,
+                                                                      const float* __restrict__ bias, const float* res, int ldr, float* out,
+                                                                      int ldo, const float* __restrict__ nw, bf16_t* __restrict__ y,
+                                                                      bf16_t* __restrict__ ylo, int ldy, float eps) {
+  __shared__ float wsum[4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  float4 keep[4];   // N <= 4096
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = tid * 4 + 1024 * j;
+    if (n >= N) break;
+    float4 acc = res ? *reinterpret_cast<const float4*>(res + (size_t)m * ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + n); acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
+    const float* pp = part + (size_t)m * npad + n;
+    const size_t stride = (size_t)M * npad;
+    int s0 = 0;
+    for (; s0 + 8 <= splits; s0 += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float4*>(pp + (size_t)(s0 + e) * stride);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { acc.x += v[e].x; acc.y += v[e].y; acc.z += v[e].z; acc.w += v[e].w; }
+    }
+    for (; s0 < splits; ++s0) {
+      const float4 v = *reinterpret_cast<const float4*>(pp + (size_t)s0 * stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = acc;
+    keep[j] = acc;
+    ss += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) wsum[tid >> 6] = ss;
+  __syncthreads();
+  const float r = rsqrtf(((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / (float)N + eps);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = tid * 4 + 1024 * j;
+    if (n >= N) break;
+    const float4 a = keep[j], w = *reinterpret_cast<const float4*>(nw + n);
+    const float o0 = w.x * (a.x * r), o1 = w.y * (a.y * r), o2 = w.z * (a.z * r), o3 = w.w * (a.w * r);
+    uint2 hv;
+    hv.x = pack_bf2(o0, o1); hv.y = pack_bf2(o2, o3);
+    *reinterpret_cast<uint2*>(y + (size_t)m * ldy + n) = hv;
+    if (ylo) {
+      uint2 lv;
+      lv.x = pack_bf2(o0 - bf_lo(hv.x), o1 - bf_hi(hv.x)); lv.y = pack_bf2(o2 - bf_lo(hv.y), o3 - bf_hi(hv.y));
+      *reinterpret_cast<uint2*>(ylo + (size_t)m * ldy + n) = lv;
+    }
+  }
+}
+
 // ---- pointwise conv with a small square weight (K = N = C in {96, 192}: the stem's third conv and the first PatchEmbed
 // 1x1), 0.9 ms of HBM-bound work per step that the tiled kernels ran at 2.3-3.1 TB/s: with a K loop of two or three tiles a
 // block is mostly prologue and epilogue.  Here the weight sits in LDS for the life of a persistent block, a wave streams
@@ -1046,6 +1120,35 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   static const int min_kt_per_range = fv_ab_env("FASTVLA_GEMM_MIN_KT") ? atoi(fv_ab_env("FASTVLA_GEMM_MIN_KT")) : 16;   // A/B
   static const int group_m_default = fv_ab_env("FASTVLA_GEMM_GROUP_M") ? atoi(fv_ab_env("FASTVLA_GEMM_GROUP_M")) : 4;   // A/B (0 = row-major walk)
   const bool asym = !no_asym && a.M <= 8192 && a.M % 256 == 0;   // the asymmetric staging addresses row + 32 from a (clamped) base row: whole row tiles only
+  // few rows (the control loop: M = 64 B rows of the decoder at B <= 2): 64-row tiles of the register-staged kernel cut along K until the chip is covered
+  // twice, >= 4 K-tiles per range; fp32 epilogues through the same reduce kernels as the 256-tile split-K below
+  static const bool no_skinny = fv_ab_env("FASTVLA_NO_SKINNY_SPLITK") != nullptr;   // A/B
+  if (!no_skinny && a.splitk_ws && f32out && a.M <= 128 && a.N % 8 == 0 && a.ksplit != 2 && !a.f16) {
+    const int tn = (a.N + BN - 1) / BN, tiles = ((a.M + 63) / 64) * tn, nkt = (a.ksplit ? 2 : 1) * ((a.K + BK - 1) / BK);
+    const int npad = tn * BN;
+    int splits = (2 * cus + tiles - 1) / tiles;
+    if (splits > nkt / 4) splits = nkt / 4;
+    while (splits > 1 && (size_t)splits * a.M * npad * sizeof(float) > a.splitk_bytes) --splits;
+    if (splits > 1) {
+      p.tiles_n = tn; p.splits = splits; p.npad = npad; p.part = a.splitk_ws; p.nwg = tiles * splits;
+      hipLaunchKernelGGL(gemm_kernel<64>, dim3(p.nwg), dim3(256), 0, s, p);
+      const long quads = (long)a.M * (a.N / 4);
+      if (a.norm_w) g_norm_fused = true;
+      if (a.norm_w && a.N <= 4096)
+        hipLaunchKernelGGL(splitk_reduce_norm_row_kernel, dim3((unsigned)a.M), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias,
+                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo,
+                           a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps);
+      else if (a.norm_w)
+        hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias,
+                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo,
+                           a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps, 0);
+      else
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias,
+                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo);
+      FV_HIP_CHECK(hipGetLastError());
+      return FV_OK;
+    }
+  }
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
   static const bool no_splitk = fv_ab_env("FASTVLA_NO_SPLITK") != nullptr, no_g256 = fv_ab_env("FASTVLA_NO_GEMM256") != nullptr;
   static const bool no_ragged_sk = fv_ab_env("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B

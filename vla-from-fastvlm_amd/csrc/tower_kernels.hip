@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
                                                                const float* __restrict__ b3, const bf16_t* __restrict__ t7,
                                                                const float* __restrict__ b7, bf16_t* __restrict__ y1,
                                                                bf16_t* __restrict__ y2, int H, int W, int C, int tiles_x,
-                                                               int nslices) {
+                                                               int nslices, int nseg) {
   using G = DpGeo<CHB, TW_>;
   constexpr int TW = G::TW, NQ = G::NQ, NTQ = G::NTQ, NEQ = G::NEQ, RS = G::RS, XR = G::XR, PR = G::PR, PLB = G::PLB;
   constexpr int NCG = G::NCG, NGG = G::NGG, NRG = G::NRG;
@@ -1155,6 +1155,10 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
+  // nseg > 1 (few strips: B <= 4): the march is cut into nseg row segments, each its own block.  Segment [g0, g1) starts one unit early (x' unit
+  // g0 - 1 feeds the first t rows; its own rows are the previous segment's to store) -- every output row is computed by the same arithmetic as in
+  // the uncut march, by exactly one block
+  const int seg = bid % nseg; bid /= nseg;
   const int slice = bid % nslices; bid /= nslices;
   const int tx = bid % tiles_x;
   const long b = bid / tiles_x;
@@ -1162,6 +1166,7 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
   const int gg = wid % NGG, rg0 = (wid / NGG) * NRG;   // wave = (16-channel group, first of its NRG 4-row groups)
   const int bch = lane >> 2, jr = lane & 3;            // lane = (channel within the group, row within the 4)
   const int ng = (H + 7) / 8;
+  const int g0 = (int)((long)seg * ng / nseg), g1 = (int)((long)(seg + 1) * ng / nseg);
   const uint32_t pl = (uint32_t)(gg >> 1) * PLB;       // the wave's plane inside a ring row
 
   s16x4 a3[3][2], a7[7][3];
@@ -1189,7 +1194,7 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
   // exec-mask branch: 20 of them per thread and step.  COLOOB + any step offset stays in [tensor bytes, 2^32) (launcher's guard).
   constexpr uint32_t COLOOB = 0x7FFFFFF0u, ROWOOB = 0x80000000u;
   const uint32_t rowbytes = (uint32_t)W * (uint32_t)C * 2u;
-  const uint32_t tbytes = (uint32_t)((size_t)gridDim.x / ((size_t)tiles_x * nslices) * H * rowbytes);
+  const uint32_t tbytes = (uint32_t)((size_t)gridDim.x / ((size_t)tiles_x * nslices * nseg) * H * rowbytes);
   // x loads are inline asm: vmcnt counts loads and stores in one in-order queue, and hipcc, unable to count the stores of a step
   // across the loop's branches, waited vmcnt(0) for the x unit -- i.e. for the write acknowledgements of every store issued after
   // those loads.  The loads are a full step old when they are needed; DP_WAIT_X leaves the younger stores outstanding.
@@ -1295,17 +1300,19 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
   static_assert(TPT <= 2, "DP_WAIT_X names the first and the last task slot");
   // x unit -2 (rows -12 .. -5) is never written: step -1 reads its last two rows, but only into x' rows < 0, which are stored as
   // zero whatever the 3x3 saw.  (Writing it raced with unit -1: their ring slots overlap and no barrier separates the two writes.)
-  DP_LOAD_XUNIT(-1)
+  // (a later segment's warm-up unit g0 - 1 would need the last two rows of x unit g0 - 2 for its first two x' rows: those rows, 8 g0 - 5 and - 4, are
+  // neither stored nor read by this segment's 7x7, which starts at x' row 8 g0 - 3)
+  DP_LOAD_XUNIT(g0 - 1)
   DP_WAIT_X(0)
-  DP_WRITE_XUNIT(-1)
-  DP_LOAD_XUNIT(0)
+  DP_WRITE_XUNIT(g0 - 1)
+  DP_LOAD_XUNIT(g0)
 #define DP_DUMMY_STORES(N) _Pragma("unroll") for (int z_ = 0; z_ < (N); ++z_) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(px[0][0]), "v"(ROWOOB), "s"(xrsrc) : "memory");
   DP_DUMMY_STORES(8)
 
 #ifdef DP_STAMPS
   unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_readcyclecounter();
 #endif
-  for (int g = -1; g < ng; ++g) {
+  for (int g = g0 - 1; g < g1; ++g) {
     DP_T(11)
     __syncthreads();   // x unit g is in its ring; the previous step's output tile and x' rows have been read
     DP_T(0)
@@ -1366,14 +1373,14 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
     DP_T(1)
     __syncthreads();   // x' unit g is in its ring; every wave is done with x unit g - 1
     DP_T(2)
-    if (g + 1 < ng) {
+    if (g + 1 < g1) {
       // x unit g + 1 was requested a step ago; younger than it are the 4 x' and 4 t stores of step g - 1 (the prologue and step -1
       // issue dropped out-of-range stores in their place so that ONE wait count fits every step)
       DP_WAIT_X(8)
       DP_WRITE_XUNIT(g + 1)
     }
     DP_T(3)
-    if (g + 2 < ng) DP_LOAD_XUNIT(g + 2)
+    if (g + 2 < g1) DP_LOAD_XUNIT(g + 2)
     DP_T(4)
     // ---- emit x' rows 8g + 3 .. 8g + 10 (columns of this strip only), v_perm transpose back to channel-contiguous pixels
     {
@@ -1387,7 +1394,7 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
           uint2 r[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const uint2*>(sP + (src ^ (uint32_t)(e * 8)));
-          const bool ok = (unsigned)(8 * g + 3 + e1row[et]) < (unsigned)H;
+          const bool ok = (unsigned)(8 * g + 3 + e1row[et]) < (unsigned)H && (g >= g0 || g0 == 0);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             u32x4 o;
@@ -1401,7 +1408,7 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
       }
     }
     DP_T(5)
-    if (g < 0) { DP_DUMMY_STORES(4) continue; }
+    if (g < g0) { DP_DUMMY_STORES(4) continue; }
     // ---- t rows 8g .. 8g + 7 = dw7x7 over x' units g - 1, g
     {
       f32x4 acc[NRG][NTQ];
@@ -1526,18 +1533,32 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __res
 // ------------------------------------------------------------------------------------------------ SE + GELU
 __global__ __launch_bounds__(256) void se_pool_kernel(const bf16_t* __restrict__ x, float* __restrict__ pooled, int P,
                                                        int C) {
-  // grid (C/8/256 ceil, B); thread = 8 channels, loops over the P pixels
-  const int ch = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (ch >= (C >> 3)) return;
+  // grid (C/8/16 ceil, B); thread = (8 channels, one of 16 interleaved pixel classes): 16 partial sums per channel, added in class order
+  // (one observation used to walk its 256 pixels on 2 blocks: 70 us of a 5 ms control-loop step)
+  __shared__ float part[16][16][8];
+  const int cgl = threadIdx.x & 15, pr = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cgl, b = blockIdx.y;
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int p = 0; p < P; ++p) {
-    float v[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)b * P + p) * C + ch * 8), v);
+  if (ch < (C >> 3)) {
+    for (int p = pr; p < P; p += 16) {
+      float v[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)b * P + p) * C + ch * 8), v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] += v[e];
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) pooled[(size_t)b * C + ch * 8 + e] = a[e] / (float)P;
+  for (int e = 0; e < 8; ++e) part[pr][cgl][e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x >> 3, e = threadIdx.x & 7, chn = blockIdx.x * 16 + c;
+    if (chn < (C >> 3)) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += part[q][c][e];
+      pooled[(size_t)b * C + chn * 8 + e] = t / (float)P;
+    }
+  }
 }
 
 // y[b][n] = act(sum_k x[b][k] W[n][k] + bias[n]); one wave per (b, n); act 0 = relu, 1 = sigmoid
@@ -1864,14 +1885,23 @@ int launch_dwconv_pair(const bf16_t* x, const bf16_t* t3, const float* b3, const
   if (geo == 1 && C % 64) geo = 0;
   const int chb = geo == 1 ? 64 : 32, tw = geo == 0 ? 32 : 16;
   const int tiles_x = (W + tw - 1) / tw, nsl = C / chb;
-  const long nstrips = (long)B * tiles_x * nsl;
+  long nstrips = (long)B * tiles_x * nsl;
   if (nstrips > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv_pair: grid too large");
+  // few strips (one observation: 24 per launch): row segments of >= 2 units until ~2 blocks per CU (each segment re-walks one unit)
+  int nseg = 1;
+  if (nstrips < 256) {
+    const int ng = (H + 7) / 8;
+    nseg = (int)((512 + nstrips - 1) / nstrips);
+    if (nseg > ng / 2) nseg = ng / 2;
+    if (nseg < 1) nseg = 1;
+  }
+  nstrips *= nseg;
   if (geo == 1)
-    hipLaunchKernelGGL((dwpair_march_kernel<64, 16>), dim3((unsigned)nstrips), dim3(256), (DpGeo<64, 16>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl);
+    hipLaunchKernelGGL((dwpair_march_kernel<64, 16>), dim3((unsigned)nstrips), dim3(256), (DpGeo<64, 16>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl, nseg);
   else if (geo == 2)
-    hipLaunchKernelGGL((dwpair_march_kernel<32, 16>), dim3((unsigned)nstrips), dim3(256), (DpGeo<32, 16>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl);
+    hipLaunchKernelGGL((dwpair_march_kernel<32, 16>), dim3((unsigned)nstrips), dim3(256), (DpGeo<32, 16>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl, nseg);
   else
-    hipLaunchKernelGGL((dwpair_march_kernel<32, 32>), dim3((unsigned)nstrips), dim3(256), (DpGeo<32, 32>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl);
+    hipLaunchKernelGGL((dwpair_march_kernel<32, 32>), dim3((unsigned)nstrips), dim3(256), (DpGeo<32, 32>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl, nseg);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -1892,7 +1922,7 @@ int launch_se_gelu(const bf16_t* x, const float* w1, const float* b1, const floa
   float* pooled = scratch;             // [B][C]
   float* hid = pooled + (size_t)B * C; // [B][R]
   float* sc = hid + (size_t)B * R;     // [B][C]
-  hipLaunchKernelGGL(se_pool_kernel, dim3((C / 8 + 255) / 256, B), dim3(256), 0, s, x, pooled, P, C);
+  hipLaunchKernelGGL(se_pool_kernel, dim3((C / 8 + 15) / 16, B), dim3(256), 0, s, x, pooled, P, C);
   hipLaunchKernelGGL(se_fc_kernel, dim3((R + 3) / 4, B), dim3(256), 0, s, pooled, w1, b1, hid, R, C, 0);
   hipLaunchKernelGGL(se_fc_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, hid, w2, b2, sc, C, R, 1);
   const long chunks = (long)B * P * (C / 8);
