@@ -441,6 +441,12 @@ int fv_op_convffn(const void* x, const void* w1, const float* b1, const void* w2
  * l < 64, d < 4, b < 2. */
 int fv_op_convffn32(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
                     int M, int C, fv_stream s);
+/* The same operator when a launch has few row tiles (one to four observations: <= 128 tiles for 256 CUs): blocks = (row tile, one of 2 / 4 / 8 ranges
+ * of the hidden units), fp32 partial sums in `part` (>= ranges x M x C floats, 16-byte aligned), then one pass adds the ranges in order and applies
+ * b2, ls and the residual exactly as the one-launch epilogue does.  Falls back to fv_op_convffn32 when M is large or `part` too small.  The engine
+ * takes this form by itself below 128 row tiles (fv_vision_forward at B <= 4). */
+int fv_op_convffn32_split(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
+                          int M, int C, float* part, size_t part_bytes, fv_stream s);
 
 #ifdef __cplusplus
 }

@@ -146,19 +146,25 @@ def test_full_size_tower_per_stage(full):
 
 
 def test_full_size_tower_microbatch_and_batch_rows(full):
-    """size-independent property at the bench batch shape: an image's tokens do not depend on its neighbours or on the
-    tower micro-batch (B=4 in one pass == the same images one at a time)."""
+    """size-independent property at the bench batch shape: an image's tokens do not depend on its neighbours or on the tower micro-batch
+    (B = 8 in one pass == the same images four at a time).  The launchers pick tile shapes by a launch's row count; down to B = 4 every kernel
+    accumulates in the same order, so the rows agree to the last bf16 rounding at most.  Below that (the control loop: one or two observations) the fused
+    ConvFFN cuts its hidden units into ranges -- another fp32 summation order, <= 1 bf16 step per output (test_fused_convffn32_hidden_ranges) -- and the
+    tower carries a rounding-level difference to its output as it carries its own bf16 roundings (two bf16 executions of the oracle sit 1.2e-2 apart,
+    DESIGN.md section 6): one image at a time is held to that distance, not to bit equality."""
     m, w, eng = full
     torch.manual_seed(12)
-    pix = eng.preprocess(torch.rand(4, 3, 336, 336).to(DEV))
+    pix = eng.preprocess(torch.rand(8, 3, 336, 336).to(DEV))
     a = eng.vision_forward(pix)
-    b = torch.cat([eng.vision_forward(pix[i:i + 1].contiguous()) for i in range(4)], dim=0)
+    b = torch.cat([eng.vision_forward(pix[i:i + 4].contiguous()) for i in (0, 4)], dim=0)
+    c = torch.cat([eng.vision_forward(pix[i:i + 1].contiguous()) for i in range(4)], dim=0)
     torch.cuda.synchronize()
-    # the launchers pick tile shapes by the launch's total row count, so the two runs may take different kernels for the same
-    # layer; every kernel accumulates K in the same order in fp32, so the rows agree to the last bf16 rounding at most
     r = rel_l2(a.cpu(), b.cpu())
-    print(f"[fastvlm-0.5b] B=4 in one pass vs one image at a time: identical={bool(torch.equal(a, b))} rel_l2={r:.2e}")
+    r1 = rel_l2(a[:4].cpu(), c.cpu())
+    print(f"[fastvlm-0.5b] B=8 in one pass vs four images at a time: identical={bool(torch.equal(a, b))} rel_l2={r:.2e}; vs one image at a time (hidden-range "
+          f"ConvFFN, row-segmented depthwise pair): rel_l2={r1:.2e}")
     assert r <= 2e-3
+    assert r1 <= 3e-2
 
 
 @pytest.mark.parametrize("splice", [False, True], ids=["literal", "splice"])

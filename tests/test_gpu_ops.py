@@ -367,6 +367,45 @@ def test_fused_convffn32(Cc, M):
     assert torch.equal(rd, out)
 
 
+@pytest.mark.parametrize("Cc,M", [(384, 4096), (384, 8192), (384, 16384 - 37), (192, 16384), (192, 65536), (96, 65536), (96, 131072), (384, 100)])
+def test_fused_convffn32_hidden_ranges(Cc, M):
+    """One to four observations give the fused ConvFFN 32 .. 128 row tiles for 256 CUs; the launcher then cuts the hidden units into 2 / 4 / 8 ranges
+    (block = row tile x range, fp32 partial sums, one reduce pass with the one-launch epilogue's arithmetic).  Against the oracle like the one-launch
+    kernel, against that kernel within one rounding of the output (the ranges change the fp32 summation order only), bit-repeatable, in place."""
+    torch.manual_seed(Cc + M + 5)
+    Hd = 4 * Cc
+    x, res = bf(torch.randn(M, Cc)), bf(torch.randn(M, Cc))
+    w1, w2 = bf(torch.randn(Hd, Cc) / math.sqrt(Cc)), bf(torch.randn(Cc, Hd) / math.sqrt(Hd))
+    b1, b2, ls = torch.randn(Hd) * 0.1, torch.randn(Cc) * 0.1, torch.rand(Cc) * 0.3 + 0.05
+    hid = bf(F.gelu(x @ w1.t() + b1))
+    ref = res + ls * (hid @ w2.t() + b2)
+    xd, rd, wqd = dev_bf16(x), dev_bf16(res), dev_bf16(_pack_wq(w1, w2))
+    b1d, b2d, lsd = dev_f32(b1), dev_f32(b2), dev_f32(ls)
+    part = torch.full((8 * M * Cc + 64,), float("nan"), dtype=torch.float32, device=DEV)
+    outs = []
+    for rep in range(2):
+        out = torch.full((M, Cc), float("nan"), dtype=torch.bfloat16, device=DEV)
+        call(lib().fv_op_convffn32_split(xd.data_ptr(), wqd.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(), rd.data_ptr(), out.data_ptr(),
+                                         M, Cc, part.data_ptr(), part.numel() * 4, stream()), "fv_op_convffn32_split")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    check_close(outs[0].float().cpu(), ref, what=f"convffn32 hidden ranges C={Cc} M={M}")
+    one = torch.empty_like(outs[0])
+    call(lib().fv_op_convffn32(xd.data_ptr(), wqd.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(), rd.data_ptr(), one.data_ptr(), M, Cc,
+                               stream()), "fv_op_convffn32")
+    torch.cuda.synchronize()
+    d = (outs[0].float() - one.float()).abs()
+    ulp = one.float().abs().clamp_min(2.0 ** -6) * 2.0 ** -7
+    assert bool((d <= ulp).all()), f"more than one bf16 step from the one-launch kernel: {float((d / ulp).max()):.2f}"
+    if M >= 4096:
+        assert float((d > 0).float().mean()) < 0.05
+    call(lib().fv_op_convffn32_split(xd.data_ptr(), wqd.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(), rd.data_ptr(), rd.data_ptr(),
+                                     M, Cc, part.data_ptr(), part.numel() * 4, stream()), "fv_op_convffn32_split in place")
+    torch.cuda.synchronize()
+    assert torch.equal(rd, outs[0])
+
+
 def _toeplitz(w, k):
     """depthwise weights (C,1,k,k) -> bf16 table [C/16][k][NM][16][4 i][4 kk] = w[ky][4m + kk - i] (fastvla_hip.h)."""
     Cc = w.shape[0]

@@ -75,6 +75,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 struct Ffn32Params {
   const bf16_t* x; const bf16_t* wq; const float* b1; const float* b2; const float* ls;
   const bf16_t* res; bf16_t* out; int M, nchunks;
+  float* part = nullptr; int hsplit = 1;   // PART instances: nchunks = chunks PER RANGE, raw fp32 sums to part[range][M][C]
 };
 
 // output accumulators pinned to the accumulator half of the register file, hidden-tile accumulators to the architectural
@@ -159,7 +160,10 @@ struct Ffn32Lds {
 
 // NW = waves per block.  4 (C = 384, 96): one wave per SIMD with all 512 registers.  8 (C = 192): two waves per SIMD with 256 registers each,
 // no AGPRs, 32 * MT rows per wave as before -- one wave's GELU and epilogue run beside its partner's MFMAs (FFN32_NW192 = 4 restores the old shape).
-template <int C, int MT, int NW = 4, bool S16 = false>
+// PART (few row tiles: one to four observations give C = 384 32 .. 128 tiles for 256 CUs, and a tile costs its whole 2.4 MB weight pass whoever else is
+// idle): block = (row tile, one of hsplit ranges of hidden chunks).  The kernel is the same chunk loop over a weight stream that starts at the range's
+// first chunk; the epilogue leaves the raw fp32 output sums in p.part[range] and ffn32_reduce_kernel adds the ranges, bias, layer scale and residual.
+template <int C, int MT, int NW = 4, bool S16 = false, bool PART = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params p) {
   using L = Ffn32Lds<C, MT, NW>;
   constexpr int NTH = 64 * NW, TROWS = 32 * NW * MT;   // threads per block, rows per row tile set
@@ -174,12 +178,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = S16 ? lane & 15 : lane & 31, fh = S16 ? lane >> 4 : lane >> 5;
-  const int nch = p.nchunks;                                   // C / 8: even, >= 4
+  const int nch = p.nchunks;                                   // C / 8 (PART: per range): even, >= 4
   const int ntiles = (p.M + TROWS - 1) / TROWS;
+  const int hrange = PART ? (int)blockIdx.x % p.hsplit : 0, tile0 = PART ? (int)blockIdx.x / p.hsplit : (int)blockIdx.x;
   // the packed weight stream through a buffer descriptor: a buffer load costs a wave ~6 clk of issue beside the MFMAs where a
   // global load costs ~23 (tools/stage_micro.hip); lane offset in a VGPR (piece of wave wid, 16 B per lane), chunk and piece in
   // the scalar offset
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.wq), 0, nch * BUF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<bf16_t*>(p.wq)) + (size_t)hrange * nch * BUF, 0, nch * BUF, 0x00020000);
   const uint32_t wvoff = (uint32_t)tid * 16u;
   // activations through descriptors too (32-bit byte offsets: M * C * 2 < 4 GiB, checked by the launcher)
   const uint32_t act_bytes = (uint32_t)p.M * (uint32_t)(C * 2);
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
                               : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.x) + xo_ + ks * 32)); \
     }                                                                                                        \
   }
-  F32_LOAD_X(blockIdx.x)
+  F32_LOAD_X(tile0)
   f32x16 oacc[S16 ? 1 : NT][S16 ? 1 : MT];
   f32x4 oacc16[S16 ? NT : 1][S16 ? MT : 1][2];
 
@@ -250,8 +255,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
     reinterpret_cast<float4*>(sb2)[i] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, b.w * l.w);
     reinterpret_cast<float4*>(sls)[i] = l;
   }
-  for (int i = tid; i < C; i += NTH) {       // sb1 holds b1 / 4: the first product runs on W1 / 4 (exact), see the GELU
-    const float4 b = reinterpret_cast<const float4*>(p.b1)[i];
+  for (int i = tid; i < (PART ? nch * 8 : C); i += NTH) {       // sb1 holds b1 / 4: the first product runs on W1 / 4 (exact), see the GELU
+    const float4 b = reinterpret_cast<const float4*>(p.b1 + (size_t)hrange * nch * 32)[i];
     reinterpret_cast<float4*>(sb1)[i] = make_float4(0.25f * b.x, 0.25f * b.y, 0.25f * b.z, 0.25f * b.w);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-tid stores are invisible to hipcc's counters
@@ -475,7 +480,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
     while (__builtin_amdgcn_s_memtime() - t0_ < wait_) __builtin_amdgcn_s_sleep(32);
   }
 #endif
-  for (int tile = blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+  // PART: the partial sums of this range through a descriptor of their own (fp32: twice the byte offsets of the bf16 rows)
+  const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(PART ? p.part + (size_t)hrange * p.M * C : nullptr, 0, PART ? act_bytes * 2u : 0u, 0x00020000);
+  const uint32_t peoff = er < ERW ? (uint32_t)(er * C + ec8) * 4u : OOB;
+  const uint32_t peoff_last = (er < ERW && (RP - 1) * ERW + er < 32) ? peoff : OOB;
+  for (int tile = tile0; tile < ntiles; tile += PART ? ntiles : (int)gridDim.x) {
     const long mb = (long)tile * TROWS + wid * (32 * MT);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -507,8 +516,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
       continue;
     }
 #endif
+    if constexpr (!PART) {
 #pragma unroll
-    for (int q0 = 0; q0 < (RD == NPASS * MT ? RD : RD - 1) && q0 < NPASS * MT; ++q0) F32_LOAD_RES(q0, mb)
+      for (int q0 = 0; q0 < (RD == NPASS * MT ? RD : RD - 1) && q0 < NPASS * MT; ++q0) F32_LOAD_RES(q0, mb)
+    }
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");  // last XDL writes of the output accumulators -> VALU reads below
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue: each wave turns 32 rows x CQ channels at a time through LDS as raw fp32 (accumulator registers 4q..4q+3 of
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
 #pragma unroll
     for (int q = 0; q < NPASS * MT; ++q) {
       const int mt = q / NPASS, pass = q % NPASS;
-      if (q == F32_XPASS) F32_LOAD_X(tile + (int)gridDim.x)   // the next tile's x fragments fly from this pass on
+      if (!PART && q == F32_XPASS) F32_LOAD_X(tile + (int)gridDim.x)   // the next tile's x fragments fly from this pass on
       if constexpr (S16) {   // tile t, pixel tile n: channels 16 t + 4 fh + 0..3 of pixel 16 n + fr
 #pragma unroll
         for (int tl = 0; tl < CQ / 16; ++tl)
@@ -551,6 +562,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
       for (int it = 0; it < RP; ++it) {
         const char* sr = it == RP - 1 ? sor_last : sor + it * (ERW * ORB);
         const float4 y0 = *reinterpret_cast<const float4*>(sr), y1 = *reinterpret_cast<const float4*>(sr + 16);
+        if constexpr (PART) {
+          typedef __attribute__((ext_vector_type(4))) unsigned int pu4;
+          const uint32_t po_ = (it == RP - 1 ? peoff_last : peoff) + 2u * (so_ + (uint32_t)(it * (ERW * C * 2)));
+          __builtin_amdgcn_raw_buffer_store_b128(pu4{__float_as_uint(y0.x), __float_as_uint(y0.y), __float_as_uint(y0.z), __float_as_uint(y0.w)}, prsrc, po_, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(pu4{__float_as_uint(y1.x), __float_as_uint(y1.y), __float_as_uint(y1.z), __float_as_uint(y1.w)}, prsrc, po_, 16, 0);
+          continue;
+        }
         const uint4 r4 = rr[q % RD][it];
         uint4 o;
         o.x = pack_bf2(bf_lo(r4.x) + fmaf(l0.x, y0.x, b0.x), bf_hi(r4.x) + fmaf(l0.y, y0.y, b0.y));
@@ -561,7 +579,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
                                                F32_ABL_NOOUT ? OOB : (it == RP - 1 ? eoff_last : eoff) + (so_ + (uint32_t)(it * (ERW * C * 2))), 0, FFN32_NT_OUT);
         if (it & 1) __builtin_amdgcn_sched_barrier(0);   // two items' operands in flight at a time
       }
-      if (RD < NPASS * MT && q + RD - 1 < NPASS * MT) F32_LOAD_RES(q + RD - 1, mb)
+      if (!PART && RD < NPASS * MT && q + RD - 1 < NPASS * MT) F32_LOAD_RES(q + RD - 1, mb)
       asm volatile("" ::: "memory");                      // the next pass's writes stay behind these reads
     }
 #ifdef FFN32_STAMPS
@@ -602,6 +620,51 @@ int num_cus32() {
   return n;
 }
 
+// out = res + ls * (sum over ranges of part[r] + b2), 8 channels per thread, ranges in order; the same fma as the fused epilogue
+__global__ __launch_bounds__(256) void ffn32_reduce_kernel(const float* __restrict__ part, int hsplit, long M, int C, const float* __restrict__ b2,
+                                                            const float* __restrict__ ls, const bf16_t* res, bf16_t* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c8 = C >> 3;
+  if (i >= M * c8) return;
+  const long m = i / c8;
+  const int c = (int)(i - m * c8) * 8;
+  float y[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = 0; r < hsplit; ++r) {
+    const float* pp = part + ((size_t)r * M + m) * C + c;
+    const float4 a = *reinterpret_cast<const float4*>(pp), b = *reinterpret_cast<const float4*>(pp + 4);
+    y[0] += a.x; y[1] += a.y; y[2] += a.z; y[3] += a.w; y[4] += b.x; y[5] += b.y; y[6] += b.z; y[7] += b.w;
+  }
+  float rv[8], o[8];
+  unpack8(*reinterpret_cast<const uint4*>(res + m * C + c), rv);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const float l = ls[c + e]; o[e] = rv[e] + fmaf(l, y[e], b2[c + e] * l); }
+  *reinterpret_cast<uint4*>(out + m * C + c) = pack8(o);
+}
+
+template <int C, int MT, int NW>
+int launch_part32(Ffn32Params p, float* part, size_t part_bytes, hipStream_t s) {
+  constexpr int LDS = Ffn32Lds<C, MT, NW>::TOTAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn32_kernel<C, MT, NW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const long tiles = ((long)p.M + 32 * NW * MT - 1) / (32 * NW * MT);
+  const int nch = p.nchunks;
+  // the largest power of two that keeps >= 6 chunks (an even count) per range, ONE round of blocks (every range writes and the reduce pass re-reads
+  // M x C floats: 16 x the bf16 output per range -- a second round costs more than the ranges save) and fits the scratch
+  int hs = 1;
+  for (int c = 2; c <= 8; c *= 2)
+    if (nch % c == 0 && (nch / c) % 2 == 0 && nch / c >= 6 && tiles * c <= num_cus32() && tiles * 4 <= num_cus32() && (size_t)c * p.M * C * sizeof(float) <= part_bytes) hs = c;   // (128 tiles in 2 ranges: measured slower than one launch)
+  if (hs == 1) return -1;   // not worth it: the caller takes the one-launch form
+  p.part = part; p.hsplit = hs; p.nchunks = nch / hs;
+  hipLaunchKernelGGL((convffn32_kernel<C, MT, NW, false, true>), dim3((unsigned)(tiles * hs)), dim3(64 * NW), LDS, s, p);
+  const long n8 = (long)p.M * (C / 8);
+  hipLaunchKernelGGL(ffn32_reduce_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, part, hs, (long)p.M, C, p.b2, p.ls, p.res, p.out);
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
 template <int C, int MT, int NW = 4, bool S16 = false>
 int launch_one32(const Ffn32Params& p, hipStream_t s) {
   constexpr int LDS = Ffn32Lds<C, MT, NW>::TOTAL;
@@ -620,6 +683,16 @@ int launch_one32(const Ffn32Params& p, hipStream_t s) {
 }  // namespace
 
 bool convffn32_supported(int C, int ratio) { return ratio == 4 && (C == 96 || C == 192 || C == 384); }
+#ifdef FFN32_NW192
+#define FFN32_NW192_DEFAULT FFN32_NW192
+#else
+#define FFN32_NW192_DEFAULT 8
+#endif
+#if defined(FFN32_MT96) || defined(FFN32_NW96)
+#define FFN32_MT96_DEFAULT 0   /* variant builds of tools/ffn32_variants.sh keep the one-launch form */
+#else
+#define FFN32_MT96_DEFAULT 4
+#endif
 
 #ifndef FFN32_S16_MASK   /* which widths run on v_mfma_f32_16x16x32_bf16: bit 0 C = 384, bit 1 C = 192, bit 2 C = 96 */
 #define FFN32_S16_MASK 0
@@ -664,7 +737,7 @@ void convffn32_pack(const float* w1, const float* w2, float* out, int C) {
 }
 
 int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const float* b2, const float* ls,
-                     const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s) {
+                     const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s, float* part, size_t part_bytes) {
   if (!x || !wq || !b1 || !b2 || !ls || !res || !out) return fv_fail(FV_ERR_ARG, "convffn32: null pointer");
   if (M <= 0 || hidden != 4 * C || !convffn32_supported(C, 4)) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: unsupported C=%d hidden=%d", C, hidden);
   if (((uintptr_t)x | (uintptr_t)wq | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ls | (uintptr_t)res | (uintptr_t)out) & 15)
@@ -672,6 +745,17 @@ int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const f
   if (x == out) return fv_fail(FV_ERR_ARG, "convffn32: x must not alias out");
   if ((size_t)M * C * 2 >= ((size_t)1 << 31)) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: M * C * 2 must stay below 2 GiB (32-bit buffer offsets)");
   Ffn32Params p{x, wq, b1, b2, ls, res, out, M, hidden / 32};
+  // few row tiles and scratch supplied: (tile, hidden range) blocks + a reduce pass (the default instances' tile heights)
+  if (part && ((uintptr_t)part & 15) == 0 && (size_t)M * C * 4 < ((size_t)1 << 31)) {
+    const int trows = C == 384 ? 128 : C == 192 ? 256 : 512;
+    if ((M + trows - 1) / trows <= num_cus32() / 2) {
+      int rc = -1;
+      if (C == 384) rc = launch_part32<384, 1, 4>(p, part, part_bytes, s);
+      else if (C == 192 && FFN32_NW192_DEFAULT == 8) rc = launch_part32<192, 1, 8>(p, part, part_bytes, s);
+      else if (C == 96 && FFN32_MT96_DEFAULT == 4) rc = launch_part32<96, 4, 4>(p, part, part_bytes, s);
+      if (rc != -1) return rc;
+    }
+  }
   switch (C) {
 #ifndef FFN32_MT96
 #define FFN32_MT96 4

@@ -165,6 +165,7 @@ struct fv_handle {
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
   bool no_ffn32 = false;      // FASTVLA_NO_FFN32=1: A/B switch back to the 16x16x32 fused ConvFFN
   TrainState train;               // unfrozen-backbone training (train_path.inc): library-owned transposed bf16 weight copies
+  float* ffn_part = nullptr;      // device: the fused ConvFFN's partial sums when a launch has few row tiles (B <= 4: launch_convffn32's hidden ranges), FFN_PART_BYTES
   unsigned* f16_flags = nullptr;  // device: [0] = activation groups clamped to the fp16 range (fv_llm_fp16_saturations),
                                   // [1] = max |scaled weight| bits seen by the loader's in-place fp16 conversion
 };
@@ -175,6 +176,8 @@ HandleScope::HandleScope(fv_handle* h) : prev(g_err_handle) { g_err_handle = h ?
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// up to 8 ranges x 128 row tiles x 128 rows x 384 channels of fp32 (C = 384 at B = 4; the narrower stages need as much at most)
+constexpr size_t FFN_PART_BYTES = (size_t)8 * 128 * 128 * 384 * 4 / 2 + (1 << 20);
 int dev_alloc(fv_handle* h, size_t bytes, void** out) {
   void* p = nullptr;
   FV_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
@@ -471,8 +474,12 @@ int dw_s1(fv_handle* h, const bf16_t* x, const float* w, const bf16_t* ttab, con
 }
 
 // fused ConvFFN pointwise half: the 32x32x16 kernel where it exists (C = 96 / 192 / 384), else the 16x16x32 one
-int fused_ffn(fv_handle* h, const FFN& f, const bf16_t* t, const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s) {
-  if (f.w2q && !h->no_ffn32 && (size_t)M * C * 2 < ((size_t)1 << 31)) return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s);
+// ranges: the inference tower lets launch_convffn32 cut the hidden units into ranges when the launch has few row tiles (B <= 2).  That changes the fp32
+// summation order (<= 1 bf16 step per output), so the TRAINING forward keeps the one-launch form at every batch size: a row's gradient must not depend
+// on how many rows share its step (tests/test_gpu_train_tower.py, B = 32 against B = 2).
+int fused_ffn(fv_handle* h, const FFN& f, const bf16_t* t, const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s, bool ranges = true) {
+  if (f.w2q && !h->no_ffn32 && (size_t)M * C * 2 < ((size_t)1 << 31))
+    return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s, ranges ? h->ffn_part : nullptr, ranges && h->ffn_part ? FFN_PART_BYTES : 0);
   return fv::launch_convffn(t, f.fc1_w, f.fc1_b, f.w2p, f.fc2_b, f.ls, res, out, M, C, hidden, s);
 }
 
@@ -683,6 +690,10 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
       o1.W8 = L.o_w8;
       o1.splitk_ws = q1.splitk_ws;
       o1.splitk_bytes = wp.splitk_bytes;
+      // policies 1 / 5: post_attention_layernorm rides on the output projection (its split-K reducer where there is one, launch_gemm's own norm launch
+      // otherwise), as input_layernorm rides on the down projection
+      const bool ln2_fused = d.llm_precision == 1 || d.llm_precision == 5;
+      if (ln2_fused) { o1.norm_w = L.ln2; o1.norm_y = xs; o1.norm_ylo = xs + Hd; o1.norm_ld = 2 * Hd; o1.norm_eps = d.rms_eps; }
       FV_TRY(gemm_p(h, o1, s));
       fv::GemmArgs d1{cs, I2, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, KS};
       d1.W8 = L.down_w8;
@@ -709,9 +720,9 @@ int decoder_layers_split(fv_handle* h, const WsPlan& wp, int B, int Tq, const in
         d1 = fv::GemmArgs{act, I, L.down_w, rows, Hd, I, nullptr, nullptr, x, Hd, x, Hd, FV_EPI_RES_F32, 0};
         d1.f16 = 1;
       } else {
-        FV_P(FV_FAM_NORM, 4.0 * rows * Hd, 8.0 * rows * Hd, fv::launch_rmsnorm(x, L.ln2, xs, xs + Hd, 2 * Hd, rows, Hd, d.rms_eps, s, 0, nullptr, lo8));
         fv::GemmArgs g1{xs, 2 * Hd, L.gu_w, rows, I2, Hd, nullptr, nullptr, nullptr, 0, cs, I2, FV_EPI_SWIGLU_SPLIT, KS};
         g1.W8 = L.gu_w8;
+        g1.splitk_ws = q1.splitk_ws; g1.splitk_bytes = wp.splitk_bytes;   // few rows: K ranges + a SwiGLU reduce (launch_gemm's few-row rule)
         FV_TRY(gemm_p(h, g1, s));  // silu(gate)*up and its hi / lo (or lo8) split happen in the epilogue: no fp32 round trip
       }
       d1.splitk_ws = wp.splitk_bytes ? reinterpret_cast<float*>(ws + wp.splitk) : nullptr;
@@ -781,6 +792,7 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
     h->f16_flags = static_cast<unsigned*>(p);
     if (rc == FV_OK && hipMemset(p, 0, 256) != hipSuccess) rc = fv_fail(FV_ERR_HIP, "fp16 flag words: memset failed");
   }
+  if (rc == FV_OK) { rc = dev_alloc(h, FFN_PART_BYTES, &p); h->ffn_part = static_cast<float*>(p); }
   if (rc != FV_OK) { fv_destroy(h); return rc; }
   *out = h;
   return FV_OK;

@@ -864,6 +864,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_row_kernel(const float
   }
 }
 
+// The few-row split-K of gate/up: part[s][m][16 j .. 16 j + 15] = 8 gate | 8 up sums of range s -> silu(gate) * up as hi | lo bf16 halves ([M][N/2 | N/2]),
+// exactly the FV_EPI_SWIGLU_SPLIT epilogue on the summed accumulators
+__global__ __launch_bounds__(256) void splitk_reduce_swiglu_kernel(const float* __restrict__ part, int splits, int M, int N, int npad, bf16_t* __restrict__ out, int ldo) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n16 = N >> 4;
+  if (i >= (long)M * n16) return;
+  const int m = (int)(i / n16), n = (int)(i % n16) * 16;
+  float g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < splits; ++s) {
+    const float* pp = part + ((size_t)s * M + m) * npad + n;
+    const float4 a = *reinterpret_cast<const float4*>(pp), b = *reinterpret_cast<const float4*>(pp + 4);
+    const float4 c = *reinterpret_cast<const float4*>(pp + 8), d = *reinterpret_cast<const float4*>(pp + 12);
+    g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
+    u[0] += c.x; u[1] += c.y; u[2] += c.z; u[3] += c.w; u[4] += d.x; u[5] += d.y; u[6] += d.z; u[7] += d.w;
+  }
+  float o[8], h8[8], l8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = silu_f(g[e]) * u[e];
+  const uint4 hv = pack8(o);
+  unpack8(hv, h8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
+  *reinterpret_cast<uint4*>(out + (size_t)m * ldo + (n >> 1)) = hv;
+  *reinterpret_cast<uint4*>(out + (size_t)m * ldo + (N >> 1) + (n >> 1)) = pack8(l8);
+}
+
 // ---- pointwise conv with a small square weight (K = N = C in {96, 192}: the stem's third conv and the first PatchEmbed
 // 1x1), 0.9 ms of HBM-bound work per step that the tiled kernels ran at 2.3-3.1 TB/s: with a K loop of two or three tiles a
 // block is mostly prologue and epilogue.  Here the weight sits in LDS for the life of a persistent block, a wave streams
@@ -1123,7 +1149,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   // few rows (the control loop: M = 64 B rows of the decoder at B <= 2): 64-row tiles of the register-staged kernel cut along K until the chip is covered
   // twice, >= 4 K-tiles per range; fp32 epilogues through the same reduce kernels as the 256-tile split-K below
   static const bool no_skinny = fv_ab_env("FASTVLA_NO_SKINNY_SPLITK") != nullptr;   // A/B
-  if (!no_skinny && a.splitk_ws && f32out && a.M <= 128 && a.N % 8 == 0 && a.ksplit != 2 && !a.f16) {
+  const bool swiglu_sk = a.epi == FV_EPI_SWIGLU_SPLIT && !a.stash && a.N % 16 == 0;
+  if (!no_skinny && a.splitk_ws && (f32out || swiglu_sk) && a.M <= 128 && a.N % 8 == 0 && a.ksplit != 2 && !a.f16) {
     const int tn = (a.N + BN - 1) / BN, tiles = ((a.M + 63) / 64) * tn, nkt = (a.ksplit ? 2 : 1) * ((a.K + BK - 1) / BK);
     const int npad = tn * BN;
     int splits = (2 * cus + tiles - 1) / tiles;
@@ -1133,6 +1160,12 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
       p.tiles_n = tn; p.splits = splits; p.npad = npad; p.part = a.splitk_ws; p.nwg = tiles * splits;
       hipLaunchKernelGGL(gemm_kernel<64>, dim3(p.nwg), dim3(256), 0, s, p);
       const long quads = (long)a.M * (a.N / 4);
+      if (swiglu_sk) {
+        const long n = (long)a.M * (a.N / 16);
+        hipLaunchKernelGGL(splitk_reduce_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, static_cast<bf16_t*>(a.out), a.ldo);
+        FV_HIP_CHECK(hipGetLastError());
+        return FV_OK;
+      }
       if (a.norm_w) g_norm_fused = true;
       if (a.norm_w && a.N <= 4096)
         hipLaunchKernelGGL(splitk_reduce_norm_row_kernel, dim3((unsigned)a.M), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias,
