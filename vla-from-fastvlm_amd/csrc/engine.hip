@@ -497,6 +497,7 @@ int run_ffn(fv_handle* h, const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t*
   fv::GemmArgs g1{dw_out, C, f.fc1_w, M, C * ratio, C, f.fc1_b, nullptr, nullptr, 0, hid, C * ratio, FV_EPI_BIAS_GELU};
   FV_TRY(gemm_p(h, g1, s));
   fv::GemmArgs g2{hid, C * ratio, f.fc2_w, M, C, C * ratio, f.fc2_b, f.ls, res_out, C, res_out, C, FV_EPI_LS_RES};
+  g2.splitk_ws = h->ffn_part; g2.splitk_bytes = h->ffn_part ? FFN_PART_BYTES : 0;   // few rows (B <= 4): launch_gemm cuts K = 4C into ranges (inference only)
   FV_TRY(gemm_p(h, g2, s));
   return FV_OK;
 }
@@ -627,6 +628,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
   FV_P(FV_FAM_ELT, 20.0 * mb * P * CO, 6.0 * mb * P * CO, fv::launch_se_gelu(oth, tw.se_w1, tw.se_b1, tw.se_w2, tw.se_b2, tower_out, se, mb, P, CO, d.tower_se_rd, s));
   // mm_projector: Linear + GELU + Linear -> fp32 tokens ([site] fast_vlm/modeling_fast_vlm.py:51-55)
   fv::GemmArgs p0{tower_out, CO, tw.pj0_w, mb * P, d.llm_hidden, CO, tw.pj0_b, nullptr, nullptr, 0, hid, d.llm_hidden, FV_EPI_BIAS_GELU};
+  p0.splitk_ws = h->ffn_part; p0.splitk_bytes = h->ffn_part ? FFN_PART_BYTES : 0;
   FV_TRY(gemm_p(h, p0, s));
   fv::GemmArgs p2{hid, d.llm_hidden, tw.pj2_w, mb * P, d.llm_hidden, d.llm_hidden, tw.pj2_b, nullptr, nullptr, 0, img_tokens, d.llm_hidden, FV_EPI_F32};
   FV_TRY(gemm_p(h, p2, s));
