@@ -663,6 +663,34 @@ def main():
                                    "reference API's loss.item() host sync every step",
                    "batch": B, "prompt_tokens": T, "tokenizer": type(pol.model.backbone.tokenizer).__name__,
                    "api": "vla_fastvlm.lerobot_fastvla.FastVLAPolicy.select_action(batch) / .forward(batch)"}
+        # ---- the control loop the reference's eval scripts actually run (reference lerobot_fastvla/modeling_fastvla.py:119-125: one observation in, one
+        # action out, the host waiting for it): select_action on B = 1 / 2 / 4 observations, synchronised every call.  The launchers take the few-row
+        # forms here (K ranges for the decoder's 64-row GEMMs, row segments of the depthwise march, hidden ranges of the fused ConvFFN).
+        control = {}
+        for Bc in (1, 2, 4):
+            cb = {"observation.images.top": images[:Bc], "observation.state": states[:Bc], "task": tasks[:Bc]}
+            ts = []
+            for it in range(25):
+                torch.cuda.synchronize()
+                t0c = time.perf_counter()
+                pol.reset()
+                a_c = pol.select_action(cb)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0c)
+            ts = sorted(ts[5:])
+            ids_c, lens_c = ids[:Bc], lens[:Bc]
+            te = []
+            for it in range(25):
+                torch.cuda.synchronize()
+                t0c = time.perf_counter()
+                eng.head_forward(flat, eng.backbone(images[:Bc], ids_c, lens_c), states[:Bc])
+                torch.cuda.synchronize()
+                te.append(time.perf_counter() - t0c)
+            te = sorted(te[5:])
+            control[f"b{Bc}"] = {"select_action_ms_median": round(1e3 * ts[len(ts) // 2], 3), "select_action_ms_min": round(1e3 * ts[0], 3),
+                                 "engine_level_ms_median": round(1e3 * te[len(te) // 2], 3)}
+        surface["control_loop"] = dict(control, note="one call = tokenizer + letterbox + tower + projector + decoder + pool + head, host-synchronised; round 4: 5.6 / 6.2 / "
+                                                      "6.6 ms at the engine level (tools/latency_small_batch.py)")
         del pol
 
     # ---- the other decoder parity mode on a second engine (same weights, inputs, head): the opt-in policy 2 trades the decoder's 1e-5

@@ -1177,14 +1177,14 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   static const int min_kt_per_range = fv_ab_env("FASTVLA_GEMM_MIN_KT") ? atoi(fv_ab_env("FASTVLA_GEMM_MIN_KT")) : 16;   // A/B
   static const int group_m_default = fv_ab_env("FASTVLA_GEMM_GROUP_M") ? atoi(fv_ab_env("FASTVLA_GEMM_GROUP_M")) : 4;   // A/B (0 = row-major walk)
   const bool asym = !no_asym && a.M <= 8192 && a.M % 256 == 0;   // the asymmetric staging addresses row + 32 from a (clamped) base row: whole row tiles only
-  // few rows (the control loop: M = 64 B rows of the decoder at B <= 2): 64-row tiles of the register-staged kernel cut along K until the chip is covered
+  // few rows (the control loop: M = 64 B rows of the decoder at B <= 4): 64-row tiles of the register-staged kernel cut along K until the chip is covered
   // twice, >= 4 K-tiles per range; fp32 epilogues through the same reduce kernels as the 256-tile split-K below
   static const bool no_skinny = fv_ab_env("FASTVLA_NO_SKINNY_SPLITK") != nullptr;   // A/B
   const bool swiglu_sk = a.epi == FV_EPI_SWIGLU_SPLIT && !a.stash && a.N % 16 == 0;
-  if (!no_skinny && a.splitk_ws && (f32out || swiglu_sk) && a.M <= 128 && a.N % 8 == 0 && a.ksplit != 2 && !a.f16) {
+  if (!no_skinny && a.splitk_ws && (f32out || swiglu_sk) && a.M <= 256 && a.N % 8 == 0 && a.ksplit != 2 && !a.f16) {
     const int tn = (a.N + BN - 1) / BN, tiles = ((a.M + 63) / 64) * tn, nkt = (a.ksplit ? 2 : 1) * ((a.K + BK - 1) / BK);
     const int npad = tn * BN;
-    int splits = (2 * cus + tiles - 1) / tiles;
+    int splits = tiles < cus ? (2 * cus + tiles - 1) / tiles : 1;   // (gate/up at M = 256 is 304 tiles: it keeps the one-launch form)
     if (splits > nkt / 4) splits = nkt / 4;
     while (splits > 1 && (size_t)splits * a.M * npad * sizeof(float) > a.splitk_bytes) --splits;
     if (splits > 1) {
