@@ -736,6 +736,65 @@ def test_gemm_splitk_few_rows_many_splits(ws_splits):
     check_close(out.cpu(), ref, rel=2e-5, amax=2e-4, what=f"split-K few rows (scratch for {ws_splits})")
 
 
+@pytest.mark.parametrize("M", [64, 128, 200, 256])
+def test_gemm_few_rows_k_ranges(M):
+    """The control loop's decoder (one to four observations x 64 tokens): 64-row tiles cut into K ranges until the chip is covered, partial sums finished by
+    the reducers -- qkv (bias, fp32), down (fp32 residual, 152 K-tiles of the split-bf16 operand) and gate/up (SwiGLU + hi | lo split; at M = 256 its 304
+    tiles keep the one-launch form).  Against fp64, against the same call without scratch (fp32 summation order only), and twice for bit-repeatability."""
+    torch.manual_seed(900 + M)
+    Hd, I, QK = 896, 4864, 1152
+    ws = torch.full((40 * M * 1280,), float("nan"), dtype=torch.float32, device=DEV)
+
+    def split(x):
+        h = bf(x)
+        return h, bf(x - h)
+
+    def run(a, lda, w, N, K, bias, res, out, epi, scratch):
+        call(lib().fv_op_gemm_splitk(a.data_ptr(), lda, w.data_ptr(), M, N, K, None if bias is None else bias.data_ptr(), None if res is None else res.data_ptr(),
+                                     0 if res is None else N, out.data_ptr(), out.shape[1], epi, 1, ws.data_ptr() if scratch else None, ws.numel() * 4 if scratch else 0,
+                                     stream()), "fv_op_gemm_splitk")
+        torch.cuda.synchronize()
+        return out
+
+    # qkv: bias, fp32 out
+    xh, xl = split(torch.randn(M, Hd))
+    Wq, bq = bf(torch.randn(QK, Hd) * 0.03), torch.randn(QK)
+    a = torch.cat([dev_bf16(xh), dev_bf16(xl)], dim=1).contiguous()
+    outs = [run(a, 2 * Hd, dev_bf16(Wq), QK, Hd, dev_f32(bq), None, torch.full((M, QK), float("nan"), device=DEV), _lib.EPI_F32, sc) for sc in (True, True, False)]
+    assert torch.equal(outs[0], outs[1])
+    check_close(outs[0].cpu(), ((xh + xl).double() @ Wq.double().t() + bq.double()).float(), rel=2e-5, amax=2e-5, what=f"qkv K ranges M={M}")
+    check_close(outs[0].cpu(), outs[2].cpu(), rel=2e-6, amax=2e-5, what="against the one-launch form")
+    # down: residual stream in place, K = 2 x 4864
+    ch, cl = split(torch.randn(M, I))
+    Wd, res = bf(torch.randn(Hd, I) * 0.02), torch.randn(M, Hd)
+    a = torch.cat([dev_bf16(ch), dev_bf16(cl)], dim=1).contiguous()
+    ref = (res.double() + (ch + cl).double() @ Wd.double().t()).float()
+    xs = []
+    for sc in (True, True, False):
+        x = dev_f32(res).clone()
+        run(a, 2 * I, dev_bf16(Wd), Hd, I, None, x, x, _lib.EPI_RES_F32, sc)
+        xs.append(x)
+    assert torch.equal(xs[0], xs[1])
+    check_close(xs[0].cpu(), ref, rel=2e-5, amax=2e-5, what=f"down K ranges M={M}")
+    check_close(xs[0].cpu(), xs[2].cpu(), rel=2e-6, amax=2e-5, what="against the one-launch form")
+    # gate / up: SwiGLU on the summed ranges, hi | lo out
+    G, U = bf(torch.randn(I, Hd) / math.sqrt(Hd)), bf(torch.randn(I, Hd) / math.sqrt(Hd))
+    Wi = torch.empty(2 * I, Hd)
+    j = torch.arange(I)
+    Wi[(j // 8) * 16 + j % 8] = G
+    Wi[(j // 8) * 16 + 8 + j % 8] = U
+    a16 = (xh + xl).double()
+    ref = (F.silu(a16 @ G.double().t()) * (a16 @ U.double().t())).float()
+    a = torch.cat([dev_bf16(xh), dev_bf16(xl)], dim=1).contiguous()
+    outs = [run(a, 2 * Hd, dev_bf16(Wi), 2 * I, Hd, None, None, torch.full((M, 2 * I), float("nan"), dtype=torch.bfloat16, device=DEV), _lib.EPI_SWIGLU_SPLIT, sc)
+            for sc in (True, True, False)]
+    assert torch.equal(outs[0], outs[1])
+    o = outs[0].float().cpu()
+    check_close(o[:, :I] + o[:, I:], ref, rel=2e-5, amax=2e-4, what=f"gate/up K ranges M={M}")
+    o1 = outs[2].float().cpu()
+    check_close(o[:, :I] + o[:, I:], o1[:, :I] + o1[:, I:], rel=2e-6, amax=2e-5, what="against the one-launch form")
+
+
 @pytest.mark.parametrize("M,N,K,ksplit,ws", [(8200, 896, 256, 0, False), (10240, 1152, 192, 1, False), (9728, 904, 128, 1, False),
                                               (896, 4864, 2048, 1, True), (900, 904, 4096, 0, True), (1152, 896, 2048, 1, True),
                                               # 11 x 12 tiles, ragged on both edges: the grouped tile walk (groups of 4 tile rows) with a last group of 3
