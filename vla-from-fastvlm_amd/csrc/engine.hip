@@ -407,7 +407,7 @@ WsPlan plan_ws(const fv_handle* h, int B, int T, int splice) {
   // (round 3: qkv and o use it too when their 256-tiles are fewer than the CUs -- the 7B widths at M = 1024 --, so it is sized for the wider of the two outputs)
   // up to 8 splits for few rows (C5's rank shape, 7B at M = 512: 28 tiles of the down projection), 4 otherwise
   // few rows (rows <= 256: one to four observations in the control loop): up to 40 K ranges of 64-row tiles (launch_gemm's few-row rule)
-  p.splitk_bytes = rows <= 256 ? (size_t)40 * rows * ((std::max((size_t)d.llm_hidden, qkvw) + 255) / 256 * 256) * 4
+  p.splitk_bytes = rows <= 256 || (rows % 256 != 0 && rows <= 1024) ? (size_t)(rows <= 256 ? 40 : 24) * rows * ((std::max((size_t)d.llm_hidden, qkvw) + 255) / 256 * 256) * 4
                                : rows % 256 == 0 ? (size_t)(rows <= 2048 ? 8 : 4) * rows * ((std::max((size_t)d.llm_hidden, qkvw) + 255) / 256 * 256) * 4 : 0;
   p.splitk = take(p.splitk_bytes);
   p.head_scr = take(fv::head_bwd_scratch_bytes(h->hd, B));

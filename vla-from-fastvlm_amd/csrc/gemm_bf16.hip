@@ -1181,7 +1181,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   // twice, >= 4 K-tiles per range; fp32 epilogues through the same reduce kernels as the 256-tile split-K below
   static const bool no_skinny = fv_ab_env("FASTVLA_NO_SKINNY_SPLITK") != nullptr;   // A/B
   const bool swiglu_sk = a.epi == FV_EPI_SWIGLU_SPLIT && !a.stash && a.N % 16 == 0;
-  if (!no_skinny && a.splitk_ws && (f32out || swiglu_sk) && a.M <= 256 && a.N % 8 == 0 && a.ksplit != 2 && !a.f16) {
+  // (M <= 256, or a row count the 256-tile split-K below does not take whole: the spliced control loop's 320 B rows)
+  if (!no_skinny && a.splitk_ws && (f32out || swiglu_sk) && (a.M <= 256 || (a.M % 256 != 0 && a.M <= 1024)) && a.N % 8 == 0 && a.ksplit != 2 && !a.f16) {
     const int tn = (a.N + BN - 1) / BN, tiles = ((a.M + 63) / 64) * tn, nkt = (a.ksplit ? 2 : 1) * ((a.K + BK - 1) / BK);
     const int npad = tn * BN;
     int splits = tiles < cus ? (2 * cus + tiles - 1) / tiles : 1;   // (gate/up at M = 256 is 304 tiles: it keeps the one-launch form)
