@@ -485,7 +485,7 @@ def main():
     # bf16 operand refresh.  Under N > 1 the gradient travels per bucket (one decoder layer = 60 MB) on a side stream while the backward
     # pass is still running.  Its own roofline fraction: algorithmic flops (tower + 3 x (projector + decoder GEMMs) + attention fwd/bwd).
     train_unfrozen = None
-    if not args.no_train_unfrozen and (world == 1 or args.train_unfrozen_dp) and args.llm_precision == 1 and model.llm.head_dim >= 64 and w is not None:
+    if not args.no_train_unfrozen and (world == 1 or args.train_unfrozen_dp) and args.llm_precision == 1 and model.llm.head_dim >= 64 and not big:
         from vla_fastvlm.training.dp import BucketedGradExchange
         Bu = min(args.unfrozen_batch, B)
         try:

@@ -368,6 +368,29 @@ def test_bench_gpus2_spawns_two_ranks_and_fills_train_dp():
     assert td["allreduce_ms"] is not None and td["ms_per_step_serial_exchange"] is not None and td["overlap_frac"] is not None
 
 
+def test_bench_gpus2_unfrozen_legs_exchange_their_buckets():
+    """`bench.py --gpus 2 --train-unfrozen-dp`: both unfrozen legs (decoder + projector + head; everything incl. the FastViT-HD tower) run on TWO ranks with
+    the per-bucket exchange under the backward pass (gloo: the ranks share this box's one GPU) -- the N > 1 form of SURVEY 8f-4 that the 8-GPU node will run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "small", "--batch", "4", "--train-batch", "4",
+                        "--unfrozen-batch", "2", "--tokens", "16", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-surface", "--train-unfrozen-dp"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2
+    for leg in ("train_unfrozen", "train_unfrozen_tower"):
+        t = line[leg]
+        assert t is not None and "error" not in t, t
+        assert t["parallelism"] == "dp2" and t["global_batch"] == 4 and t["value"] > 0 and t["collectives_per_step"] >= 2
+    assert line["train_unfrozen_tower"]["buckets"] > line["train_unfrozen"]["buckets"] and line["train_unfrozen_tower"]["fp16_saturations"] == 0
+
+
 def test_image_prefix_cache_in_the_backbone():
     """SURVEY.md 8f-1 through the plugin-side class: FastVLMBackbone in splice mode with `cache_image_prefix` keeps every image's
     decoder prefix (LRU keyed by a device-side hash of the image tensor).  Misses, hits, a frame repeated inside one batch and a
