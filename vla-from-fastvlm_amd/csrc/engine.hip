@@ -165,6 +165,7 @@ struct fv_handle {
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
   bool no_ffn32 = false;      // FASTVLA_NO_FFN32=1: A/B switch back to the 16x16x32 fused ConvFFN
   TrainState train;               // unfrozen-backbone training (train_path.inc): library-owned transposed bf16 weight copies
+  int train_depth = 0;            // > 0 while a training entry point runs (TrainScope): gemm_p then keeps the few-row GEMM forms off
   float* ffn_part = nullptr;      // device: the fused ConvFFN's partial sums when a launch has few row tiles (B <= 4: launch_convffn32's hidden ranges), FFN_PART_BYTES
   unsigned* f16_flags = nullptr;  // device: [0] = activation groups clamped to the fp16 range (fv_llm_fp16_saturations),
                                   // [1] = max |scaled weight| bits seen by the loader's in-place fp16 conversion
@@ -178,6 +179,13 @@ size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // up to 8 ranges x 128 row tiles x 128 rows x 384 channels of fp32 (C = 384 at B = 4; the narrower stages need as much at most)
 constexpr size_t FFN_PART_BYTES = (size_t)8 * 128 * 128 * 384 * 4 / 2 + (1 << 20);
+struct TrainScope {   // RAII: every return path of a training entry point leaves the handle as it found it
+  fv_handle* h;
+  explicit TrainScope(fv_handle* hh) : h(hh) { ++h->train_depth; }
+  ~TrainScope() { --h->train_depth; }
+  TrainScope(const TrainScope&) = delete;
+  TrainScope& operator=(const TrainScope&) = delete;
+};
 int dev_alloc(fv_handle* h, size_t bytes, void** out) {
   void* p = nullptr;
   FV_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
@@ -452,7 +460,9 @@ void prof_end(fv_handle* h, hipStream_t s) {
     if (_rc != FV_OK) return _rc;                \
   } while (0)
 
-int gemm_p(fv_handle* h, const fv::GemmArgs& g, hipStream_t s) {
+int gemm_p(fv_handle* h, const fv::GemmArgs& g_in, hipStream_t s) {
+  fv::GemmArgs g = g_in;
+  if (h->train_depth > 0) g.few_rows = 0;   // inside fv_train_forward_backward / fv_train_tower_*: the large-batch kernels at every row count
   const double M = g.M, N = g.N, K = g.K;
   const bool f32o = g.epi == FV_EPI_RES_F32 || g.epi == FV_EPI_F32;
   double bytes = (M * K + N * K) * 2 + M * ((g.epi == FV_EPI_SWIGLU || g.epi == FV_EPI_SWIGLU_F16) ? N / 2 : N) * (f32o ? 4 : 2);  // SPLIT: N bf16 columns

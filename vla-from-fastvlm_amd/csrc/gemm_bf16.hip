@@ -1048,6 +1048,34 @@ thread_local bool g_norm_fused = false;   // set by launch_gemm_core when the sp
 
 static int launch_gemm_core(const GemmArgs& a, hipStream_t s);
 
+// the second pass of every K-range form: sums the ranges' fp32 partials in range order and applies the launch's epilogue (bias / fp32 residual, + the
+// NEXT RMSNorm where one is attached, SwiGLU + hi | lo split, or a bf16 epilogue).  lo8: the normalised operand's remainder leaves as fp8 (policy 5).
+static int launch_splitk_reduce(const GemmArgs& a, int splits, int npad, bool few_rows, int lo8, hipStream_t s) {
+  const float* res32 = a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr;
+  if (a.epi == FV_EPI_SWIGLU_SPLIT) {
+    const long n = (long)a.M * (a.N / 16);
+    hipLaunchKernelGGL(splitk_reduce_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, static_cast<bf16_t*>(a.out), a.ldo);
+  } else if (a.epi == FV_EPI_BIAS || a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES) {
+    const long n = (long)a.M * (a.N / 8);
+    hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias, a.epi, a.scale,
+                       static_cast<const bf16_t*>(a.res), a.ldr, static_cast<bf16_t*>(a.out), a.ldo);
+  } else if (a.norm_w && few_rows && a.N <= 4096 && !lo8) {   // a block per row: many ranges, few rows
+    g_norm_fused = true;
+    hipLaunchKernelGGL(splitk_reduce_norm_row_kernel, dim3((unsigned)a.M), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias, res32, a.ldr,
+                       static_cast<float*>(a.out), a.ldo, a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps);
+  } else if (a.norm_w) {
+    g_norm_fused = true;
+    hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias, res32, a.ldr,
+                       static_cast<float*>(a.out), a.ldo, a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps, lo8);
+  } else {
+    const long quads = (long)a.M * (a.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias, res32, a.ldr,
+                       static_cast<float*>(a.out), a.ldo);
+  }
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.norm_w) {   // a following RMSNorm of the fp32 output rows: fused into the split-K reducer when that path is taken
     const bool f32 = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
@@ -1179,7 +1207,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   const bool asym = !no_asym && a.M <= 8192 && a.M % 256 == 0;   // the asymmetric staging addresses row + 32 from a (clamped) base row: whole row tiles only
   // few rows (the control loop: M = 64 B rows of the decoder at B <= 4): 64-row tiles of the register-staged kernel cut along K until the chip is covered
   // twice, >= 4 K-tiles per range; fp32 epilogues through the same reduce kernels as the 256-tile split-K below
-  static const bool no_skinny = fv_ab_env("FASTVLA_NO_SKINNY_SPLITK") != nullptr;   // A/B
+  static const bool no_skinny_env = fv_ab_env("FASTVLA_NO_SKINNY_SPLITK") != nullptr;   // A/B
+  const bool no_skinny = no_skinny_env || !a.few_rows;
   const bool swiglu_sk = a.epi == FV_EPI_SWIGLU_SPLIT && !a.stash && a.N % 16 == 0;
   // (M <= 256, or a row count the 256-tile split-K below does not take whole: the spliced control loop's 320 B rows)
   if (!no_skinny && a.splitk_ws && (f32out || swiglu_sk) && (a.M <= 256 || (a.M % 256 != 0 && a.M <= 1024)) && a.N % 8 == 0 && a.ksplit != 2 && !a.f16) {
@@ -1191,27 +1220,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     if (splits > 1) {
       p.tiles_n = tn; p.splits = splits; p.npad = npad; p.part = a.splitk_ws; p.nwg = tiles * splits;
       hipLaunchKernelGGL(gemm_kernel<64>, dim3(p.nwg), dim3(256), 0, s, p);
-      const long quads = (long)a.M * (a.N / 4);
-      if (swiglu_sk) {
-        const long n = (long)a.M * (a.N / 16);
-        hipLaunchKernelGGL(splitk_reduce_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, static_cast<bf16_t*>(a.out), a.ldo);
-        FV_HIP_CHECK(hipGetLastError());
-        return FV_OK;
-      }
-      if (a.norm_w) g_norm_fused = true;
-      if (a.norm_w && a.N <= 4096)
-        hipLaunchKernelGGL(splitk_reduce_norm_row_kernel, dim3((unsigned)a.M), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias,
-                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo,
-                           a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps);
-      else if (a.norm_w)
-        hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias,
-                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo,
-                           a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps, 0);
-      else
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias,
-                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo);
-      FV_HIP_CHECK(hipGetLastError());
-      return FV_OK;
+      return launch_splitk_reduce(a, splits, npad, true, 0, s);
     }
   }
   // bf16 epilogues with few 64-row tiles and a long K (scratch supplied by the inference tower only): K ranges of >= 8 K-tiles until the chip is covered twice
@@ -1226,11 +1235,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     if (splits > 1) {
       p.tiles_n = tn; p.splits = splits; p.npad = npad; p.part = a.splitk_ws; p.nwg = tiles * splits;
       hipLaunchKernelGGL(gemm_kernel<64>, dim3(p.nwg), dim3(256), 0, s, p);
-      const long n = (long)a.M * (a.N / 8);
-      hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias, a.epi, a.scale,
-                         static_cast<const bf16_t*>(a.res), a.ldr, static_cast<bf16_t*>(a.out), a.ldo);
-      FV_HIP_CHECK(hipGetLastError());
-      return FV_OK;
+      return launch_splitk_reduce(a, splits, npad, true, 0, s);
     }
   }
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
@@ -1273,17 +1278,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
       else if (a.f16) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, true>), g2, dim3(512), 2 * 512 * 128, s, p);
       else if (asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), g2, dim3(512), 2 * 512 * 128, s, p);
       else hipLaunchKernelGGL((gemm256_kernel<8, 4>), g2, dim3(512), 2 * 512 * 128, s, p);
-      const long quads = (long)a.M * (a.N / 4);
-      if (a.norm_w) g_norm_fused = true;
-      if (a.norm_w)
-        hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, p.npad, a.bias,
-                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo,
-                           a.norm_w, a.norm_y, a.norm_ylo, a.norm_ld, a.norm_eps, a.ksplit == 2 ? 1 : 0);
-      else
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, p.npad, a.bias,
-                           a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr, a.ldr, static_cast<float*>(a.out), a.ldo);
-      FV_HIP_CHECK(hipGetLastError());
-      return FV_OK;
+      return launch_splitk_reduce(a, splits, p.npad, false, a.ksplit == 2 ? 1 : 0, s);
     }
   }
   static const bool no_pw = fv_ab_env("FASTVLA_NO_PWCONV") != nullptr;

@@ -25,6 +25,8 @@ struct GemmArgs {
   int f16 = 0;                  // 1: A and W hold fp16 bits (v_mfma_f32_16x16x32_f16); not together with ksplit
   float* splitk_ws = nullptr;   // optional scratch for split-K partial sums (fp32 epilogues, few output tiles, long K)
   size_t splitk_bytes = 0;
+  int few_rows = 1;             // 0: never the few-row K-range forms (64-row tiles x K ranges; the control loop's shapes).  The training path clears it: those
+                                // forms add in another fp32 order, and a row's gradient must not depend on how many rows share its step
   // optional RMSNorm of the fp32 output rows (the decoder's next-layer input_layernorm): y (+ y_lo) = bf16 hi (+ lo) of
   // w * out * rsqrt(mean(out^2) + eps), row stride norm_ld; fused into the split-K reducer, a separate launch otherwise
   const float* norm_w = nullptr; bf16_t* norm_y = nullptr; bf16_t* norm_ylo = nullptr; int norm_ld = 0; float norm_eps = 0.f;
