@@ -323,8 +323,13 @@ def test_bench_shape_b32_gradient_equals_the_two_row_run():
         worst = max(worst, (e, k))
     errs = sorted(((rel_l2(n32[k].cpu(), n2[k].cpu()), k) for k in n2 if float(n2[k].norm()) > 1e-12), reverse=True)
     print("   worst ten:", "; ".join(f"{k.replace(VT, 'VT.')} {e:.2e}" for e, k in errs[:10]), "| tensors above 3e-3:", sum(1 for e, _ in errs if e > 3e-3))
+    dec = [(e, k) for e, k in errs if VT not in k]
+    print("   worst five outside the tower:", "; ".join(f"{k} {e:.2e}" for e, k in dec[:5]), "| decoder-side tensors above 1e-3:", sum(1 for e, _ in dec if e > 1e-3), "of", len(dec))
     print(f"[bench shape B=32 vs B=2, everything trainable, 0.5B] actions rows 0-1 rel_l2 {ra:.2e}; worst gradient tensor {worst[1]} {worst[0]:.2e} ({len(n2)} tensors, "
           f"{eng.fp16_saturations()} fp16 saturations)")
-    assert worst[0] <= 3e-3, worst     # other tile shapes / K ranges at other row counts: the fp16 operand roundings differ, the sums agree
+    # other tile shapes / K ranges at other row counts: the fp16 operand roundings differ, the sums agree.  The per-unit bar (UNIT_TOL): the worst tensor
+    # has sat at 2.7e-3 .. 2.9e-3 (layer scales of stage 2 / 3, whose gradient is a difference of large sums); every decoder-side tensor within 1e-3
+    assert worst[0] <= UNIT_TOL, worst
+    assert all(e <= 1.2e-3 for e, _ in dec), dec[:3]
     assert eng.fp16_saturations() == 0
     eng.close()
