@@ -124,7 +124,11 @@ int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hi
                   int resize_with_padding, void* pix_out, fv_stream s);
 /* replaces the vision tower + mm_projector inside LlavaQwen2ForCausalLM.forward (call site fastvlm_adapter.py:533):
  * pix (B,S,S,4) bf16 -> img_tokens (B, (S/64)^2, llm_hidden) f32.  tower_out (B,(S/64)^2,tower_out_dim) bf16 may be
- * NULL. */
+ * NULL.
+ * Kernel forms follow a launch's own tile count: at B <= 2 the fused ConvFFN runs in hidden ranges and the last stages' GEMMs in K ranges (another fp32
+ * summation order: <= 1 bf16 step per output), at B <= 4 the depthwise march in row segments (bit-identical to the uncut march); B >= 4 gives an image the
+ * same tokens whatever its neighbours.  The same holds for the decoder (fv_llm_forward_pooled: K ranges for <= 256 rows and for ragged row counts <= 1024);
+ * the fv_train_* entry points never take these forms. */
 int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, fv_stream s);
 /* fv_preprocess + fv_vision_forward in one (the on-device input pipeline): the stem kernel samples the SOURCE images
  * (B,C,Hin,Win) f32 | u8 through resize_with_pad's arithmetic itself (model/fastvlm_adapter.py:36-55,479-488 then :533), so the letterboxed
