@@ -736,6 +736,54 @@ def test_gemm_splitk_few_rows_many_splits(ws_splits):
     check_close(out.cpu(), ref, rel=2e-5, amax=2e-4, what=f"split-K few rows (scratch for {ws_splits})")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 37888, 1024, "swiglu"), (4096, 9728, 1024, "swiglu"), (1024, 18944 + 256 * 10, 1024, "res_f32")])
+def test_gemm_tail_round_as_k_ranges(M, N, K, epi):
+    """2.3 rounds of 256-tiles cost three rounds of time: with scratch, launch_gemm runs the full rounds' column panels as they are and the remaining panels
+    as a K-range problem of their own (7B gate/up at M = 1024: 592 tiles; 0.5B gate/up at M = 4096: 608; an fp32-residual shape with bias).  Every column
+    against the same call without scratch (fp32 summation order only), a sample of columns on both sides of the cut against fp64, twice for repeatability."""
+    torch.manual_seed(M + N + K)
+    xh = bf(torch.randn(M, K))
+    xl = bf(torch.randn(M, K) * 2.0 ** -9)
+    a = torch.cat([dev_bf16(xh), dev_bf16(xl)], dim=1).contiguous()
+    W = bf(torch.randn(N, K) / math.sqrt(K))
+    w = dev_bf16(W)
+    ws = torch.full((8 * M * 4608,), float("nan"), dtype=torch.float32, device=DEV)
+    a16 = (xh + xl).double()
+    if epi == "swiglu":
+        outs = []
+        for sc in (True, True, False):
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            call(lib().fv_op_gemm_splitk(a.data_ptr(), 2 * K, w.data_ptr(), M, N, K, None, None, 0, out.data_ptr(), N, _lib.EPI_SWIGLU_SPLIT, 1,
+                                         ws.data_ptr() if sc else None, ws.numel() * 4 if sc else 0, stream()), "fv_op_gemm_splitk")
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0].float()).any()
+        o, o1 = outs[0].float().cpu(), outs[2].float().cpu()
+        I = N // 2
+        check_close(o[:, :I] + o[:, I:], o1[:, :I] + o1[:, I:], rel=2e-6, amax=2e-5, what="tail form against the one-launch form")
+        cols = torch.cat([torch.arange(0, 64), torch.arange(I - 64, I), torch.arange(I // 2 - 32, I // 2 + 32)])   # outputs at both ends and in the middle
+        rows16 = ((cols // 8) * 16)[:, None]
+        G = W[(rows16 + (cols % 8)[:, None]).flatten()].double()
+        U = W[(rows16 + 8 + (cols % 8)[:, None]).flatten()].double()
+        ref = (F.silu(a16 @ G.t()) * (a16 @ U.t())).float()
+        check_close((o[:, :I] + o[:, I:])[:, cols], ref, rel=2e-5, amax=2e-4, what=f"tail form {M}x{N}x{K} against fp64")
+    else:
+        b, res = torch.randn(N), torch.randn(M, N)
+        bd = dev_f32(b)
+        xs = []
+        for sc in (True, True, False):
+            x = dev_f32(res).clone()
+            call(lib().fv_op_gemm_splitk(a.data_ptr(), 2 * K, w.data_ptr(), M, N, K, bd.data_ptr(), x.data_ptr(), N, x.data_ptr(), N, _lib.EPI_RES_F32, 1,
+                                         ws.data_ptr() if sc else None, ws.numel() * 4 if sc else 0, stream()), "fv_op_gemm_splitk")
+            torch.cuda.synchronize()
+            xs.append(x)
+        assert torch.equal(xs[0], xs[1])
+        check_close(xs[0].cpu(), xs[2].cpu(), rel=2e-6, amax=2e-5, what="tail form against the one-launch form")
+        cols = torch.cat([torch.arange(0, 128), torch.arange(N - 128, N)])
+        ref = (res[:, cols].double() + b[cols].double() + a16 @ W[cols].double().t()).float()
+        check_close(xs[0].cpu()[:, cols], ref, rel=2e-5, amax=2e-5, what=f"tail form {M}x{N}x{K} res_f32 against fp64")
+
+
 @pytest.mark.parametrize("M", [64, 128, 200, 256])
 def test_gemm_few_rows_k_ranges(M):
     """The control loop's decoder (one to four observations x 64 tokens): 64-row tiles cut into K ranges until the chip is covered, partial sums finished by

@@ -26,7 +26,8 @@ constexpr int LDC = BN + 4;                       // fp32 epilogue image row str
 struct Params {
   const bf16_t* A; const bf16_t* W; const float* bias; const float* scale; const void* res; void* out;
   int M, N, K, lda, ldr, ldo, epi, tiles_n, nwg, ksplit;   // (fp16 operands are a template parameter of the kernels, not a field)
-  int splits = 1, npad = 0; float* part = nullptr;   // split-K (gemm256 only): units = tiles x splits, partials [split][M][npad]
+  int splits = 1, npad = 0; float* part = nullptr;   // split-K: units = tiles x splits, partials [split][M][npad]
+  int lo_off = 0;                                    // SWIGLU_SPLIT: column of the lo half (N / 2 of the WHOLE problem when this launch is a column range of it)
   // gemm256 only: tiles_m > 0 = walk the tiles column-major (the row tiles of ONE weight column tile are neighbours: same XCD, same
   // time).  For few row tiles against many weight columns (the 7B decoder at M = 1024: 4 x 148) the row-major walk makes every XCD
   // stream 32 different 3.7 MB weight tiles per round and each weight tile is fetched by four XCDs: 2.2 GB per launch, 4.3 TB/s.
@@ -266,8 +267,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
           unpack8(hv, h8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
-          if (LO8) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(out + (size_t)gm * p.ldo + (p.N >> 1)) + (gn >> 1)) = pack_lo8(l8);
-          else *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + (p.N >> 1) + (gn >> 1)) = pack8(l8);
+          if (LO8) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(out + (size_t)gm * p.ldo + p.lo_off) + (gn >> 1)) = pack_lo8(l8);
+          else *reinterpret_cast<uint4*>(out + (size_t)gm * p.ldo + p.lo_off + (gn >> 1)) = pack8(l8);
         }
       }
     }
@@ -684,8 +685,8 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
         for (int e = 0; e < 8; ++e) l8[e] = o8[e] - h8[e];
         bf16_t* op = static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + go;
         *reinterpret_cast<uint4*>(op) = hv;
-        if (LO8) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + (p.N >> 1)) + go) = pack_lo8(l8);
-        else *reinterpret_cast<uint4*>(op + (p.N >> 1)) = pack8(l8);
+        if (LO8) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + p.lo_off) + go) = pack_lo8(l8);
+        else *reinterpret_cast<uint4*>(op + p.lo_off) = pack8(l8);
         asm volatile("" ::: "memory");
         continue;
       }
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
 
 // The few-row split-K of gate/up: part[s][m][16 j .. 16 j + 15] = 8 gate | 8 up sums of range s -> silu(gate) * up as hi | lo bf16 halves ([M][N/2 | N/2]),
 // exactly the FV_EPI_SWIGLU_SPLIT epilogue on the summed accumulators
-__global__ __launch_bounds__(256) void splitk_reduce_swiglu_kernel(const float* __restrict__ part, int splits, int M, int N, int npad, bf16_t* __restrict__ out, int ldo) {
+__global__ __launch_bounds__(256) void splitk_reduce_swiglu_kernel(const float* __restrict__ part, int splits, int M, int N, int npad, bf16_t* __restrict__ out, int ldo, int lo_off) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int n16 = N >> 4;
   if (i >= (long)M * n16) return;
@@ -918,7 +919,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_swiglu_kernel(const float* 
 #pragma unroll
   for (int e = 0; e < 8; ++e) l8[e] = o[e] - h8[e];
   *reinterpret_cast<uint4*>(out + (size_t)m * ldo + (n >> 1)) = hv;
-  *reinterpret_cast<uint4*>(out + (size_t)m * ldo + (N >> 1) + (n >> 1)) = pack8(l8);
+  *reinterpret_cast<uint4*>(out + (size_t)m * ldo + lo_off + (n >> 1)) = pack8(l8);
 }
 
 // ---- pointwise conv with a small square weight (K = N = C in {96, 192}: the stem's third conv and the first PatchEmbed
@@ -1054,7 +1055,7 @@ static int launch_splitk_reduce(const GemmArgs& a, int splits, int npad, bool fe
   const float* res32 = a.epi == FV_EPI_RES_F32 ? static_cast<const float*>(a.res) : nullptr;
   if (a.epi == FV_EPI_SWIGLU_SPLIT) {
     const long n = (long)a.M * (a.N / 16);
-    hipLaunchKernelGGL(splitk_reduce_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, static_cast<bf16_t*>(a.out), a.ldo);
+    hipLaunchKernelGGL(splitk_reduce_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, static_cast<bf16_t*>(a.out), a.ldo, a.lo_off ? a.lo_off : a.N / 2);
   } else if (a.epi == FV_EPI_BIAS || a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES) {
     const long n = (long)a.M * (a.N / 8);
     hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.splitk_ws, splits, a.M, a.N, npad, a.bias, a.epi, a.scale,
@@ -1174,7 +1175,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.bias | (uintptr_t)a.scale) & 15)
     return fv_fail(FV_ERR_ARG, "gemm: pointers must be 16-byte aligned");
   Params p;
-  p.A = a.A; p.W = a.W; p.bias = a.bias; p.scale = a.scale; p.res = a.res; p.out = a.out;
+  p.A = a.A; p.W = a.W; p.bias = a.bias; p.scale = a.scale; p.res = a.res; p.out = a.out; p.lo_off = a.lo_off ? a.lo_off : a.N / 2;
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldr = a.ldr; p.ldo = a.ldo; p.epi = a.epi;
   p.ksplit = a.ksplit == 2 ? 2 : (a.ksplit ? 1 : 0);
   p.sat = a.sat;
@@ -1205,6 +1206,31 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   static const int min_kt_per_range = fv_ab_env("FASTVLA_GEMM_MIN_KT") ? atoi(fv_ab_env("FASTVLA_GEMM_MIN_KT")) : 16;   // A/B
   static const int group_m_default = fv_ab_env("FASTVLA_GEMM_GROUP_M") ? atoi(fv_ab_env("FASTVLA_GEMM_GROUP_M")) : 4;   // A/B (0 = row-major walk)
   const bool asym = !no_asym && a.M <= 8192 && a.M % 256 == 0;   // the asymmetric staging addresses row + 32 from a (clamped) base row: whole row tiles only
+  // The tail.  A problem of r >= 1 full rounds of 256-tiles plus a short last round (7B gate/up at M = 1024: 592 tiles = 2.31 rounds on 256 CUs, i.e. three
+  // rounds of time) is cut at a column: the full rounds' column panels run as they are, the remaining panels as a K-range problem of their own (one more
+  // short round + a reduce pass over those columns).  Whole column panels only; inference only (the cut depends on the row count).
+  static const bool no_tail_env = fv_ab_env("FASTVLA_NO_GEMM_TAIL") != nullptr;   // A/B
+  if (!no_tail_env && !a.no_tail && a.few_rows && a.splitk_ws && !a.norm_w && !a.stash && !a.f16 && a.ksplit != 2 && a.M % 256 == 0 && a.N % 256 == 0 &&
+      a.K % 64 == 0 && (f32out || (a.epi == FV_EPI_SWIGLU_SPLIT && a.N % 512 == 0)) && gemm_glds_tile(a) == 256) {
+    const int tmr = a.M / 256, tn = a.N / 256, tiles = tmr * tn, rem = tiles % cus, nkt = (a.ksplit ? 2 : 1) * (a.K / 64);
+    if (tiles > cus && rem > 0 && 2 * rem <= cus && rem % tmr == 0 && nkt >= 32) {
+      const int n0 = (tn - rem / tmr) * 256;   // columns [0, n0): the full rounds; [n0, N): the tail
+      const int lo = a.lo_off ? a.lo_off : a.N / 2;
+      GemmArgs a1 = a, a2 = a;
+      a1.N = n0; a1.no_tail = 1; a1.lo_off = lo;
+      a2.N = a.N - n0; a2.no_tail = 1; a2.lo_off = lo;
+      a2.W = a.W + (size_t)n0 * a.K;
+      if (a.bias) a2.bias = a.bias + n0;
+      if (f32out) {
+        a2.out = static_cast<float*>(a.out) + n0;
+        if (a.res) a2.res = static_cast<const float*>(a.res) + n0;
+      } else {
+        a2.out = static_cast<bf16_t*>(a.out) + n0 / 2;
+      }
+      const int rc = launch_gemm(a1, s);
+      return rc != FV_OK ? rc : launch_gemm(a2, s);
+    }
+  }
   // few rows (the control loop: M = 64 B rows of the decoder at B <= 4): 64-row tiles of the register-staged kernel cut along K until the chip is covered
   // twice, >= 4 K-tiles per range; fp32 epilogues through the same reduce kernels as the 256-tile split-K below
   static const bool no_skinny_env = fv_ab_env("FASTVLA_NO_SKINNY_SPLITK") != nullptr;   // A/B
@@ -1241,7 +1267,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   // split-K: fp32 output, few 256-tiles, long K, scratch supplied -> one (tile, K-range) unit per CU, then a reduce pass
   static const bool no_splitk = fv_ab_env("FASTVLA_NO_SPLITK") != nullptr, no_g256 = fv_ab_env("FASTVLA_NO_GEMM256") != nullptr;
   static const bool no_ragged_sk = fv_ab_env("FASTVLA_NO_GEMM_RAGGED") != nullptr;   // A/B
-  if (!no_splitk && a.splitk_ws && f32out && !no_g256 && (a.M % 256 == 0 || (!no_ragged_sk && a.N % 8 == 0)) && a.K % 64 == 0 && a.N % 4 == 0 &&
+  if (!no_splitk && a.splitk_ws && (f32out || (swiglu_sk && a.M % 256 == 0 && a.N % 256 == 0)) && !no_g256 && (a.M % 256 == 0 || (!no_ragged_sk && a.N % 8 == 0)) && a.K % 64 == 0 && a.N % 4 == 0 &&
       (size_t)a.M * a.lda * 2 < ((size_t)1 << 32) && (size_t)a.N * a.K * 2 < ((size_t)1 << 32)) {
     const int tmr = (a.M + 255) / 256;            // a ragged last row tile: staging clamps its rows, the partial-sum stores skip them
     const int tn = (a.N + 255) / 256, tiles = tmr * tn, nkt = a.ksplit == 2 ? a.K / 64 + a.K / 128 : (a.ksplit ? 2 : 1) * (a.K / 64);

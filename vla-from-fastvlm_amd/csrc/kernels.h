@@ -25,6 +25,9 @@ struct GemmArgs {
   int f16 = 0;                  // 1: A and W hold fp16 bits (v_mfma_f32_16x16x32_f16); not together with ksplit
   float* splitk_ws = nullptr;   // optional scratch for split-K partial sums (fp32 epilogues, few output tiles, long K)
   size_t splitk_bytes = 0;
+  int lo_off = 0;               // FV_EPI_SWIGLU_SPLIT: column of the lo half in an output row (0 = N / 2).  launch_gemm's tail sub-launch (a column range of the
+                                // problem) sets it to the whole problem's N / 2
+  int no_tail = 0;              // 1: do not cut the last partial round of tiles off as a K-range sub-launch (set on the two sub-launches themselves)
   int few_rows = 1;             // 0: never the few-row K-range forms (64-row tiles x K ranges; the control loop's shapes).  The training path clears it: those
                                 // forms add in another fp32 order, and a row's gradient must not depend on how many rows share its step
   // optional RMSNorm of the fp32 output rows (the decoder's next-layer input_layernorm): y (+ y_lo) = bf16 hi (+ lo) of
