@@ -237,7 +237,10 @@ def test_small_policy_everything_trainable_matches_autograd():
     tok_c, tout_c = eng.vision_forward(pix, return_tower_out=True)
     tower_out_train = eng.train_tower_forward(pix, tws)
     torch.cuda.synchronize()
-    assert torch.equal(tout_c, tower_out_train)        # the inference path (fused stem) and the training forward read the same refreshed operand images ...
+    # the inference path (fused stem; at this row count also K ranges in the last stage's fc2: another fp32 summation order) and the training forward read the
+    # same refreshed operand images: a stale image would sit at the size of the AdamW step (lr 1e-3 on weights of 5e-2: percent level), not at a rounding
+    r_ct = rel_l2(tout_c.float().cpu(), tower_out_train.float().cpu())
+    assert r_ct <= 2e-3, r_ct
     got_new = eng.train_named_tensors(new)
     w2 = {}
     for k, t in got_new.items():

@@ -1122,7 +1122,7 @@ static int launch_gemm_tn(const GemmArgs& a, hipStream_t s) {
   if (a.splitk_ws) {
     const double tile_us = (double)nkt * 64.0 * 131072.0 / 1.0e6 / 4.0, part_us = 2.0 * (double)a.M * (tn * 256) * 4.0 / 4.0e6;
     double best = 1e30;
-    for (int sN = 1; sN <= 128; ++sN) {   // (up to 128 ranges: the tower's weight gradients are 1 .. 12 tiles over a contraction of 10^5 .. 10^6 pixels)
+    for (int sN = 1; sN <= 256; ++sN) {   // (up to 256 ranges: the tower's weight gradients are 1 .. 12 tiles over a contraction of 10^5 .. 10^7 pixels; the stem's is ONE tile over 8.4 M rows)
       if (sN > 1 && (nkt / sN < 16 || (size_t)sN * a.M * (tn * 256) * sizeof(float) > a.splitk_bytes)) break;
       const long units = (long)tiles * sN, rounds = (units + cus - 1) / cus;
       const double t = (double)rounds * tile_us / sN + (sN > 1 ? sN * part_us : 0.0);
