@@ -654,8 +654,9 @@ int launch_part32(Ffn32Params p, float* part, size_t part_bytes, hipStream_t s) 
   // the largest power of two that keeps >= 6 chunks (an even count) per range, ONE round of blocks (every range writes and the reduce pass re-reads
   // M x C floats: 16 x the bf16 output per range -- a second round costs more than the ranges save) and fits the scratch
   int hs = 1;
+  static const int max_tiles = fv_ab_env("FASTVLA_FFN32_RANGE_TILES") ? atoi(fv_ab_env("FASTVLA_FFN32_RANGE_TILES")) : num_cus32() / 4;   // A/B (tools build)
   for (int c = 2; c <= 8; c *= 2)
-    if (nch % c == 0 && (nch / c) % 2 == 0 && nch / c >= 6 && tiles * c <= num_cus32() && tiles * 4 <= num_cus32() && (size_t)c * p.M * C * sizeof(float) <= part_bytes) hs = c;   // (128 tiles in 2 ranges: measured slower than one launch)
+    if (nch % c == 0 && (nch / c) % 2 == 0 && nch / c >= 6 && tiles * c <= num_cus32() && tiles <= max_tiles && (size_t)c * p.M * C * sizeof(float) <= part_bytes) hs = c;   // (128 tiles in 2 ranges: measured slower than one launch)
   if (hs == 1) return -1;   // not worth it: the caller takes the one-launch form
   p.part = part; p.hsplit = hs; p.nchunks = nch / hs;
   hipLaunchKernelGGL((convffn32_kernel<C, MT, NW, false, true>), dim3((unsigned)(tiles * hs)), dim3(64 * NW), LDS, s, p);
@@ -748,7 +749,7 @@ int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const f
   // few row tiles and scratch supplied: (tile, hidden range) blocks + a reduce pass (the default instances' tile heights)
   if (part && ((uintptr_t)part & 15) == 0 && (size_t)M * C * 4 < ((size_t)1 << 31)) {
     const int trows = C == 384 ? 128 : C == 192 ? 256 : 512;
-    if ((M + trows - 1) / trows <= num_cus32() / 2) {
+    if ((M + trows - 1) / trows <= num_cus32() / 2) {   // (launch_part32 narrows this to a quarter of the CUs: 128 tiles in 2 ranges measured no faster)
       int rc = -1;
       if (C == 384) rc = launch_part32<384, 1, 4>(p, part, part_bytes, s);
       else if (C == 192 && FFN32_NW192_DEFAULT == 8) rc = launch_part32<192, 1, 8>(p, part, part_bytes, s);
