@@ -99,7 +99,9 @@ typedef struct fv_adamw_hparams {
 } fv_adamw_hparams;
 
 /* ---- lifecycle -------------------------------------------------------------------------------------------- */
-/* replaces FastVLMBackbone.__init__ / _load_model (model/fastvlm_adapter.py:90-201): create the engine ...   */
+/* replaces FastVLMBackbone.__init__ / _load_model (model/fastvlm_adapter.py:90-201): create the engine ...
+ * The handle owns its weights, the RoPE table, a few KB of counters and ~100 MB of scratch for the few-row launch forms of the tower (fused-ConvFFN
+ * hidden ranges, K ranges of the last stages' GEMMs: one to four observations); everything batch-sized is the caller's (fv_workspace_bytes). */
 int fv_create(const fv_model_desc* desc, int device, fv_handle** out);
 /* ... and pack/fold the frozen weights (BN folding, gate/up interleave, qkv concat, bf16) into library memory. */
 int fv_load_weights(fv_handle* h, const fv_tensor_desc* tensors, int n);
