@@ -132,6 +132,10 @@ int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hi
  * same tokens whatever its neighbours.  The same holds for the decoder (fv_llm_forward_pooled: K ranges for <= 256 rows and for ragged row counts <= 1024);
  * the fv_train_* entry points never take these forms. */
 int fv_vision_forward(fv_handle* h, const void* pix, int B, void* img_tokens, void* tower_out, fv_stream s);
+/* on != 0: the tower keeps the large-batch kernel forms at every batch size (no hidden ranges of the fused ConvFFN, no K ranges in its last stages): an
+ * image evaluated alone then gets the tokens it gets inside a batch, bit for bit (measured), at ~0.9 ms per step of a one-observation control loop (4.75 instead of 3.83 ms).
+ * Off by default (the host side switches it with FASTVLA_BATCH_INVARIANT=1).  The row-segmented depthwise march is bit-identical and stays on. */
+int fv_set_batch_invariant(fv_handle* h, int on);
 /* fv_preprocess + fv_vision_forward in one (the on-device input pipeline): the stem kernel samples the SOURCE images
  * (B,C,Hin,Win) f32 | u8 through resize_with_pad's arithmetic itself (model/fastvlm_adapter.py:36-55,479-488 then :533), so the letterboxed
  * (B,S,S,4) frame is never written or read.  Same tokens as the two-call form, bit for bit.  Needs the fused stem (first stage width 96). */

@@ -165,6 +165,16 @@ def test_full_size_tower_microbatch_and_batch_rows(full):
           f"ConvFFN, row-segmented depthwise pair): rel_l2={r1:.2e}")
     assert r <= 2e-3
     assert r1 <= 3e-2
+    # fv_set_batch_invariant: the tower keeps the large-batch forms at every batch size -- one image at a time then agrees to the last rounding too
+    eng.set_batch_invariant(True)
+    try:
+        d = torch.cat([eng.vision_forward(pix[i:i + 1].contiguous()) for i in range(4)], dim=0)
+        torch.cuda.synchronize()
+    finally:
+        eng.set_batch_invariant(False)
+    r2 = rel_l2(a[:4].cpu(), d.cpu())
+    print(f"[fastvlm-0.5b] batch-invariant tower, one image at a time: rel_l2={r2:.2e}")
+    assert r2 <= 2e-3
 
 
 @pytest.mark.parametrize("splice", [False, True], ids=["literal", "splice"])

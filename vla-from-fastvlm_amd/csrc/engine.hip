@@ -165,6 +165,7 @@ struct fv_handle {
   bool no_mfma_dw = false;    // FASTVLA_NO_MFMA_DW=1: A/B switch back to the VALU depthwise kernels
   bool no_ffn32 = false;      // FASTVLA_NO_FFN32=1: A/B switch back to the 16x16x32 fused ConvFFN
   TrainState train;               // unfrozen-backbone training (train_path.inc): library-owned transposed bf16 weight copies
+  int batch_invariant = 0;        // fv_set_batch_invariant: the inference tower never takes the range forms either
   int train_depth = 0;            // > 0 while a training entry point runs (TrainScope): gemm_p then keeps the few-row GEMM forms off
   float* ffn_part = nullptr;      // device: the fused ConvFFN's partial sums when a launch has few row tiles (B <= 4: launch_convffn32's hidden ranges), FFN_PART_BYTES
   unsigned* f16_flags = nullptr;  // device: [0] = activation groups clamped to the fp16 range (fv_llm_fp16_saturations),
@@ -489,7 +490,8 @@ int dw_s1(fv_handle* h, const bf16_t* x, const float* w, const bf16_t* ttab, con
 // on how many rows share its step (tests/test_gpu_train_tower.py, B = 32 against B = 2).
 int fused_ffn(fv_handle* h, const FFN& f, const bf16_t* t, const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s, bool ranges = true) {
   if (f.w2q && !h->no_ffn32 && (size_t)M * C * 2 < ((size_t)1 << 31))
-    return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s, ranges ? h->ffn_part : nullptr, ranges && h->ffn_part ? FFN_PART_BYTES : 0);
+    return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s, ranges && !h->batch_invariant ? h->ffn_part : nullptr,
+                                ranges && !h->batch_invariant && h->ffn_part ? FFN_PART_BYTES : 0);
   return fv::launch_convffn(t, f.fc1_w, f.fc1_b, f.w2p, f.fc2_b, f.ls, res, out, M, C, hidden, s);
 }
 
@@ -507,7 +509,7 @@ int run_ffn(fv_handle* h, const FFN& f, bf16_t* x_dw_in, bf16_t* dw_out, bf16_t*
   fv::GemmArgs g1{dw_out, C, f.fc1_w, M, C * ratio, C, f.fc1_b, nullptr, nullptr, 0, hid, C * ratio, FV_EPI_BIAS_GELU};
   FV_TRY(gemm_p(h, g1, s));
   fv::GemmArgs g2{hid, C * ratio, f.fc2_w, M, C, C * ratio, f.fc2_b, f.ls, res_out, C, res_out, C, FV_EPI_LS_RES};
-  g2.splitk_ws = h->ffn_part; g2.splitk_bytes = h->ffn_part ? FFN_PART_BYTES : 0;   // few rows (B <= 4): launch_gemm cuts K = 4C into ranges (inference only)
+  if (!h->batch_invariant) { g2.splitk_ws = h->ffn_part; g2.splitk_bytes = h->ffn_part ? FFN_PART_BYTES : 0; }   // few rows (B <= 2): launch_gemm cuts K = 4C into ranges (inference only)
   FV_TRY(gemm_p(h, g2, s));
   return FV_OK;
 }
@@ -638,7 +640,7 @@ int tower_pass(fv_handle* h, const bf16_t* pix, int b0, int mb, bf16_t* tower_ou
   FV_P(FV_FAM_ELT, 20.0 * mb * P * CO, 6.0 * mb * P * CO, fv::launch_se_gelu(oth, tw.se_w1, tw.se_b1, tw.se_w2, tw.se_b2, tower_out, se, mb, P, CO, d.tower_se_rd, s));
   // mm_projector: Linear + GELU + Linear -> fp32 tokens ([site] fast_vlm/modeling_fast_vlm.py:51-55)
   fv::GemmArgs p0{tower_out, CO, tw.pj0_w, mb * P, d.llm_hidden, CO, tw.pj0_b, nullptr, nullptr, 0, hid, d.llm_hidden, FV_EPI_BIAS_GELU};
-  p0.splitk_ws = h->ffn_part; p0.splitk_bytes = h->ffn_part ? FFN_PART_BYTES : 0;
+  if (!h->batch_invariant) { p0.splitk_ws = h->ffn_part; p0.splitk_bytes = h->ffn_part ? FFN_PART_BYTES : 0; }
   FV_TRY(gemm_p(h, p0, s));
   fv::GemmArgs p2{hid, d.llm_hidden, tw.pj2_w, mb * P, d.llm_hidden, d.llm_hidden, tw.pj2_b, nullptr, nullptr, 0, img_tokens, d.llm_hidden, FV_EPI_F32};
   FV_TRY(gemm_p(h, p2, s));
@@ -1152,6 +1154,13 @@ int fv_llm_forward_pooled(fv_handle* h, const int32_t* ids, const int32_t* lens,
 // [k | v] rows; fv_llm_forward_pooled_prefixed then runs only the text positions against them -- same arithmetic as
 // fv_llm_forward_pooled(img_tokens != NULL), 1/5 of its rows at T = 64, and no tower / projector / prefix pass at all for an image
 // (or a batch of images) whose prefix is already held.
+int fv_set_batch_invariant(fv_handle* h, int on) {
+  HandleScope _hs(h);
+  if (!h) return fv_fail(FV_ERR_ARG, "fv_set_batch_invariant: null handle");
+  h->batch_invariant = on != 0;
+  return FV_OK;
+}
+
 int fv_llm_fp16_saturations(fv_handle* h, uint64_t* count_out, int reset) {
   HandleScope _hs(h);
   if (!h || !count_out) return fv_fail(FV_ERR_ARG, "fv_llm_fp16_saturations: null argument");

@@ -93,6 +93,7 @@ SIGNATURES = {
     "fv_vision_forward_unit_taps": (_i, [_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), _i, _vp]),
     "fv_llm_forward_pooled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fv_llm_fp16_saturations": (_i, [_vp, C.POINTER(_u64), _i]),
+    "fv_set_batch_invariant": (_i, [_vp, _i]),
     "fv_llm_prefix_bytes": (_i, [_vp, _i, _i, C.POINTER(C.c_size_t)]),
     "fv_llm_prefix": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "fv_llm_forward_pooled_prefixed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

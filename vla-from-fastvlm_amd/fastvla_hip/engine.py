@@ -65,6 +65,8 @@ class FastVLAEngine:
         # FASTVLA_FUSED_LETTERBOX=1: backbone() hands raw images to the stem (fv_vision_forward_images) instead of letterboxing first
         self.fused_letterbox = os.environ.get("FASTVLA_FUSED_LETTERBOX", "0") == "1" and model.tower.dims[0] == 96
         self.overlap_streams = os.environ.get("FASTVLA_OVERLAP", "1") == "1"
+        if os.environ.get("FASTVLA_BATCH_INVARIANT", "0") == "1":   # an image's tower tokens do not depend on the batch it is evaluated in (see set_batch_invariant)
+            self.set_batch_invariant(True)
         offs = (C.c_int64 * 13)()
         _lib.check(self.lib.fv_head_layout(self.h, C.byref(offs)), "fv_head_layout")
         self.head_offsets = list(offs)
@@ -265,6 +267,11 @@ class FastVLAEngine:
         _lib.check(self.lib.fv_llm_forward_pooled(self.h, ids.data_ptr(), lens.data_ptr(), _ptr(img_tokens), ni, B, T,
                                                   pool_mode, pooled.data_ptr(), _stream()), "fv_llm_forward_pooled")
         return pooled
+
+    def set_batch_invariant(self, on: bool = True) -> None:
+        """fv_set_batch_invariant: the tower keeps the large-batch kernel forms at every batch size, so an image evaluated alone gets the tokens it
+        gets inside a batch (bit for bit); costs ~0.9 ms per one-observation step.  FASTVLA_BATCH_INVARIANT=1 switches it on at creation."""
+        _lib.check(self.lib.fv_set_batch_invariant(self.h, int(bool(on))), "fv_set_batch_invariant", self.h)
 
     def fp16_saturations(self, reset: bool = False) -> int:
         """How many 8-value activation groups the fp16 single-pass projections (llm_precision >= 2) had to clamp to +-65504 since the
