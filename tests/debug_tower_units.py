@@ -1,8 +1,8 @@
-"""debug: per-tensor gradient errors of the tower units on the small preset (emulated-bf16 oracle vs all-fp32 oracle), for a few gscale values"""
+"""(test infrastructure, not collected by pytest: it uses the oracle, so it lives under tests/)  debug: per-tensor gradient errors of the tower units on the small preset (emulated-bf16 oracle vs all-fp32 oracle), for a few gscale values"""
 import sys
 from pathlib import Path
 root = Path(__file__).resolve().parent.parent
-sys.path[:0] = [str(root), str(root / "vla-from-fastvlm_amd"), str(root / "tests")]
+sys.path[:0] = [str(root), str(root / "vla-from-fastvlm_amd"), str(root / "tests")]   # root = the repo (this file sits in tests/)
 import torch
 from gpu_util import DEV, rel_l2
 from fastvla_hip import FastVLAEngine, arch, weights
