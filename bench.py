@@ -81,13 +81,18 @@ def parse():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-train-unfrozen", action="store_true", help="skip the unfrozen decoder + projector training leg (SURVEY.md 8f-4)")
     ap.add_argument("--no-train-tower", action="store_true", help="skip the everything-trainable leg (tower backward too)")
-    ap.add_argument("--train-unfrozen-dp", action="store_true", help="N > 1: run the unfrozen training leg too (per-bucket all-reduce under the backward pass); off by default at N > 1 so that "
-                                                                    "a failure of ONE rank inside this secondary leg can never hang the collectives of a scaling run before its JSON line is out")
+    ap.add_argument("--train-unfrozen-dp", action="store_true", help="(accepted for compatibility: at N > 1 the unfrozen training legs run by default since round 6 -- the ranks agree on "
+                                                                    "their set-up before the first collective and --secondary-deadline bounds the whole tail; --no-train-unfrozen-dp skips them)")
     ap.add_argument("--unfrozen-batch", type=int, default=int(os.environ.get("FASTVLA_UNFROZEN_BATCH", "32")), help="per-GPU batch of the unfrozen training leg (C3's rank shape)")
-    ap.add_argument("--fv-comm-check", action="store_true",
-                    help="N > 1 on the RCCL backend: also build a communicator through the library's own C ABI (fv_comm_*) and push one "
-                         "all-reduce of ones through fv_allreduce_grads (off by default: the timed path uses torch.distributed's communicator, "
-                         "and a second communicator is one more thing that can stall a scaling run)")
+    ap.add_argument("--fv-comm-check", action="store_true", help="(accepted for compatibility: the check below is on by default since round 6)")
+    ap.add_argument("--no-fv-comm-check", action="store_true",
+                    help="N > 1 on the RCCL backend: skip the live check of the library's own communicator (fv_comm_* + one all-reduce of ones through "
+                         "fv_allreduce_grads).  By default it runs LAST, after every measurement, on a helper thread with a time limit: a failure or a stall is "
+                         "recorded in dist.fv_comm and can neither abort nor hang the line")
+    ap.add_argument("--no-train-unfrozen-dp", action="store_true", help="N > 1: skip the unfrozen training legs (per-bucket all-reduce under the backward pass)")
+    ap.add_argument("--secondary-deadline", type=float, default=float(os.environ.get("FASTVLA_BENCH_DEADLINE", "420")),
+                    help="N > 1: seconds the legs after the headline measurement may take in total; past it rank 0 prints the line with what it has "
+                         "(dist.deadline_hit = true) and every rank exits -- a secondary leg can delay a scaling run, not lose it")
     ap.add_argument("--no-alt", action="store_true", help="skip the second engine that times the OTHER decoder parity mode (llm_precision 1 <-> 2)")
     ap.add_argument("--no-surface", action="store_true", help="skip the plugin-surface leg (FastVLAPolicy.select_action / forward)")
     ap.add_argument("--cpu-sample", type=int, default=6)   # ~12 s of host work on 16 threads
@@ -216,16 +221,8 @@ def main():
     # communicator made through the library's own C ABI (fv_comm_*) with one all-reduce through fv_allreduce_grads as a live check
     dist_info = None
     if world > 1:
-        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": torch.cuda.get_device_name(dev)}
-        if args.fv_comm_check and args.backend == "nccl" and ndev >= world:
-            box = [eng.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            comm = eng.comm_init(box[0], rank, world)
-            probe = torch.ones(1024, dtype=torch.float32, device=dev)
-            eng.allreduce_grads(comm, probe)
-            torch.cuda.synchronize()
-            dist_info["fv_comm"] = {"ranks": world, "allreduce_of_ones": float(probe[0]), "ok": bool((probe == world).all())}
-            eng.comm_destroy(comm)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": torch.cuda.get_device_name(dev), "deadline_hit": False,
+                     "fv_comm": None}   # filled by the live check at the very end of the run (see fv_comm_live_check)
 
     # trainable head: torch.nn default-style init, identical on every rank
     g = torch.Generator().manual_seed(4321)
@@ -410,11 +407,63 @@ def main():
                     "n": r["launches"] // ps,
                     "tflops": round(_fl(r) / max(r["ms"], 1e-9) / 1e9, 1)} for r in top]
 
+    # ---- the line, as a closure over everything measured so far: the legs below fill their own fields in.  At N > 1 a watchdog bounds them -- whatever a
+    # secondary leg does on hardware nobody has run it on yet (a stalled collective, one rank failing alone), the headline of a scaling run still gets printed.
+    power_info_ = power_info
+    train = train_unfrozen = train_unfrozen_tower = surface = prefix = alt = cpu = c1 = None
+    emitted = threading.Lock()
+
+    def emit():
+        if rank != 0 or not emitted.acquire(blocking=False):
+            return
+        out = {
+            "metric": "policy steps/sec (img+prompt->action) FastVLM-0.5B bs=64" if args.model == "fastvlm-0.5b" and B == 64
+                      else f"policy steps/sec (img+prompt->action) {args.model} bs={B}",
+            "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (seeded random weights + inputs; no checkpoint/dataset reachable offline)",
+            "config": {"workload": f"{args.model} select_action: letterbox {args.image}^2->{model.tower.image_size}^2, FastViT-HD, "
+                                   f"projector, Qwen2 decoder ({'256 image tokens + ' if args.splice else 'text-only, reference-literal: '}"
+                                   f"{T}-token prompt), last-token pool, action head",
+                       "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "image": args.image,
+                       "parallelism": f"replicas x{world} (no collective on the inference path)",
+                       "splice_image_tokens": bool(args.splice), "tower_microbatch": args.microbatch,
+                       "stream_overlap": bool(eng.overlap_streams and not args.splice),
+                       "llm_precision": {0: "bf16 operands", 1: "split-bf16 (hi+lo) operands, fp32 attention",
+                                         2: "split-bf16 qkv/o, fp16 gate/up/down (one pass), fp32 attention",
+                                         3: "split-bf16 qkv/o/down, fp16 gate/up (one pass), fp32 attention",
+                                         4: "split-bf16 qkv/o/gate/up, fp16 down (one pass), fp32 attention",
+                                         5: "bf16 hi + fp8 lo operands (lo product on the scaled fp8 MFMA, 1.5 passes), fp32 attention"}[args.llm_precision]},
+            "samples_per_s": round(value * B, 2),
+            "roofline": roofline, "power": power_info_, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "train_unfrozen": train_unfrozen, "train_unfrozen_tower": train_unfrozen_tower, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
+            "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
+        }
+        print(json.dumps(out), flush=True)
+
+    watchdog = None
+    if world > 1:
+        def on_deadline():
+            dist_info["deadline_hit"] = True
+            dist_info["deadline_s"] = args.secondary_deadline
+            emit()
+            sys.stdout.flush()
+            os._exit(0)     # a rank stuck in a collective cannot be joined: every rank runs this timer and leaves by itself
+        watchdog = threading.Timer(args.secondary_deadline, on_deadline)
+        watchdog.daemon = True
+        watchdog.start()
+
+    def ranks_agree(ok: bool) -> bool:
+        """N > 1: a leg starts its collectives only if EVERY rank finished the leg's set-up (allocations are where one rank fails alone)."""
+        if world == 1:
+            return ok
+        t_ = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+        return bool(int(t_) == 1)
+
     # ---- data-parallel training step (C3): forward + MSE + head backward + all-reduce + clip + AdamW.
     # Pipelined as vla_fastvlm.training.Trainer runs it: the frozen backbone forward of batch k+1 is enqueued between the
     # START of batch k's gradient all-reduce (side stream, RCCL over xGMI) and the optimiser kernel that needs its result,
     # so the collective runs underneath ~30 ms of tower kernels.  One timed step = one backbone forward + one head step.
-    train = None
     if not args.no_train:
         from vla_fastvlm.training.dp import GradExchange
         Bt = args.train_batch
@@ -484,20 +533,25 @@ def main():
     # kept + MSE + backward over 494 M parameters (dgrad / wgrad on the forward's GEMM kernels, split-bf16 gradient operands) + clip + AdamW +
     # bf16 operand refresh.  Under N > 1 the gradient travels per bucket (one decoder layer = 60 MB) on a side stream while the backward
     # pass is still running.  Its own roofline fraction: algorithmic flops (tower + 3 x (projector + decoder GEMMs) + attention fwd/bwd).
-    train_unfrozen = None
-    if not args.no_train_unfrozen and (world == 1 or args.train_unfrozen_dp) and args.llm_precision == 1 and model.llm.head_dim >= 64 and not big:
+    if not args.no_train_unfrozen and (world == 1 or not args.no_train_unfrozen_dp) and args.llm_precision == 1 and model.llm.head_dim >= 64 and not big:
         from vla_fastvlm.training.dp import BucketedGradExchange
         Bu = min(args.unfrozen_batch, B)
         try:
-            eng.train_begin()
-            tensors_u, total_u, nb_u = eng.train_layout()
-            flat_u = torch.zeros(total_u, dtype=torch.float32, device=dev)
-            eng.train_export_params(flat_u)
-            flat_u[: flat.numel()].copy_(flat)
-            flat_u0 = flat_u.clone()              # the weights as loaded: committed back after the leg (bf16 -> fp32 -> bf16 is exact)
-            g_u, m_u, v_u = torch.zeros_like(flat_u), torch.zeros_like(flat_u), torch.zeros_like(flat_u)
-            ws_u = eng.train_workspace(Bu, T)
-            bex = BucketedGradExchange(dev, min_numel=1 << 22)
+            setup_err = None
+            try:
+                eng.train_begin()
+                tensors_u, total_u, nb_u = eng.train_layout()
+                flat_u = torch.zeros(total_u, dtype=torch.float32, device=dev)
+                eng.train_export_params(flat_u)
+                flat_u[: flat.numel()].copy_(flat)
+                flat_u0 = flat_u.clone()              # the weights as loaded: committed back after the leg (bf16 -> fp32 -> bf16 is exact)
+                g_u, m_u, v_u = torch.zeros_like(flat_u), torch.zeros_like(flat_u), torch.zeros_like(flat_u)
+                ws_u = eng.train_workspace(Bu, T)
+                bex = BucketedGradExchange(dev, min_numel=1 << 22)
+            except Exception as exc_:
+                setup_err = exc_
+            if not ranks_agree(setup_err is None):
+                raise RuntimeError(f"set-up failed on {'this' if setup_err is not None else 'another'} rank: {setup_err!r}")
             ust = {"step": 0}
 
             def step_unfrozen():
@@ -513,6 +567,12 @@ def main():
 
             nsu = max(2, args.steps // 4)
             elu = timed(step_unfrozen, nsu, 2)
+            exch_u = None
+            if world > 1:    # the same step with the collectives left out: what the per-bucket exchange still EXPOSES (0 = fully hidden under the backward pass)
+                bex.dry_run = True
+                elu_dry = timed(step_unfrozen, nsu, 1)
+                bex.dry_run = False
+                exch_u = {"ms_per_step_without_exchange": round(1e3 * elu_dry / nsu, 3), "exchange_exposed_ms": round(1e3 * (elu - elu_dry) / nsu, 3)}
             eng.train_set_forward_f16(True)                           # opt-in: the training forward's projections in ONE fp16 pass (half the forward's MFMA work)
             elu_f16 = timed(step_unfrozen, nsu, 1)
             eng.train_set_forward_f16(False)
@@ -535,6 +595,7 @@ def main():
             train_unfrozen = {"value": round(world * nsu / elu, 3), "unit": "train steps/s (whole job)", "ms_per_step": round(1e3 * elu / nsu, 3),
                               "batch_per_gpu": Bu, "global_batch": Bu * world, "tokens_per_sample": Ni_u + T, "trainable_params": int(total_u),
                               "grad_bytes": int(total_u * 4), "buckets": nb_u, "collectives_per_step": len(bex.launched), "parallelism": f"dp{world}",
+                              "exchange": exch_u,
                               "algorithmic_tflop_per_step": round(step_fl / 1e12, 2),
                               "roofline": {"bound": "mfma", "achieved": round(step_fl / (elu / nsu) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                            "frac": round(step_fl / (elu / nsu) / 1e12 / MFMA_PEAK_TFLOPS, 4),
@@ -556,20 +617,28 @@ def main():
     # unit's tensors kept + the unfrozen step above + the tower's backward (recomputed ConvFFN hidden, fp16 dgrad / TN wgrad GEMMs, depthwise / attention / norm
     # backward kernels) + clip + AdamW over 494 M + 125 M parameters + refresh of every packed operand image.  Algorithmic flops: 3 x (tower + projector + decoder
     # GEMMs) + attention fwd/bwd (the recomputed fc1 of every ConvFFN is executed, not counted).
-    train_unfrozen_tower = None
-    if train_unfrozen is not None and "error" not in train_unfrozen and not args.no_train_tower:
+    run_tower_leg = train_unfrozen is not None and "error" not in train_unfrozen and not args.no_train_tower
+    if world > 1 and not args.no_train_unfrozen and not args.no_train_unfrozen_dp:
+        run_tower_leg = ranks_agree(run_tower_leg)      # the previous leg may have failed on one rank only
+    if run_tower_leg:
         try:
-            eng.train_tower_begin()
-            tensors_t, total_t, nb_t = eng.train_layout()
-            flat_t = torch.zeros(total_t, dtype=torch.float32, device=dev)
-            eng.train_export_params(flat_t)
-            flat_t[: flat.numel()].copy_(flat)
-            flat_t0 = flat_t.clone()
-            g_t, m_t, v_t = torch.zeros_like(flat_t), torch.zeros_like(flat_t), torch.zeros_like(flat_t)
-            ws_t, tws_t = eng.train_workspace(Bu, T), eng.train_tower_workspace(Bu)
-            dto_t = torch.zeros(Bu, model.tower.num_tokens, model.tower.out_dim, dtype=torch.float16, device=dev)
-            eng.train_set_tower_grad(dto_t)
-            bex_t = BucketedGradExchange(dev, min_numel=1 << 22)
+            setup_err = None
+            try:
+                eng.train_tower_begin()
+                tensors_t, total_t, nb_t = eng.train_layout()
+                flat_t = torch.zeros(total_t, dtype=torch.float32, device=dev)
+                eng.train_export_params(flat_t)
+                flat_t[: flat.numel()].copy_(flat)
+                flat_t0 = flat_t.clone()
+                g_t, m_t, v_t = torch.zeros_like(flat_t), torch.zeros_like(flat_t), torch.zeros_like(flat_t)
+                ws_t, tws_t = eng.train_workspace(Bu, T), eng.train_tower_workspace(Bu)
+                dto_t = torch.zeros(Bu, model.tower.num_tokens, model.tower.out_dim, dtype=torch.float16, device=dev)
+                eng.train_set_tower_grad(dto_t)
+                bex_t = BucketedGradExchange(dev, min_numel=1 << 22)
+            except Exception as exc_:
+                setup_err = exc_
+            if not ranks_agree(setup_err is None):
+                raise RuntimeError(f"set-up failed on {'this' if setup_err is not None else 'another'} rank: {setup_err!r}")
             tst = {"step": 0}
 
             def step_tower():
@@ -586,6 +655,12 @@ def main():
 
             nstw = max(2, args.steps // 4)
             eltw = timed(step_tower, nstw, 2)
+            exch_t = None
+            if world > 1:
+                bex_t.dry_run = True
+                eltw_dry = timed(step_tower, nstw, 1)
+                bex_t.dry_run = False
+                exch_t = {"ms_per_step_without_exchange": round(1e3 * eltw_dry / nstw, 3), "exchange_exposed_ms": round(1e3 * (eltw - eltw_dry) / nstw, 3)}
             sat_t = eng.fp16_saturations()
             # where the step goes: one more step under the per-launch event profiler
             eng.profile(True)
@@ -596,6 +671,7 @@ def main():
             train_unfrozen_tower = {"value": round(world * nstw / eltw, 3), "unit": "train steps/s (whole job)", "ms_per_step": round(1e3 * eltw / nstw, 3),
                                     "batch_per_gpu": Bu, "global_batch": Bu * world, "trainable_params": int(total_t), "tower_params": int(total_t - total_u),
                                     "grad_bytes": int(total_t * 4), "buckets": nb_t, "collectives_per_step": len(bex_t.launched), "parallelism": f"dp{world}",
+                                    "exchange": exch_t,
                                     "algorithmic_tflop_per_step": round(step_fl_t / 1e12, 2),
                                     "roofline": {"bound": "mfma", "achieved": round(step_fl_t / (eltw / nstw) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                  "frac": round(step_fl_t / (eltw / nstw) / 1e12 / MFMA_PEAK_TFLOPS, 4),
@@ -850,30 +926,47 @@ def main():
               "gpu_vs_cpu_algorithmic": round(statistics.mean(alg) / (g_el / 10), 1),
               "parity_actions_rel_l2_step1": float((g_first - first_pred).norm() / first_pred.norm())}
 
-    if rank == 0:
-        out = {
-            "metric": "policy steps/sec (img+prompt->action) FastVLM-0.5B bs=64" if args.model == "fastvlm-0.5b" and B == 64
-                      else f"policy steps/sec (img+prompt->action) {args.model} bs={B}",
-            "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (seeded random weights + inputs; no checkpoint/dataset reachable offline)",
-            "config": {"workload": f"{args.model} select_action: letterbox {args.image}^2->{model.tower.image_size}^2, FastViT-HD, "
-                                   f"projector, Qwen2 decoder ({'256 image tokens + ' if args.splice else 'text-only, reference-literal: '}"
-                                   f"{T}-token prompt), last-token pool, action head",
-                       "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "image": args.image,
-                       "parallelism": f"replicas x{world} (no collective on the inference path)",
-                       "splice_image_tokens": bool(args.splice), "tower_microbatch": args.microbatch,
-                       "stream_overlap": bool(eng.overlap_streams and not args.splice),
-                       "llm_precision": {0: "bf16 operands", 1: "split-bf16 (hi+lo) operands, fp32 attention",
-                                         2: "split-bf16 qkv/o, fp16 gate/up/down (one pass), fp32 attention",
-                                         3: "split-bf16 qkv/o/down, fp16 gate/up (one pass), fp32 attention",
-                                         4: "split-bf16 qkv/o/gate/up, fp16 down (one pass), fp32 attention",
-                                         5: "bf16 hi + fp8 lo operands (lo product on the scaled fp8 MFMA, 1.5 passes), fp32 attention"}[args.llm_precision]},
-            "samples_per_s": round(value * B, 2),
-            "roofline": roofline, "power": power_info, "cpu_baseline": cpu, "cpu_baseline_c1": c1, "train_dp": train, "train_unfrozen": train_unfrozen, "train_unfrozen_tower": train_unfrozen_tower, "surface": surface, "dist": dist_info, "splice_prefix_cache": prefix, "other_parity_mode": alt,
-            "families": families, "gemm_shapes": gemm_shapes, "weights_load_s": round(t_load, 1),
-        }
-        print(json.dumps(out))
+    # ---- N > 1 on RCCL: the library's OWN communicator (fv_comm_* through the C ABI) -- unique id from rank 0, init on every rank, one all-reduce of ones
+    # through fv_allreduce_grads.  Last thing of the run, on a helper thread with a time limit: a failure is recorded, a stall is recorded and the process
+    # leaves without joining it; neither costs the line.
+    stalled = False
+    if world > 1 and dist_info is not None and not args.no_fv_comm_check:
+        if args.backend != "nccl" or ndev < world:
+            dist_info["fv_comm"] = {"ok": None, "skipped": f"backend {args.backend}, {ndev} device(s) for {world} ranks: RCCL needs one GPU per rank"}
+        else:
+            res = {}
+
+            def fv_comm_live_check():
+                try:
+                    box = [eng.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    t0_ = time.perf_counter()
+                    comm = eng.comm_init(box[0], rank, world)
+                    res["init_ms"] = round(1e3 * (time.perf_counter() - t0_), 1)
+                    probe = torch.ones(1 << 20, dtype=torch.float32, device=dev)
+                    eng.allreduce_grads(comm, probe)
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                    for _ in range(5):
+                        eng.allreduce_grads(comm, probe)
+                    torch.cuda.synchronize()
+                    res["allreduce_4mib_ms"] = round(1e3 * (time.perf_counter() - t0_) / 5, 3)
+                    res.update(ranks=world, allreduce_of_ones=float(probe[0]), ok=bool(float(probe[0]) == float(world) ** 6 and bool((probe == probe[0]).all())))
+                    eng.comm_destroy(comm)
+                except Exception as exc_:
+                    res.update(ok=False, error=f"{type(exc_).__name__}: {exc_}")
+
+            th = threading.Thread(target=fv_comm_live_check, daemon=True)
+            th.start()
+            th.join(timeout=90.0)
+            stalled = th.is_alive()
+            dist_info["fv_comm"] = {"ok": False, "error": "no answer within 90 s (stalled in fv_comm_init / fv_allreduce_grads)", **res} if stalled else res
+    if watchdog is not None:
+        watchdog.cancel()
+    emit()
+    if stalled:
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 

@@ -6,6 +6,7 @@ Restates src/vla_fastvlm/model/fastvlm_adapter.py:
   _normalize_channels       :444-449 (gray -> 3ch repeat, >3ch -> first 3)
   _resize_image             :451-461
   _prepare_images_tensor    :479-488
+  _maybe_normalize_imagenet :463-477 (after the letterbox: pad pixels are normalised too)
 
 The bilinear resampling is written out explicitly (no F.interpolate) so that it is an independent statement of
 ``torch.nn.functional.interpolate(mode="bilinear", align_corners=False, antialias=False)``:
@@ -75,3 +76,26 @@ def letterbox(x: torch.Tensor, size: int, pad_value: float = 0.0, resize_with_pa
     out = torch.full((x.shape[0], 3, max(size, rh), max(size, rw)), float(pad_value), dtype=torch.float32)
     out[:, :, pt:pt + rh, pl:pl + rw] = r
     return out
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def normalize_imagenet(x: torch.Tensor, torchvision_branch: bool = True) -> torch.Tensor:
+    """fastvlm_adapter.py:463-477 on the letterboxed (B,3,S,S) fp32 tensor.  torchvision_branch=True (:471-477, what an installed reference runs --
+    torchvision is a declared dependency, pyproject.toml:33): `if x.max() > 1.5: x = x / 255.0` over the WHOLE batch tensor, then TF.normalize =
+    x.sub_(mean[:, None, None]).div_(std[:, None, None]) in the tensor's dtype.  False (:466-470, the branch without torchvision, the one the golden
+    vectors of tests/golden/g1_normalize.npz were produced by): (x - mean) / std alone."""
+    x = x.to(torch.float32)
+    mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=torch.float32).view(1, 3, 1, 1)
+    if torchvision_branch and float(x.max()) > 1.5:
+        x = x / 255.0
+    return (x - mean) / std
+
+
+def prepare_images(x: torch.Tensor, size: int, pad_value: float = 0.0, resize_with_padding: bool = True, normalize: bool = False,
+                   torchvision_branch: bool = True) -> torch.Tensor:
+    """_prepare_images_tensor :479-488: letterbox, then the optional normalisation."""
+    y = letterbox(x, size, pad_value, resize_with_padding)
+    return normalize_imagenet(y, torchvision_branch) if normalize else y

@@ -6,6 +6,7 @@
 Only inputs and expected outputs are stored (small .npz / .json); nothing of the reference's source travels.
 What is driven:
   G1 letterbox        vla_fastvlm.model.fastvlm_adapter.resize_with_pad / _prepare_images_tensor
+  G1b normalisation   FastVLMBackbone._maybe_normalize_imagenet through _prepare_images_tensor (the branch the container's reference takes)
   G2 pooling          FastVLMBackbone._pool_hidden (both modes, incl. an all-pad row)
   G3 head             FastVLMWithExpert (stub backbone) + FastVLAPolicy.compute_loss -> actions, loss, 12 grads
   G4 task table       FastVLAProcessor.normalize_tasks
@@ -74,6 +75,26 @@ def g1_letterbox():
     out.update(ns_seed=104, ns_sums=ns_out.double().sum(dim=(0, 2, 3)), ns_samples=ns_out[0][:, ys, xs],
                ns_first_row=int((ns_out[0, 0].abs().sum(dim=1) > 0).nonzero()[0]))
     npz("g1_letterbox.npz", **out)
+
+
+def g1_normalize():
+    """_maybe_normalize_imagenet (fastvlm_adapter.py:463-477) through _prepare_images_tensor, normalize_imagenet=True.  torchvision is absent from the build
+    container, so the imported reference takes its :466-470 branch ((x - mean) / std, no value-range test); the file records which branch ran.  The
+    torchvision branch (:471-477) is the same arithmetic once x.max() <= 1.5 -- the 0..1 cases below pin it too -- and divides by 255 first otherwise
+    (restated in oracle/preprocess.py, not drivable here)."""
+    import vla_fastvlm.model.fastvlm_adapter as fa
+    torch.manual_seed(111)
+    bb = FastVLMBackbone.__new__(FastVLMBackbone)
+    torch.nn.Module.__init__(bb)
+    bb.config = FastVLMBackboneConfig(pad_value=0.25, normalize_imagenet=True)
+    bb.expected_size = 64
+    unit = torch.rand(2, 3, 30, 40)
+    gray = torch.rand(1, 1, 17, 33)
+    wide = torch.rand(1, 3, 50, 20) * 255.0
+    npz("g1_normalize.npz", has_torchvision=int(fa._HAS_TV),
+        unit=unit, unit_out=bb._prepare_images_tensor(unit, torch.device("cpu")),
+        gray=gray, gray_out=bb._prepare_images_tensor(gray, torch.device("cpu")),
+        wide=wide, wide_out=bb._prepare_images_tensor(wide, torch.device("cpu")))
 
 
 def g2_pool():
@@ -215,5 +236,5 @@ def g7_config_contract():
 if __name__ == "__main__":
     os.environ.setdefault("HF_HUB_OFFLINE", "1")
     torch.set_num_threads(4)
-    g1_letterbox(); g2_pool(); g3_head(); g4_tasks(); g5_tower_names(); g6_schedules(); g7_config_contract()
+    g1_letterbox(); g1_normalize(); g2_pool(); g3_head(); g4_tasks(); g5_tower_names(); g6_schedules(); g7_config_contract()
     print("golden fixtures written to", HERE)

@@ -10,7 +10,8 @@ DEV = "cuda:0"
 
 
 def lib():
-    return fastvla_hip.load()
+    """product entry points + the TEST-ONLY fv_op_* ones (tests/_native/libfastvla_hip_testops.so, include/fastvla_hip_testops.h)"""
+    return fastvla_hip._lib.load_testops()
 
 
 def stream():

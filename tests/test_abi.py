@@ -8,16 +8,23 @@ import pytest
 import fastvla_hip
 from fastvla_hip import _lib
 
-HEADER = Path(__file__).resolve().parent.parent / "include" / "fastvla_hip.h"
+INCLUDE = Path(__file__).resolve().parent.parent / "include"
+HEADER, OPS_HEADER = INCLUDE / "fastvla_hip.h", INCLUDE / "fastvla_hip_testops.h"
 
 
-def _declared():
-    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+def _declared(header=HEADER):
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
     out = {}
     for m in re.finditer(r"\b(?:int|void|const char\*)\s+(fv_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
     return out
+
+
+def _exports(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", str(path)], check=True, capture_output=True, text=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("fv_")}
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -29,12 +36,29 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
         assert len(_lib.SIGNATURES[name][1]) == nargs, f"{name}: header has {nargs} args, ctypes table {len(_lib.SIGNATURES[name][1])}"
     assert set(_lib.SIGNATURES) == set(decl)
+    # the product ABI is exactly the header: nothing else named fv_* leaves the library -- in particular none of the tests' op-level entry points
+    exp = _exports(fastvla_hip.library_path())
+    assert exp == set(decl), (sorted(exp - set(decl)), sorted(set(decl) - exp))
+    assert not any(n.startswith("fv_op_") for n in exp | set(decl) | set(_lib.SIGNATURES))
+
+
+def test_test_only_op_library_matches_its_header():
+    """the 25 fv_op_* entry points the parity tests drive live in a library of their own (tests/_native/, csrc/ops_api.hip), declared in
+    include/fastvla_hip_testops.h; its fv::launch_* references bind to the loaded product library."""
+    decl = _declared(OPS_HEADER)
+    assert len(decl) >= 20 and all(n.startswith("fv_op_") for n in decl)
+    both = _lib.load_testops()
+    for name, nargs in decl.items():
+        assert hasattr(both, name), f"{name} declared in the test-ops header but not exported"
+        assert len(_lib.OPS_SIGNATURES[name][1]) == nargs, f"{name}: header has {nargs} args, ctypes table {len(_lib.OPS_SIGNATURES[name][1])}"
+    assert set(_lib.OPS_SIGNATURES) == set(decl) == _exports(_lib.testops_path())
+    assert not hasattr(fastvla_hip.load(), "fv_op_gemm")
 
 
 def test_version_and_error_string_without_gpu():
     lib = fastvla_hip.load()
     assert b"gfx950" in lib.fv_version()
-    assert lib.fv_op_gemm(None, 8, None, 8, 8, 8, None, None, None, 0, None, 8, 0, None) == -1  # argument check only
+    assert _lib.load_testops().fv_op_gemm(None, 8, None, 8, 8, 8, None, None, None, 0, None, 8, 0, None) == -1  # argument check only
     assert b"null" in lib.fv_last_error(None)
 
 
@@ -53,6 +77,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
     monkeypatch.delenv("FASTVLA_HIP_LIB")
     monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "_OPS", None)
     _lib.load()
 
 

@@ -155,6 +155,26 @@ def test_stem_conv_and_letterbox():
     check_close(got, preprocess.letterbox(img, S, resize_with_padding=False), rel=3e-3, amax=5e-3, what="stretch")
     with pytest.raises(ValueError):
         eng.preprocess(torch.zeros(3, 8, 8))
+    # ---- normalize_imagenet (reference fastvlm_adapter.py:463-477) folded into the letterbox: against the golden vectors the imported reference produced
+    # (its branch without the value-range test) and against the oracle's torchvision branch, whose `max > 1.5 -> / 255` is decided on the device
+    import numpy as np
+    from pathlib import Path
+    g = np.load(Path(__file__).parent / "golden" / "g1_normalize.npz")
+    for k in ("unit", "gray", "wide"):
+        src, ref = torch.from_numpy(g[k]), torch.from_numpy(g[k + "_out"])
+        got = eng.preprocess(src.to(DEV), pad_value=0.25, normalize_imagenet=True, range_heuristic=bool(int(g["has_torchvision"])))
+        torch.cuda.synchronize()
+        got = got.float().cpu()
+        assert float(got[..., 3].abs().max()) == 0.0
+        check_close(got[..., :3].permute(0, 3, 1, 2), ref, rel=3e-3, amax=5e-3 * max(1.0, float(ref.abs().max())), what=f"normalize_imagenet golden {k}")
+    for name, src in (("0..255 f32", torch.rand(2, 3, 33, 20) * 255.0), ("u8", (torch.rand(1, 3, 19, 40) * 255).to(torch.uint8)), ("0..1 f32", torch.rand(2, 3, 33, 20)),
+                      ("0..1 with a pad of 2", torch.rand(1, 3, 10, 30))):
+        pad = 2.0 if "pad of 2" in name else 0.25    # the pad pixels count in the maximum the reference tests (x.max() of the letterboxed tensor)
+        ref = preprocess.prepare_images(src.float(), S, pad, True, normalize=True, torchvision_branch=True)
+        got = eng.preprocess(src.to(DEV), pad_value=pad, normalize_imagenet=True).float().cpu()[..., :3].permute(0, 3, 1, 2)
+        check_close(got, ref, rel=3e-3, amax=5e-3 * max(1.0, float(ref.abs().max())), what=f"normalize_imagenet {name}")
+        # one rounding only: the result is the bf16 image of the fp32 oracle value up to the last fp32 bit of the interpolation
+        assert float((got - ref.bfloat16().float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
     # stem conv on the bf16 pixels
     x = pix.float().cpu()[..., :3].permute(0, 3, 1, 2)
     w = torch.randn(C0, 3, 3, 3) / 5
@@ -910,7 +930,8 @@ def _e4m3(t):
 
 
 @pytest.mark.parametrize("M,N,K,epi,ws", [(100, 256, 896, "f32", False), (4096, 1152, 896, "f32", False), (512, 896, 4864, "res", True),
-                                            (8200, 896, 1152, "res", False), (4096, 2560, 256, "swiglu", False), (96, 128, 896, "swiglu", False)])
+                                            (8200, 896, 1152, "res", False), (4096, 2560, 256, "swiglu", False), (96, 128, 896, "swiglu", False),
+                                            (256, 17920, 1536, "swiglu", True)])   # the 1.5B gate/up at 256 rows WITH scratch: the K-range forms must not take it
 def test_gemm_hi_lo8_operands(M, N, K, epi, ws):
     """llm_precision = 5's projections (round 4): A = bf16 hi + ONE fp8 e4m3 byte of remainder (x 2^8) per element, the lo product on
     v_mfma_scale_f32_16x16x128_f8f6f4 against the weights' fp8 copy (x 2^6), through the register-staged kernel, the 256-tile kernel
@@ -933,7 +954,7 @@ def test_gemm_hi_lo8_operands(M, N, K, epi, ws):
     assert torch.equal(a[:, :K].float().cpu(), hi)
     got_lo = a.view(torch.uint8).view(M, 4 * K)[:, 2 * K:3 * K].view(torch.float8_e4m3fn).float().cpu() / 256.0
     assert torch.equal(got_lo, lo8) and torch.equal(w8[:, :K].view(torch.float8_e4m3fn).float().cpu() / 64.0, W8)
-    wsb = torch.empty(8 * 1024 * 1024, dtype=torch.float32, device=DEV) if ws else None
+    wsb = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=DEV) if ws else None   # two ranges of 256 x 17920 fp32 partials fit
     wsp, wsn = (wsb.data_ptr(), wsb.numel() * 4) if ws else (None, 0)
     if epi == "swiglu":
         I = N // 2

@@ -161,6 +161,25 @@ def test_prompt_feature_cache_matches_uncached():
     assert torch.equal(bb.forward_ids(images, ids2, mask), mixed)
 
 
+def test_backbone_normalize_imagenet_is_plumbed():
+    """SURVEY 8 a7 / VERDICT r5 #5: `normalize_imagenet=True` (reference model/fastvlm_adapter.py:463-477, applied at :487 after the letterbox) no longer raises: the
+    backbone's pixels are the oracle's letterbox + normalisation (torchvision branch: what an installed reference runs), and the pooled features change with it."""
+    from oracle import preprocess
+    from vla_fastvlm.model.fastvlm_adapter import FastVLMBackbone, FastVLMBackboneConfig
+    torch.manual_seed(9)
+    bb = FastVLMBackbone(FastVLMBackboneConfig(model_id="synthetic:tiny:3", normalize_imagenet=True, pad_value=0.5))
+    plain = FastVLMBackbone(FastVLMBackboneConfig(model_id="synthetic:tiny:3", pad_value=0.5))
+    S = int(bb.expected_size)
+    for img in (torch.rand(2, 3, 40, 52), torch.rand(2, 3, 40, 52) * 255.0, (torch.rand(2, 30, 44, 3) * 255).to(torch.uint8)):
+        pix = bb._prepare_images_tensor(img, DEV)
+        torch.cuda.synchronize()
+        x = img.permute(0, 3, 1, 2) if img.shape[-1] == 3 else img
+        ref = preprocess.prepare_images(x.float(), S, 0.5, True, normalize=True, torchvision_branch=True)
+        got = pix.float().cpu()[..., :3].permute(0, 3, 1, 2)
+        assert float((got - ref).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
+        assert not torch.equal(pix, plain._prepare_images_tensor(img, DEV))
+
+
 # ------------------------------------------------------------------------------------------------ round 2: step body
 def _dev(batch):
     return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -388,6 +407,11 @@ def test_bench_gpus2_unfrozen_legs_exchange_their_buckets():
         t = line[leg]
         assert t is not None and "error" not in t, t
         assert t["parallelism"] == "dp2" and t["global_batch"] == 4 and t["value"] > 0 and t["collectives_per_step"] >= 2
+        # what the per-bucket exchange still exposes = the step with its collectives minus the same step without them
+        assert isinstance(t["exchange"]["exchange_exposed_ms"], float) and t["exchange"]["ms_per_step_without_exchange"] > 0
+    d = line["dist"]
+    assert d["world_size"] == 2 and d["deadline_hit"] is False and d["fv_comm"]["ok"] is None and "RCCL" in d["fv_comm"]["skipped"]   # gloo rehearsal: no RCCL communicator
+    assert line["train_dp"]["allreduce_ms"] is not None and line["train_dp"]["overlap_frac"] is not None
     assert line["train_unfrozen_tower"]["buckets"] > line["train_unfrozen"]["buckets"] and line["train_unfrozen_tower"]["fp16_saturations"] == 0
 
 

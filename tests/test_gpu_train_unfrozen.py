@@ -10,6 +10,7 @@ already states (oracle/train_unfrozen.py), on the same seeded weights, the same 
   * four FULL-WIDTH FastVLM-0.5B decoder layers (hidden 896, 14 q / 2 kv heads of 64, inter 4864) the same way.
 """
 import ctypes as C
+import json
 import math
 
 import pytest
@@ -388,7 +389,9 @@ def test_policy_level_unfrozen_training_overfits_one_batch_and_exports_the_train
     k0 = "model.backbone.model.model.layers.0.mlp.down_proj.weight"
     assert torch.equal(sd[k0], after["model.layers.0.mlp.down_proj.weight"].cpu()) and not torch.equal(sd[k0], before["model.layers.0.mlp.down_proj.weight"].cpu())
     again = load_policy_from_checkpoint(str(out_dir)).to(DEV)
-    assert again.model.backbone.splice_image_tokens is True and "model.backbone.splice_image_tokens" in sd   # the mode the decoder was trained in travels with the file
+    # the mode the decoder was trained in travels BESIDE the reference's two files (hip_extras.json), never inside them: policy_state_dict.pt keeps the reference's keys
+    assert again.model.backbone.splice_image_tokens is True and "model.backbone.splice_image_tokens" not in sd
+    assert json.loads((out_dir / "hip_extras.json").read_text())["splice_image_tokens"] is True
     with torch.no_grad():
         a2 = again(batch["images"], batch["states"], batch["tasks"])
     torch.cuda.synchronize()
@@ -486,7 +489,9 @@ def test_trainer_fit_with_the_backbone_unfrozen_saves_and_resumes(tmp_path, towe
     ck = tmp_path / "b" / "checkpoints" / "step-3"
     sd = torch.load(ck / "policy_state_dict.pt", map_location="cpu")
     opt = torch.load(ck / "optimizer.pt", map_location="cpu")
-    assert any(k.startswith("model.backbone.model.model.layers.") for k in sd) and "model.backbone.splice_image_tokens" in sd    # the trained VLM travels by default
+    assert any(k.startswith("model.backbone.model.model.layers.") for k in sd) and "model.backbone.splice_image_tokens" not in sd    # the trained VLM travels by default
+    assert json.loads((ck / "hip_extras.json").read_text()) == {"splice_image_tokens": True, "train_backbone": True, "train_tower": bool(tower)}
+    assert opt["train_tower"] is bool(tower) and opt["train_backbone"] is True
     assert opt["m"].numel() == b._unfrozen.flat.numel() and int(opt["step"]) == 3
     if tower:
         assert any(".vision_tower." in k and k.endswith("convffn.conv.bn.running_var") for k in sd)

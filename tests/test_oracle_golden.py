@@ -41,6 +41,26 @@ def test_letterbox_headline_size(golden_dir):
     assert first == int(g["ns_first_row"]) == 1024 - 768  # padding goes on TOP
 
 
+def test_normalize_imagenet_golden(golden_dir):
+    """_maybe_normalize_imagenet (reference model/fastvlm_adapter.py:463-477) after the letterbox: the oracle against what the imported reference produced
+    (the branch recorded in the file: no torchvision in the build container -> :466-470).  Where the batch maximum is <= 1.5 the torchvision branch is the
+    same arithmetic, so those cases pin it as well; beyond 1.5 it divides by 255 first (restatement only)."""
+    g = np.load(golden_dir / "g1_normalize.npz")
+    tv = bool(int(g["has_torchvision"]))
+    for k in ("unit", "gray", "wide"):
+        out = preprocess.prepare_images(_t(g[k]), 64, 0.25, True, normalize=True, torchvision_branch=tv)
+        ref = _t(g[k + "_out"])
+        assert out.shape == ref.shape
+        assert float((out - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max())), k
+    for k in ("unit", "gray"):   # max <= 1.5 (values in [0, 1), pad 0.25): both branches agree bit for bit
+        a = preprocess.prepare_images(_t(g[k]), 64, 0.25, True, normalize=True, torchvision_branch=True)
+        b = preprocess.prepare_images(_t(g[k]), 64, 0.25, True, normalize=True, torchvision_branch=False)
+        assert torch.equal(a, b)
+    w = preprocess.prepare_images(_t(g["wide"]), 64, 0.25, True, normalize=True, torchvision_branch=True)
+    lb = preprocess.letterbox(_t(g["wide"]), 64, 0.25)
+    assert float(lb.max()) > 1.5 and torch.equal(w, preprocess.normalize_imagenet(lb / 255.0, torchvision_branch=False))
+
+
 def test_letterbox_rejects_non_4d():
     with pytest.raises(ValueError):
         preprocess.letterbox(torch.zeros(3, 8, 8), 16)

@@ -24,7 +24,7 @@ dq = torch.empty(B * T, ld, device=dev)
 osc = torch.empty(B * T, 2 * qd, dtype=torch.bfloat16, device=dev)
 st = torch.empty(2 * B * H * T, device=dev)
 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
-lib = _lib.load()
+lib = _lib.load_testops()
 for _ in range(a.iters):
     _lib.check(lib.fv_op_attention_bwd(qkv.data_ptr(), ld, dO.data_ptr(), dq.data_ptr(), osc.data_ptr(), st.data_ptr(), B, T, H, KV, D, lens.data_ptr(), 1e6,
                                        torch.cuda.current_stream().cuda_stream), "fv_op_attention_bwd")

@@ -13,7 +13,7 @@ sys.path.insert(0, str(ROOT))
 import fastvla_hip  # noqa: E402
 from test_gpu_ops import _toeplitz  # noqa: E402
 
-lib = fastvla_hip.load()
+lib = fastvla_hip._lib.load_testops()
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 torch.manual_seed(0)

@@ -13,7 +13,7 @@ sys.path.insert(0, str(ROOT))
 import fastvla_hip  # noqa: E402
 from test_gpu_ops import _pack_w2, _pack_wq  # noqa: E402
 
-lib = fastvla_hip.load()
+lib = fastvla_hip._lib.load_testops()
 dev = "cuda:0"
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 st = torch.cuda.current_stream().cuda_stream

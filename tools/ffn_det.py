@@ -2,7 +2,7 @@ import sys, math, torch
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/vla-from-fastvlm_amd'); sys.path.insert(0,'/root/repo/tests')
 import fastvla_hip
 from test_gpu_ops import _pack_wq
-lib=fastvla_hip.load(); dev="cuda:0"; st=torch.cuda.current_stream().cuda_stream
+lib=fastvla_hip._lib.load_testops(); dev="cuda:0"; st=torch.cuda.current_stream().cuda_stream
 for C,M in ((192,131149),(384,70001),(96,150013),(192,131072)):
     torch.manual_seed(1)
     Hd=4*C

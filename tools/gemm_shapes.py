@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--tn", action="store_true", help="also: the weight-gradient problems on the NT kernel and on the TN instance")
     a = ap.parse_args()
-    L = _lib.load()
+    L = _lib.load_testops()
     dev = torch.device("cuda:0")
     B = a.batch
     T = B * 64
@@ -127,4 +127,4 @@ def tn_vs_nt(L, dev, s, iters=20):
 if __name__ == "__main__":
     main()
     if "--tn" in sys.argv:
-        tn_vs_nt(_lib.load(), torch.device("cuda:0"), torch.cuda.current_stream().cuda_stream)
+        tn_vs_nt(_lib.load_testops(), torch.device("cuda:0"), torch.cuda.current_stream().cuda_stream)

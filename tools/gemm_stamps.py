@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vla-from-fastvlm_amd"))
 from fastvla_hip import _lib  # noqa: E402
 
-L = _lib.load()
+L = _lib.load_testops()
 dev = torch.device("cuda:0")
 s = torch.cuda.current_stream().cuda_stream
 B = 64

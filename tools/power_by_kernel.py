@@ -15,7 +15,7 @@ sys.path.insert(0, str(ROOT))
 import fastvla_hip  # noqa: E402
 from test_gpu_ops import _pack_wq, _toeplitz  # noqa: E402
 
-lib = fastvla_hip.load()
+lib = fastvla_hip._lib.load_testops()
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 SECS = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0

@@ -154,6 +154,7 @@ struct fv_handle {
   void* const* taps = nullptr;  // fv_vision_forward_taps: per-stage copies of the activation map (parity tests)
   int n_taps = 0;
   struct LbSrc { const void* img; int dtype, C, Hin, Win; float pad; int letterbox; };
+  unsigned* lb_vmax = nullptr;   // fv_preprocess_normalized: the letterboxed batch's maximum (ordered-integer image), 4 device bytes
   const LbSrc* lbsrc = nullptr;  // fv_vision_forward_images: the stem samples the source images itself (no letterboxed frame)
   void* const* utaps = nullptr; // fv_vision_forward_unit_taps: one copy per tower unit (stem, RepCPE, block, PatchEmbed)
   int n_utaps = 0;
@@ -182,8 +183,8 @@ size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 constexpr size_t FFN_PART_BYTES = (size_t)8 * 128 * 128 * 384 * 4 / 2 + (1 << 20);
 struct TrainScope {   // RAII: every return path of a training entry point leaves the handle as it found it
   fv_handle* h;
-  explicit TrainScope(fv_handle* hh) : h(hh) { ++h->train_depth; }
-  ~TrainScope() { --h->train_depth; }
+  explicit TrainScope(fv_handle* hh) : h(hh) { if (h) ++h->train_depth; }   // null-tolerant as HandleScope is: the entry point's own check reports FV_ERR_ARG
+  ~TrainScope() { if (h) --h->train_depth; }
   TrainScope(const TrainScope&) = delete;
   TrainScope& operator=(const TrainScope&) = delete;
 };
@@ -1025,6 +1026,27 @@ int fv_preprocess(fv_handle* h, const void* img, int dtype, int B, int C, int Hi
   prof_begin(h, FV_FAM_ELT, 30.0 * B * S * S, (double)B * C * Hin * Win * (dtype == FV_U8 ? 1 : 4) + B * S * S * 8.0, st);
   const int rc = fv::launch_letterbox(img, dtype, B, C, Hin, Win, h->d.image_size, pad_value, resize_with_padding,
                                       static_cast<bf16_t*>(pix_out), st);
+  prof_end(h, st);
+  return rc;
+}
+
+int fv_preprocess_normalized(fv_handle* h, const void* img, int dtype, int B, int C, int Hin, int Win, float pad_value, int resize_with_padding,
+                             const float* mean3, const float* std3, int range_heuristic, void* pix_out, fv_stream s) {
+  HandleScope _hs(h);
+  if (!h) return fv_fail(FV_ERR_ARG, "null handle");
+  if (!mean3 || !std3) return fv_fail(FV_ERR_ARG, "fv_preprocess_normalized: mean / std must be given (3 floats each, host memory)");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (range_heuristic && !h->lb_vmax) {
+    void* p = nullptr;
+    FV_HIP_CHECK(hipSetDevice(h->device));
+    FV_TRY(dev_alloc(h, 16, &p));
+    h->lb_vmax = static_cast<unsigned*>(p);
+  }
+  const double S = h->d.image_size;
+  const double in_bytes = (double)B * C * Hin * Win * (dtype == FV_U8 ? 1 : 4);
+  prof_begin(h, FV_FAM_ELT, (range_heuristic ? 66.0 : 36.0) * B * S * S, (range_heuristic ? 2.0 : 1.0) * in_bytes + B * S * S * 8.0, st);
+  const int rc = fv::launch_letterbox_norm(img, dtype, B, C, Hin, Win, h->d.image_size, pad_value, resize_with_padding, mean3, std3, range_heuristic,
+                                           h->lb_vmax, static_cast<bf16_t*>(pix_out), st);
   prof_end(h, st);
   return rc;
 }

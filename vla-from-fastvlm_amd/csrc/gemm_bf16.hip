@@ -1236,7 +1236,9 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   // twice, >= 4 K-tiles per range; fp32 epilogues through the same reduce kernels as the 256-tile split-K below
   static const bool no_skinny_env = fv_ab_env("FASTVLA_NO_SKINNY_SPLITK") != nullptr;   // A/B
   const bool no_skinny = no_skinny_env || !a.few_rows;
-  const bool swiglu_sk = a.epi == FV_EPI_SWIGLU_SPLIT && !a.stash && a.N % 16 == 0;
+  // (the SwiGLU reducer writes its lo half as bf16: the hi + lo8 form, whose consumer reads fp8 bytes there, and the fp16 form keep the one-launch
+  // epilogue -- policy 5's gate/up at 256 x 17920 x 1536 would otherwise pick 2 ranges here)
+  const bool swiglu_sk = a.epi == FV_EPI_SWIGLU_SPLIT && !a.stash && a.N % 16 == 0 && a.ksplit != 2 && !a.f16;
   // (M <= 256, or a row count the 256-tile split-K below does not take whole: the spliced control loop's 320 B rows)
   if (!no_skinny && a.splitk_ws && (f32out || swiglu_sk) && (a.M <= 256 || (a.M % 256 != 0 && a.M <= 1024)) && a.N % 8 == 0 && a.ksplit != 2 && !a.f16) {
     const int tn = (a.N + BN - 1) / BN, tiles = ((a.M + 63) / 64) * tn, nkt = (a.ksplit ? 2 : 1) * ((a.K + BK - 1) / BK);

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/fastvla_hip.h"
+#include "../../include/fastvla_hip_testops.h"   // enum fv_gemm_epilogue (the fv_op_* declarations in it are test-only: ops_api.hip)
 #include "common.h"
 
 namespace fv {
@@ -60,6 +61,8 @@ int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const f
 
 int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox,
                      bf16_t* pix, hipStream_t s);
+int launch_letterbox_norm(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox, const float* mean3,
+                          const float* std3, int range_heuristic, unsigned* vmax_scratch, bf16_t* pix, hipStream_t s);
 int launch_stem_conv(const bf16_t* pix, const float* w, const float* bias, bf16_t* y, int B, int S, int Cout,
                      hipStream_t s);
 // implicit-GEMM stem on MFMA; wp = stem_mfma_pack image ([Cout][64] bf16), Cout % 16 == 0

@@ -1,4 +1,4 @@
-// ops_api.hip -- op-level C entry points (include/fastvla_hip.h, "op-level entry points"): one kernel each, so the
+// ops_api.hip -- op-level C entry points (include/fastvla_hip_testops.h: TEST-ONLY, built into tests/_native/libfastvla_hip_testops.so, not into the product library): one kernel each, so the
 // parity tests can check every kernel of the path against the oracle on its own.  No engine state is involved.
 #include <cmath>
 #include <vector>

@@ -70,9 +70,21 @@ __device__ __forceinline__ uint2 lb_pixel(const LbParams& p, int b, int y, int x
 // source row) consecutive rows share their two source rows, so the 4 taps x 3 channels are fetched again only when y0 moves -- a
 // third of the loads and of the x arithmetic of the one-pixel-per-thread form, the same values bit for bit.
 constexpr int LB_R = 4;
-__global__ __launch_bounds__(256) void letterbox_kernel(LbParams p) {
+// MODE 1 / 2: FastVLMBackbone._maybe_normalize_imagenet (model/fastvlm_adapter.py:463-477) on top of the letterbox.  The reference decides from the maximum of the
+// WHOLE letterboxed batch (pad pixels included) whether the values are 0..255 (`x.max() > 1.5` -> x / 255), then applies (x - mean) / std per channel, every step
+// in fp32 on the host.  Here: MODE 1 evaluates the same letterboxed values without storing them and leaves their maximum in nrm.vmax (an ordered-integer image of
+// the float, atomicMax: exact and order-independent); MODE 2 reads that maximum on the device (no host synchronisation), divides by 255 if the reference would
+// (IEEE division, as ATen's), subtracts and divides by the per-channel constants (IEEE, one rounding each: TF.normalize's sub_ / div_) and rounds to bf16 ONCE.
+struct LbNorm { float mean[3], std[3]; unsigned* vmax; int heuristic; };
+__device__ __forceinline__ unsigned lb_ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float lb_unord(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+template <int MODE>
+__global__ __launch_bounds__(256) void letterbox_kernel(LbParams p, LbNorm nrm) {
+  bool by255 = false;
+  if constexpr (MODE == 2) by255 = nrm.heuristic && lb_unord(*nrm.vmax) > 1.5f;
+  float vmax = -INFINITY;
   const int x = blockIdx.x * 256 + threadIdx.x, yb = blockIdx.y * LB_R, b = blockIdx.z;
-  if (x >= p.S) return;
+  if (MODE != 1 && x >= p.S) return;
   const int dx = x - p.pl;
   const bool xin = dx >= 0 && dx < p.rw;
   // ATen area_pixel_compute_source_index, align_corners=False: src = max((dst+0.5)*scale-0.5, 0)
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(256) void letterbox_kernel(LbParams p) {
 #pragma unroll
   for (int r = 0; r < LB_R; ++r) {
     const int y = yb + r;
-    if (y >= p.S) break;
+    if (y >= p.S || x >= p.S) break;
     float v[3] = {p.pad, p.pad, p.pad};
     const int dy = y - p.pt;
     if (xin && dy >= 0 && dy < p.rh) {
@@ -105,10 +117,24 @@ __global__ __launch_bounds__(256) void letterbox_kernel(LbParams p) {
       for (int c = 0; c < nc; ++c) v[c] = lb_lerp(t0[c], t1[c], wy);
       if (nc == 1) v[1] = v[2] = v[0];  // gray -> repeat (fastvlm_adapter.py:445-446)
     }
+    if constexpr (MODE == 1) { vmax = fmaxf(vmax, fmaxf(v[0], fmaxf(v[1], v[2]))); continue; }
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float t = v[c];
+        if (by255) t = __fdiv_rn(t, 255.0f);
+        v[c] = __fdiv_rn(__fsub_rn(t, nrm.mean[c]), nrm.std[c]);
+      }
+    }
     uint2 o;
     o.x = pack_bf2(v[0], v[1]);
     o.y = pack_bf2(v[2], 0.0f);
     *reinterpret_cast<uint2*>(p.pix + (((size_t)b * p.S + y) * p.S + x) * 4) = o;
+  }
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    if ((threadIdx.x & 63) == 0 && vmax > -INFINITY) atomicMax(nrm.vmax, lb_ord(vmax));
   }
 }
 
@@ -1623,7 +1649,30 @@ int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win,
   if (!img || !pix) return fv_fail(FV_ERR_ARG, "letterbox: null pointer");
   LbParams p;
   FV_TRY_RC(lb_params(img, dtype, B, C, Hin, Win, S, pad_value, letterbox, pix, p));
-  hipLaunchKernelGGL(letterbox_kernel, dim3((S + 255) / 256, (S + LB_R - 1) / LB_R, B), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(letterbox_kernel<0>, dim3((S + 255) / 256, (S + LB_R - 1) / LB_R, B), dim3(256), 0, s, p, LbNorm{});
+  FV_HIP_CHECK(hipGetLastError());
+  return FV_OK;
+}
+
+// letterbox + _maybe_normalize_imagenet (fastvlm_adapter.py:463-477).  range_heuristic != 0: the torchvision branch's `x.max() > 1.5 -> x / 255` (two launches:
+// the maximum of the letterboxed batch, then the store; vmax_scratch = 4 device bytes); 0: the branch without it ((x - mean) / std alone)
+int launch_letterbox_norm(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox, const float* mean3,
+                          const float* std3, int range_heuristic, unsigned* vmax_scratch, bf16_t* pix, hipStream_t s) {
+  if (!img || !pix || !mean3 || !std3 || (range_heuristic && !vmax_scratch)) return fv_fail(FV_ERR_ARG, "letterbox_norm: null pointer");
+  LbParams p;
+  FV_TRY_RC(lb_params(img, dtype, B, C, Hin, Win, S, pad_value, letterbox, pix, p));
+  LbNorm n{};
+  for (int c = 0; c < 3; ++c) {
+    if (!(std3[c] != 0.0f)) return fv_fail(FV_ERR_ARG, "letterbox_norm: std[%d] must be non-zero", c);
+    n.mean[c] = mean3[c]; n.std[c] = std3[c];
+  }
+  n.vmax = vmax_scratch; n.heuristic = range_heuristic ? 1 : 0;
+  const dim3 grid((S + 255) / 256, (S + LB_R - 1) / LB_R, B);
+  if (range_heuristic) {
+    FV_HIP_CHECK(hipMemsetAsync(vmax_scratch, 0, 4, s));   // ordered image 0 = below every float
+    hipLaunchKernelGGL(letterbox_kernel<1>, grid, dim3(256), 0, s, p, n);
+  }
+  hipLaunchKernelGGL(letterbox_kernel<2>, grid, dim3(256), 0, s, p, n);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }

@@ -86,6 +86,7 @@ SIGNATURES = {
     "fv_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "fv_bind_workspace": (_i, [_vp, _vp, C.c_size_t]),
     "fv_preprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "fv_preprocess_normalized": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp]),
     "fv_vision_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "fv_vision_forward_images": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "fv_vision_forward_taps": (_i, [_vp, _vp, _i, _vp, _vp, C.POINTER(_vp), _i, _vp]),
@@ -128,6 +129,10 @@ SIGNATURES = {
     "fv_profile": (_i, [_vp, _i]),
     "fv_profile_read": (_i, [_vp, C.POINTER(ProfileEntry), C.POINTER(GemmProfile), _i, C.POINTER(_i)]),
     "fv_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(AdamWHParams), _i64, _vp, _vp]),
+}
+
+# TEST-ONLY op-level entry points (include/fastvla_hip_testops.h, tests/_native/libfastvla_hip_testops.so): not part of the product library
+OPS_SIGNATURES = {
     "fv_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "fv_op_gemm_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _vp]),
     "fv_op_gemm_lo8": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _vp]),
@@ -156,6 +161,7 @@ SIGNATURES = {
 }
 
 _LIB = None
+_OPS = None
 
 
 def library_path() -> Path:
@@ -182,6 +188,53 @@ def load():
         fn.argtypes = args
     _LIB = lib
     return lib
+
+
+def testops_path() -> Path:
+    """The test-only op library that goes with library_path(): FASTVLA_HIP_TESTOPS_LIB, or `<name>_testops.so` beside a FASTVLA_HIP_LIB override (the tools'
+    A/B build), or tests/_native/libfastvla_hip_testops.so of this checkout."""
+    env = os.environ.get("FASTVLA_HIP_TESTOPS_LIB")
+    if env:
+        return Path(env)
+    if os.environ.get("FASTVLA_HIP_LIB"):
+        lp = library_path()
+        return lp.with_name(lp.stem + "_testops.so")
+    return Path(__file__).resolve().parents[2] / "tests" / "_native" / "libfastvla_hip_testops.so"
+
+
+class _WithTestOps:
+    """What the parity tests and tools/ call through: product entry points from libfastvla_hip.so, fv_op_* from the test-only library."""
+
+    def __init__(self, product, ops):
+        self._product, self._ops = product, ops
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._product, name)
+        except AttributeError:
+            return getattr(self._ops, name)
+
+
+def load_testops():
+    """TESTS / tools only: libfastvla_hip.so (re-opened RTLD_GLOBAL so that the op library's fv::launch_* references bind to it) + the op library."""
+    global _OPS
+    if _OPS is not None:
+        return _OPS
+    product = load()
+    path = testops_path()
+    if not path.is_file():
+        raise FastVLAHipError(f"{path} not found: `make -C vla-from-fastvlm_amd/csrc` builds it beside the product library (test-only entry points)")
+    try:
+        C.CDLL(str(library_path()), mode=C.RTLD_GLOBAL)
+        ops = C.CDLL(str(path))
+    except OSError as exc:
+        raise FastVLAHipError(f"cannot load {path}: {exc}") from exc
+    for name, (res, args) in OPS_SIGNATURES.items():
+        fn = getattr(ops, name)
+        fn.restype = res
+        fn.argtypes = args
+    _OPS = _WithTestOps(product, ops)
+    return _OPS
 
 
 def check(rc: int, what: str = "", handle=None) -> None:

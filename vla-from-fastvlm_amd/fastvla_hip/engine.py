@@ -65,7 +65,14 @@ class FastVLAEngine:
         # FASTVLA_FUSED_LETTERBOX=1: backbone() hands raw images to the stem (fv_vision_forward_images) instead of letterboxing first
         self.fused_letterbox = os.environ.get("FASTVLA_FUSED_LETTERBOX", "0") == "1" and model.tower.dims[0] == 96
         self.overlap_streams = os.environ.get("FASTVLA_OVERLAP", "1") == "1"
-        if os.environ.get("FASTVLA_BATCH_INVARIANT", "0") == "1":   # an image's tower tokens do not depend on the batch it is evaluated in (see set_batch_invariant)
+        # An image's tower tokens must not depend on the batch it is evaluated in once they are CONSUMED (splice mode: the small-batch kernel forms put 1.7e-2
+        # between an observation alone and the same observation inside a batch).  FASTVLA_BATCH_INVARIANT=1 / 0 fixes the choice; unset, the numerics follow the
+        # mode: tokens_consumed(True) -- the host side calls it whenever the tower output feeds the decoder -- switches the large-batch forms on, literal mode
+        # (tokens computed and dropped) keeps the fast small-batch forms.
+        env = os.environ.get("FASTVLA_BATCH_INVARIANT")
+        self._invariant_policy: Optional[bool] = None if env in (None, "") else env == "1"
+        self._invariant_on = False
+        if self._invariant_policy:
             self.set_batch_invariant(True)
         offs = (C.c_int64 * 13)()
         _lib.check(self.lib.fv_head_layout(self.h, C.byref(offs)), "fv_head_layout")
@@ -168,7 +175,12 @@ class FastVLAEngine:
             _lib.check(self.lib.fv_bind_workspace(self.h, base + off, self._ws.numel() - off), "fv_bind_workspace")
 
     # ---------------------------------------------------------------- frozen backbone
-    def preprocess(self, images: torch.Tensor, pad_value: float = 0.0, resize_with_padding: bool = True) -> torch.Tensor:
+    IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)   # reference model/fastvlm_adapter.py:468-469,475-476
+
+    def preprocess(self, images: torch.Tensor, pad_value: float = 0.0, resize_with_padding: bool = True, normalize_imagenet: bool = False,
+                   range_heuristic: bool = True) -> torch.Tensor:
+        """letterbox (+ the reference's `_maybe_normalize_imagenet`, :463-477, when asked; range_heuristic = its torchvision branch, which is what an installed
+        reference runs: torchvision is one of its dependencies)."""
         if images.ndim != 4:
             raise ValueError(f"(B,C,H,W) expected, but got shape {tuple(images.shape)}")
         if images.dtype == torch.uint8:
@@ -180,6 +192,12 @@ class FastVLAEngine:
         B, Cc, H, W = images.shape
         S = self.model.tower.image_size
         pix = torch.empty(B, S, S, 4, dtype=torch.bfloat16, device=self.device)
+        if normalize_imagenet:
+            import ctypes
+            mean, std = (ctypes.c_float * 3)(*self.IMAGENET_MEAN), (ctypes.c_float * 3)(*self.IMAGENET_STD)
+            _lib.check(self.lib.fv_preprocess_normalized(self.h, images.data_ptr(), dt, B, Cc, H, W, float(pad_value), int(resize_with_padding), mean, std,
+                                                         int(range_heuristic), pix.data_ptr(), _stream()), "fv_preprocess_normalized")
+            return pix
         _lib.check(self.lib.fv_preprocess(self.h, images.data_ptr(), dt, B, Cc, H, W, float(pad_value),
                                           int(resize_with_padding), pix.data_ptr(), _stream()), "fv_preprocess")
         return pix
@@ -272,6 +290,13 @@ class FastVLAEngine:
         """fv_set_batch_invariant: the tower keeps the large-batch kernel forms at every batch size, so an image evaluated alone gets the tokens it
         gets inside a batch (bit for bit); costs ~0.9 ms per one-observation step.  FASTVLA_BATCH_INVARIANT=1 switches it on at creation."""
         _lib.check(self.lib.fv_set_batch_invariant(self.h, int(bool(on))), "fv_set_batch_invariant", self.h)
+        self._invariant_on = bool(on)
+
+    def tokens_consumed(self, consumed: bool) -> None:
+        """The caller says whether the tower tokens of the calls that follow feed the decoder (splice mode) or are dropped (the literal reference): unless
+        FASTVLA_BATCH_INVARIANT pins the choice, batch invariance of the tower follows that (VERDICT r5 #6)."""
+        if self._invariant_policy is None and bool(consumed) != self._invariant_on:
+            self.set_batch_invariant(bool(consumed))
 
     def fp16_saturations(self, reset: bool = False) -> int:
         """How many 8-value activation groups the fp16 single-pass projections (llm_precision >= 2) had to clamp to +-65504 since the

@@ -107,13 +107,16 @@ class FastVLAPolicy(nn.Module):
             self._opt_state = st
         return st
 
-    def load_optimizer_state(self, m: torch.Tensor, v: torch.Tensor, step: int, flat: Optional[torch.Tensor] = None) -> None:
+    def load_optimizer_state(self, m: torch.Tensor, v: torch.Tensor, step: int, flat: Optional[torch.Tensor] = None,
+                             train_tower: Optional[bool] = None) -> None:
         """Restore AdamW moments and the bias-correction step (Trainer._load_checkpoint; reference trainer.py:257-262
-        restores them through accelerator.load_state)."""
+        restores them through accelerator.load_state).  train_tower: what optimizer.pt recorded about the run being resumed (None: a round-5 file, which
+        did not record it -- FASTVLA_TRAIN_TOWER decides then, as before)."""
         head_numel = sum(p.numel() for p in self.model.head_parameters())
-        if self._unfrozen is None and m.numel() > 2 * head_numel:
-            # moments of a whole-backbone run (training/unfrozen.py writes one flat m / v over every trainable tensor): the run resumes unfrozen
-            self.enable_backbone_training()
+        if self._unfrozen is None and (train_tower is not None or m.numel() > 2 * head_numel):
+            # moments of a whole-backbone run (training/unfrozen.py writes one flat m / v over every trainable tensor): the run resumes unfrozen,
+            # training what the checkpointed run trained
+            self.enable_backbone_training(tower=train_tower)
         if self._unfrozen is not None:
             u = self._unfrozen
             if m.numel() != u.m.numel():

@@ -151,9 +151,6 @@ class FastVLMBackbone(nn.Module):
             raise ValueError("the HIP decoder masks RIGHT padding; tokenizer_padding_side must be 'right'")
         if self.config.image_feature_pool not in ("last_token", "mean_pool"):
             raise ValueError(f"unknown image_feature_pool '{self.config.image_feature_pool}'")
-        if self.config.normalize_imagenet:
-            raise NotImplementedError("normalize_imagenet=True is not plumbed by the reference's public configs and is "
-                                      "not implemented on the HIP path")
         self.tokenizer = self._load_tokenizer()
         self.processor = None
         self.image_processor = None
@@ -400,7 +397,10 @@ class FastVLMBackbone(nn.Module):
         if x.shape[1] > 4:
             x = x[:, :3]  # reference _normalize_channels :447-448
         eng = self.engine(device if torch.device(device).type == "cuda" else None)
-        pix = eng.preprocess(x.to(eng.device), self.config.pad_value, self.config.resize_with_padding)
+        # normalize_imagenet (reference _maybe_normalize_imagenet :463-477, after the letterbox :486-487): folded into the letterbox kernel, with the
+        # value-range test of the reference's torchvision branch (what an installed reference runs) decided on the device
+        pix = eng.preprocess(x.to(eng.device), self.config.pad_value, self.config.resize_with_padding,
+                             normalize_imagenet=bool(self.config.normalize_imagenet))
         return pix.as_subclass(PreparedPixels)
 
     def _prep_text(self, tasks: List[str], device: torch.device) -> Dict[str, Tensor]:
@@ -454,6 +454,8 @@ class FastVLMBackbone(nn.Module):
         lens = attention_mask.to(torch.int32).sum(dim=1).to(torch.int32)
         mode = 0 if self.config.image_feature_pool == "last_token" else 1
         literal = not self.splice_image_tokens
+        eng.tokens_consumed(not literal)   # spliced tokens feed the decoder: the tower then keeps one set of kernel forms at every batch size (an observation's
+                                           # action must not depend on how many observations were evaluated with it); literal mode drops them and stays fast
         if (not literal and self.cache_image_prefix and mode == 0 and eng.llm_precision >= 1 and eng.model.llm.head_dim >= 64
                 and torch.is_tensor(images) and images.ndim == 4):
             return self._pooled_through_prefix_cache(eng, images, input_ids, lens)

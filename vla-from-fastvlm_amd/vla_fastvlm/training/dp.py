@@ -84,6 +84,7 @@ class BucketedGradExchange:
         self._flat: Optional[torch.Tensor] = None
         self._held: Optional[tuple] = None      # (offset, numel) waiting to be merged with an adjacent bucket
         self.launched: list = []                 # (offset, numel) of every collective of the current step, in launch order
+        self.dry_run = False                     # measurement only (bench.py): the bookkeeping of a step without its collectives -- what the exchange exposes
 
     def begin(self, flat_grads: torch.Tensor) -> None:
         self._flat, self._held, self.launched = flat_grads, None, []
@@ -91,7 +92,7 @@ class BucketedGradExchange:
     def _launch(self, off: int, n: int) -> None:
         flat = self._flat
         self.launched.append((off, n))
-        if world_size(self.group) == 1:
+        if world_size(self.group) == 1 or self.dry_run:
             return
         piece = flat[off: off + n]
         if flat.is_cuda and self.stream is not None:

@@ -128,7 +128,8 @@ class Trainer:
             return
         flat = core.materialize(self.device)
         if self._resume_opt is not None and hasattr(self.model, "load_optimizer_state"):
-            self.model.load_optimizer_state(self._resume_opt["m"], self._resume_opt["v"], int(self._resume_opt["step"]), flat=self._resume_opt.get("flat"))
+            self.model.load_optimizer_state(self._resume_opt["m"], self._resume_opt["v"], int(self._resume_opt["step"]), flat=self._resume_opt.get("flat"),
+                                            train_tower=self._resume_opt.get("train_tower"))
             self._resume_opt = None
         un = getattr(self.model, "_unfrozen", None)
         if un is not None:
@@ -219,6 +220,7 @@ class Trainer:
                 # the fp32 MASTER of an unfrozen run: the VLM tensors of policy_state_dict.pt come back through the engine's bf16 operand copies, and a master
                 # rebuilt from those has lost the low bits every later update (~1e-3 of a bf16 ulp) lives in
                 rec["flat"] = un.flat.cpu()
+                rec["train_backbone"], rec["train_tower"] = True, bool(un.train_tower)   # what the run trains comes back from the checkpoint, not from the environment
             torch.save(rec, d / "optimizer.pt")
 
     def _load_checkpoint(self, path: str) -> None:
@@ -240,6 +242,10 @@ class Trainer:
         # `.io_norm.` / splice-mode keys exist in state_dict() only while they are on, so a freshly built model does not list them -- let them
         # through (FastVLMBackbone._load_from_state_dict re-applies them)
         self.model.load_state_dict({k: v for k, v in state.items() if k in own or any(m in k for m in EXTRA_STATE_MARKS)}, strict=False)
+        from ..utils.checkpoint import read_extras
+        ex = read_extras(p)
+        if "splice_image_tokens" in ex:
+            self.model.model.backbone.splice_image_tokens = bool(ex["splice_image_tokens"])
         if (p / "optimizer.pt").is_file():
             self._resume_opt = torch.load(p / "optimizer.pt", map_location="cpu")  # applied by _sync_replicas()
             self.global_step = int(self._resume_opt.get("global_step", 0))

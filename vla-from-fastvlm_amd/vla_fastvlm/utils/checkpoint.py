@@ -22,8 +22,18 @@ import torch
 from ..fastvla import FastVLAConfig, FastVLAPolicy
 
 BACKBONE_PREFIX = "model.backbone.model."
+# run properties of THIS build that are not tensors of the reference's module tree: written beside the two reference files, never into them, so that the
+# reference's strict `load_state_dict` / `FastVLAConfig(**payload)` accept a checkpoint of an unfrozen run as it is.  Keys: "splice_image_tokens"
+# (the decoder was trained on [image tokens | text]: inference must run the same graph), "train_backbone", "train_tower".
+EXTRAS_FILE = "hip_extras.json"
+SPLICE_KEY_MARK = ".splice_image_tokens"
+
+
+def read_extras(checkpoint_dir) -> dict:
+    f = Path(checkpoint_dir) / EXTRAS_FILE
+    return json.loads(f.read_text()) if f.is_file() else {}
 # state-dict keys of this build that exist only while their feature is on (so a default policy keeps exactly the reference's keys): folded
-# dataset statistics, and the spliced-sequence mode an unfrozen run trains the decoder in (FastVLMBackbone._save_to_state_dict)
+# dataset statistics (FastVLMBackbone._save_to_state_dict), and -- in files written by round 5 -- the spliced-sequence mode of an unfrozen run (now in EXTRAS_FILE)
 EXTRA_STATE_MARKS = (".io_norm.", ".splice_image_tokens")
 
 
@@ -44,8 +54,11 @@ def load_policy_from_checkpoint(checkpoint_dir: str, device: torch.device | None
     missing = [k for k in own if k not in state]
     if missing:
         raise KeyError(f"checkpoint lacks head tensors: {missing}")
-    extra = {k: v for k, v in state.items() if any(m in k for m in EXTRA_STATE_MARKS)}   # folded dataset statistics / the splice mode travel with the state dict
+    extra = {k: v for k, v in state.items() if any(m in k for m in EXTRA_STATE_MARKS)}   # folded dataset statistics travel with the state dict (round-5 files: the splice mode too)
     policy.load_state_dict({**{k: state[k] for k in own}, **extra})
+    ex = read_extras(root)
+    if "splice_image_tokens" in ex:
+        policy.model.backbone.splice_image_tokens = bool(ex["splice_image_tokens"])
     policy.eval()
     return policy
 
@@ -57,7 +70,13 @@ def save_policy_checkpoint(policy: FastVLAPolicy, checkpoint_dir: str, include_b
     d = Path(checkpoint_dir)
     d.mkdir(parents=True, exist_ok=True)
     (d / "policy_config.json").write_text(json.dumps(dataclasses.asdict(policy.config), indent=2))
-    state = {k: v.detach().cpu().clone() for k, v in policy.state_dict().items()}
+    # (the splice mode goes to the side file: policy_state_dict.pt keeps the reference's keys only, + `io_norm.*` while dataset statistics are folded)
+    state = {k: v.detach().cpu().clone() for k, v in policy.state_dict().items() if SPLICE_KEY_MARK not in k}
+    un = getattr(policy, "_unfrozen", None)
+    extras = {"splice_image_tokens": bool(policy.model.backbone.splice_image_tokens), "train_backbone": un is not None,
+              "train_tower": bool(un is not None and un.train_tower)}
+    if any(extras.values()):
+        (d / EXTRAS_FILE).write_text(json.dumps(extras, indent=2))
     if include_backbone:
         embed = None
         for name, t in policy.model.backbone.source_tensors():
