@@ -1434,6 +1434,9 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
       }
     }
     DP_T(5)
+#ifdef DP_NO_T7   /* tools/dw_variants.sh only (VERDICT r5 #1's table): the pair WITHOUT its 7x7 half -- x -> x' alone, what the march costs once t is made by the ConvFFN */
+    { DP_DUMMY_STORES(4) continue; }
+#endif
     if (g < g0) { DP_DUMMY_STORES(4) continue; }
     // ---- t rows 8g .. 8g + 7 = dw7x7 over x' units g - 1, g
     {

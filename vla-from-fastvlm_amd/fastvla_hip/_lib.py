@@ -221,6 +221,13 @@ def load_testops():
     if _OPS is not None:
         return _OPS
     product = load()
+    if hasattr(product, "fv_op_gemm"):      # a tools/ variant build that links the op entry points into the one library (tools/dw_variants.sh, ffn32_variants.sh)
+        for name, (res, args) in OPS_SIGNATURES.items():
+            fn = getattr(product, name)
+            fn.restype = res
+            fn.argtypes = args
+        _OPS = product
+        return _OPS
     path = testops_path()
     if not path.is_file():
         raise FastVLAHipError(f"{path} not found: `make -C vla-from-fastvlm_amd/csrc` builds it beside the product library (test-only entry points)")
