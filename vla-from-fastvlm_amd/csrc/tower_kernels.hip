@@ -1155,7 +1155,7 @@ struct DpGeo {
   static constexpr int NCG = CHB / 8;      // 16-byte channel groups per pixel
   static constexpr int NGG = CHB / 16;     // 16-channel MFMA groups = waves across channels
   static constexpr int NRG = NGG / 2;      // 4-row groups one wave computes per 8-row unit
-  static constexpr int OCC = LDS <= 40 * 1024 ? 3 : 2;   // blocks per CU the kernel is compiled for (registers: 512 / (4 * OCC / 4))
+  static constexpr int OCC = 3 * LDS <= 160 * 1024 ? 3 : 2;   // blocks per CU the kernel is compiled for (registers: 512 / (4 * OCC / 4))
 };
 #ifdef DP_STAMPS
 __device__ unsigned long long g_dp_stamps[512 * 16];   // diagnostics: per block (first 512), clocks per phase summed over the steps (wave 0)
@@ -1930,12 +1930,16 @@ int launch_dwconv_pair(const bf16_t* x, const bf16_t* t3, const float* b3, const
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpair_march_kernel<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, DpGeo<32, 32>::LDS));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpair_march_kernel<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, DpGeo<64, 16>::LDS));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpair_march_kernel<32, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, DpGeo<32, 16>::LDS));
+#if DP_DEFAULT_GEO == 3
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpair_march_kernel<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DpGeo<64, 8>::LDS));
+#endif
     attr_set = true;
   }
   // geometry: 0 = 32 columns x 32 channels (two blocks per CU), 1 = 16 x 64 (full cache lines), 2 = 16 x 32 (three blocks per CU)
+  // (3, tools/dw_variants.sh only: 8 columns x 64 channels -- full cache lines AND three blocks per CU at 50.7 KB, for twice the halo columns per output column)
   int geo = DP_DEFAULT_GEO;
-  if (geo == 1 && C % 64) geo = 0;
-  const int chb = geo == 1 ? 64 : 32, tw = geo == 0 ? 32 : 16;
+  if ((geo == 1 || geo == 3) && C % 64) geo = 0;
+  const int chb = (geo == 1 || geo == 3) ? 64 : 32, tw = geo == 0 ? 32 : geo == 3 ? 8 : 16;
   const int tiles_x = (W + tw - 1) / tw, nsl = C / chb;
   long nstrips = (long)B * tiles_x * nsl;
   if (nstrips > 0x7fffffffL) return fv_fail(FV_ERR_ARG, "dwconv_pair: grid too large");
@@ -1948,6 +1952,11 @@ int launch_dwconv_pair(const bf16_t* x, const bf16_t* t3, const float* b3, const
     if (nseg < 1) nseg = 1;
   }
   nstrips *= nseg;
+#if DP_DEFAULT_GEO == 3
+  if (geo == 3)
+    hipLaunchKernelGGL((dwpair_march_kernel<64, 8>), dim3((unsigned)nstrips), dim3(256), (DpGeo<64, 8>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl, nseg);
+  else
+#endif
   if (geo == 1)
     hipLaunchKernelGGL((dwpair_march_kernel<64, 16>), dim3((unsigned)nstrips), dim3(256), (DpGeo<64, 16>::LDS), s, x, t3, b3, t7, b7, y1, y2, H, W, C, tiles_x, nsl, nseg);
   else if (geo == 2)
