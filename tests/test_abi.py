@@ -100,7 +100,7 @@ def test_convffn32_chunk_loop_has_no_register_file_copies(tmp_path):
                     "--cuda-device-only", str(src), "-o", str(out)], check=True, capture_output=True)
     text = out.read_text()
     kernels = re.findall(r"^(_ZN2fv[^\n]*convffn32_kernel[^\n:]*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
-    assert len(kernels) == 6   # three widths, each also as the hidden-range (PART) instance of the control-loop path
+    assert len(kernels) == 9   # three widths, each also as the hidden-range (PART) instance of the control-loop path and as the STASH instance of the training forward
     for name, body in kernels:
         lines = body.split("\n")
         starts = [i for i, l in enumerate(lines) if "Inner Loop Header: Depth=2" in l]

@@ -76,7 +76,18 @@ struct Ffn32Params {
   const bf16_t* x; const bf16_t* wq; const float* b1; const float* b2; const float* ls;
   const bf16_t* res; bf16_t* out; int M, nchunks;
   float* part = nullptr; int hsplit = 1;   // PART instances: nchunks = chunks PER RANGE, raw fp32 sums to part[range][M][C]
+  // STASH instances (the tower's TRAINING forward, round 6): the hidden activations leave the chip on the way -- sh[M][4C] fp16 = gelu(a) exactly as the second
+  // product consumed it (the bf16 operand value, widened), sy[M][4C] fp16 = a / 4 (the pre-activation in the kernel's own scaling) -- so that the backward needs no
+  // recompute GEMM: the fc2 weight gradient contracts over sh, the fc2 input gradient's epilogue multiplies by gelu'(4 sy) (FV_EPI_MUL_GELUP)
+  bf16_t* sh = nullptr; bf16_t* sy = nullptr;
 };
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pk_h2_rtz(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+// two bf16 values (one dword) -> the same two values x 4 as fp16 (exact: a bf16 significand fits fp16's, and the hidden activations sit far inside its range)
+__device__ __forceinline__ uint32_t bf2_to_h2_x4(uint32_t u) {
+  const f16x2_t h = __builtin_bit_cast(f16x2_t, pk_h2_rtz(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)));
+  return __builtin_bit_cast(uint32_t, h * (f16x2_t){(_Float16)4.0f, (_Float16)4.0f});
+}
 
 // output accumulators pinned to the accumulator half of the register file, hidden-tile accumulators to the architectural
 // half (the GELU reads them); see convffn_fused.hip for why these MFMAs are asm statements
@@ -163,8 +174,9 @@ struct Ffn32Lds {
 // PART (few row tiles: one to four observations give C = 384 32 .. 128 tiles for 256 CUs, and a tile costs its whole 2.4 MB weight pass whoever else is
 // idle): block = (row tile, one of hsplit ranges of hidden chunks).  The kernel is the same chunk loop over a weight stream that starts at the range's
 // first chunk; the epilogue leaves the raw fp32 output sums in p.part[range] and ffn32_reduce_kernel adds the ranges, bias, layer scale and residual.
-template <int C, int MT, int NW = 4, bool S16 = false, bool PART = false>
+template <int C, int MT, int NW = 4, bool S16 = false, bool PART = false, bool STASH = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params p) {
+  static_assert(!STASH || (!S16 && !PART), "the stash rides on the one-launch 32x32x16 form");
   using L = Ffn32Lds<C, MT, NW>;
   constexpr int NTH = 64 * NW, TROWS = 32 * NW * MT;   // threads per block, rows per row tile set
   constexpr int N1 = C / 16;                   // fragment reads of the first product (either MFMA shape)
@@ -191,6 +203,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, act_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, act_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, act_bytes, 0x00020000);
+  // STASH: [M][4C] fp16 rows (8 C bytes each: the launcher keeps M * 8 C below 2 GiB); a row past M carries an offset the descriptor drops
+  const __amdgpu_buffer_rsrc_t shrsrc = __builtin_amdgcn_make_buffer_rsrc(STASH ? p.sh : nullptr, 0, STASH ? act_bytes * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t syrsrc = __builtin_amdgcn_make_buffer_rsrc(STASH ? p.sy : nullptr, 0, STASH ? act_bytes * 4u : 0u, 0x00020000);
+  uint32_t srow[STASH ? MT : 1];   // byte offset of the lane's pixel row (+ 16 fh) in the stash tensors, per tile
   // LDS address of this wave's first 1 KB piece in slot 0 (wave-uniform: M0 of the add-tid stores)
   const uint32_t wm0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)smem + (uint32_t)wid * 1024u);
 
@@ -452,11 +468,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
               _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                       \
                 f32x2 g[4] = {{hacc[mt][8 * s + 0], hacc[mt][8 * s + 1]}, {hacc[mt][8 * s + 2], hacc[mt][8 * s + 3]}, \
                               {hacc[mt][8 * s + 4], hacc[mt][8 * s + 5]}, {hacc[mt][8 * s + 6], hacc[mt][8 * s + 7]}}; \
+                uint32_t yq[4];                                                                                     \
+                if constexpr (STASH) { _Pragma("unroll") for (int e = 0; e < 4; ++e) yq[e] = pk_h2_rtz(g[e].x, g[e].y); } \
                 F32_GELU(g)                                                                                         \
                 uint4 u;                                                                                            \
                 u.x = pack_bf2(g[0].x, g[0].y); u.y = pack_bf2(g[1].x, g[1].y);                                     \
                 u.z = pack_bf2(g[2].x, g[2].y); u.w = pack_bf2(g[3].x, g[3].y);                                     \
                 hf[mt][s] = __builtin_bit_cast(bf16x8, u);                                                          \
+                if constexpr (STASH) {                                                                              \
+                  /* the lane holds hidden 16 s + 4 fh + 0..3 (dwords 0, 1) and 16 s + 8 + 4 fh + 0..3 (dwords 2, 3) of its pixel; the lane 32 further (fh ^ 1) */ \
+                  /* holds the runs in between: one v_permlane32_swap per dword pair gives fh = 0 the hidden 16 s + 0..7 and fh = 1 the hidden 16 s + 8..15 --   */ \
+                  /* 16 contiguous bytes per lane, 32 per pixel row and instruction                                                                               */ \
+                  uint32_t hq[4] = {bf2_to_h2_x4(u.x), bf2_to_h2_x4(u.y), bf2_to_h2_x4(u.z), bf2_to_h2_x4(u.w)};   \
+                  _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                   \
+                    const auto sy_ = __builtin_amdgcn_permlane32_swap(yq[e], yq[e + 2], false, false);              \
+                    yq[e] = sy_[0]; yq[e + 2] = sy_[1];                                                             \
+                    const auto sh_ = __builtin_amdgcn_permlane32_swap(hq[e], hq[e + 2], false, false);              \
+                    hq[e] = sh_[0]; hq[e + 2] = sh_[1];                                                             \
+                  }                                                                                                 \
+                  typedef __attribute__((ext_vector_type(4))) unsigned int su4_;                                    \
+                  __builtin_amdgcn_raw_buffer_store_b128(su4_{hq[0], hq[1], hq[2], hq[3]}, shrsrc, srow[mt], hc * 64 + s * 32, 0); \
+                  __builtin_amdgcn_raw_buffer_store_b128(su4_{yq[0], yq[1], yq[2], yq[3]}, syrsrc, srow[mt], hc * 64 + s * 32, 0); \
+                }                                                                                                   \
                 __builtin_amdgcn_sched_barrier(0); /* one group of four chains at a time */                         \
               }                                                                                                     \
             }                                                                                                       \
@@ -486,6 +519,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
   const uint32_t peoff_last = (er < ERW && (RP - 1) * ERW + er < 32) ? peoff : OOB;
   for (int tile = tile0; tile < ntiles; tile += PART ? ntiles : (int)gridDim.x) {
     const long mb = (long)tile * TROWS + wid * (32 * MT);
+    if constexpr (STASH) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const long m_ = mb + mt * 32 + fr;
+        srow[mt] = m_ < (long)p.M ? (uint32_t)m_ * (uint32_t)(C * 8) + (uint32_t)fh * 16u : 0x80000000u;
+      }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -666,17 +706,17 @@ int launch_part32(Ffn32Params p, float* part, size_t part_bytes, hipStream_t s) 
   return FV_OK;
 }
 
-template <int C, int MT, int NW = 4, bool S16 = false>
+template <int C, int MT, int NW = 4, bool S16 = false, bool STASH = false>
 int launch_one32(const Ffn32Params& p, hipStream_t s) {
   constexpr int LDS = Ffn32Lds<C, MT, NW>::TOTAL;
   static bool attr_set = false;
   if (!attr_set) {
-    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn32_kernel<C, MT, NW, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convffn32_kernel<C, MT, NW, S16, false, STASH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const long tiles = ((long)p.M + 32 * NW * MT - 1) / (32 * NW * MT);
   const long blocks = tiles < num_cus32() ? tiles : num_cus32();   // one persistent block per CU, tiles dealt round-robin
-  hipLaunchKernelGGL((convffn32_kernel<C, MT, NW, S16>), dim3((unsigned)blocks), dim3(64 * NW), LDS, s, p);
+  hipLaunchKernelGGL((convffn32_kernel<C, MT, NW, S16, false, STASH>), dim3((unsigned)blocks), dim3(64 * NW), LDS, s, p);
   FV_HIP_CHECK(hipGetLastError());
   return FV_OK;
 }
@@ -737,8 +777,10 @@ void convffn32_pack(const float* w1, const float* w2, float* out, int C) {
   }
 }
 
+bool convffn32_stash_supported(int M, int C) { return convffn32_supported(C, 4) && !shape16(C) && (size_t)M * C * 8 < ((size_t)1 << 31); }
+
 int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const float* b2, const float* ls,
-                     const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s, float* part, size_t part_bytes) {
+                     const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s, float* part, size_t part_bytes, bf16_t* stash_h, bf16_t* stash_y) {
   if (!x || !wq || !b1 || !b2 || !ls || !res || !out) return fv_fail(FV_ERR_ARG, "convffn32: null pointer");
   if (M <= 0 || hidden != 4 * C || !convffn32_supported(C, 4)) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: unsupported C=%d hidden=%d", C, hidden);
   if (((uintptr_t)x | (uintptr_t)wq | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ls | (uintptr_t)res | (uintptr_t)out) & 15)
@@ -746,6 +788,14 @@ int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const f
   if (x == out) return fv_fail(FV_ERR_ARG, "convffn32: x must not alias out");
   if ((size_t)M * C * 2 >= ((size_t)1 << 31)) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: M * C * 2 must stay below 2 GiB (32-bit buffer offsets)");
   Ffn32Params p{x, wq, b1, b2, ls, res, out, M, hidden / 32};
+  if (stash_h || stash_y) {   // the training forward: the one-launch form, hidden activations written out on the way (never the hidden-range forms)
+    if (!stash_h || !stash_y || (((uintptr_t)stash_h | (uintptr_t)stash_y) & 15) || !convffn32_stash_supported(M, C))
+      return fv_fail(FV_ERR_ARG, "convffn32: the stash needs both tensors, 16-byte aligned, the 32x32x16 form and M * 8C below 2 GiB");
+    p.sh = stash_h; p.sy = stash_y;
+    if (C == 96) return launch_one32<96, 4, 4, false, true>(p, s);
+    if (C == 192) return launch_one32<192, 1, 8, false, true>(p, s);
+    return launch_one32<384, 1, 4, false, true>(p, s);
+  }
   // few row tiles and scratch supplied: (tile, hidden range) blocks + a reduce pass (the default instances' tile heights)
   if (part && ((uintptr_t)part & 15) == 0 && (size_t)M * C * 4 < ((size_t)1 << 31)) {
     const int trows = C == 384 ? 128 : C == 192 ? 256 : 512;

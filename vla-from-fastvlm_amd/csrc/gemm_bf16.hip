@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
       const float4 hi = *reinterpret_cast<const float4*>(p.bias + gn + 4);
       v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
     }
-    if (epi == FV_EPI_GELU_GRAD || epi == FV_EPI_MUL_AUX || epi == FV_EPI_F16) {   // the tower backward's fp16 outputs
+    if (epi == FV_EPI_GELU_GRAD || epi == FV_EPI_MUL_AUX || epi == FV_EPI_MUL_GELUP || epi == FV_EPI_F16) {   // the tower backward's fp16 outputs
       if (epi == FV_EPI_GELU_GRAD) {
         float g8[8];
         gelu_and_grad8(v, g8);
@@ -304,6 +304,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
         unpack8_h(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), a8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= a8[e];
+      } else if (epi == FV_EPI_MUL_GELUP) {   // aux = the pre-activation / 4 as the training forward's fused ConvFFN stashed it: times gelu'(a)
+        float a8[8];
+        unpack8_h(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), a8);
+        mul_gelu_grad8(v, a8);
       }
       count_f16_sat8(v, p.sat);
       *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8_h(v);
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
         const float4 y0 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32);
         const float4 y1 = *reinterpret_cast<const float4*>(so + row * ORB + c8 * 32 + 16);
         float v[8] = {y0.x + bs[0], y0.y + bs[1], y0.z + bs[2], y0.w + bs[3], y1.x + bs[4], y1.y + bs[5], y1.z + bs[6], y1.w + bs[7]};
-        if (p.epi == FV_EPI_GELU_GRAD || p.epi == FV_EPI_MUL_AUX || p.epi == FV_EPI_F16) {   // the tower backward's fp16 outputs
+        if (p.epi == FV_EPI_GELU_GRAD || p.epi == FV_EPI_MUL_AUX || p.epi == FV_EPI_MUL_GELUP || p.epi == FV_EPI_F16) {   // the tower backward's fp16 outputs
           if (p.epi == FV_EPI_GELU_GRAD) {
             float g8[8];
             gelu_and_grad8(v, g8);
@@ -711,6 +715,10 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
             unpack8_h(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), a8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= a8[e];
+          } else if (p.epi == FV_EPI_MUL_GELUP) {
+            float a8[8];
+            unpack8_h(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), a8);
+            mul_gelu_grad8(v, a8);
           }
           count_f16_sat8(v, p.sat);
           *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8_h(v);
@@ -1014,7 +1022,7 @@ int gemm_glds_tile(const GemmArgs& a) {
   // 4 GiB or more go to the register-staged kernel, which addresses with size_t
   if ((size_t)a.M * a.lda * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return 0;
   const bool f32 = a.epi == FV_EPI_RES_F32 || a.epi == FV_EPI_F32;
-  const bool f16_epi = a.epi == FV_EPI_GELU_GRAD || a.epi == FV_EPI_MUL_AUX || a.epi == FV_EPI_F16;   // the tower backward's (2-byte fp16 outputs: the bf16 epilogues' store loop)
+  const bool f16_epi = a.epi == FV_EPI_GELU_GRAD || a.epi == FV_EPI_MUL_AUX || a.epi == FV_EPI_MUL_GELUP || a.epi == FV_EPI_F16;   // the tower backward's (2-byte fp16 outputs: the bf16 epilogues' store loop)
   if (a.epi != FV_EPI_BIAS && a.epi != FV_EPI_BIAS_GELU && a.epi != FV_EPI_LS_RES && a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16 && !f32 && !f16_epi) return 0;
   if ((a.epi == FV_EPI_SWIGLU_SPLIT || a.epi == FV_EPI_SWIGLU_F16) && a.bias) return 0;
   // (a 128 x 256 variant for shapes whose last round of 256-tiles is mostly idle -- the decoder's gate/up, 608 tiles = 2.4
@@ -1159,10 +1167,10 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   if (a.tn) return launch_gemm_tn(a, s);
   if (a.K % 8 || a.lda % 8 || a.N % 8) return fv_fail(FV_ERR_ARG, "gemm: K, lda, N must be multiples of 8 (K=%d lda=%d N=%d)", a.K, a.lda, a.N);
   if (a.lda < a.K) return fv_fail(FV_ERR_ARG, "gemm: lda < K");
-  if (a.epi < FV_EPI_BIAS || a.epi > FV_EPI_F16 || a.epi == 6) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
-  if ((a.epi == FV_EPI_GELU_GRAD || a.epi == FV_EPI_MUL_AUX || a.epi == FV_EPI_F16) && a.ksplit) return fv_fail(FV_ERR_ARG, "gemm: the fp16-output epilogues take no ksplit");
+  if (a.epi < FV_EPI_BIAS || a.epi > FV_EPI_MUL_GELUP || a.epi == 6) return fv_fail(FV_ERR_ARG, "gemm: bad epilogue %d", a.epi);
+  if ((a.epi == FV_EPI_GELU_GRAD || a.epi == FV_EPI_MUL_AUX || a.epi == FV_EPI_MUL_GELUP || a.epi == FV_EPI_F16) && a.ksplit) return fv_fail(FV_ERR_ARG, "gemm: the fp16-output epilogues take no ksplit");
   if (a.epi == FV_EPI_GELU_GRAD && (!a.stash || ((uintptr_t)a.stash & 15))) return fv_fail(FV_ERR_ARG, "gemm: GELU_GRAD needs a 16-byte aligned stash (gelu' output)");
-  if (a.epi == FV_EPI_MUL_AUX && (!a.res || a.ldr % 8 || a.ldr < a.N)) return fv_fail(FV_ERR_ARG, "gemm: MUL_AUX needs the fp16 factor in res");
+  if ((a.epi == FV_EPI_MUL_AUX || a.epi == FV_EPI_MUL_GELUP) && (!a.res || a.ldr % 8 || a.ldr < a.N)) return fv_fail(FV_ERR_ARG, "gemm: MUL_AUX / MUL_GELUP need the fp16 factor in res");
   if (a.f16 && a.ksplit) return fv_fail(FV_ERR_ARG, "gemm: fp16 operands are a single pass (no ksplit)");
   if (a.f16 && (a.epi == FV_EPI_BIAS_GELU || a.epi == FV_EPI_LS_RES || a.epi == FV_EPI_SWIGLU))
     return fv_fail(FV_ERR_UNSUPPORTED, "gemm: fp16 operands go with the BIAS / F32 / RES_F32 / SWIGLU_SPLIT / SWIGLU_F16 epilogues");

@@ -181,6 +181,12 @@ int fv_op_convffn32(const void* x, const void* wq, const float* b1, const float*
                               static_cast<bf16_t*>(out), M, C, 4 * C, static_cast<hipStream_t>(s));
 }
 
+int fv_op_convffn32_stash(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
+                          int M, int C, void* stash_h, void* stash_y, fv_stream s) {
+  return fv::launch_convffn32(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(wq), b1, b2, ls, static_cast<const bf16_t*>(res),
+                              static_cast<bf16_t*>(out), M, C, 4 * C, static_cast<hipStream_t>(s), nullptr, 0, static_cast<bf16_t*>(stash_h), static_cast<bf16_t*>(stash_y));
+}
+
 int fv_op_convffn32_split(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
                           int M, int C, float* part, size_t part_bytes, fv_stream s) {
   return fv::launch_convffn32(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(wq), b1, b2, ls, static_cast<const bf16_t*>(res),
