@@ -322,6 +322,10 @@ int fv_train_forward_backward(fv_handle* h, const float* flat_params, const void
 int fv_train_tower_begin(fv_handle* h);
 int fv_train_tower_workspace_bytes(fv_handle* h, int B, size_t* out_bytes);
 int fv_train_tower_forward(fv_handle* h, const void* pix, int B, void* tws, size_t tws_bytes, void* tower_out, fv_stream s);
+/* Binds (NULL: unbinds) the buffer fv_train_forward_backward leaves dL/d(tower_out) in.  That gradient carries a power-of-two scale of its own, chosen on the device every
+ * step and taken out again by fv_train_tower_backward.  A CHANGE of binding resets the scale to 1 (a configuration call: it synchronises the device); binding the buffer
+ * that is already bound is a no-op, so a training loop may call this every step.  A caller that fills a gradient buffer ITSELF and hands it to fv_train_tower_backward
+ * (no fv_train_forward_backward in between) must have changed the binding since the last fv_train_forward_backward -- e.g. bind NULL first, as the unit tests do. */
 int fv_train_set_tower_grad(fv_handle* h, void* d_tower_out_f16);
 int fv_train_tower_backward(fv_handle* h, const void* pix, const void* d_tower_out_f16, int B, void* tws, size_t tws_bytes, float* flat_grads, fv_bucket_cb cb,
                             void* user, fv_stream s);
