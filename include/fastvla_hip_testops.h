@@ -30,7 +30,7 @@ enum fv_gemm_epilogue {
   FV_EPI_GELU_GRAD = 9,   /* a = acc + bias: out f16 = gelu(a) (the 5e-5 minimax Phi of the forward kernels, rounded to a bf16 value first; out may be NULL), stash f16 = gelu'(a), both [M][ldo] */
   FV_EPI_MUL_AUX = 10,    /* out f16 = acc * aux_f16[m][n] (aux = res, row stride ldr; out may alias aux)                              */
   FV_EPI_F16 = 11,        /* out f16 = acc + bias                                                                                      */
-  FV_EPI_MUL_GELUP = 12   /* out f16 = acc * gelu'(4 * aux_f16[m][n]): aux = the pre-activation / 4 the training forward's fused ConvFFN stashed (round 6) */
+  FV_EPI_MUL_GELUP = 12   /* out f16 = acc * gelu'(4 * aux_f16[m][n]); stash f16 (optional) = gelu(4 * aux) rounded to bf16: aux = the pre-activation / 4 the training forward's fused ConvFFN stashed (round 6) */
 };
 /* out[M,N] = A[M,K] (bf16, row stride lda) x W[N,K]^T (bf16) with fp32 accumulation on MFMA */
 int fv_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const float* scale,
@@ -135,10 +135,13 @@ int fv_op_convffn32(const void* x, const void* wq, const float* b1, const float*
  * of the hidden units), fp32 partial sums in `part` (>= ranges x M x C floats, 16-byte aligned), then one pass adds the ranges in order and applies
  * b2, ls and the residual exactly as the one-launch epilogue does.  Falls back to fv_op_convffn32 when M is large or `part` too small.  The engine
  * takes this form by itself below 128 row tiles (fv_vision_forward at B <= 4). */
-/* the TRAINING forward's form of fv_op_convffn32 (round 6): the same output, and the hidden activations on the way out -- stash_h (M,4C) fp16 = gelu(fc1(x) + b1) as the
- * second product consumed it (rounded to bf16, widened exactly), stash_y (M,4C) fp16 = (fc1(x) + b1) / 4 (round towards zero).  M * 8C < 2 GiB. */
+/* the TRAINING forward's form of fv_op_convffn32 (round 6): the same output bits, and the pre-activation on the way out -- stash_y (M,4C) fp16 = (fc1(x) + b1) / 4
+ * (round towards zero), in natural column order.  M * 8C < 2 GiB. */
 int fv_op_convffn32_stash(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
-                          int M, int C, void* stash_h, void* stash_y, fv_stream s);
+                          int M, int C, void* stash_y, fv_stream s);
+/* the fc2 input gradient of the tower's backward as it runs there: fp16 operands, out f16 = (A . W^T) * gelu'(4 aux), h_out f16 (may be NULL) = gelu(4 aux) rounded to
+ * a bf16 value (the fc2 weight gradient's operand), aux = fv_op_convffn32_stash's stash_y */
+int fv_op_gemm_f16_gelup(const void* A, int lda, const void* W, int M, int N, int K, const void* aux, int ldaux, void* out, int ldo, void* h_out, fv_stream s);
 int fv_op_convffn32_split(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
                           int M, int C, float* part, size_t part_bytes, fv_stream s);
 

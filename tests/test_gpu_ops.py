@@ -389,10 +389,10 @@ def test_fused_convffn32(Cc, M):
 
 @pytest.mark.parametrize("Cc,M", [(384, 4096), (384, 1000), (192, 8192 + 77), (96, 16384), (96, 700)])
 def test_fused_convffn32_stash_and_gelup_epilogue(Cc, M):
-    """Round 6, the tower's TRAINING forward: the fused ConvFFN leaves its hidden activations behind (convffn32.hip STASH) -- stash_h = gelu(fc1(x) + b1) exactly as the
-    second product consumed it (the bf16 value, as fp16), stash_y = (fc1(x) + b1) / 4 -- with the SAME output bits as the inference instance; and the fc2 input
-    gradient's epilogue FV_EPI_MUL_GELUP (out = acc * gelu'(4 aux)) against torch ([UNVENDORED] mci.py ConvFFN; the backward the reference would run through autograd,
-    training/trainer.py:175)."""
+    """Round 6, the tower's TRAINING forward: the fused ConvFFN leaves its pre-activation behind (convffn32.hip STASH: stash_y = (fc1(x) + b1) / 4 as fp16, natural column
+    order) with the SAME output bits as the inference instance; and the fc2 input gradient's epilogue FV_EPI_MUL_GELUP turns it into both things the backward needs from
+    ONE read -- out = acc * gelu'(4 aux) and gelu(4 aux) rounded to a bf16 value (the fc2 weight gradient's operand: what the second product of the forward consumed) --
+    against torch ([UNVENDORED] mci.py ConvFFN; the backward the reference would run through autograd, training/trainer.py:175)."""
     torch.manual_seed(Cc + M + 9)
     Hd = 4 * Cc
     x, res = bf(torch.randn(M, Cc)), bf(torch.randn(M, Cc))
@@ -403,34 +403,38 @@ def test_fused_convffn32_stash_and_gelup_epilogue(Cc, M):
     b1d, b2d, lsd = dev_f32(b1), dev_f32(b2), dev_f32(ls)
     out, ref_out = (torch.full((M, Cc), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(2))
     guard = 64
-    sh = torch.full((M + guard, Hd), float("nan"), dtype=torch.float16, device=DEV)
     sy = torch.full((M + guard, Hd), float("nan"), dtype=torch.float16, device=DEV)
     call(lib().fv_op_convffn32_stash(xd.data_ptr(), wqd.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(), rd.data_ptr(), out.data_ptr(), M, Cc,
-                                     sh.data_ptr(), sy.data_ptr(), stream()), "fv_op_convffn32_stash")
+                                     sy.data_ptr(), stream()), "fv_op_convffn32_stash")
     call(lib().fv_op_convffn32(xd.data_ptr(), wqd.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), lsd.data_ptr(), rd.data_ptr(), ref_out.data_ptr(), M, Cc, stream()),
          "fv_op_convffn32")
     torch.cuda.synchronize()
     assert torch.equal(out, ref_out)                                            # the stash changes nothing about the output
-    assert torch.isnan(sh[M:].float()).all() and torch.isnan(sy[M:].float()).all()   # rows past M are not written
-    h, y = sh[:M].float().cpu(), sy[:M].float().cpu()
-    assert torch.equal(h, bf(h))                                                # the operand the second product consumed: bf16 values
+    assert torch.isnan(sy[M:].float()).all()                                    # rows past M are not written
+    y = sy[:M].float().cpu()
     check_close(y, (a / 4).float(), rel=1e-3, amax=2e-3, what=f"stashed pre-activation / 4, C={Cc}")
-    check_close(h, F.gelu(a).float(), rel=4e-3, amax=2e-2, what=f"stashed hidden, C={Cc}")
-    # the forward computes gelu(4 y) / 4 from ITS y: the stashed pair is consistent to the bf16 rounding of h and the fp16 rounding of y
-    assert float((h - F.gelu(4.0 * y.double()).float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(h.abs().max()))
-    # FV_EPI_MUL_GELUP through the fp16 GEMM: dA = (G . W2s) * gelu'(a), a = 4 * stash_y
+    # FV_EPI_MUL_GELUP through the fp16 GEMM: dA = (G . W2s) * gelu'(a), h = gelu(a), a = 4 * stash_y
     Mg = min(M, 2048) // 8 * 8
     G = (torch.randn(Mg, Cc) * 0.05).half()
     W2s = (torch.randn(Hd, Cc) / math.sqrt(Cc)).half()                          # [N = 4C][K = C]: the transposed, layer-scaled fc2 copy of the backward
-    dA = torch.full((Mg, Hd), float("nan"), dtype=torch.float16, device=DEV)
     Gd, Wd = G.to(DEV), W2s.to(DEV)
-    call(lib().fv_op_gemm_f16(Gd.data_ptr(), Cc, Wd.data_ptr(), Mg, Hd, Cc, None, sy.data_ptr(), Hd, dA.data_ptr(), Hd, 12, None, 0, stream()),
-         "fv_op_gemm_f16 MUL_GELUP")
+    dA = torch.full((Mg, Hd), float("nan"), dtype=torch.float16, device=DEV)
+    hO = torch.full((Mg, Hd), float("nan"), dtype=torch.float16, device=DEV)
+    call(lib().fv_op_gemm_f16_gelup(Gd.data_ptr(), Cc, Wd.data_ptr(), Mg, Hd, Cc, sy.data_ptr(), Hd, dA.data_ptr(), Hd, hO.data_ptr(), stream()), "fv_op_gemm_f16_gelup")
     torch.cuda.synchronize()
     av = (4.0 * y[:Mg].double()).requires_grad_(True)
     F.gelu(av).sum().backward()
     ref = (G.double() @ W2s.double().t()) * av.grad
     check_close(dA.float().cpu(), ref.float(), rel=2e-3, amax=4e-3, what=f"MUL_GELUP epilogue C={Cc}")
+    h = hO.float().cpu()
+    assert torch.equal(h, bf(h))                                                # bf16 values: the operand form the forward's second product consumed
+    check_close(h, F.gelu(av.detach()).float(), rel=4e-3, amax=8e-3, what=f"MUL_GELUP's gelu(a), C={Cc}")
+    check_close(h, F.gelu(a[:Mg]).float(), rel=5e-3, amax=2e-2, what=f"... against the unrounded pre-activation, C={Cc}")
+    # without the second output the first is unchanged
+    dA2 = torch.full((Mg, Hd), float("nan"), dtype=torch.float16, device=DEV)
+    call(lib().fv_op_gemm_f16_gelup(Gd.data_ptr(), Cc, Wd.data_ptr(), Mg, Hd, Cc, sy.data_ptr(), Hd, dA2.data_ptr(), Hd, None, stream()), "fv_op_gemm_f16_gelup (no h)")
+    torch.cuda.synchronize()
+    assert torch.equal(dA, dA2)
 
 
 @pytest.mark.parametrize("Cc,M", [(384, 4096), (384, 8192), (384, 16384 - 37), (192, 16384), (192, 65536), (96, 65536), (96, 131072), (384, 100)])

@@ -256,14 +256,16 @@ __device__ __forceinline__ void gelu_and_grad2(const f32x2 x, f32x2& g, f32x2& d
   g = x * Phi;
   dg = __builtin_elementwise_fma(x, phi, Phi);
 }
-// v[8] *= gelu'(4 y[8]): the fc2 input gradient's epilogue against the pre-activation / 4 the training forward stashed (FV_EPI_MUL_GELUP)
-__device__ __forceinline__ void mul_gelu_grad8(float* v, const float* y) {
+// v[8] *= gelu'(4 y[8]), h[8] = gelu(4 y[8]): the fc2 input gradient's epilogue against the pre-activation / 4 the training forward stashed (FV_EPI_MUL_GELUP)
+__device__ __forceinline__ void mul_gelu_grad8(float* v, const float* y, float* h) {
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
     f32x2 g, dg;
     gelu_and_grad2((f32x2){4.0f * y[e], 4.0f * y[e + 1]}, g, dg);
     v[e] *= dg.x;
     v[e + 1] *= dg.y;
+    h[e] = g.x;
+    h[e + 1] = g.y;
   }
 }
 __device__ __forceinline__ void gelu_and_grad8(float* v, float* d) {   // v[8] -> gelu in place, d[8] = gelu'

@@ -76,18 +76,13 @@ struct Ffn32Params {
   const bf16_t* x; const bf16_t* wq; const float* b1; const float* b2; const float* ls;
   const bf16_t* res; bf16_t* out; int M, nchunks;
   float* part = nullptr; int hsplit = 1;   // PART instances: nchunks = chunks PER RANGE, raw fp32 sums to part[range][M][C]
-  // STASH instances (the tower's TRAINING forward, round 6): the hidden activations leave the chip on the way -- sh[M][4C] fp16 = gelu(a) exactly as the second
-  // product consumed it (the bf16 operand value, widened), sy[M][4C] fp16 = a / 4 (the pre-activation in the kernel's own scaling) -- so that the backward needs no
-  // recompute GEMM: the fc2 weight gradient contracts over sh, the fc2 input gradient's epilogue multiplies by gelu'(4 sy) (FV_EPI_MUL_GELUP)
-  bf16_t* sh = nullptr; bf16_t* sy = nullptr;
+  // STASH instances (the tower's TRAINING forward, round 6): the pre-activation leaves the chip on the way -- sy[M][4C] fp16 = a / 4 (the kernel's own scaling) -- so
+  // that the backward needs no recompute GEMM: the fc2 input gradient's epilogue (FV_EPI_MUL_GELUP) multiplies by gelu'(4 sy) and writes gelu(4 sy), the fc2 weight
+  // gradient's operand, from the same read.  (Stashing gelu(a) here as well was measured: the kernel runs at the power cap, every byte it stores costs its energy in
+  // time -- 315 -> 471 us per C = 384 launch with both tensors; the memory-bound epilogue over there writes the second tensor almost for free.)
+  bf16_t* sy = nullptr;
 };
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 __device__ __forceinline__ uint32_t pk_h2_rtz(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
-// two bf16 values (one dword) -> the same two values x 4 as fp16 (exact: a bf16 significand fits fp16's, and the hidden activations sit far inside its range)
-__device__ __forceinline__ uint32_t bf2_to_h2_x4(uint32_t u) {
-  const f16x2_t h = __builtin_bit_cast(f16x2_t, pk_h2_rtz(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)));
-  return __builtin_bit_cast(uint32_t, h * (f16x2_t){(_Float16)4.0f, (_Float16)4.0f});
-}
 
 // output accumulators pinned to the accumulator half of the register file, hidden-tile accumulators to the architectural
 // half (the GELU reads them); see convffn_fused.hip for why these MFMAs are asm statements
@@ -204,7 +199,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, act_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, act_bytes, 0x00020000);
   // STASH: [M][4C] fp16 rows (8 C bytes each: the launcher keeps M * 8 C below 2 GiB); a row past M carries an offset the descriptor drops
-  const __amdgpu_buffer_rsrc_t shrsrc = __builtin_amdgcn_make_buffer_rsrc(STASH ? p.sh : nullptr, 0, STASH ? act_bytes * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t syrsrc = __builtin_amdgcn_make_buffer_rsrc(STASH ? p.sy : nullptr, 0, STASH ? act_bytes * 4u : 0u, 0x00020000);
   uint32_t srow[STASH ? MT : 1];   // byte offset of the lane's pixel row (+ 16 fh) in the stash tensors, per tile
   // LDS address of this wave's first 1 KB piece in slot 0 (wave-uniform: M0 of the add-tid stores)
@@ -476,19 +470,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void convffn32_kernel(Ffn32Params 
                 u.z = pack_bf2(g[2].x, g[2].y); u.w = pack_bf2(g[3].x, g[3].y);                                     \
                 hf[mt][s] = __builtin_bit_cast(bf16x8, u);                                                          \
                 if constexpr (STASH) {                                                                              \
-                  /* the lane holds hidden 16 s + 4 fh + 0..3 (dwords 0, 1) and 16 s + 8 + 4 fh + 0..3 (dwords 2, 3) of its pixel; the lane 32 further (fh ^ 1) */ \
-                  /* holds the runs in between: one v_permlane32_swap per dword pair gives fh = 0 the hidden 16 s + 0..7 and fh = 1 the hidden 16 s + 8..15 --   */ \
-                  /* 16 contiguous bytes per lane, 32 per pixel row and instruction                                                                               */ \
-                  uint32_t hq[4] = {bf2_to_h2_x4(u.x), bf2_to_h2_x4(u.y), bf2_to_h2_x4(u.z), bf2_to_h2_x4(u.w)};   \
+                  /* the lane holds a / 4 of hidden 16 s + 4 fh + 0..3 (dwords 0, 1) and 16 s + 8 + 4 fh + 0..3 (dwords 2, 3) of its pixel; the lane 32 further   */ \
+                  /* (fh ^ 1) holds the runs in between: one v_permlane32_swap per dword pair gives fh = 0 the hidden 16 s + 0..7 and fh = 1 the hidden            */ \
+                  /* 16 s + 8..15 -- 16 contiguous bytes per lane, 32 per pixel row and instruction                                                                */ \
                   _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                   \
                     const auto sy_ = __builtin_amdgcn_permlane32_swap(yq[e], yq[e + 2], false, false);              \
                     yq[e] = sy_[0]; yq[e + 2] = sy_[1];                                                             \
-                    const auto sh_ = __builtin_amdgcn_permlane32_swap(hq[e], hq[e + 2], false, false);              \
-                    hq[e] = sh_[0]; hq[e + 2] = sh_[1];                                                             \
                   }                                                                                                 \
                   typedef __attribute__((ext_vector_type(4))) unsigned int su4_;                                    \
-                  __builtin_amdgcn_raw_buffer_store_b128(su4_{hq[0], hq[1], hq[2], hq[3]}, shrsrc, srow[mt], hc * 64 + s * 32, 0); \
-                  __builtin_amdgcn_raw_buffer_store_b128(su4_{yq[0], yq[1], yq[2], yq[3]}, syrsrc, srow[mt], hc * 64 + s * 32, 0); \
+                  /* the chunk's column offset rides in the VGPR offset, NOT in the scalar one: with a register in soffset hipcc assumes that a VALU write of the    */ \
+                  /* store's data registers right behind a 16-byte buffer store is safe (GCNHazardRecognizer: "only if not using a register in soffset") -- on gfx950 */ \
+                  /* it is not: the C = 192 instance stored its NEXT instruction's results in lanes 12-15 / 28-31 (tests/test_gpu_ops.py, stash)                      */ \
+                  __builtin_amdgcn_raw_buffer_store_b128(su4_{yq[0], yq[1], yq[2], yq[3]}, syrsrc, srow[mt] + (uint32_t)(hc * 64 + s * 32), 0, 0); \
+                  asm volatile("s_nop 1" ::: "memory"); /* ... and the statements that follow are inline asm, which hipcc pads for nothing: the wait states by hand */ \
                 }                                                                                                   \
                 __builtin_amdgcn_sched_barrier(0); /* one group of four chains at a time */                         \
               }                                                                                                     \
@@ -780,7 +774,7 @@ void convffn32_pack(const float* w1, const float* w2, float* out, int C) {
 bool convffn32_stash_supported(int M, int C) { return convffn32_supported(C, 4) && !shape16(C) && (size_t)M * C * 8 < ((size_t)1 << 31); }
 
 int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const float* b2, const float* ls,
-                     const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s, float* part, size_t part_bytes, bf16_t* stash_h, bf16_t* stash_y) {
+                     const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s, float* part, size_t part_bytes, bf16_t* stash_y) {
   if (!x || !wq || !b1 || !b2 || !ls || !res || !out) return fv_fail(FV_ERR_ARG, "convffn32: null pointer");
   if (M <= 0 || hidden != 4 * C || !convffn32_supported(C, 4)) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: unsupported C=%d hidden=%d", C, hidden);
   if (((uintptr_t)x | (uintptr_t)wq | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ls | (uintptr_t)res | (uintptr_t)out) & 15)
@@ -788,10 +782,10 @@ int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const f
   if (x == out) return fv_fail(FV_ERR_ARG, "convffn32: x must not alias out");
   if ((size_t)M * C * 2 >= ((size_t)1 << 31)) return fv_fail(FV_ERR_UNSUPPORTED, "convffn32: M * C * 2 must stay below 2 GiB (32-bit buffer offsets)");
   Ffn32Params p{x, wq, b1, b2, ls, res, out, M, hidden / 32};
-  if (stash_h || stash_y) {   // the training forward: the one-launch form, hidden activations written out on the way (never the hidden-range forms)
-    if (!stash_h || !stash_y || (((uintptr_t)stash_h | (uintptr_t)stash_y) & 15) || !convffn32_stash_supported(M, C))
-      return fv_fail(FV_ERR_ARG, "convffn32: the stash needs both tensors, 16-byte aligned, the 32x32x16 form and M * 8C below 2 GiB");
-    p.sh = stash_h; p.sy = stash_y;
+  if (stash_y) {   // the training forward: the one-launch form, hidden activations written out on the way (never the hidden-range forms)
+    if (((uintptr_t)stash_y & 15) || !convffn32_stash_supported(M, C))
+      return fv_fail(FV_ERR_ARG, "convffn32: the stash must be 16-byte aligned and needs the 32x32x16 form and M * 8C below 2 GiB");
+    p.sy = stash_y;
     if (C == 96) return launch_one32<96, 4, 4, false, true>(p, s);
     if (C == 192) return launch_one32<192, 1, 8, false, true>(p, s);
     return launch_one32<384, 1, 4, false, true>(p, s);

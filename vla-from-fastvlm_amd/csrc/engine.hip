@@ -489,11 +489,11 @@ int dw_s1(fv_handle* h, const bf16_t* x, const float* w, const bf16_t* ttab, con
 // ranges: the inference tower lets launch_convffn32 cut the hidden units into ranges when the launch has few row tiles (B <= 2).  That changes the fp32
 // summation order (<= 1 bf16 step per output), so the TRAINING forward keeps the one-launch form at every batch size: a row's gradient must not depend
 // on how many rows share its step (tests/test_gpu_train_tower.py, B = 32 against B = 2).
-// stash_h / stash_y (the tower's training forward): the hidden activations written out by the one-launch 32x32x16 kernel (ffn_stash_ok says whether it can)
+// stash_y (the tower's training forward): the pre-activation / 4 written out by the one-launch 32x32x16 kernel (ffn_stash_ok says whether it can)
 bool ffn_stash_ok(const fv_handle* h, const FFN& f, int M, int C) { return f.w2q && !h->no_ffn32 && fv::convffn32_stash_supported(M, C); }
 int fused_ffn(fv_handle* h, const FFN& f, const bf16_t* t, const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s, bool ranges = true,
-              bf16_t* stash_h = nullptr, bf16_t* stash_y = nullptr) {
-  if (stash_h) return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s, nullptr, 0, stash_h, stash_y);
+              bf16_t* stash_y = nullptr) {
+  if (stash_y) return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s, nullptr, 0, stash_y);
   if (f.w2q && !h->no_ffn32 && (size_t)M * C * 2 < ((size_t)1 << 31))
     return fv::launch_convffn32(t, f.w2q, f.fc1_b, f.fc2_b, f.ls, res, out, M, C, hidden, s, ranges && !h->batch_invariant ? h->ffn_part : nullptr,
                                 ranges && !h->batch_invariant && h->ffn_part ? FFN_PART_BYTES : 0);

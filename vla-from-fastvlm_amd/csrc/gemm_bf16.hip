@@ -304,10 +304,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Params p) {
         unpack8_h(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), a8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= a8[e];
-      } else if (epi == FV_EPI_MUL_GELUP) {   // aux = the pre-activation / 4 as the training forward's fused ConvFFN stashed it: times gelu'(a)
-        float a8[8];
+      } else if (epi == FV_EPI_MUL_GELUP) {   // aux = the pre-activation / 4 as the training forward's fused ConvFFN stashed it: times gelu'(a); gelu(a) leaves too
+        float a8[8], h8[8];
         unpack8_h(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), a8);
-        mul_gelu_grad8(v, a8);
+        mul_gelu_grad8(v, a8, h8);
+        if (p.stash) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h8[e] = bf2f(f2bf(h8[e]));   // the forward's hidden is a bf16 MFMA operand: the same rounding here
+          *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.stash) + (size_t)gm * p.ldo + gn) = pack8_h(h8);
+        }
       }
       count_f16_sat8(v, p.sat);
       *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8_h(v);
@@ -716,9 +721,14 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm256_kernel(Para
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= a8[e];
           } else if (p.epi == FV_EPI_MUL_GELUP) {
-            float a8[8];
+            float a8[8], h8[8];
             unpack8_h(*reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.res) + (size_t)gm * p.ldr + gn), a8);
-            mul_gelu_grad8(v, a8);
+            mul_gelu_grad8(v, a8, h8);
+            if (p.stash) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) h8[e] = bf2f(f2bf(h8[e]));
+              *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.stash) + (size_t)gm * p.ldo + gn) = pack8_h(h8);
+            }
           }
           count_f16_sat8(v, p.sat);
           *reinterpret_cast<uint4*>(static_cast<bf16_t*>(p.out) + (size_t)gm * p.ldo + gn) = pack8_h(v);
@@ -1189,7 +1199,8 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
   p.ksplit = a.ksplit == 2 ? 2 : (a.ksplit ? 1 : 0);
   p.sat = a.sat;
   p.stash = a.stash; p.stash_f16 = a.stash_f16;
-  if (a.stash && a.epi != FV_EPI_GELU_GRAD && ((a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16) || ((uintptr_t)a.stash & 15) || (a.stash_f16 && !a.sat)))
+  if (a.stash && a.epi == FV_EPI_MUL_GELUP) { if ((uintptr_t)a.stash & 15) return fv_fail(FV_ERR_ARG, "gemm: MUL_GELUP's gelu(a) output must be 16-byte aligned"); }
+  else if (a.stash && a.epi != FV_EPI_GELU_GRAD && ((a.epi != FV_EPI_SWIGLU_SPLIT && a.epi != FV_EPI_SWIGLU_F16) || ((uintptr_t)a.stash & 15) || (a.stash_f16 && !a.sat)))
     return fv_fail(FV_ERR_ARG, "gemm: stash goes with FV_EPI_SWIGLU_SPLIT / FV_EPI_SWIGLU_F16 (16-byte aligned; the fp16 form with a saturation counter)");
   p.W8 = static_cast<const uint8_t*>(a.W8);
   if (a.ksplit == 2) {

@@ -58,7 +58,7 @@ bool convffn32_supported(int C, int ratio);
 void convffn32_pack(const float* w1, const float* w2, float* out, int C);
 int launch_convffn32(const bf16_t* x, const bf16_t* wq, const float* b1, const float* b2, const float* ls,
                      const bf16_t* res, bf16_t* out, int M, int C, int hidden, hipStream_t s, float* part = nullptr, size_t part_bytes = 0,
-                     bf16_t* stash_h = nullptr, bf16_t* stash_y = nullptr);   // stash_*: [M][4C] fp16, the training forward's gelu(a) and a / 4 (convffn32.hip STASH)
+                     bf16_t* stash_y = nullptr);   // stash_y: [M][4C] fp16, the training forward's pre-activation / 4 (convffn32.hip STASH)
 bool convffn32_stash_supported(int M, int C);
 
 int launch_letterbox(const void* img, int dtype, int B, int C, int Hin, int Win, int S, float pad_value, int letterbox,

@@ -182,9 +182,17 @@ int fv_op_convffn32(const void* x, const void* wq, const float* b1, const float*
 }
 
 int fv_op_convffn32_stash(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
-                          int M, int C, void* stash_h, void* stash_y, fv_stream s) {
+                          int M, int C, void* stash_y, fv_stream s) {
+  if (!stash_y) return fv_fail(FV_ERR_ARG, "fv_op_convffn32_stash: null stash");
   return fv::launch_convffn32(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(wq), b1, b2, ls, static_cast<const bf16_t*>(res),
-                              static_cast<bf16_t*>(out), M, C, 4 * C, static_cast<hipStream_t>(s), nullptr, 0, static_cast<bf16_t*>(stash_h), static_cast<bf16_t*>(stash_y));
+                              static_cast<bf16_t*>(out), M, C, 4 * C, static_cast<hipStream_t>(s), nullptr, 0, static_cast<bf16_t*>(stash_y));
+}
+// fv_op_gemm_f16 with FV_EPI_MUL_GELUP and its second output: out f16 = acc * gelu'(4 aux), h_out f16 = gelu(4 aux) rounded to bf16
+int fv_op_gemm_f16_gelup(const void* A, int lda, const void* W, int M, int N, int K, const void* aux, int ldaux, void* out, int ldo, void* h_out, fv_stream s) {
+  fv::GemmArgs g{static_cast<const bf16_t*>(A), lda, static_cast<const bf16_t*>(W), M, N, K, nullptr, nullptr, aux, ldaux, out, ldo, FV_EPI_MUL_GELUP};
+  g.f16 = 1;
+  g.stash = h_out;
+  return fv::launch_gemm(g, static_cast<hipStream_t>(s));
 }
 
 int fv_op_convffn32_split(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,

@@ -154,7 +154,8 @@ OPS_SIGNATURES = {
     "fv_op_dwconv_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "fv_op_convffn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fv_op_convffn32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "fv_op_convffn32_stash": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "fv_op_convffn32_stash": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "fv_op_gemm_f16_gelup": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "fv_op_convffn32_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_size_t, _vp]),
     "fv_op_attention_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "fv_op_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
