@@ -1039,6 +1039,11 @@ int gemm_glds_tile(const GemmArgs& a) {
   // rounds -- was measured slower, 184 vs 150 us: 64 x 64 per wave reads a third more LDS per MFMA)
   // few rows (M <= 2048, the column-major walk): the alternative is the register-staged kernel on 64- / 128-row tiles, and a half-filled
   // round of 256-tiles beats it -- 7B gate/up at M = 512 (296 tiles) 10.5 -> 8.9 ms per step, 0.5B at M = 1024 (152 tiles) 0.96 -> 0.71
+  // round 6 experiment (tools build only, FASTVLA_F16_TILE128=1): the tower backward's short-K fp16 GEMMs (K = C <= 512: six K-tiles, then an epilogue that is
+  // ~45 % of a 256 x 256 tile's time with ONE block per CU to hide its LDS turn and dependent aux loads) on 128 x 128 tiles at TWO blocks per CU, so that one
+  // block's epilogue runs under the other's K loop
+  static const bool f16_tile128 = fv_ab_env("FASTVLA_F16_TILE128") != nullptr;
+  if (f16_tile128 && a.f16 && f16_epi && !a.tn && a.K <= 512 && a.M % 128 == 0 && a.N % 128 == 0 && (long)(a.M / 128) * (a.N / 128) >= 512) return 128;
   constexpr int min_tiles_small_m = 128;
   if (a.M % 256 == 0 && a.N % 256 == 0 && (long)(a.M / 256) * (a.N / 256) >= (a.M <= 2048 ? min_tiles_small_m : 320)) return 256;
   // fp32 epilogues (the decoder's projections and every dgrad / wgrad of the unfrozen training path: N = 896, 1152, 4864, M = 896 ...)
@@ -1056,7 +1061,7 @@ int gemm_glds_tile(const GemmArgs& a) {
   // 128-tiles: one wave per SIMD and a K-tile of 32 MFMAs per wave cannot cover a memory latency per K-tile, so a long K
   // loop (the decoder's down projection, K = 2 x 4864) is slower here than on the 128-tile register-staged kernel at three
   // blocks per CU; short ones (qkv / o, K <= 1024) are on par
-  if (a.f16) return 0;   // fp16 operands: the 256-tile kernel or the register-staged one (no 128-tile instance is built for them)
+  if (a.f16) return 0;   // fp16 operands: the 256-tile kernel or the register-staged one (the 128-tile instance below is the short-K backward's only)
   if (a.M % 128 == 0 && a.N % 128 == 0 && (long)(a.M / 128) * (a.N / 128) >= 128 && a.K >= 512 && a.K <= 1024) return 128;
   return 0;
 }
@@ -1219,6 +1224,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<8, 4, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
     FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4, 2, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
+    FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
   }
   static const bool colmajor_ok = fv_ab_env("FASTVLA_NO_GEMM_COLMAJOR") == nullptr;   // A/B
   constexpr int cm_max = 8;   // (16 measured at the headline shape in round 3: gate/up -3.5 %, split-K down +9 %, step unchanged)
@@ -1362,6 +1368,7 @@ static int launch_gemm_core(const GemmArgs& a, hipStream_t s) {
     else if (gt == 256 && a.f16) hipLaunchKernelGGL((gemm256_kernel<8, 4, false, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else if (gt == 256 && asym) hipLaunchKernelGGL((gemm256_kernel<8, 4, true>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
     else if (gt == 256) hipLaunchKernelGGL((gemm256_kernel<8, 4>), dim3(grid), dim3(512), 2 * 512 * 128, s, p);
+    else if (a.f16) hipLaunchKernelGGL((gemm256_kernel<4, 2, false, true>), dim3(grid), dim3(256), 2 * 256 * 128, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<4, 2>), dim3(grid), dim3(256), 2 * 256 * 128, s, p);
     FV_HIP_CHECK(hipGetLastError());
     return FV_OK;
