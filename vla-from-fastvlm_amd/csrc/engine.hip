@@ -810,6 +810,7 @@ int fv_create(const fv_model_desc* desc, int device, fv_handle** out) {
     rc = dev_alloc(h, 256, &p);
     h->f16_flags = static_cast<unsigned*>(p);
     if (rc == FV_OK && hipMemset(p, 0, 256) != hipSuccess) rc = fv_fail(FV_ERR_HIP, "fp16 flag words: memset failed");
+    h->lb_vmax = h->f16_flags + 32;   // a word of the same block (nothing is allocated inside fv_preprocess_normalized: the call stays capturable)
   }
   if (rc == FV_OK) { rc = dev_alloc(h, FFN_PART_BYTES, &p); h->ffn_part = static_cast<float*>(p); }
   if (rc != FV_OK) { fv_destroy(h); return rc; }
@@ -1040,12 +1041,6 @@ int fv_preprocess_normalized(fv_handle* h, const void* img, int dtype, int B, in
   if (!h) return fv_fail(FV_ERR_ARG, "null handle");
   if (!mean3 || !std3) return fv_fail(FV_ERR_ARG, "fv_preprocess_normalized: mean / std must be given (3 floats each, host memory)");
   hipStream_t st = static_cast<hipStream_t>(s);
-  if (range_heuristic && !h->lb_vmax) {
-    void* p = nullptr;
-    FV_HIP_CHECK(hipSetDevice(h->device));
-    FV_TRY(dev_alloc(h, 16, &p));
-    h->lb_vmax = static_cast<unsigned*>(p);
-  }
   const double S = h->d.image_size;
   const double in_bytes = (double)B * C * Hin * Win * (dtype == FV_U8 ? 1 : 4);
   prof_begin(h, FV_FAM_ELT, (range_heuristic ? 66.0 : 36.0) * B * S * S, (range_heuristic ? 2.0 : 1.0) * in_bytes + B * S * S * 8.0, st);
