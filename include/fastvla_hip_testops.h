@@ -142,6 +142,10 @@ int fv_op_convffn32_stash(const void* x, const void* wq, const float* b1, const 
 /* the fc2 input gradient of the tower's backward as it runs there: fp16 operands, out f16 = (A . W^T) * gelu'(4 aux), h_out f16 (may be NULL) = gelu(4 aux) rounded to
  * a bf16 value (the fc2 weight gradient's operand), aux = fv_op_convffn32_stash's stash_y */
 int fv_op_gemm_f16_gelup(const void* A, int lda, const void* W, int M, int N, int K, const void* aux, int ldaux, void* out, int ldo, void* h_out, fv_stream s);
+/* tap + bias gradients of a depthwise / channel-multiplier conv as the tower's backward computes them: x bf16 (B,H,W,C), dy fp16 bits (B,Ho,Wo,C*mult) ->
+ * dw f32 tap-major [k*k][C*mult], db f32 [C*mult]; scratch_floats >= (B * ceil(W / 32) or 512) * (k*k + 1) * C*mult (the call checks).  Stride-1 maps with C % 32 == 0,
+ * W >= 32, H >= 16 and k = 7 run on the matrix cores (dw_wgrad_mfma_kernel, round 6), everything else on the VALU forms. */
+int fv_op_dw_wgrad(const void* x, const void* dy, float* dw, float* db, float* scratch, size_t scratch_floats, int B, int H, int W, int C, int k, int stride, int mult, fv_stream s);
 int fv_op_convffn32_split(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
                           int M, int C, float* part, size_t part_bytes, fv_stream s);
 

@@ -476,6 +476,37 @@ def test_fused_convffn32_hidden_ranges(Cc, M):
     assert torch.equal(rd, outs[0])
 
 
+@pytest.mark.parametrize("k,C,H,W,B", [(7, 64, 16, 32, 2), (7, 384, 64, 64, 2), (7, 96, 40, 72, 1), (3, 192, 24, 100, 2), (3, 32, 17, 33, 3), (7, 32, 19, 50, 2),
+                                        (7, 1536, 16, 16, 2), (3, 96, 12, 16, 1)])   # the last two: maps narrower than a strip -> the VALU form
+def test_dw_wgrad_matches_autograd(k, C, H, W, B):
+    """Tap + bias gradients of the stride-1 depthwise convs of the tower's backward (round 6: the 7x7 on the matrix cores for C % 32 == 0, W >= 32, H >= 16 -- one
+    v_mfma_f32_4x4x4_16B_f16 block per channel, x rows against shifted windows of a dy row, 32-column strips marching down the map -- the 3x3 and narrow maps on the VALU form)
+    against torch.autograd over F.conv2d(groups = C) in fp64 ([UNVENDORED] mci.py RepMixer / ConvFFN depthwise convs; training/trainer.py:175 loss.backward())."""
+    torch.manual_seed(k * 100 + C + W)
+    x = bf(torch.randn(B, C, H, W))
+    dy = (torch.randn(B, C, H, W) * 0.25).half()
+    w = torch.zeros(C, 1, k, k, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), w, bias, padding=k // 2, groups=C)
+    y.backward(dy.double())
+    ref_w = w.grad.reshape(C, k * k).t().contiguous().float()      # tap-major [k*k][C]
+    ref_b = bias.grad.float()
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    nfl = max(512, B * ((W + 31) // 32)) * (k * k + 1) * C + 1024
+    scr = torch.full((nfl,), float("nan"), dtype=torch.float32, device=DEV)
+    outs = []
+    for rep in range(2):
+        dw = torch.full((k * k, C), float("nan"), dtype=torch.float32, device=DEV)
+        db = torch.full((C,), float("nan"), dtype=torch.float32, device=DEV)
+        call(lib().fv_op_dw_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), scr.data_ptr(), nfl, B, H, W, C, k, 1, 1, stream()), "fv_op_dw_wgrad")
+        torch.cuda.synchronize()
+        outs.append((dw.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # fixed-order partial sums: bit-repeatable
+    check_close(outs[0][0], ref_w, rel=2e-5, amax=1e-4, what=f"dw{k}x{k} tap gradients C={C} {H}x{W}")
+    check_close(outs[0][1], ref_b, rel=2e-5, amax=1e-4, what=f"dw{k}x{k} bias gradient C={C} {H}x{W}")
+
+
 def _toeplitz(w, k):
     """depthwise weights (C,1,k,k) -> bf16 table [C/16][k][NM][16][4 i][4 kk] = w[ky][4m + kk - i] (fastvla_hip.h)."""
     Cc = w.shape[0]

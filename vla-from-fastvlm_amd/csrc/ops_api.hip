@@ -195,6 +195,13 @@ int fv_op_gemm_f16_gelup(const void* A, int lda, const void* W, int M, int N, in
   return fv::launch_gemm(g, static_cast<hipStream_t>(s));
 }
 
+// tap + bias gradients of a depthwise conv (the kernels behind the tower's backward): x bf16 (B,H,W,C), dy fp16 (B,Ho,Wo,C*mult) -> dw f32 tap-major [k*k][C*mult], db [C*mult]
+int fv_op_dw_wgrad(const void* x, const void* dy, float* dw, float* db, float* scratch, size_t scratch_floats, int B, int H, int W, int C, int k, int stride, int mult, fv_stream s) {
+  const int pad = k / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (scratch_floats < fv::dw_bwd_scratch_floats(B, Ho, Wo, C * mult, k)) return fv_fail(FV_ERR_ARG, "fv_op_dw_wgrad: scratch too small (%zu floats needed)", fv::dw_bwd_scratch_floats(B, Ho, Wo, C * mult, k));
+  return fv::launch_dw_wgrad(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dy), dw, db, scratch, B, H, W, C, k, stride, mult, static_cast<hipStream_t>(s));
+}
+
 int fv_op_convffn32_split(const void* x, const void* wq, const float* b1, const float* b2, const float* ls, const void* res, void* out,
                           int M, int C, float* part, size_t part_bytes, fv_stream s) {
   return fv::launch_convffn32(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(wq), b1, b2, ls, static_cast<const bf16_t*>(res),

@@ -239,6 +239,212 @@ __global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------ depthwise tap gradients on the matrix cores (round 6)
+// dw[ky][kx][c] = sum_{b,r,q} dy[b][r][q][c] x[b][r + ky - P][q + kx - P][c] is, per channel, a correlation of two images: 49 (9) outputs, the contraction over ALL
+// pixels.  v_mfma_f32_4x4x4_16B_f16 multiplies sixteen independent 4x4 blocks -- block = channel, as in the forward's Toeplitz kernels -- with
+//     contraction k = 4 consecutive COLUMNS of an x quad Qx;  A_c[i][k] = x[r - P + 4 Rg + i][X0 + 4 Qx + k]        (i: four x rows, Rg in {0, 1})
+//                                                            B_c[k][j] = dy[r][D0 + 4 Qx - (s + j) + k]             (j: four column shifts, s in {0, 4})
+//     D_c[i][j] += A_c B_c = the contribution of dy row r / x quad Qx to tap (ky = 4 Rg + i, kx = s + j)            (X0 = strip - P, D0 = strip: the shift is K-free)
+// 4 MFMAs per (dy row, x quad, 16 channels) cover the 8 x 8 tap slots of which 49 are the 7x7's (77 % useful); the 3x3 takes one (Rg = 0, s = 0).  A is an aligned
+// cell of the x ring ([row][quad][channel][4 columns], the forward kernels' layout, x widened bf16 -> fp16 EXACTLY on its way into LDS); B is a 4-column window of the
+// dy row that starts (s + j) columns to the left of the x quad -- a per-lane constant shift: two neighbouring dy cells, three v_cndmask and two v_perm -- and the s = 4
+// window of quad Qx IS the s = 0 window of quad Qx - 1, so one window is built per (row, quad).  One block = (image, 32-column strip, 32-channel slice) marching down
+// the map in units of 8 rows (x ring of 16 rows, one dy unit), accumulators live across the whole march; per-block partial sums, fixed-order reduce (no atomics).
+// The bias gradient is summed from the dy tasks while they are in registers.
+template <int K>
+struct DwWgGeo {
+  static constexpr int PAD = K / 2, NQX = (32 + 2 * PAD + 3) / 4, NQD = NQX + 2;   // x quads per ring row; dy cells per row: quads -2 .. NQX - 1 (only 0 .. 7 carry data)
+  static constexpr int RSX = NQX * 256 + 64, RSD = NQD * 256 + 64;
+  static constexpr int NS = K > 4 ? 2 : 1, NRG = K > 4 ? 2 : 1;
+  static constexpr int LDS = 16 * RSX + 8 * RSD;
+};
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_w;
+typedef __attribute__((ext_vector_type(4))) short s16x4_w;
+template <int K>
+__global__ __launch_bounds__(256, 2) void dw_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int H, int W, int C,
+                                                                int tiles_x, int nslices) {
+  using G = DwWgGeo<K>;
+  constexpr int PAD = G::PAD, NQX = G::NQX, RSX = G::RSX, RSD = G::RSD, NS = G::NS, NRG = G::NRG, NT = K * K + 1;
+  extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+  char* sX = wg_smem;                 // x ring: image row rho at ring row (rho - PAD) & 15
+  char* sD = wg_smem + 16 * RSX;      // dy unit: row r & 7, cell index = quad + 2
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = bid % nslices; bid /= nslices;
+  const int tx = bid % tiles_x;
+  const long b = bid / tiles_x;
+  const int c0 = slice * 32;
+  const int gg = wid & 1, rg = wid >> 1;          // wave = (16-channel group, 4 of the unit's 8 dy rows)
+  const int bch = lane >> 2, jr = lane & 3;       // lane = (channel within the group, row i of A / shift j of B)
+  const int ng = (H + 7) / 8;
+
+  // ---- staging: tasks of 4 pixels x 8 channels, transposed in registers (v_perm) into the cell layout
+  constexpr int NTX = 8 * NQX * 4, TPX = (NTX + 255) / 256;
+  uint4 px[TPX][4], pd[4];
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define WG_LOAD_X(U)                                                                                             \
+  {                                                                                                              \
+    _Pragma("unroll") for (int tt = 0; tt < TPX; ++tt) {                                                         \
+      const int task = tid + 256 * tt;                                                                           \
+      const int cg = task & 3, quad = (task >> 2) % NQX, row = (task >> 2) / NQX;                                \
+      const int iy = 8 * (U) + PAD + row, ix0 = tx * 32 - PAD + quad * 4;                                        \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                            \
+        const int ix = ix0 + j;                                                                                  \
+        px[tt][j] = (task < NTX && iy >= 0 && iy < H && ix >= 0 && ix < W)                                       \
+                        ? *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + cg * 8)  \
+                        : make_uint4(0, 0, 0, 0);                                                                \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+#define WG_LOAD_D(U)                                                                                             \
+  {                                                                                                              \
+    const int cg = tid & 3, quad = (tid >> 2) & 7, row = tid >> 5;                                               \
+    const int iy = 8 * (U) + row, ix0 = tx * 32 + quad * 4;                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+      const int ix = ix0 + j;                                                                                    \
+      pd[j] = ((U) < ng && iy < H && ix < W) ? *reinterpret_cast<const uint4*>(dy + (((size_t)b * H + iy) * W + ix) * C + c0 + cg * 8) : make_uint4(0, 0, 0, 0); \
+    }                                                                                                            \
+  }
+  // bf16 pair (one dword) -> the same two values as fp16 (exact: 8 significant bits; activations far inside fp16's range)
+  auto bf2h = [](uint32_t u) -> uint32_t { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u))); };
+#define WG_WRITE_X(U)                                                                                            \
+  {                                                                                                              \
+    _Pragma("unroll") for (int tt = 0; tt < TPX; ++tt) {                                                         \
+      const int task = tid + 256 * tt;                                                                           \
+      if (task < NTX) {                                                                                          \
+        const int cg = task & 3, quad = (task >> 2) % NQX, row = (task >> 2) / NQX;                              \
+        const uint32_t d[4][4] = {{px[tt][0].x, px[tt][0].y, px[tt][0].z, px[tt][0].w}, {px[tt][1].x, px[tt][1].y, px[tt][1].z, px[tt][1].w}, \
+                                  {px[tt][2].x, px[tt][2].y, px[tt][2].z, px[tt][2].w}, {px[tt][3].x, px[tt][3].y, px[tt][3].z, px[tt][3].w}}; \
+        const uint32_t dst = (uint32_t)((8 * ((U) & 1) + row) * RSX + quad * 256 + cg * 64) | (uint32_t)((((quad & 3) << 1) | (cg >> 1)) << 3); \
+        _Pragma("unroll") for (int dd = 0; dd < 4; ++dd) {                                                       \
+          uint2 ev, od;                                                                                          \
+          ev.x = bf2h(__builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x05040100u));                                   \
+          ev.y = bf2h(__builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x05040100u));                                   \
+          od.x = bf2h(__builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x07060302u));                                   \
+          od.y = bf2h(__builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x07060302u));                                   \
+          *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd) * 8))) = ev;                                 \
+          *reinterpret_cast<uint2*>(sX + (dst ^ (uint32_t)((2 * dd + 1) * 8))) = od;                             \
+        }                                                                                                        \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+#define WG_WRITE_D()                                                                                             \
+  {                                                                                                              \
+    const int cg = tid & 3, quad = (tid >> 2) & 7, row = tid >> 5, qc = quad + 2;                                \
+    const uint32_t d[4][4] = {{pd[0].x, pd[0].y, pd[0].z, pd[0].w}, {pd[1].x, pd[1].y, pd[1].z, pd[1].w},         \
+                              {pd[2].x, pd[2].y, pd[2].z, pd[2].w}, {pd[3].x, pd[3].y, pd[3].z, pd[3].w}};        \
+    const uint32_t dst = (uint32_t)(row * RSD + qc * 256 + cg * 64) | (uint32_t)((((qc & 3) << 1) | (cg >> 1)) << 3); \
+    _Pragma("unroll") for (int dd = 0; dd < 4; ++dd) {                                                           \
+      uint2 ev, od;                                                                                              \
+      ev.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x05040100u);                                             \
+      ev.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x05040100u);                                             \
+      od.x = __builtin_amdgcn_perm(d[1][dd], d[0][dd], 0x07060302u);                                             \
+      od.y = __builtin_amdgcn_perm(d[3][dd], d[2][dd], 0x07060302u);                                             \
+      *reinterpret_cast<uint2*>(sD + (dst ^ (uint32_t)((2 * dd) * 8))) = ev;                                     \
+      *reinterpret_cast<uint2*>(sD + (dst ^ (uint32_t)((2 * dd + 1) * 8))) = od;                                 \
+      /* the bias gradient: this thread's 8 channels, 4 pixels each */                                           \
+      bsum[2 * dd] += (h2f_lo(d[0][dd]) + h2f_lo(d[1][dd])) + (h2f_lo(d[2][dd]) + h2f_lo(d[3][dd]));             \
+      bsum[2 * dd + 1] += (h2f_hi(d[0][dd]) + h2f_hi(d[1][dd])) + (h2f_hi(d[2][dd]) + h2f_hi(d[3][dd]));         \
+    }                                                                                                            \
+  }
+  // the dy cells outside the strip (quads -2, -1 and 8 .. NQX - 1) are zero for the whole march
+  for (int i = tid; i < 8 * (G::NQD - 8) * 32; i += 256) {
+    const int ch = i & 31, z = (i >> 5) % (G::NQD - 8), row = (i >> 5) / (G::NQD - 8);
+    const int qc = z < 2 ? z : z + 8;
+    *reinterpret_cast<uint2*>(sD + row * RSD + qc * 256 + ch * 8) = make_uint2(0u, 0u);
+  }
+  uint32_t sw[4];   // the lane's swizzled channel offsets (one per cell index & 3)
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sw[v] = (uint32_t)(((gg * 16 + bch) ^ ((v << 1) | gg)) << 3);
+  // per-lane window selectors: shift j = jr -> the window starts 4 - j columns into [cell Q - 1 | cell Q] (j = 0: the cell Q itself)
+  const bool j0 = jr == 0, j3 = jr == 3;
+  const uint32_t selw = (jr & 1) ? 0x05040302u : 0x03020100u;
+
+  f32x4 acc[NS][NRG];
+#pragma unroll
+  for (int sI = 0; sI < NS; ++sI)
+#pragma unroll
+    for (int r = 0; r < NRG; ++r) acc[sI][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  WG_LOAD_X(-1)
+  WG_WRITE_X(-1)
+  WG_LOAD_X(0)
+  WG_WRITE_X(0)
+  WG_LOAD_D(0)
+  WG_WRITE_D()
+  if (ng > 1) { WG_LOAD_X(1) WG_LOAD_D(1) }
+  for (int g = 0; g < ng; ++g) {
+    __syncthreads();   // x units g - 1, g and dy unit g are in LDS
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int lr = rg * 4 + rr;                                   // dy row within the unit; image row r = 8 g + lr
+      const char* drow = sD + lr * RSD;
+      uint32_t xrow[NRG];                                           // ring row of the lane's x row: image row r - PAD + 4 Rg + i -> (r - 2 PAD + 4 Rg + i) & 15
+#pragma unroll
+      for (int r = 0; r < NRG; ++r) xrow[r] = (uint32_t)((8 * g + lr - 2 * PAD + 4 * r + jr) & 15) * RSX;
+      uint2 cprev = *reinterpret_cast<const uint2*>(drow + sw[1] + 1 * 256);   // dy quad -1 (cell 1): zero
+      s16x4_w bprev = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < NQX; ++q) {
+        const uint2 cq = *reinterpret_cast<const uint2*>(drow + sw[(q + 2) & 3] + (q + 2) * 256);   // dy quad q
+        // window of shift j over [cprev | cq] = dwords d0 d1 d2 d3: j = 0: (d2, d3); 1: d1 d2 d3 >> 16; 2: (d1, d2); 3: d0 d1 d2 >> 16
+        const uint32_t e0 = j3 ? cprev.x : (j0 ? cq.x : cprev.y);
+        const uint32_t e1 = j3 ? cprev.y : (j0 ? cq.y : cq.x);
+        const uint32_t e2 = j3 ? cq.x : cq.y;
+        uint2 wv;
+        wv.x = __builtin_amdgcn_perm(e1, e0, selw);
+        wv.y = __builtin_amdgcn_perm(e2, e1, selw);
+        const s16x4_w bq = __builtin_bit_cast(s16x4_w, wv);
+#pragma unroll
+        for (int r = 0; r < NRG; ++r) {
+          const s16x4_w a = __builtin_bit_cast(s16x4_w, *reinterpret_cast<const uint2*>(sX + xrow[r] + sw[q & 3] + q * 256));
+          acc[0][r] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4_w, a), __builtin_bit_cast(f16x4_w, bq), acc[0][r], 0, 0, 0);
+          if (NS > 1) acc[NS - 1][r] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4_w, a), __builtin_bit_cast(f16x4_w, bprev), acc[NS - 1][r], 0, 0, 0);
+        }
+        cprev = cq;
+        bprev = bq;
+      }
+    }
+    __syncthreads();   // every wave is done with x unit g - 1 and dy unit g
+    if (g + 1 < ng) { WG_WRITE_X(g + 1) WG_WRITE_D() }
+    if (g + 2 < ng) { WG_LOAD_X(g + 2) WG_LOAD_D(g + 2) }
+  }
+  __syncthreads();
+  // ---- fold: the two row-half waves of a channel group add up; then part[(blk * NT + t) * C + c]; bias sums over the 64 threads of a channel group of 8
+  float* sF = reinterpret_cast<float*>(wg_smem);   // [wave 4][lane 64][NS * NRG * 4] taps, then [256][8] bias
+  constexpr int NV = NS * NRG * 4;
+#pragma unroll
+  for (int sI = 0; sI < NS; ++sI)
+#pragma unroll
+    for (int r = 0; r < NRG; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sF[(wid * 64 + lane) * NV + (sI * NRG + r) * 4 + i] = acc[sI][r][i];
+  float* sB = sF + 4 * 64 * NV;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sB[tid * 8 + e] = bsum[e];
+  __syncthreads();
+  const size_t blk = (size_t)b * tiles_x + tx;
+  for (int o = tid; o < 2 * 64 * NV; o += 256) {
+    const int v = o % NV, ln = (o / NV) & 63, g2 = o / (NV * 64);
+    const int i = v & 3, r = (v >> 2) % NRG, sI = (v >> 2) / NRG;
+    const int ky = 4 * r + i, kx = 4 * sI + (ln & 3);
+    if (ky < K && kx < K) {
+      const float sum = sF[((g2 + 0) * 64 + ln) * NV + v] + sF[((g2 + 2) * 64 + ln) * NV + v];
+      part[(blk * NT + ky * K + kx) * C + c0 + g2 * 16 + (ln >> 2)] = sum;
+    }
+  }
+  if (tid < 32) {   // channel c0 + tid = group cg = tid / 8, element tid % 8: the threads with (t & 3) == cg hold its sums, added in thread order
+    const int cg = tid >> 3, e = tid & 7;
+    float sum = 0.f;
+    for (int t = cg; t < 256; t += 4) sum += sB[t * 8 + e];
+    part[(blk * NT + K * K) * C + c0 + tid] = sum;
+  }
+#undef WG_LOAD_X
+#undef WG_LOAD_D
+#undef WG_WRITE_X
+#undef WG_WRITE_D
+}
+
 // out[i] = sum_p part[p * stride + i] (fixed order), i < n; the first n1 results go to out1, the rest to out2 (taps | bias, dw | db ...)
 // The same stride-1 form with the INPUT tile staged through LDS (round 5; the default): the register-blocked kernel above reads every input row K times from
 // global memory with two waves per SIMD to hide it behind -- it ran at 1/12 of its packed-FMA time.  Here a block = CS channels x NPS consecutive output rows of
@@ -1126,6 +1332,31 @@ int launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, float* db, flo
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
   const int CS = pick_slab(Co, 128);
   const int nslabs = Co / CS, NPS = 256 / (CS / 2), NT = k * k + 1;
+  // round 6: stride-1 maps of the RepMixer stages on the matrix cores (dw_wgrad_mfma_kernel): 32-column strips x 32-channel slices marching down the map
+  static const bool no_wg_mfma = fv_ab_env("FASTVLA_NO_DW_WGRAD_MFMA") != nullptr;   // A/B (tools build)
+  // (k = 7 only: measured per launch at C = 384, B = 32: 186 -> 98 us, against a ~80 us floor of its two input passes; the 3x3 instance is correct -- it stays compiled
+  // for the tools build's FASTVLA_DW_WGRAD_MFMA3=1 -- but at 90 us it does not beat the VALU form's 88: both already sit at that floor)
+  static const bool wg_mfma3 = fv_ab_env("FASTVLA_DW_WGRAD_MFMA3") != nullptr;
+  if (!no_wg_mfma && (k == 7 || (k == 3 && wg_mfma3)) && stride == 1 && mult == 1 && Ci % 32 == 0 && Wi >= 32 && Hi >= 16 && (long)B * ((Wi + 31) / 32) <= 512 &&
+      (size_t)B * Hi * Wi * Ci * 2 < ((size_t)1 << 40)) {
+    const int tiles_x = (Wi + 31) / 32, nsl = Ci / 32;
+    const long nb = (long)B * tiles_x, nstrips = nb * nsl;
+    if (nstrips <= 0x7fffffffL && (size_t)nb * NT * Co <= dw_bwd_scratch_floats(B, Ho, Wo, Co, k)) {
+      if (k == 7) {
+        static bool attr7 = false;
+        if (!attr7) { FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_mfma_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, DwWgGeo<7>::LDS)); attr7 = true; }
+        hipLaunchKernelGGL((dw_wgrad_mfma_kernel<7>), dim3((unsigned)nstrips), dim3(256), (DwWgGeo<7>::LDS), s, x, dy, scratch, Hi, Wi, Ci, tiles_x, nsl);
+      } else {
+        static bool attr3 = false;
+        if (!attr3) { FV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wgrad_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, DwWgGeo<3>::LDS)); attr3 = true; }
+        hipLaunchKernelGGL((dw_wgrad_mfma_kernel<3>), dim3((unsigned)nstrips), dim3(256), (DwWgGeo<3>::LDS), s, x, dy, scratch, Hi, Wi, Ci, tiles_x, nsl);
+      }
+      const long n = (long)NT * Co;
+      hipLaunchKernelGGL(partial_reduce_kernel, dim3(gridr(n)), dim3(256), 0, s, scratch, nb, n, n, (long)k * k * Co, dw, db, 1.0f);
+      FV_HIP_CHECK(hipGetLastError());
+      return FV_OK;
+    }
+  }
   if ((k == 3 || k == 7) && Wo >= 8 && CS >= 32 * mult) {   // the LDS-staged form (dw_wgrad_lds_kernel)
     const int NPSl = 256 / (CS / 2);
     const int gpi = (Ho + NPSl - 1) / NPSl, ngroups = B * gpi;

@@ -156,6 +156,7 @@ OPS_SIGNATURES = {
     "fv_op_convffn32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fv_op_convffn32_stash": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "fv_op_gemm_f16_gelup": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "fv_op_dw_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_size_t, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fv_op_convffn32_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_size_t, _vp]),
     "fv_op_attention_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "fv_op_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
