@@ -1157,6 +1157,12 @@ struct DpGeo {
   static constexpr int NRG = NGG / 2;      // 4-row groups one wave computes per 8-row unit
   static constexpr int OCC = 3 * LDS <= 160 * 1024 ? 3 : 2;   // blocks per CU the kernel is compiled for (registers: 512 / (4 * OCC / 4))
 };
+// (DP_ABL & 32, tools/dw_variants.sh only, results wrong: the step's four barriers removed -- an upper bound on what FEWER barriers per row, i.e. a 16-row march step, could buy)
+#if DP_ABL & 32
+#define DP_BARRIER asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define DP_BARRIER __syncthreads();
+#endif
 #ifdef DP_STAMPS
 __device__ unsigned long long g_dp_stamps[512 * 16];   // diagnostics: per block (first 512), clocks per phase summed over the steps (wave 0)
 #define DP_T(I) { const unsigned long long n_ = __builtin_readcyclecounter(); if (tid == 0) st_[I] += n_ - t0_; t0_ = __builtin_readcyclecounter(); }
@@ -1340,7 +1346,7 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
 #endif
   for (int g = g0 - 1; g < g1; ++g) {
     DP_T(11)
-    __syncthreads();   // x unit g is in its ring; the previous step's output tile and x' rows have been read
+    DP_BARRIER   // x unit g is in its ring; the previous step's output tile and x' rows have been read
     DP_T(0)
     // ---- x' unit g = dw3x3 over x units g - 1, g: lane's row r' = 8g + 3 + rg*4 + jr, NQ quads of columns.
     // The operand rows (one per (row group, ky): NQ ds_read_b64) are requested TWO rows ahead of the MFMAs that take them and the
@@ -1397,7 +1403,7 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
       }
     }
     DP_T(1)
-    __syncthreads();   // x' unit g is in its ring; every wave is done with x unit g - 1
+    DP_BARRIER   // x' unit g is in its ring; every wave is done with x unit g - 1
     DP_T(2)
     if (g + 1 < g1) {
       // x unit g + 1 was requested a step ago; younger than it are the 4 x' and 4 t stores of step g - 1 (the prologue and step -1
@@ -1470,7 +1476,7 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
       }
 #undef DP_RD7
       DP_T(6)
-      __syncthreads();   // every wave is done with x' unit g - 1: the slots the next unit will take carry the t tile out
+      DP_BARRIER   // every wave is done with x' unit g - 1: the slots the next unit will take carry the t tile out
       DP_T(7)
 #pragma unroll
       for (int rgi = 0; rgi < NRG; ++rgi) {
@@ -1485,7 +1491,7 @@ __global__ __launch_bounds__(256, (DpGeo<CHB, TW_>::OCC)) void dwpair_march_kern
       }
     }
     DP_T(8)
-    __syncthreads();
+    DP_BARRIER
     DP_T(9)
     {
       const uint32_t src = (uint32_t)((8 * g + 11 + e2row + 112) % PR) * RS + e2src;
