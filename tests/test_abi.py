@@ -43,7 +43,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_test_only_op_library_matches_its_header():
-    """the 25 fv_op_* entry points the parity tests drive live in a library of their own (tests/_native/, csrc/ops_api.hip), declared in
+    """the fv_op_* entry points the parity tests drive (25 at the time, 28 now) live in a library of their own (tests/_native/, csrc/ops_api.hip), declared in
     include/fastvla_hip_testops.h; its fv::launch_* references bind to the loaded product library."""
     decl = _declared(OPS_HEADER)
     assert len(decl) >= 20 and all(n.startswith("fv_op_") for n in decl)
