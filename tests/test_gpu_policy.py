@@ -415,6 +415,27 @@ def test_bench_gpus2_unfrozen_legs_exchange_their_buckets():
     assert line["train_unfrozen_tower"]["buckets"] > line["train_unfrozen"]["buckets"] and line["train_unfrozen_tower"]["fp16_saturations"] == 0
 
 
+def test_bench_gpus2_deadline_prints_the_headline_and_leaves():
+    """the legs behind the headline measurement of an N > 1 run sit under a watchdog (`--secondary-deadline`): past it rank 0 prints the line with what it
+    has (`dist.deadline_hit`), every rank leaves by itself, the launcher sees exit code 0 -- a stalled secondary leg can delay a scaling run, never lose it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "tiny", "--batch", "4", "--train-batch", "4",
+                        "--tokens", "16", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--secondary-deadline", "0.02"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"] is not None
+    assert line["dist"]["deadline_hit"] is True and line["dist"]["world_size"] == 2
+
+
 def test_image_prefix_cache_in_the_backbone():
     """SURVEY.md 8f-1 through the plugin-side class: FastVLMBackbone in splice mode with `cache_image_prefix` keeps every image's
     decoder prefix (LRU keyed by a device-side hash of the image tensor).  Misses, hits, a frame repeated inside one batch and a
